@@ -1,0 +1,144 @@
+"""Generate the golden fixtures from the UNMODIFIED reference, run on CPU through oracle/ref_shim.py.
+
+    python tests/golden/make_golden.py        # needs /root/reference; writes tests/golden/*.pt
+
+The reference has no golden vectors of its own for this path, so these files pin the
+oracle (and through it the HIP path) to what the reference code itself computes.  Weights are the
+deterministic synthetic weights of oracle/synth.py, so only inputs and expected outputs are stored.
+"""
+import math
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import ref_shim as R  # noqa: E402
+from oracle import synth  # noqa: E402
+
+MICRO = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_rel_bucket_size=4,
+             text_bucket_size=256, audio_bucket_size=512)
+TINY = dict(embed_dim=256, ffn_embed_dim=1024, layers=4, attention_heads=4)  # BASELINE config 1
+
+
+def build_ref_model(cfg_kw, vocab, head_type="val"):
+    rt = R.ref("one_peace.models.one_peace.one_peace_retrieval")
+    cfg = R.make_cfg(**cfg_kw)
+    torch.manual_seed(0)
+    m = rt.OnePeaceRetrievalModel(cfg, R.TinyDictionary(vocab), head_type)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.split(".")[-1] in synth.NON_SYNTH for k in missing), (missing, unexpected)
+    m.eval()
+    return m, shapes
+
+
+def grads_summary(model, names):
+    out = {}
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        out[n + "#norm"] = p.grad.double().norm().float()
+        if n in names or p.grad.numel() <= 4096:
+            out[n] = p.grad.clone()
+        elif p.grad.dim() == 2:
+            out[n + "#rows4"] = p.grad[:4].clone()
+    return out
+
+
+def micro_fixture():
+    vocab = 1000
+    m, shapes = build_ref_model(MICRO, vocab)
+    B = 4
+    inp = synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=vocab)
+    crit = R.ref("one_peace.criterions.image_text_retrieval_loss")
+    acrit = R.ref("one_peace.criterions.audio_text_retrieval_loss")
+    itc = crit.ImageTextRetrievalCriterion(None, label_smoothing=0.0)
+    atc = acrit.AudioTextRetrievalCriterion(None, label_smoothing=0.1)
+
+    t = m(src_tokens=inp["src_tokens"], encoder_type="text")
+    i = m(src_images=inp["src_images"], encoder_type="image")
+    a = m(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")
+    scale = m(return_logit_scale=True)
+    l_it, i2t, t2i = itc.compute_itc_loss(i, t, i.data, t.data, scale)
+    l_at, a2t, t2a = atc.compute_atc_loss(a, t, a.data, t.data, scale)
+    loss = l_it + l_at
+    m.zero_grad()
+    loss.backward()
+    keep = {"logit_scale", "encoder_wrapper.fusion_model.layers.0.self_attn.q_proj.weight",
+            "encoder_wrapper.fusion_model.layers.1.image_ffn.0.wi_0.weight",
+            "encoder_wrapper.fusion_model.layers.1.text_ffn.3.weight",
+            "encoder_wrapper.fusion_model.layers.0.audio_ffn.0.wi_1.weight"}
+    grads = grads_summary(m, keep)
+
+    # joint streams through ModelWrapper (encoder_type vl / al), eval mode
+    with torch.no_grad():
+        vl_t, vl_i, _ = m.encoder_wrapper(src_tokens=inp["src_tokens"], src_images=inp["src_images"], encoder_type="vl")
+        al_t, _, al_a = m.encoder_wrapper(src_tokens=inp["src_tokens"], src_audios=inp["src_audios"],
+                                          audio_padding_masks=inp["audio_padding_masks"], encoder_type="al")
+        feats_t = m.encoder_wrapper(src_tokens=inp["src_tokens"], encoder_type="text")[0]
+        feats_i = m.encoder_wrapper(src_images=inp["src_images"], encoder_type="image")[1]
+    fx = dict(cfg=MICRO, vocab=vocab, shapes=shapes, inputs=inp,
+              text_logits=t.detach(), image_logits=i.detach(), audio_logits=a.detach(),
+              text_feats=feats_t, image_feats=feats_i, scale=scale.detach(),
+              itc_loss=l_it.detach(), atc_loss=l_at.detach(), i2t=i2t, t2i=t2i, a2t=a2t, t2a=t2a,
+              vl_text=vl_t, vl_image=vl_i, al_text=al_t, al_audio=al_a, grads=grads,
+              text_rp_bucket_sum=m.encoder_wrapper.text_adapter.rp_bucket.sum(),
+              image_rp_bucket=m.encoder_wrapper.image_adapter.rp_bucket.clone(),
+              audio_rp_bucket_sum=m.encoder_wrapper.audio_adapter.rp_bucket.sum(),
+              text_rp_bucket_corner=m.encoder_wrapper.text_adapter.rp_bucket[:40, :40].clone(),
+              audio_rp_bucket_row=m.encoder_wrapper.audio_adapter.rp_bucket[700, :].clone())
+    torch.save(fx, os.path.join(HERE, "micro_retrieval.pt"))
+    print("micro: itc %.6f atc %.6f" % (l_it.item(), l_at.item()))
+
+
+def tiny_text_fixture():
+    """BASELINE.json configs[0]: tiny encoder (H=256, L=4) text-only extract_text_features, bs=8 seq=64."""
+    m, shapes = build_ref_model(dict(TINY, use_image_moe=False, use_audio_moe=False), 50265, head_type="text")
+    inp = synth.synth_inputs(8, text_len=63)
+    with torch.no_grad():
+        out = m(src_tokens=inp["src_tokens"], encoder_type="text")
+    shapes = {k: v for k, v in shapes.items()}
+    torch.save(dict(cfg=dict(TINY, use_image_moe=False, use_audio_moe=False), shapes=shapes,
+                    inputs=inp, text_logits=out), os.path.join(HERE, "tiny_text.pt"))
+    print("tiny text:", out.shape, out[0, :4])
+
+
+def layer_fixture():
+    """One encoder layer at a 4B-like aspect (hd=64) incl. drop-path, padded keys, all three FFNs + grads."""
+    tl = R.ref("one_peace.models.transformer.transformer_layer")
+    cfg = R.make_cfg(embed_dim=192, ffn_embed_dim=384, layers=1, attention_heads=3).encoder
+    torch.manual_seed(0)
+    layer = tl.TransformerEncoderLayer(cfg, drop_path_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+    sd = synth.synth_state_dict(shapes)
+    layer.load_state_dict(sd)
+    layer.eval()
+    S, B, H = 37, 3, 192
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(S, B, H, generator=g)
+    bias = 0.5 * torch.randn(B, 3, S, S, generator=g)
+    bias[1, :, :, 30:] = float("-inf")
+    out = {}
+    for et in ("text", "image", "audio"):
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi, None, self_attn_bias=bias, encoder_type=et)
+        w = torch.randn(y.shape, generator=torch.Generator().manual_seed(2))
+        layer.zero_grad()
+        (y * w).sum().backward()
+        out[et] = dict(y=y.detach(), dx=xi.grad.clone(), grads=grads_summary(layer, ()))
+    torch.save(dict(shapes=shapes, x=x, bias=bias, heads=3, out=out), os.path.join(HERE, "layer.pt"))
+    print("layer:", out["text"]["y"].norm().item())
+
+
+if __name__ == "__main__":
+    assert R.reference_available(), "needs /root/reference"
+    micro_fixture()
+    tiny_text_fixture()
+    layer_fixture()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".pt"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -1,0 +1,95 @@
+// Shared device/host helpers for the ONE-PEACE gfx950 (CDNA4) kernels.
+// Wavefront = 64 lanes everywhere; nothing here is portable to 32-wide hardware on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define OP_OK 0
+#define OP_EINVAL (-22)
+#define OP_ENOTSUP (-95)
+
+// dtype codes of the C ABI
+#define OP_DT_BF16 0
+#define OP_DT_F32 1
+
+extern "C" void op_set_error(const char* fmt, ...);
+
+#define OP_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      op_set_error(__VA_ARGS__);           \
+      return OP_EINVAL;                    \
+    }                                      \
+  } while (0)
+
+#define OP_LAUNCH_CHECK()                                                  \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      op_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,          \
+                   hipGetErrorString(e__));                                \
+      return (int)e__;                                                     \
+    }                                                                      \
+  } while (0)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- 8-element vector load/store with fp32 math --------------------------------------------------
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = r;
+  }
+};
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu(x) = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,486 @@
+// HBM-bound helper kernels of the ONE-PEACE hot path (gfx950): transposes, column reductions, GeGLU backward,
+// layer-scale/drop-path residual backward, L2-normalise, InfoNCE rows, AdamW, relative-position bias tables.
+// All move 16-byte vectors per lane, accumulate in fp32 and are deterministic (two-stage reductions, no
+// floating-point atomics except the relative-position table scatter which is documented below).
+#include "common.h"
+
+namespace {
+
+constexpr int CS_MAX_PARTS = 256;
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 2-D transpose  out[c][r] = in[r][c]   (64x64 tiles through LDS, 8-byte global accesses on both sides)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                        int rows, int cols, int64_t ld_in, int64_t ld_out) {
+  __shared__ bf16_t tile[64][64 + 2];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 elements each along the fast axis
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + k * 16, c = c0 + tx * 4;
+    if (r < rows) {
+      if (c + 3 < cols) {
+        bf16x4 v = *reinterpret_cast<const bf16x4*>(in + (int64_t)r * ld_in + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[ty + k * 16][tx * 4 + j] = v[j];
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (c + j < cols) tile[ty + k * 16][tx * 4 + j] = in[(int64_t)r * ld_in + c + j];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + k * 16, r = r0 + tx * 4;  // output row = input column
+    if (c < cols) {
+      if (r + 3 < rows) {
+        bf16x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = tile[tx * 4 + j][ty + k * 16];
+        *reinterpret_cast<bf16x4*>(out + (int64_t)c * ld_out + r) = v;
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (r + j < rows) out[(int64_t)c * ld_out + r + j] = tile[tx * 4 + j][ty + k * 16];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// column sums:  part[p][n] = sum over this block's rows of  rs[m] * x[m][n] * (y ? y[m][n] : 1)
+// grid = (ceil(N / 512), parts); block 256 = 4 waves x 64 lanes x 8 columns
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
+                                                             const float* __restrict__ rowscale, int rps,
+                                                             float* __restrict__ part, int64_t M, int N, int64_t ld) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < N) {
+    for (int64_t m = (int64_t)blockIdx.y * 4 + wid; m < M; m += (int64_t)gridDim.y * 4) {
+      float xv[8];
+      Vec8<bf16_t>::load(x + m * ld + c, xv);
+      float s = rowscale ? rowscale[m / rps] : 1.f;
+      if (y) {
+        float yv[8];
+        Vec8<bf16_t>::load(y + m * ld + c, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += s * xv[j] * yv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += s * xv[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wid][lane * 8 + j] = a[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int cc = blockIdx.x * 512 + i;
+    if (cc < N) part[(int64_t)blockIdx.y * N + cc] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
+}
+
+// out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_p part[p][n]
+template <typename T>
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, int parts, int N, const bf16_t* __restrict__ mul,
+                                     T* __restrict__ out, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float a = 0.f;
+  for (int p = 0; p < parts; ++p) a += part[(int64_t)p * N + n];
+  if (mul) a *= (float)mul[n];
+  out[n] = (T)(a + (accumulate ? (float)out[n] : 0.f));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// GeGLU backward (transformer_layer.py:64-67):  g = gelu(h0) * h1
+//   dh0 = dg * h1 * gelu'(h0),  dh1 = dg * gelu(h0)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict__ dg, const bf16_t* __restrict__ h0,
+                                                        const bf16_t* __restrict__ h1, bf16_t* __restrict__ dh0,
+                                                        bf16_t* __restrict__ dh1, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float g[8], a[8], b[8], o0[8], o1[8];
+    Vec8<bf16_t>::load(dg + i * 8, g);
+    Vec8<bf16_t>::load(h0 + i * 8, a);
+    Vec8<bf16_t>::load(h1 + i * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o0[j] = g[j] * b[j] * gelu_erf_grad(a[j]);
+      o1[j] = g[j] * gelu_erf(a[j]);
+    }
+    Vec8<bf16_t>::store(dh0 + i * 8, o0);
+    Vec8<bf16_t>::store(dh1 + i * 8, o1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// residual/layer-scale backward (transformer_layer.py:70-88):  out = resid + rs[m] * gamma[n] * y[m][n]
+//   dy[m][n] = rs[m] * gamma[n] * dout[m][n]   (written to dbranch)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_rows_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ gamma,
+                                                         const float* __restrict__ rowscale, int rps,
+                                                         bf16_t* __restrict__ dbranch, int64_t M, int N) {
+  const int n8 = N / 8;
+  const int64_t total = M * n8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / n8;
+    const int c = (int)(i - m * n8) * 8;
+    float d[8], gv[8];
+    Vec8<bf16_t>::load(dout + m * N + c, d);
+    const float s = rowscale ? rowscale[m / rps] : 1.f;
+    if (gamma) {
+      Vec8<bf16_t>::load(gamma + c, gv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] *= s * gv[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] *= s;
+    }
+    Vec8<bf16_t>::store(dbranch + m * N + c, d);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// F.normalize(x, dim=1) (one_peace_retrieval.py:112): y = x / max(||x||, eps); one wave per row
+// ------------------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const bf16_t* __restrict__ x, TO* __restrict__ y,
+                                                         float* __restrict__ inv_norm, int rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float ss = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    float v[8];
+    Vec8<bf16_t>::load(x + (int64_t)row * cols + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+  }
+  ss = wave_sum(ss);
+  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+  for (int c = lane * 8; c < cols; c += 512) {
+    float v[8];
+    Vec8<bf16_t>::load(x + (int64_t)row * cols + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= inv;
+    Vec8<TO>::store(y + (int64_t)row * cols + c, v);
+  }
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+
+// dx = inv * (dy - y * <y, dy>)   (valid while ||x|| > eps, which always holds for projected CLS features)
+template <typename TY>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const TY* __restrict__ dy, const TY* __restrict__ y,
+                                                         const float* __restrict__ inv_norm, bf16_t* __restrict__ dx,
+                                                         int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float dot = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    float a[8], b[8];
+    Vec8<TY>::load(dy + (int64_t)row * cols + c, a);
+    Vec8<TY>::load(y + (int64_t)row * cols + c, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dot += a[j] * b[j];
+  }
+  dot = wave_sum(dot);
+  const float inv = inv_norm[row];
+  for (int c = lane * 8; c < cols; c += 512) {
+    float a[8], b[8];
+    Vec8<TY>::load(dy + (int64_t)row * cols + c, a);
+    Vec8<TY>::load(y + (int64_t)row * cols + c, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = inv * (a[j] - b[j] * dot);
+    Vec8<bf16_t>::store(dx + (int64_t)row * cols + c, a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// InfoNCE rows (image_text_pretrain_loss.py:164-185 + adjust_label_smoothed_nll_loss :17-27).
+// One workgroup per row of sim [rows][n] (fp32).  Writes the row loss, the argmax hit, <dsim, sim> (for the
+// logit-scale gradient) and overwrites sim with d(loss_row)/d(sim) * gscale.
+//   loss_row = -(1-eps-e)*lp[t] - e*sum_j lp[j],  e = eps/(n-1),  lp = sim - lse
+//   d/ds_k   = p_k*((1-eps-e) + n*e) - (1-eps-e)*[k==t] - e
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ sim, int n, int64_t ld, int target0,
+                                                           float eps_ls, float gscale, float* __restrict__ row_loss,
+                                                           float* __restrict__ row_hit, float* __restrict__ row_dot,
+                                                           int write_grad) {
+  __shared__ float red[4];
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  const int row = blockIdx.x;
+  float* s = sim + (int64_t)row * ld;
+  const int tgt = target0 + row;
+  float mx = -INFINITY;
+  int amax = 0x7fffffff;
+  float sum = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    const float v = s[k];
+    sum += v;
+    if (v > mx) { mx = v; amax = k; }  // first maximum within this thread's increasing k
+  }
+  // block arg-max (ties -> smallest index, as torch.argmax on CPU returns the first maximal element)
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o);
+    const int oi = __shfl_xor(amax, o);
+    if (om > mx || (om == mx && oi < amax)) { mx = om; amax = oi; }
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = mx; redi[threadIdx.x >> 6] = amax; }
+  __syncthreads();
+  mx = redv[0]; amax = redi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (redv[w] > mx || (redv[w] == mx && redi[w] < amax)) { mx = redv[w]; amax = redi[w]; }
+  const float ssum = block_sum_256(sum, red);
+  float ex = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) ex += __expf(s[k] - mx);
+  const float lse = mx + logf(block_sum_256(ex, red));
+  const float e = (eps_ls != 0.f) ? eps_ls / (float)(n - 1) : 0.f;
+  const float wt = 1.f - eps_ls - e;
+  const float st = s[tgt];
+  const float loss = -wt * (st - lse) - e * (ssum - (float)n * lse);
+  float dot = 0.f;
+  if (write_grad) {
+    const float pk_coef = wt + (float)n * e;
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) {
+      const float v = s[k];
+      float d = __expf(v - lse) * pk_coef - e - (k == tgt ? wt : 0.f);
+      d *= gscale;
+      dot += d * v;
+      s[k] = d;
+    }
+    dot = block_sum_256(dot, red);
+  }
+  if (threadIdx.x == 0) {
+    row_loss[row] = loss;
+    row_hit[row] = (amax == tgt) ? 1.f : 0.f;
+    row_dot[row] = dot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// AdamW as the reference does it (one_peace/optim/adam.py:186-253): fp32 math on bf16 params, decoupled
+// decay applied to the parameter before the Adam update, eps added to sqrt(v).
+// Algorithmic bytes: 22 B/param (p r+w 4, g r 2, m and v r+w 16).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n8,
+                                                    float beta1, float beta2, float eps, float step_size,
+                                                    float decay_mul, float grad_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float pv[8], gv[8], mv[8], vv[8];
+    Vec8<bf16_t>::load(p + i * 8, pv);
+    Vec8<bf16_t>::load(g + i * 8, gv);
+    Vec8<float>::load(m + i * 8, mv);
+    Vec8<float>::load(v + i * 8, vv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gr = gv[j] * grad_scale;
+      mv[j] = mv[j] * beta1 + (1.f - beta1) * gr;
+      vv[j] = vv[j] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[j]) + eps;
+      pv[j] = pv[j] * decay_mul - step_size * (mv[j] / denom);
+    }
+    Vec8<bf16_t>::store(p + i * 8, pv);
+    Vec8<float>::store(m + i * 8, mv);
+    Vec8<float>::store(v + i * 8, vv);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Relative-position bias (adapter/image.py:164-171, text.py:76-83, audio.py:117-124):
+// bias[h][i][j] = table[bucket[i][j]][h].  The reference expands this to [B, heads, S, S] per forward; here it
+// is built ONCE per table as [heads][S][Spad] bf16 and shared by every sample (attention reads it from L2).
+// Columns j >= S are zero-filled (the attention kernels mask them by index).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relpos_build_kernel(const bf16_t* __restrict__ table, const int* __restrict__ bucket,
+                                                           int64_t bucket_ld, bf16_t* __restrict__ out, int heads, int S,
+                                                           int Spad) {
+  const int64_t total = (int64_t)S * Spad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / Spad), j = (int)(idx - (int64_t)i * Spad);
+    if (j < S) {
+      const int b = bucket[(int64_t)i * bucket_ld + j];
+      for (int h = 0; h < heads; ++h) out[((int64_t)h * S + i) * Spad + j] = table[(int64_t)b * heads + h];
+    } else {
+      for (int h = 0; h < heads; ++h) out[((int64_t)h * S + i) * Spad + j] = (bf16_t)0.f;
+    }
+  }
+}
+
+// dtable[bucket[i][j]][h] += dbias[h][i][j]  (fp32 atomics: <= heads*S*S adds onto num_rel*heads addresses once
+// per backward; summation order is not fixed, error is fp32 round-off of a few-thousand-term sum)
+__global__ __launch_bounds__(256) void relpos_bwd_kernel(const float* __restrict__ dbias, const int* __restrict__ bucket,
+                                                         int64_t bucket_ld, float* __restrict__ dtable, int heads, int S,
+                                                         int Spad) {
+  const int64_t total = (int64_t)S * S;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int i = (int)(idx / S), j = (int)(idx - (int64_t)i * S);
+    const int b = bucket[(int64_t)i * bucket_ld + j];
+    for (int h = 0; h < heads; ++h) atomicAdd(&dtable[(int64_t)b * heads + h], dbias[((int64_t)h * S + i) * Spad + j]);
+  }
+}
+
+inline int ew_grid(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream) {
+  OP_CHECK_ARG(in && out && rows >= 0 && cols >= 0, "transpose: bad args");
+  OP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "transpose: leading dims must be multiples of 4");
+  if (rows == 0 || cols == 0) return OP_OK;
+  dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)rows,
+                     (int)cols, ld_in, ld_out);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int64_t op_colsum_workspace_bytes(int64_t N) { return (int64_t)CS_MAX_PARTS * N * (int64_t)sizeof(float); }
+
+// out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_m rowscale[m/rps] * x[m][n] * (y ? y[m][n] : 1)
+// out_dtype: 0 bf16, 1 f32.  y, rowscale, mul nullable.
+int op_colsum(const void* x, const void* y, const float* rowscale, int64_t rows_per_sample, const void* mul, void* out,
+              void* workspace, int64_t M, int64_t N, int accumulate, int out_dtype, void* stream) {
+  OP_CHECK_ARG(x && out && workspace, "colsum: null pointer");
+  OP_CHECK_ARG(N > 0 && N % 8 == 0, "colsum: N must be a multiple of 8");
+  hipStream_t s = (hipStream_t)stream;
+  int parts = (int)((M + 63) / 64);
+  if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
+  if (parts < 1) parts = 1;
+  dim3 grid(ceil_div(N, 512), parts);
+  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y, rowscale,
+                     (int)(rows_per_sample > 0 ? rows_per_sample : 1), (float*)workspace, M, (int)N, N);
+  OP_LAUNCH_CHECK();
+  if (out_dtype == OP_DT_BF16)
+    hipLaunchKernelGGL((colsum_reduce_kernel<bf16_t>), dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)workspace, parts,
+                       (int)N, (const bf16_t*)mul, (bf16_t*)out, accumulate);
+  else
+    hipLaunchKernelGGL((colsum_reduce_kernel<float>), dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)workspace, parts,
+                       (int)N, (const bf16_t*)mul, (float*)out, accumulate);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int op_geglu_bwd(const void* dg, const void* h0, const void* h1, void* dh0, void* dh1, int64_t numel, void* stream) {
+  OP_CHECK_ARG(dg && h0 && h1 && dh0 && dh1, "geglu_bwd: null pointer");
+  OP_CHECK_ARG(numel % 8 == 0, "geglu_bwd: numel must be a multiple of 8");
+  if (numel == 0) return OP_OK;
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dg,
+                     (const bf16_t*)h0, (const bf16_t*)h1, (bf16_t*)dh0, (bf16_t*)dh1, numel / 8);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// dbranch[m][n] = rowscale[m/rps] * gamma[n] * dout[m][n]   (gamma, rowscale nullable)
+int op_scale_rows(const void* dout, const void* gamma, const float* rowscale, int64_t rows_per_sample, void* dbranch,
+                  int64_t M, int64_t N, void* stream) {
+  OP_CHECK_ARG(dout && dbranch, "scale_rows: null pointer");
+  OP_CHECK_ARG(N % 8 == 0, "scale_rows: N must be a multiple of 8");
+  if (M == 0) return OP_OK;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(ew_grid(M * (N / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (const bf16_t*)gamma, rowscale, (int)(rows_per_sample > 0 ? rows_per_sample : 1), (bf16_t*)dbranch, M,
+                     (int)N);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// y (out_dtype 0 bf16 / 1 f32) = x / max(||x||_2, eps) per row; inv_norm[rows] saved for the backward
+int op_l2norm_fwd(const void* x, void* y, float* inv_norm, int64_t rows, int64_t cols, float eps, int out_dtype, void* stream) {
+  OP_CHECK_ARG(x && y && cols % 8 == 0, "l2norm_fwd: bad args");
+  if (rows == 0) return OP_OK;
+  if (out_dtype == OP_DT_BF16)
+    hipLaunchKernelGGL((l2norm_fwd_kernel<bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (bf16_t*)y, inv_norm, (int)rows, (int)cols, eps);
+  else
+    hipLaunchKernelGGL((l2norm_fwd_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (float*)y, inv_norm, (int)rows, (int)cols, eps);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int op_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int64_t cols, int y_dtype,
+                  void* stream) {
+  OP_CHECK_ARG(dy && y && inv_norm && dx && cols % 8 == 0, "l2norm_bwd: bad args");
+  if (rows == 0) return OP_OK;
+  if (y_dtype == OP_DT_BF16)
+    hipLaunchKernelGGL((l2norm_bwd_kernel<bf16_t>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, (const bf16_t*)y, inv_norm, (bf16_t*)dx, (int)rows, (int)cols);
+  else
+    hipLaunchKernelGGL((l2norm_bwd_kernel<float>), dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dy, (const float*)y, inv_norm, (bf16_t*)dx, (int)rows, (int)cols);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// sim [rows][n] fp32 (ld) is overwritten by gscale * d loss_row / d sim when write_grad != 0.
+int op_infonce_rows(float* sim, int64_t rows, int64_t n, int64_t ld, int64_t target0, float label_smoothing, float gscale,
+                    float* row_loss, float* row_hit, float* row_dot, int write_grad, void* stream) {
+  OP_CHECK_ARG(sim && row_loss && row_hit && row_dot, "infonce_rows: null pointer");
+  OP_CHECK_ARG(n >= 2 && target0 >= 0 && target0 + rows <= n, "infonce_rows: targets out of range");
+  if (rows == 0) return OP_OK;
+  hipLaunchKernelGGL(infonce_rows_kernel, dim3((int)rows), dim3(256), 0, (hipStream_t)stream, sim, (int)n, ld, (int)target0,
+                     label_smoothing, gscale, row_loss, row_hit, row_dot, write_grad);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// One AdamW update over a flat bf16 parameter range (numel % 8 == 0).  step >= 1.
+int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, float grad_scale, void* stream) {
+  OP_CHECK_ARG(p && g && m && v, "adamw: null pointer");
+  OP_CHECK_ARG(numel % 8 == 0 && step >= 1, "adamw: numel must be a multiple of 8 and step >= 1");
+  if (numel == 0) return OP_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+  const float decay_mul = 1.f - weight_decay * lr;
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (const bf16_t*)g,
+                     m, v, numel / 8, beta1, beta2, eps, step_size, decay_mul, grad_scale);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int op_relpos_bias_build(const void* table, const int* bucket, int64_t bucket_ld, void* out, int64_t heads, int64_t S,
+                         int64_t Spad, void* stream) {
+  OP_CHECK_ARG(table && bucket && out && Spad >= S && Spad % 8 == 0, "relpos_bias_build: bad args");
+  hipLaunchKernelGGL(relpos_build_kernel, dim3(ew_grid(S * Spad)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table,
+                     bucket, bucket_ld, (bf16_t*)out, (int)heads, (int)S, (int)Spad);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int op_relpos_bias_bwd(const float* dbias, const int* bucket, int64_t bucket_ld, float* dtable, int64_t heads, int64_t S,
+                       int64_t Spad, void* stream) {
+  OP_CHECK_ARG(dbias && bucket && dtable, "relpos_bias_bwd: null pointer");
+  hipLaunchKernelGGL(relpos_bwd_kernel, dim3(ew_grid(S * S)), dim3(256), 0, (hipStream_t)stream, dbias, bucket, bucket_ld,
+                     dtable, (int)heads, (int)S, (int)Spad);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+}  // extern "C"

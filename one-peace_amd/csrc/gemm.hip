@@ -1,0 +1,421 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] . B[N,K]^T  (both operands K-contiguous = nn.Linear layout)
+// with the epilogues the ONE-PEACE encoder layer needs fused in.
+//
+// Replaces (reference file:line):
+//   * q/k/v/out projections, multihead_attention.py:63-66,103-105,124 (three weights = three "segments"
+//     of one launch; k_proj has no bias)
+//   * GeGLU  gelu(x W0^T) * (x W1^T), transformer_layer.py:54-67      -> EPI_GEGLU (two weights, one launch)
+//   * fused_dropout_res  residual + droppath(gamma * y), transformer_layer.py:70-88 -> EPI_RESID
+//   * scale * local @ all^T of the contrastive head, image_text_pretrain_loss.py:171-172 -> EPI_F32
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+// 16x16x32 accumulators), BK = 64, two LDS buffers (2 x 32 KiB), one barrier per K-tile.  Operand tiles
+// are [128 rows][64 k] bf16 (128-byte rows) with the 16-byte slot index XOR-ed by (row & 7): the
+// ds_read_b128 fragment reads are then bank-conflict free (each 16-lane group covers all 64 banks once).
+// Staging is either LDS-DMA (global_load_lds_dwordx4: the swizzle is applied to the per-lane SOURCE address,
+// the LDS image stays lane-linear) or a register-staged fallback with identical LDS image.
+//
+// The MFMA is issued "swapped" (first operand = weight rows, second = activation rows) so that a lane ends
+// up with 16 *contiguous output columns* of one output row: weight row i of a 16-row fragment lands in lanes
+// (i>>2) as register (i&3), and the loader permutes which weight row sits in LDS row p so that lane group g
+// owns columns g*16 .. g*16+15 of the wave's 64.  Every C row is therefore written as 128 contiguous bytes
+// by 4 lanes with 16-byte stores.
+//
+// Roofline: MFMA (dense bf16, 2.5 PFLOP/s).  Algorithmic work = 2*M*N*K flops per launch.
+#include "common.h"
+
+namespace {
+
+enum { EPI_BIAS = 0, EPI_F32 = 1, EPI_GEGLU = 2, EPI_RESID = 3 };
+
+struct GemmArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B[3]; int64_t ldb; int n_seg;
+  const bf16_t* bias[3];
+  void* C; int64_t ldc;
+  bf16_t* H0; bf16_t* H1;
+  const bf16_t* resid; int64_t ldr;
+  const bf16_t* gamma; const float* rowscale; int rows_per_sample;
+  const float* alpha;
+  int M, N, K;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BM = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// LDS row p of the weight tile -> output column (relative to the tile) it feeds.
+template <int EPI>
+__device__ __forceinline__ int w_row_to_col(int p) {
+  const int i = p & 15;
+  if (EPI == EPI_GEGLU) {
+    const int pp = p & 63;  // rows 0..63 <- W0, 64..127 <- W1, same column map
+    return (pp >> 5) * 32 + (i >> 2) * 8 + ((pp >> 4) & 1) * 4 + (i & 3);
+  }
+  return (p & ~63) + (i >> 2) * 16 + ((p >> 4) & 3) * 4 + (i & 3);
+}
+
+template <int EPI, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 64 : 128;
+
+  // ---- workgroup -> tile (XCD-contiguous chunks, then grouped along M for L2 reuse of the W panels) ----
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM, n0 = pid_n * BN_OUT;
+
+  // ---- per-thread staging addresses: 4 x 16-byte slots of A and of B per K-tile ----
+  const bf16_t* srcA[4];
+  const bf16_t* srcB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid;
+    const int row = q >> 3, pc = q & 7;
+    const int c = pc ^ (row & 7);
+    const int gm = min(m0 + row, p.M - 1);
+    srcA[i] = p.A + (int64_t)gm * p.lda + c * 8;
+    int gn = min(n0 + w_row_to_col<EPI>(row), p.N - 1);
+    const bf16_t* base;
+    if (EPI == EPI_GEGLU) {
+      base = (row < 64) ? p.B[0] : p.B[1];
+    } else {
+      const int seg = gn / p.n_seg;
+      base = p.B[seg];
+      gn -= seg * p.n_seg;
+    }
+    srcB[i] = base + (int64_t)gn * p.ldb + c * 8;
+  }
+
+  f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes) inside a tile: row*128 + ((kk*4+g) ^ (row&7))*16, row&7 == t&7
+  int rdW[4], rdX[4], swz[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) swz[kk] = ((kk * 4 + g) ^ (t & 7)) << 4;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int row = (EPI == EPI_GEGLU) ? ((ni >> 1) * 64 + wn * 32 + (ni & 1) * 16 + t) : (wn * 64 + ni * 16 + t);
+    rdW[ni] = row * 128;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) rdX[mi] = (wm * 64 + mi * 16 + t) * 128;
+
+  const int nk = p.K / BK;
+  u32x4 ra[4], rb[4];
+
+  auto stage_glds = [&](int buf) {
+    char* la = smem + buf * (2 * TILE_BYTES);
+    char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int wbase = (i * 256 + wid * 64) * 16;  // wave-uniform; hardware adds lane*16
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcA[i],
+                                       (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcB[i],
+                                       (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
+    }
+  };
+  auto load_regs = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const u32x4*>(srcA[i]);
+      rb[i] = *reinterpret_cast<const u32x4*>(srcB[i]);
+    }
+  };
+  auto write_regs = [&](int buf) {
+    char* la = smem + buf * (2 * TILE_BYTES);
+    char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = (i * 256 + tid) * 16;
+      *reinterpret_cast<u32x4*>(la + off) = ra[i];
+      *reinterpret_cast<u32x4*>(lb + off) = rb[i];
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { srcA[i] += BK; srcB[i] += BK; }
+  };
+  auto compute = [&](int buf) {
+    const char* la = smem + buf * (2 * TILE_BYTES);
+    const char* lb = la + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 wf[4], xf[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(lb + rdW[ni] + swz[kk]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(la + rdX[mi] + swz[kk]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+    }
+  };
+
+  if (GLDS) {
+    stage_glds(0);
+    advance();
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // tile kt landed; everyone is done reading the other buffer
+      if (kt + 1 < nk) { stage_glds((kt + 1) & 1); advance(); }
+      compute(kt & 1);
+    }
+  } else {
+    load_regs();
+    advance();
+    write_regs(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) { load_regs(); advance(); }
+      compute(kt & 1);
+      if (kt + 1 < nk) write_regs((kt + 1) & 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: lane (g, t) holds, for mi = 0..3, row m = m0 + wm*64 + mi*16 + t and ------------------
+  //      columns ncol0 .. ncol0+15 (acc[ni][mi][r] <-> column ncol0 + ni*4 + r)                     ------
+  if (EPI == EPI_GEGLU) {
+    const int f0 = n0 + wn * 32 + g * 8;  // 8 contiguous f:  acc[nl][mi][r] = h0, acc[2+nl][mi][r] = h1, f = f0 + nl*4 + r
+    if (f0 >= p.N) return;
+    bf16_t* G = (bf16_t*)p.C;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = m0 + wm * 64 + mi * 16 + t;
+      if (m >= p.M) continue;
+      float go[8], h0[8], h1[8];
+#pragma unroll
+      for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[nl][mi][r], b = acc[2 + nl][mi][r];
+          h0[nl * 4 + r] = a;
+          h1[nl * 4 + r] = b;
+          go[nl * 4 + r] = gelu_erf(a) * b;
+        }
+      Vec8<bf16_t>::store(G + (int64_t)m * p.ldc + f0, go);
+      if (p.H0) {
+        Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + f0, h0);
+        Vec8<bf16_t>::store(p.H1 + (int64_t)m * p.ldc + f0, h1);
+      }
+    }
+    return;
+  }
+
+  const int nc0 = n0 + wn * 64 + g * 16;
+  if (nc0 >= p.N) return;
+  float bv[16];
+  {
+    const int seg = nc0 / p.n_seg;
+    const bf16_t* bp = p.bias[seg];
+    if (bp) {
+      float tmp[8];
+      Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg), tmp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = tmp[j];
+      if (nc0 + 8 < p.N) {
+        Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg) + 8, tmp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[8 + j] = tmp[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[8 + j] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+    }
+  }
+  const bool second = nc0 + 8 < p.N;
+  float alpha = 1.f;
+  if (EPI == EPI_F32 && p.alpha) alpha = *p.alpha;
+  float gv[16];
+  if (EPI == EPI_RESID) {
+    if (p.gamma) {
+      float tmp[8];
+      Vec8<bf16_t>::load(p.gamma + nc0, tmp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = tmp[j];
+      if (second) {
+        Vec8<bf16_t>::load(p.gamma + nc0 + 8, tmp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[8 + j] = tmp[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gv[j] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = m0 + wm * 64 + mi * 16 + t;
+    if (m >= p.M) continue;
+    float o[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[ni * 4 + r] = acc[ni][mi][r];
+    if (EPI == EPI_BIAS) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] += bv[j];
+    } else if (EPI == EPI_F32) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = alpha * o[j] + bv[j];
+    } else if (EPI == EPI_RESID) {
+      float rs = 1.f;
+      if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
+      float rv[16];
+      float tmp[8];
+      Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0, tmp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rv[j] = tmp[j];
+      if (second) {
+        Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0 + 8, tmp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[8 + j] = tmp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] += bv[j];
+      if (p.H0) {  // branch output y (pre layer-scale), needed by the backward pass for d gamma
+        float lo[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
+        Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0, lo);
+        if (second) Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0 + 8, hi);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = rv[j] + rs * gv[j] * o[j];
+    }
+    if (EPI == EPI_F32) {
+      float* C = (float*)p.C + (int64_t)m * p.ldc + nc0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q >= 2 && !second) break;
+        *reinterpret_cast<f32x4*>(C + q * 4) = (f32x4){o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
+      }
+    } else {
+      bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + nc0;
+      float lo[8], hi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
+      Vec8<bf16_t>::store(C, lo);
+      if (second) Vec8<bf16_t>::store(C + 8, hi);
+    }
+  }
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, int glds, hipStream_t s) {
+  const int grid = a.tiles_m * a.tiles_n;
+  const size_t sh = 4 * TILE_BYTES;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[glds ? 1 : 0]) {
+    hipError_t e = glds ? hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)
+                        : hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) { op_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set[glds ? 1 : 0] = true;
+  }
+  if (glds)
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), dim3(grid), dim3(256), sh, s, a);
+  else
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), dim3(grid), dim3(256), sh, s, a);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int g_default_glds = 1;
+
+}  // namespace
+
+extern "C" int op_prof_begin(int family, double work, void* stream);
+extern "C" void op_prof_end(int slot, void* stream);
+
+extern "C" {
+
+// 1 = LDS-DMA staging (default), 0 = register-staged fallback.  Returns the previous value.
+int op_gemm_set_staging(int glds) {
+  int old = g_default_glds;
+  g_default_glds = glds ? 1 : 0;
+  return old;
+}
+
+// Generic entry.  epilogue: 0 bias->bf16, 1 alpha*acc+bias -> f32, 2 GeGLU, 3 residual.
+//   A [M,K] bf16 (lda), B0/B1/B2: weight segments [n_seg, K] each (ldb); for GeGLU B0 = wi_0, B1 = wi_1 [N, K].
+//   bias0..2 nullable [n_seg] bf16.  C [M,N] (ldc) bf16 (f32 for epilogue 1).
+//   GeGLU: C = gelu(h0)*h1, optional h0/h1 [M,N] bf16 (same ldc) for the backward pass.
+//   residual: C = resid + rowscale[m / rows_per_sample] * gamma[n] * (acc + bias[n]); gamma, rowscale nullable;
+//             resid may alias C (in-place accumulate); h0 (optional) receives y = acc + bias.
+int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
+               const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
+               const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
+               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* stream) {
+  OP_CHECK_ARG(A && B0 && C, "gemm_nt: null A/B/C");
+  OP_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
+  OP_CHECK_ARG(K % BK == 0, "gemm_nt: K=%lld must be a multiple of %d (pad on the host)", (long long)K, BK);
+  OP_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: N, lda, ldb must be multiples of 8");
+  OP_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "gemm_nt: bad epilogue %d", epilogue);
+  if (M == 0) return OP_OK;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.lda = lda;
+  a.B[0] = (const bf16_t*)B0; a.B[1] = (const bf16_t*)B1; a.B[2] = (const bf16_t*)B2; a.ldb = ldb;
+  a.bias[0] = (const bf16_t*)bias0; a.bias[1] = (const bf16_t*)bias1; a.bias[2] = (const bf16_t*)bias2;
+  a.C = C; a.ldc = ldc; a.H0 = (bf16_t*)h0; a.H1 = (bf16_t*)h1;
+  a.resid = (const bf16_t*)resid; a.ldr = ldr; a.gamma = (const bf16_t*)gamma; a.rowscale = rowscale;
+  a.rows_per_sample = rows_per_sample > 0 ? (int)rows_per_sample : 1;
+  a.alpha = alpha;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.n_seg = (int)(n_seg > 0 ? n_seg : N);
+  a.tiles_m = ceil_div(M, BM);
+  if (epilogue == EPI_GEGLU) {
+    OP_CHECK_ARG(B1, "gemm_nt: GeGLU needs two weights");
+    OP_CHECK_ARG((h0 == nullptr) == (h1 == nullptr), "gemm_nt: GeGLU h0/h1 must both be given or both null");
+    a.n_seg = (int)N;
+    a.tiles_n = ceil_div(N, 64);
+  } else {
+    const int nsegs = ceil_div(N, a.n_seg);
+    OP_CHECK_ARG(nsegs <= 3, "gemm_nt: at most 3 weight segments");
+    OP_CHECK_ARG(nsegs == 1 || a.n_seg % 128 == 0, "gemm_nt: multi-segment launch needs n_seg %% 128 == 0");
+    OP_CHECK_ARG(nsegs < 2 || B1, "gemm_nt: missing B1");
+    OP_CHECK_ARG(nsegs < 3 || B2, "gemm_nt: missing B2");
+    a.tiles_n = ceil_div(N, 128);
+  }
+  if (epilogue == EPI_RESID) OP_CHECK_ARG(resid, "gemm_nt: residual epilogue needs resid");
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)M * (double)N * (double)K * (epilogue == EPI_GEGLU ? 2.0 : 1.0);
+  const int slot = op_prof_begin(0, flops, stream);
+  int rc;
+  switch (epilogue) {
+    case EPI_BIAS: rc = launch<EPI_BIAS>(a, g_default_glds, s); break;
+    case EPI_F32: rc = launch<EPI_F32>(a, g_default_glds, s); break;
+    case EPI_GEGLU: rc = launch<EPI_GEGLU>(a, g_default_glds, s); break;
+    default: rc = launch<EPI_RESID>(a, g_default_glds, s); break;
+  }
+  op_prof_end(slot, stream);
+  return rc;
+}
+
+}  // extern "C"

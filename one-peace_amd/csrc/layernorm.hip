@@ -1,0 +1,322 @@
+// LayerNorm forward/backward for gfx950, optional fused exact-erf GELU on the output.
+//
+// Replaces: one_peace/models/components.py:23-26,47-52 (torch.nn.LayerNorm / flash_attn layer_norm seam)
+// and, with act=1, the LayerNorm->GELU pairs of adapter/image.py:66-75 and adapter/audio.py:293-301.
+//
+// Roofline: pure HBM.  Algorithmic bytes (bf16): fwd 4*cols B/row (+8 B stats), bwd 6*cols B/row
+// read (x, dy) + write (dx) (+ the two [cols] reductions, negligible).
+// Mapping: one wavefront (64 lanes) per row when cols <= 2048, a whole 256-thread workgroup per row
+// above that; every lane moves 16-byte (bf16x8) or 32-byte (f32x8) chunks, statistics in fp32 with a
+// centred second pass (same numerics as torch: biased variance, eps inside the rsqrt).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_BLOCKS = 1024;
+
+template <int NW>
+__device__ __forceinline__ float group_sum(float v, float* red) {
+  v = wave_sum(v);
+  if (NW == 1) return v;
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+template <typename T, int CH, int NW, bool GELU>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                     const T* __restrict__ b, T* __restrict__ y,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int64_t rows, int cols, float eps) {
+  __shared__ float red[4];
+  constexpr int G = 64 * NW;
+  const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
+  const int64_t row0 = (NW == 1) ? ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) : blockIdx.x;
+  const int64_t rstep = (NW == 1) ? (int64_t)gridDim.x * 4 : gridDim.x;
+  const float inv = 1.0f / (float)cols;
+
+  float wv[CH][8], bv[CH][8];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (tig + G * i) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wv[i][j] = 1.f; bv[i][j] = 0.f; }
+    if (c < cols) {
+      if (w) Vec8<T>::load(w + c, wv[i]);
+      if (b) Vec8<T>::load(b + c, bv[i]);
+    }
+  }
+  // NW == 4: every thread of the block walks the same rows (uniform trip count -> barriers are safe)
+  for (int64_t row = row0; row < rows; row += rstep) {
+    const T* xr = x + row * (int64_t)cols;
+    float v[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        Vec8<T>::load(xr + c, v[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[i][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+      }
+    }
+    const float mean = group_sum<NW>(s, red) * inv;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; ss += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(group_sum<NW>(ss, red) * inv + eps);
+    T* yr = y + row * (int64_t)cols;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = (v[i][j] - mean) * rstd * wv[i][j] + bv[i][j];
+          o[j] = GELU ? gelu_erf(t) : t;
+        }
+        Vec8<T>::store(yr + c, o);
+      }
+    }
+    if (tig == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+  }
+}
+
+// dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw = sum_rows dy*xhat;  db = sum_rows dy.
+// Partial dw/db of each workgroup go to ws[gridDim.x][2][cols] (fp32); ln_bwd_reduce_kernel folds them.
+template <typename T, int CH, int NW, bool GELU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                     const T* __restrict__ w, const T* __restrict__ b,
+                                                     const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, T* __restrict__ dx,
+                                                     float* __restrict__ ws, int64_t rows, int cols) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // NW==1: [4][cols] ; NW==4: [4]
+  float* red = smem;
+  constexpr int G = 64 * NW;
+  const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
+  const int wid = threadIdx.x >> 6;
+  const int64_t row0 = (NW == 1) ? ((int64_t)blockIdx.x * 4 + wid) : blockIdx.x;
+  const int64_t rstep = (NW == 1) ? (int64_t)gridDim.x * 4 : gridDim.x;
+  const float inv = 1.0f / (float)cols;
+
+  float wv[CH][8], bv[CH][8], dwa[CH][8], dba[CH][8];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (tig + G * i) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wv[i][j] = 1.f; bv[i][j] = 0.f; dwa[i][j] = 0.f; dba[i][j] = 0.f; }
+    if (c < cols) {
+      if (w) Vec8<T>::load(w + c, wv[i]);
+      if (GELU && b) Vec8<T>::load(b + c, bv[i]);
+    }
+  }
+  for (int64_t row = row0; row < rows; row += rstep) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const T* xr = x + row * (int64_t)cols;
+    const T* gr = dy + row * (int64_t)cols;
+    float xh[CH][8], g[CH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        Vec8<T>::load(xr + c, xh[i]);
+        Vec8<T>::load(gr + c, g[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (xh[i][j] - mean) * rstd;
+          if (GELU) g[i][j] *= gelu_erf_grad(xh[i][j] * wv[i][j] + bv[i][j]);
+          dwa[i][j] += g[i][j] * xh[i][j];
+          dba[i][j] += g[i][j];
+          const float gw = g[i][j] * wv[i][j];
+          g[i][j] = gw;
+          s1 += gw;
+          s2 += gw * xh[i][j];
+        }
+      }
+    }
+    const float c1 = group_sum<NW>(s1, red) * inv;
+    const float c2 = group_sum<NW>(s2, red) * inv;
+    T* dr = dx + row * (int64_t)cols;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - c1 - xh[i][j] * c2);
+        Vec8<T>::store(dr + c, o);
+      }
+    }
+  }
+  if (ws == nullptr) return;  // uniform
+  float* wsb = ws + (int64_t)blockIdx.x * 2 * cols;
+  if (NW == 1) {
+    // fold the 4 waves (same column mapping, different rows) through LDS, dw then db
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) smem[wid * cols + c + j] = pass == 0 ? dwa[i][j] : dba[i][j];
+        }
+      }
+      __syncthreads();
+      for (int c = threadIdx.x; c < cols; c += 256)
+        wsb[pass * cols + c] = smem[c] + smem[cols + c] + smem[2 * cols + c] + smem[3 * cols + c];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wsb[c + j] = dwa[i][j]; wsb[cols + c + j] = dba[i][j]; }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nparts, int cols, T* __restrict__ dw,
+                                     T* __restrict__ db, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f, bsum = 0.f;
+  for (int p = 0; p < nparts; ++p) {
+    a += ws[(int64_t)p * 2 * cols + c];
+    bsum += ws[(int64_t)p * 2 * cols + cols + c];
+  }
+  if (dw) dw[c] = (T)(a + (accumulate ? (float)dw[c] : 0.f));
+  if (db) db[c] = (T)(bsum + (accumulate ? (float)db[c] : 0.f));
+}
+
+inline int ln_grid(int64_t rows, int nw) {
+  int64_t blocks = nw == 1 ? (rows + 3) / 4 : rows;
+  if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+template <typename T, bool GELU>
+int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
+                    int cols, float eps, hipStream_t s) {
+  const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* Y = (T*)y;
+#define LN_F(CH, NW) \
+  hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU>), dim3(ln_grid(rows, NW)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps)
+  if (cols <= 512) LN_F(1, 1);
+  else if (cols <= 1024) LN_F(2, 1);
+  else if (cols <= 1536) LN_F(3, 1);
+  else if (cols <= 2048) LN_F(4, 1);
+  else if (cols <= 4096) LN_F(2, 4);
+  else if (cols <= 6144) LN_F(3, 4);
+  else if (cols <= 8192) LN_F(4, 4);
+  else { op_set_error("layernorm: cols %d > 8192 unsupported", cols); return OP_ENOTSUP; }
+#undef LN_F
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+template <typename T, bool GELU>
+int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
+                    void* dx, void* dw, void* db, float* ws, int64_t rows, int cols, int accumulate, hipStream_t s) {
+  const T* DY = (const T*)dy; const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* DX = (T*)dx;
+  int grid = 0;
+  float* wsk = (dw || db) ? ws : nullptr;
+#define LN_B(CH, NW)                                                                                        \
+  do {                                                                                                      \
+    grid = ln_grid(rows, NW);                                                                               \
+    size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
+                       rstd, DX, wsk, rows, cols);                                                          \
+  } while (0)
+  if (cols <= 512) LN_B(1, 1);
+  else if (cols <= 1024) LN_B(2, 1);
+  else if (cols <= 1536) LN_B(3, 1);
+  else if (cols <= 2048) LN_B(4, 1);
+  else if (cols <= 4096) LN_B(2, 4);
+  else if (cols <= 6144) LN_B(3, 4);
+  else if (cols <= 8192) LN_B(4, 4);
+  else { op_set_error("layernorm: cols %d > 8192 unsupported", cols); return OP_ENOTSUP; }
+#undef LN_B
+  OP_LAUNCH_CHECK();
+  if (wsk) {
+    hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(ceil_div(cols, 256)), dim3(256), 0, s, ws, grid, cols, (T*)dw,
+                       (T*)db, accumulate);
+    OP_LAUNCH_CHECK();
+  }
+  return OP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Bytes of fp32 workspace op_layernorm_bwd needs for dw/db partials.
+int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
+  (void)rows;
+  return (int64_t)LN_MAX_BLOCKS * 2 * cols * (int64_t)sizeof(float);
+}
+
+int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
+                     int64_t cols, float eps, int act_gelu, int dtype, void* stream) {
+  OP_CHECK_ARG(x && y, "layernorm_fwd: null x/y");
+  OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0, "layernorm_fwd: cols=%lld must be a positive multiple of 8",
+               (long long)cols);
+  if (rows == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OP_DT_BF16)
+    return act_gelu ? ln_fwd_dispatch<bf16_t, true>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s)
+                    : ln_fwd_dispatch<bf16_t, false>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s);
+  if (dtype == OP_DT_F32)
+    return act_gelu ? ln_fwd_dispatch<float, true>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s)
+                    : ln_fwd_dispatch<float, false>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s);
+  op_set_error("layernorm_fwd: bad dtype %d", dtype);
+  return OP_EINVAL;
+}
+
+int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
+                     void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int act_gelu,
+                     int accumulate, int dtype, void* stream) {
+  OP_CHECK_ARG(dy && x && dx && mean && rstd, "layernorm_bwd: null pointer");
+  OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0, "layernorm_bwd: cols=%lld must be a positive multiple of 8",
+               (long long)cols);
+  OP_CHECK_ARG(!(dw || db) || workspace, "layernorm_bwd: dw/db requested without workspace");
+  if (rows == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == OP_DT_BF16)
+    return act_gelu ? ln_bwd_dispatch<bf16_t, true>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+                                                    (int)cols, accumulate, s)
+                    : ln_bwd_dispatch<bf16_t, false>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+                                                     (int)cols, accumulate, s);
+  if (dtype == OP_DT_F32)
+    return act_gelu ? ln_bwd_dispatch<float, true>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+                                                   (int)cols, accumulate, s)
+                    : ln_bwd_dispatch<float, false>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+                                                    (int)cols, accumulate, s);
+  op_set_error("layernorm_bwd: bad dtype %d", dtype);
+  return OP_EINVAL;
+}
+
+}  // extern "C"

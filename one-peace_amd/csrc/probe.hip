@@ -1,0 +1,88 @@
+// Hardware-semantics probes (test infrastructure compiled into the library so they travel to the GPU box).
+// They execute raw MFMA / transpose-read / LDS-DMA instructions on host-supplied register images and dump the
+// raw results, so the lane<->element maps the real kernels rely on are *measured* (tests/test_probes.py), not
+// assumed from documentation.
+#include "common.h"
+
+namespace {
+
+__global__ void probe_mfma16_kernel(const bf16_t* a, const bf16_t* b, float* d, int n) {
+  const int l = threadIdx.x;
+  for (int r = 0; r < n; ++r) {
+    bf16x8 av = *reinterpret_cast<const bf16x8*>(a + ((int64_t)r * 64 + l) * 8);
+    bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + ((int64_t)r * 64 + l) * 8);
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+    *reinterpret_cast<f32x4*>(d + ((int64_t)r * 64 + l) * 4) = c;
+  }
+}
+
+__global__ void probe_mfma32_kernel(const bf16_t* a, const bf16_t* b, float* d, int n) {
+  const int l = threadIdx.x;
+  for (int r = 0; r < n; ++r) {
+    bf16x8 av = *reinterpret_cast<const bf16x8*>(a + ((int64_t)r * 64 + l) * 8);
+    bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + ((int64_t)r * 64 + l) * 8);
+    f32x16 c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, c, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[((int64_t)r * 64 + l) * 16 + i] = c[i];
+  }
+}
+
+// LDS image of 8192 bf16 (16 KiB); each run: lane reads ds_read_b64_tr_b16 at byte address addr[run][lane]
+__global__ void probe_tr16_kernel(const bf16_t* img, const int* addr, bf16_t* out, int n) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[8192];
+  const int l = threadIdx.x;
+  for (int i = l; i < 8192; i += 64) lds[i] = img[i];
+  __syncthreads();
+  for (int r = 0; r < n; ++r) {
+    const int a = addr[r * 64 + l];
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)((__attribute__((address_space(3))) char*)lds + a));
+    *reinterpret_cast<s16x4*>(out + ((int64_t)r * 64 + l) * 4) = v;
+  }
+}
+
+// One wave issues global_load_lds_dwordx4 from src + src_off[lane] to LDS base `lds_base` (bytes); the 16 KiB LDS
+// (pre-filled with 0xFFFF) is dumped.
+__global__ void probe_glds_kernel(const char* src, const int* src_off, int lds_base, unsigned short* dump) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[8192];
+  const int l = threadIdx.x;
+  for (int i = l; i < 8192; i += 64) lds[i] = 0xFFFF;
+  __syncthreads();
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + src_off[l]),
+                                   (__attribute__((address_space(3))) void*)((char*)lds + lds_base), 16, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = l; i < 8192; i += 64) dump[i] = lds[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream) {
+  hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, d, n);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+int op_probe_mfma32(const void* a, const void* b, float* d, int n, void* stream) {
+  hipLaunchKernelGGL(probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, d, n);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+int op_probe_tr16(const void* img, const int* addr, void* out, int n, void* stream) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)img, addr, (bf16_t*)out, n);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+int op_probe_glds(const void* src, const int* src_off, int lds_base, void* dump, void* stream) {
+  hipLaunchKernelGGL(probe_glds_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const char*)src, src_off, lds_base,
+                     (unsigned short*)dump);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+}  // extern "C"

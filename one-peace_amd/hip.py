@@ -1,0 +1,286 @@
+"""ctypes binding of the C-ABI HIP library (include/onepeace_hip.h).
+
+Every entry point takes raw device pointers + sizes + a hipStream_t; this module converts torch tensors,
+passes ``torch.cuda.current_stream()`` and turns a non-zero return code into ``RuntimeError`` (so the
+reference trainer's OOM / NaN handling paths still see Python exceptions).  There is NO CPU
+fallback here: if the library is missing, loading fails loudly.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libonepeace_hip.so")
+_lib = None
+
+DT_BF16, DT_F32 = 0, 1
+EPI_BIAS, EPI_F32, EPI_GEGLU, EPI_RESID = 0, 1, 2, 3
+PROF_GEMM, PROF_ATTN = 0, 1
+
+P = c_void_p
+I64 = c_int64
+
+# name -> (restype, argtypes); kept in the order of include/onepeace_hip.h
+SIGNATURES = {
+    "op_abi_version": (c_int, []),
+    "op_last_error": (ctypes.c_char_p, []),
+    "op_prof_enable": (c_int, [c_int]),
+    "op_prof_collect": (c_int, [P, P, P, c_int]),
+    "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
+    "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
+    "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
+    "op_gemm_set_staging": (c_int, [c_int]),
+    "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
+                           c_int, P]),
+    "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
+    "op_colsum_workspace_bytes": (I64, [I64]),
+    "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
+    "op_geglu_bwd": (c_int, [P, P, P, P, P, I64, P]),
+    "op_scale_rows": (c_int, [P, P, P, I64, P, I64, I64, P]),
+    "op_l2norm_fwd": (c_int, [P, P, P, I64, I64, c_float, c_int, P]),
+    "op_l2norm_bwd": (c_int, [P, P, P, P, I64, I64, c_int, P]),
+    "op_infonce_rows": (c_int, [P, I64, I64, I64, I64, c_float, c_float, P, P, P, c_int, P]),
+    "op_adamw_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, I64, c_float, P]),
+    "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, P]),
+    "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
+    "op_attn_fwd": (c_int, [P, P, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
+    "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
+    "op_probe_mfma32": (c_int, [P, P, P, c_int, P]),
+    "op_probe_tr16": (c_int, [P, P, P, c_int, P]),
+    "op_probe_glds": (c_int, [P, P, c_int, P, P]),
+}
+
+
+def lib():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s not found: build it with `python one-peace_amd/build.py` (hipcc, gfx950). "
+                "There is no CPU fallback for the HIP path." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def available():
+    return os.path.exists(LIB_PATH) and torch.cuda.is_available()
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().op_last_error()
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float32:
+        return DT_F32
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+
+def _req(t, name, dtype=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA(HIP) tensor" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+# ---------------------------------------------------------------------------------------------------
+# thin tensor-level wrappers (no autograd here; see ops.py)
+# ---------------------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True):
+    _req(x2d, "x")
+    rows, cols = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = rstd = None
+    if want_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _check(lib().op_layernorm_fwd(ptr(x2d), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
+                                  int(gelu), _dt(x2d), stream()), "op_layernorm_fwd")
+    return y, mean, rstd
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="ws"):
+    """Grow-only scratch buffer per (device, tag); caller-owned memory as the C ABI requires."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None, db=None, accumulate=False):
+    rows, cols = x.shape
+    dx = torch.empty_like(x)
+    ws = None
+    if need_wgrad and w is not None:
+        if dw is None:
+            dw = torch.empty_like(w)
+            db = torch.empty_like(w)
+            accumulate = False
+        ws = workspace(lib().op_layernorm_bwd_workspace_bytes(rows, cols), x.device, "ln")
+    else:
+        dw = db = None
+    _check(lib().op_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db),
+                                  ptr(ws), rows, cols, int(gelu), int(accumulate), _dt(x), stream()), "op_layernorm_bwd")
+    return dx, dw, db
+
+
+def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h1=None, resid=None, gamma=None,
+            rowscale=None, rows_per_sample=0, alpha=None, N=None, ldc=None):
+    """C[M,N] = A[M,K] @ cat(Bs)[N,K]^T with the fused epilogue.  Bs: list of 1-3 [n_seg,K] weights (GeGLU: [W0, W1])."""
+    M, K = A.shape
+    Bs = list(Bs) + [None] * (3 - len(Bs))
+    biases = list(biases or []) + [None] * (3 - len(biases or []))
+    if epilogue == EPI_GEGLU:
+        Nn = Bs[0].shape[0]
+    else:
+        Nn = N if N is not None else sum(b.shape[0] for b in Bs if b is not None)
+        if n_seg == 0:
+            n_seg = Bs[0].shape[0]
+    if out is None:
+        out = torch.empty(M, Nn, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16, device=A.device)
+    ldc_ = ldc if ldc is not None else out.stride(0)
+    _check(lib().op_gemm_nt(ptr(A), A.stride(0), ptr(Bs[0]), ptr(Bs[1]), ptr(Bs[2]), Bs[0].stride(0), n_seg,
+                            ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), ptr(out), ldc_, ptr(h0), ptr(h1),
+                            ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
+                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, stream()), "op_gemm_nt")
+    return out
+
+
+def transpose(x2d, out=None):
+    rows, cols = x2d.shape
+    if out is None:
+        out = torch.empty(cols, rows, dtype=x2d.dtype, device=x2d.device)
+    _check(lib().op_transpose(ptr(x2d), ptr(out), rows, cols, x2d.stride(0), out.stride(0), stream()), "op_transpose")
+    return out
+
+
+def colsum(x, y=None, rowscale=None, rows_per_sample=0, mul=None, out=None, accumulate=False, out_dtype=torch.bfloat16):
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, dtype=out_dtype, device=x.device)
+        accumulate = False
+    ws = workspace(lib().op_colsum_workspace_bytes(N), x.device, "colsum")
+    _check(lib().op_colsum(ptr(x), ptr(y), ptr(rowscale), rows_per_sample, ptr(mul), ptr(out), ptr(ws), M, N,
+                           int(accumulate), _dt(out), stream()), "op_colsum")
+    return out
+
+
+def geglu_bwd(dg, h0, h1):
+    dh0, dh1 = torch.empty_like(h0), torch.empty_like(h1)
+    _check(lib().op_geglu_bwd(ptr(dg), ptr(h0), ptr(h1), ptr(dh0), ptr(dh1), dg.numel(), stream()), "op_geglu_bwd")
+    return dh0, dh1
+
+
+def scale_rows(dout, gamma=None, rowscale=None, rows_per_sample=0):
+    M, N = dout.shape
+    out = torch.empty_like(dout)
+    _check(lib().op_scale_rows(ptr(dout), ptr(gamma), ptr(rowscale), rows_per_sample, ptr(out), M, N, stream()),
+           "op_scale_rows")
+    return out
+
+
+def l2norm_fwd(x, out_dtype=torch.bfloat16, eps=1e-12):
+    rows, cols = x.shape
+    y = torch.empty(rows, cols, dtype=out_dtype, device=x.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(lib().op_l2norm_fwd(ptr(x), ptr(y), ptr(inv), rows, cols, eps, _dt(y), stream()), "op_l2norm_fwd")
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    rows, cols = y.shape
+    dx = torch.empty(rows, cols, dtype=torch.bfloat16, device=y.device)
+    _check(lib().op_l2norm_bwd(ptr(dy), ptr(y), ptr(inv), ptr(dx), rows, cols, _dt(y), stream()), "op_l2norm_bwd")
+    return dx
+
+
+def infonce_rows(sim, target0, label_smoothing=0.0, gscale=1.0, write_grad=True):
+    rows, n = sim.shape
+    dev = sim.device
+    loss = torch.empty(rows, dtype=torch.float32, device=dev)
+    hit = torch.empty(rows, dtype=torch.float32, device=dev)
+    dot = torch.empty(rows, dtype=torch.float32, device=dev)
+    _check(lib().op_infonce_rows(ptr(sim), rows, n, sim.stride(0), target0, label_smoothing, gscale, ptr(loss), ptr(hit),
+                                 ptr(dot), int(write_grad), stream()), "op_infonce_rows")
+    return loss, hit, dot
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _check(lib().op_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                               grad_scale, stream()), "op_adamw_step")
+
+
+def relpos_bias_build(table, bucket_i32, S, Spad):
+    heads = table.shape[1]
+    out = torch.empty(heads, S, Spad, dtype=torch.bfloat16, device=table.device)
+    _check(lib().op_relpos_bias_build(ptr(table), ptr(bucket_i32), bucket_i32.stride(0), ptr(out), heads, S, Spad,
+                                      stream()), "op_relpos_bias_build")
+    return out
+
+
+def relpos_bias_bwd(dbias_f32, bucket_i32, num_rel, S, Spad):
+    heads = dbias_f32.shape[0]
+    dtable = torch.zeros(num_rel, heads, dtype=torch.float32, device=dbias_f32.device)
+    _check(lib().op_relpos_bias_bwd(ptr(dbias_f32), ptr(bucket_i32), bucket_i32.stride(0), ptr(dtable), heads, S, Spad,
+                                    stream()), "op_relpos_bias_bwd")
+    return dtable
+
+
+def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, out=None, want_lse=True):
+    """q, k, v: bf16 views into [B*S, ld] rows (head h at columns h*64..); returns out [B*S, heads*64], lse."""
+    dev = q.device
+    H = heads * 64
+    if out is None:
+        out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, heads, S, dtype=torch.float32, device=dev) if want_lse else None
+    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), ptr(key_pad), ptr(out), out.stride(0), ptr(lse), B, S,
+                             Spad, heads, 64, scale, stream()), "op_attn_fwd")
+    return out, lse
+
+
+class profile_kernels:
+    """Context manager: record HIP-event pairs around gemm/attention launches on their launch stream."""
+
+    def __enter__(self):
+        lib().op_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().op_prof_enable(0)
+
+    @staticmethod
+    def collect(n=4):
+        ms = (c_double * n)()
+        cnt = (c_int64 * n)()
+        work = (c_double * n)()
+        lib().op_prof_collect(ms, cnt, work, n)
+        return [dict(ms=ms[i], count=cnt[i], work=work[i]) for i in range(n)]

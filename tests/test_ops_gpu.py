@@ -1,0 +1,293 @@
+"""Op-level parity: every C-ABI kernel against the CPU oracle (fp32) on identical bf16-rounded inputs.
+Tolerances are the ones stated in tests/util.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import onepeace_oracle as O
+from tests.util import assert_close, bf16_round
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def hipmod():
+    from one_peace_amd import hip
+    return hip
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return bf16_round(torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale)
+
+
+def dev_bf16(t):
+    return t.to(torch.bfloat16).to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 64), (37, 384), (130, 512), (257, 768), (300, 1536), (64, 2048), (33, 6144), (9, 8192)])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_layernorm_fwd_bwd_bf16(rows, cols, gelu):
+    hip = hipmod()
+    x, w, b, dy = rnd(rows, cols, seed=1, scale=2.0), 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3), rnd(rows, cols, seed=4)
+    w, b = bf16_round(w), bf16_round(b)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = O.layer_norm(xr, wr, br)
+    if gelu:
+        ref = O.gelu_erf(ref)
+    ref.backward(dy)
+    y, mean, rstd = hip.layernorm_fwd(dev_bf16(x), dev_bf16(w), dev_bf16(b), gelu=gelu)
+    assert_close(y, ref, what="ln y")
+    assert_close(mean, x.mean(-1), fro=1e-5, mx=1e-5, what="mean") if x.mean(-1).abs().max() > 1e-3 else None
+    dx, dw, db = hip.layernorm_bwd(dev_bf16(dy), dev_bf16(x), dev_bf16(w), dev_bf16(b), mean, rstd, gelu=gelu)
+    assert_close(dx, xr.grad, what="ln dx")
+    assert_close(dw, wr.grad, what="ln dw")
+    assert_close(db, br.grad, what="ln db")
+
+
+def test_layernorm_fp32_no_affine():
+    hip = hipmod()
+    x = torch.randn(50, 1536, generator=torch.Generator().manual_seed(5))
+    dy = torch.randn(50, 1536, generator=torch.Generator().manual_seed(6))
+    xr = x.clone().requires_grad_(True)
+    ref = O.layer_norm(xr)
+    ref.backward(dy)
+    y, mean, rstd = hip.layernorm_fwd(x.to(DEV), None, None)
+    assert_close(y, ref, fro=1e-6, mx=1e-5, what="ln fp32")
+    dx, _, _ = hip.layernorm_bwd(dy.to(DEV), x.to(DEV), None, None, mean, rstd, need_wgrad=False)
+    assert_close(dx, xr.grad, fro=1e-5, mx=1e-4, what="ln fp32 dx")
+
+
+GEMM_SHAPES = [(128, 128, 64), (300, 384, 192), (1000, 1536, 256), (257, 136, 128), (64, 4608, 1536), (4099, 256, 1024)]
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias(M, N, K, glds):
+    hip = hipmod()
+    hip.lib().op_gemm_set_staging(glds)
+    try:
+        A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+        ref = A @ W.t() + b
+        out = hip.gemm_nt(dev_bf16(A), [dev_bf16(W)], [dev_bf16(b)])
+        assert_close(out, ref, what="gemm bias glds=%d" % glds)
+        out32 = hip.gemm_nt(dev_bf16(A), [dev_bf16(W)], None, epilogue=hip.EPI_F32,
+                            alpha=torch.tensor([0.5], device=DEV))
+        assert_close(out32, 0.5 * (A @ W.t()), fro=1e-5, mx=1e-4, what="gemm f32")
+    finally:
+        hip.lib().op_gemm_set_staging(1)
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+def test_gemm_three_segments_qkv(glds):
+    hip = hipmod()
+    hip.lib().op_gemm_set_staging(glds)
+    try:
+        M, H = 333, 256
+        A = rnd(M, H, seed=1)
+        Ws = [rnd(H, H, seed=10 + i, scale=H ** -0.5) for i in range(3)]
+        bq, bv = rnd(H, seed=20), rnd(H, seed=21)
+        ref = torch.cat([A @ Ws[0].t() + bq, A @ Ws[1].t(), A @ Ws[2].t() + bv], dim=1)
+        out = hip.gemm_nt(dev_bf16(A), [dev_bf16(w) for w in Ws], [dev_bf16(bq), None, dev_bf16(bv)], n_seg=H, N=3 * H)
+        assert_close(out, ref, what="qkv gemm")
+    finally:
+        hip.lib().op_gemm_set_staging(1)
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,F_,K", [(200, 256, 128), (515, 1024, 256), (130, 6144, 1536)])
+def test_gemm_geglu(M, F_, K, glds):
+    hip = hipmod()
+    hip.lib().op_gemm_set_staging(glds)
+    try:
+        A, W0, W1 = rnd(M, K, seed=1), rnd(F_, K, seed=2, scale=K ** -0.5), rnd(F_, K, seed=3, scale=K ** -0.5)
+        h0r, h1r = A @ W0.t(), A @ W1.t()
+        ref = O.gelu_erf(h0r) * h1r
+        h0 = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+        h1 = torch.empty_like(h0)
+        out = hip.gemm_nt(dev_bf16(A), [dev_bf16(W0), dev_bf16(W1)], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+        assert_close(out, ref, what="geglu")
+        assert_close(h0, h0r, what="h0")
+        assert_close(h1, h1r, what="h1")
+        out2 = hip.gemm_nt(dev_bf16(A), [dev_bf16(W0), dev_bf16(W1)], epilogue=hip.EPI_GEGLU)
+        assert torch.equal(out2, out)
+    finally:
+        hip.lib().op_gemm_set_staging(1)
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+def test_gemm_residual_epilogue(glds):
+    hip = hipmod()
+    hip.lib().op_gemm_set_staging(glds)
+    try:
+        B, S, H, K = 5, 37, 256, 512
+        M = B * S
+        A, W, b = rnd(M, K, seed=1), rnd(H, K, seed=2, scale=K ** -0.5), rnd(H, seed=3)
+        res, gamma = rnd(M, H, seed=4), bf16_round(0.1 + torch.rand(H, generator=torch.Generator().manual_seed(5)))
+        rs = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25])
+        y = A @ W.t() + b
+        ref = res + rs.repeat_interleave(S)[:, None] * gamma * y
+        ybuf = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+        out = hip.gemm_nt(dev_bf16(A), [dev_bf16(W)], [dev_bf16(b)], epilogue=hip.EPI_RESID, resid=dev_bf16(res),
+                          gamma=dev_bf16(gamma), rowscale=rs.to(DEV), rows_per_sample=S, h0=ybuf)
+        assert_close(out, ref, what="resid")
+        assert_close(ybuf, y, what="branch y")
+        # in-place accumulate: C = C + A W^T
+        C = dev_bf16(res)
+        hip.gemm_nt(dev_bf16(A), [dev_bf16(W)], None, out=C, epilogue=hip.EPI_RESID, resid=C)
+        assert_close(C, res + A @ W.t(), what="accumulate")
+    finally:
+        hip.lib().op_gemm_set_staging(1)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 64), (257, 1536), (1000, 136), (3, 8)])
+def test_transpose(rows, cols):
+    hip = hipmod()
+    x = rnd(rows, cols, seed=7)
+    out = hip.transpose(dev_bf16(x))
+    assert torch.equal(out.float().cpu(), x.t())
+
+
+def test_colsum_and_scale_rows():
+    hip = hipmod()
+    B, S, N = 6, 50, 1536
+    M = B * S
+    x, y = rnd(M, N, seed=1), rnd(M, N, seed=2)
+    rs = torch.tensor([1.0, 0.0, 2.0, 1.0, 0.5, 1.0])
+    mul = rnd(N, seed=3)
+    rsm = rs.repeat_interleave(S)[:, None]
+    out = hip.colsum(dev_bf16(x), dev_bf16(y), rs.to(DEV), S, dev_bf16(mul))
+    assert_close(out, mul * (rsm * x * y).sum(0), what="colsum xy")
+    out2 = hip.colsum(dev_bf16(x), out_dtype=torch.float32)
+    assert_close(out2, x.sum(0), fro=1e-5, mx=1e-4, what="colsum f32")
+    acc = dev_bf16(mul)
+    hip.colsum(dev_bf16(x), out=acc, accumulate=True)
+    assert_close(acc, mul + x.sum(0), what="colsum acc")
+    sr = hip.scale_rows(dev_bf16(x), dev_bf16(mul), rs.to(DEV), S)
+    assert_close(sr, rsm * mul * x, what="scale_rows")
+
+
+def test_geglu_bwd():
+    hip = hipmod()
+    M, F_ = 130, 1024
+    dg, h0, h1 = rnd(M, F_, seed=1), rnd(M, F_, seed=2, scale=2.0), rnd(M, F_, seed=3)
+    a, b = h0.clone().requires_grad_(True), h1.clone().requires_grad_(True)
+    (O.gelu_erf(a) * b).backward(dg)
+    d0, d1 = hip.geglu_bwd(dev_bf16(dg), dev_bf16(h0), dev_bf16(h1))
+    assert_close(d0, a.grad, what="dh0")
+    assert_close(d1, b.grad, what="dh1")
+
+
+def test_l2norm():
+    hip = hipmod()
+    x = rnd(19, 1536, seed=1, scale=3.0)
+    dy = torch.randn(19, 1536, generator=torch.Generator().manual_seed(2))
+    xr = x.clone().requires_grad_(True)
+    ref = O.l2_normalize(xr)
+    ref.backward(dy)
+    y, inv = hip.l2norm_fwd(dev_bf16(x), out_dtype=torch.float32)
+    assert_close(y, ref, fro=1e-6, mx=1e-5, what="l2norm")
+    dx = hip.l2norm_bwd(dy.to(DEV), y, inv)
+    assert_close(dx, xr.grad, what="l2norm dx")
+
+
+@pytest.mark.parametrize("eps", [0.0, 0.1])
+def test_infonce_rows(eps):
+    hip = hipmod()
+    rows, n, t0 = 16, 48, 16
+    sim = 5 * torch.randn(rows, n, generator=torch.Generator().manual_seed(1))
+    sr = sim.clone().requires_grad_(True)
+    tgt = torch.arange(rows) + t0
+    lp = F.log_softmax(sr, dim=-1)
+    nll = -lp.gather(-1, tgt[:, None]).squeeze(-1)
+    if eps:
+        e = eps / (n - 1)
+        nll = (1 - eps - e) * nll + e * (-lp.sum(-1))
+    nll.sum().backward()
+    s = sim.to(DEV).contiguous()
+    loss, hit, dot = hip.infonce_rows(s, t0, eps, gscale=1.0)
+    assert_close(loss, nll, fro=1e-5, mx=1e-5, what="row loss")
+    assert_close(s, sr.grad, fro=1e-5, mx=1e-4, what="dsim")
+    assert torch.equal(hit.cpu(), (sim.argmax(1) == tgt).float())
+    assert_close(dot, (sr.grad * sim).sum(1), fro=1e-4, mx=1e-4, what="dot")
+
+
+def test_adamw_matches_reference_rule():
+    hip = hipmod()
+    n = 4096 + 8
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.01)
+    m = torch.zeros(n); v = torch.zeros(n)
+    pd, gd, md, vd = dev_bf16(p0), dev_bf16(g), m.to(DEV), v.to(DEV)
+    pr = p0.to(torch.bfloat16)
+    for step in (1, 2, 3):
+        O.adamw_step(pr, g.to(torch.bfloat16), m, v, step, lr=1e-2, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.05)
+        hip.adamw_step(pd, gd, md, vd, 1e-2, 0.9, 0.98, 1e-6, 0.05, step)
+    assert_close(md, m, fro=1e-6, mx=1e-5, what="m")
+    assert_close(vd, v, fro=1e-6, mx=1e-5, what="v")
+    # bf16 parameter: allow 1 ulp on a tiny fraction (fp32 op-order differences before the final rounding)
+    diff = (pd.float().cpu() - pr.float()).abs()
+    assert (diff > 0).float().mean() < 0.01 and float(diff.max()) <= float(pr.float().abs().max()) * 2 ** -7
+
+
+def test_relpos_bias_build_and_bwd():
+    hip = hipmod()
+    heads, n = 3, 4
+    num_rel = (2 * n - 1) ** 2 + 3
+    bucket = O.image_bucket_position(n, num_rel)
+    S = n * n + 1
+    Spad = 64
+    table = rnd(num_rel, heads, seed=1)
+    ref = O.rel_pos_bias(table, bucket)
+    out = hip.relpos_bias_build(dev_bf16(table), bucket.to(torch.int32).to(DEV), S, Spad)
+    assert torch.equal(out[:, :, :S].float().cpu(), ref)
+    assert float(out[:, :, S:].abs().max()) == 0.0
+    dbias = torch.randn(heads, S, Spad, generator=torch.Generator().manual_seed(2))
+    tr = table.clone().requires_grad_(True)
+    O.rel_pos_bias(tr, bucket).backward(dbias[:, :, :S])
+    dt = hip.relpos_bias_bwd(dbias.to(DEV), bucket.to(torch.int32).to(DEV), num_rel, S, Spad)
+    assert_close(dt, tr.grad, fro=1e-5, mx=1e-4, what="dtable")
+
+
+def _attn_ref(q, k, v, heads, scale, bias, key_pad):
+    """q,k,v: [B,S,H] fp32; bias [heads,S,S]; key_pad [B,S] bool.  multihead_attention.py:102-115."""
+    B, S, H = q.shape
+    hd = H // heads
+    qh, kh, vh = (t.reshape(B, S, heads, hd).transpose(1, 2) for t in (q, k, v))
+    s = (qh * scale) @ kh.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias[None]
+    if key_pad is not None:
+        s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, S, H), torch.logsumexp(s, dim=-1)
+
+
+@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", [(2, 37, 2, True, True), (3, 64, 4, True, True), (2, 257, 3, True, False),
+                                                       (1, 130, 2, False, False), (2, 300, 2, False, True), (1, 1025, 1, True, False)])
+def test_attention_forward(B, S, heads, use_bias, use_pad):
+    hip = hipmod()
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=1)
+    Spad = ((S + 63) // 64) * 64
+    bias = rnd(heads, S, S, seed=2) if use_bias else None
+    key_pad = None
+    if use_pad:
+        key_pad = torch.zeros(B, S, dtype=torch.bool)
+        for b in range(B):
+            key_pad[b, S - 1 - 3 * b:] = True
+        key_pad[0, :] = False
+    q, k, v = (qkv[:, i * H:(i + 1) * H].reshape(B, S, H) for i in range(3))
+    ref, lse_ref = _attn_ref(q, k, v, heads, 0.125, bias, key_pad)
+    d = dev_bf16(qkv)
+    bias_d = None
+    if use_bias:
+        bias_d = torch.zeros(heads, S, Spad, dtype=torch.bfloat16, device=DEV)
+        bias_d[:, :, :S] = bias.to(torch.bfloat16).to(DEV)
+    pad_d = None
+    if use_pad:
+        pad_d = torch.ones(B, Spad, dtype=torch.uint8, device=DEV)
+        pad_d[:, :S] = key_pad.to(torch.uint8).to(DEV)
+    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+    assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
+    assert_close(lse, lse_ref, fro=1e-3, mx=2e-3, what="lse")

@@ -31,7 +31,8 @@ struct AttnArgs {
   const bf16_t* bias;      // [heads][S][Spad] or null
   const uint8_t* key_pad;  // [B][Spad] (1 = padded key) or null
   bf16_t* out; int64_t ldo;
-  float* lse;              // [B][heads][S]
+  float* lse;              // [B][heads][lse_ld]
+  int64_t lse_ld;
   int B, S, Spad, heads;
   float scale;
 };
@@ -225,7 +226,447 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(ot[qb][db][r] * inv);
       *reinterpret_cast<bf16x4*>(op + db * 16 + g * 4) = o;
     }
-    if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.S + qi] = m_run[qb] + logf(l);
+    if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.lse_ld + qi] = m_run[qb] + logf(l);
+  }
+}
+
+
+// =====================================================================================================================
+// Backward.  With P = softmax(scale*QK^T + bias), D[q] = sum_d dO[q][d]*O[q][d]:
+//   dP = dO V^T,  dS = P o (dP - D),  dV = P^T dO,  dK = scale * dS^T Q,  dQ = scale * dS K,  dBias = sum_b dS.
+// Three kernels, each recomputing P from the saved log-sum-exp (no S x S tensor is ever stored):
+//   attn_bwd_dkdv : workgroup owns 128 keys (4 waves x 32), loops over 64-query tiles; un-swapped S[q][key] so that
+//                   P / dS are already in second-operand layout for the contractions over queries
+//                   (dV^T = dO^T P, dK^T = Q^T dS; dO^T / Q^T fragments by ds_read_b64_tr_b16 from the same LDS tiles).
+//   attn_bwd_dq   : workgroup owns 128 queries, loops over 64-key tiles; swapped S^T[key][q] as in the forward;
+//                   dQ^T = K^T dS^T with K^T fragments by transpose-read.
+//   attn_bwd_dbias: workgroup owns a (128-query, 64-key) tile of one head and loops over the samples of its batch
+//                   chunk, accumulating dS in registers (the reference gets this from autograd's sum over the
+//                   expanded batch dim, adapter/image.py:164-171); chunks are combined with fp32 atomics.
+// =====================================================================================================================
+struct AttnBwdArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; int64_t ld;
+  const bf16_t* dout; int64_t ldo;   // [B*S][ldo]
+  const bf16_t* bias;                // [heads][S][Spad]  (rows = query)
+  const bf16_t* biasT;               // [heads][S][Spad]  (rows = key), same values transposed
+  const uint8_t* key_pad;            // [B][Spad]
+  const float* lse;                  // [B][heads][Spad]
+  const float* delta;                // [B][heads][Spad]
+  bf16_t* dq; bf16_t* dk; bf16_t* dv; int64_t ldg;  // gradient rows (same packing as q/k/v)
+  float* dbias;                      // [heads][S][Spad] fp32, pre-zeroed
+  int B, S, Spad, heads, bchunk;
+  float scale;
+};
+
+// D[b][h][q] = sum_d dO * O ; one thread per (row, head, 8 dims), 8-lane groups reduce
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                         int64_t ldo, float* __restrict__ delta, int B, int S, int Spad,
+                                                         int heads) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = heads * 8;
+  const int64_t row = gid / per_row;
+  const int rem = (int)(gid - row * per_row);
+  float s = 0.f;
+  if (row < (int64_t)B * S) {
+    float a[8], b[8];
+    Vec8<bf16_t>::load(dout + row * ldo + rem * 8, a);
+    Vec8<bf16_t>::load(out + row * ldo + rem * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += a[j] * b[j];
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  if (row < (int64_t)B * S && (rem & 7) == 0) {
+    const int h = rem >> 3;
+    const int64_t bb = row / S;
+    const int qi = (int)(row - bb * S);
+    delta[(bb * heads + h) * Spad + qi] = s;
+  }
+}
+
+// byte offset of the 8-byte piece a transpose-read lane supplies inside a [64 rows][64 cols] bf16 tile stored with
+// 128-byte rows and 16-byte slots XOR-swizzled by (row & 7):  row = rowblk*16 + g*4 + (t>>2), cols db*16 + (t&3)*4 ..+3
+__device__ __forceinline__ int tr_off_swz(int rowblk, int db, int g, int t) {
+  const int row = rowblk * 16 + g * 4 + (t >> 2);
+  const int c = db * 2 + ((t >> 1) & 1);
+  return row * 128 + ((c ^ (row & 7)) << 4) + (t & 1) * 8;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+  char* ldsQ = smem;
+  char* ldsO = smem + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kbase = blockIdx.x * 128 + wid * 32;
+  const bool wave_active = kbase < p.S;
+  const int64_t row_base = (int64_t)b * p.S;
+
+  // K, V fragments (second operand): lane (g,t) <- X[kbase + kb*16 + t][kk*32 + g*8 ..]
+  bf16x8 kf[2][2], vf[2][2];
+  bool kmask[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int key = kbase + kb * 16 + t;
+    const int kc = min(key, p.S - 1);
+    const int64_t off = (row_base + kc) * p.ld + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      kf[kb][kk] = *reinterpret_cast<const bf16x8*>(p.k + off + kk * 32 + g * 8);
+      vf[kb][kk] = *reinterpret_cast<const bf16x8*>(p.v + off + kk * 32 + g * 8);
+    }
+    kmask[kb] = (key >= p.S) || (p.key_pad && p.key_pad[(int64_t)b * p.Spad + kc]);
+  }
+  f32x4 dvT[2][4], dkT[2][4];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) { dvT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  u32x4 rq[2], ro[2];
+  int st_row[2], st_c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c2 = tid + 256 * i; st_row[i] = c2 >> 3; st_c[i] = c2 & 7; }
+  auto load_tile = [&](int q0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int qr = min(q0 + st_row[i], p.S - 1);
+      rq[i] = *reinterpret_cast<const u32x4*>(p.q + (row_base + qr) * p.ld + h * HD + st_c[i] * 8);
+      ro[i] = *reinterpret_cast<const u32x4*>(p.dout + (row_base + qr) * p.ldo + h * HD + st_c[i] * 8);
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = st_row[i] * 128 + ((st_c[i] ^ (st_row[i] & 7)) << 4);
+      *reinterpret_cast<u32x4*>(ldsQ + off) = rq[i];
+      *reinterpret_cast<u32x4*>(ldsO + off) = ro[i];
+    }
+  };
+  int trsw[4];  // transpose-read piece offset for rowblk 0; rowblk adds 16 rows = 2048 bytes (row & 7 unchanged)
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+
+  const int ntiles = (p.S + 63) / 64;
+  const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * p.Spad;
+  const float* del_b = p.delta + ((int64_t)b * p.heads + h) * p.Spad;
+  load_tile(0);
+  for (int qt = 0; qt < ntiles; ++qt) {
+    const int q0 = qt * 64;
+    __syncthreads();
+    write_tile();
+    __syncthreads();
+    if (qt + 1 < ntiles) load_tile(q0 + 64);
+    if (!wave_active) continue;
+
+    // per 32-query half m:  S[q][key] = Q K^T, dP[q][key] = dO V^T  (lane (g,t): q = qb*16 + g*4 + r, key = t),
+    // then P, dS in place, then dV^T[d][key] += dO^T[d][q] P[q][key] and dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x4 s[2][2], dp[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int qb = 2 * m + j;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int off = (qb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4);
+          const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(ldsQ + off);
+          const bf16x8 ofr = *reinterpret_cast<const bf16x8*>(ldsO + off);
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][kk], s[j][kb], 0, 0, 0);
+            dp[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kb][kk], dp[j][kb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int qrow = q0 + (2 * m + j) * 16 + g * 4;  // + r
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_b + qrow);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_b + qrow);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int key = min(kbase + kb * 16 + t, p.S - 1);
+          float bb[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.biasT) {
+            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.biasT + ((int64_t)h * p.S + key) * p.Spad + qrow);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool dead = kmask[kb] || (qrow + r >= p.S);
+            const float pr = dead ? 0.f : __expf(s[j][kb][r] * p.scale + bb[r] - l4[r]);
+            s[j][kb][r] = pr;
+            dp[j][kb][r] = pr * (dp[j][kb][r] - d4[r]);
+          }
+        }
+      }
+      bf16x8 pfr[2], dsf[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0[r] = s[0][kb][r]; a1[r] = s[1][kb][r];
+          b0[r] = dp[0][kb][r]; b1[r] = dp[1][kb][r];
+        }
+        pfr[kb] = pack8(a0, a1);
+        dsf[kb] = pack8(b0, b1);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 oT = join_tr(tr_read(ldsO + trsw[db] + (2 * m) * 2048), tr_read(ldsO + trsw[db] + (2 * m + 1) * 2048));
+        const bf16x8 qT = join_tr(tr_read(ldsQ + trsw[db] + (2 * m) * 2048), tr_read(ldsQ + trsw[db] + (2 * m + 1) * 2048));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          dvT[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT, pfr[kb], dvT[kb][db], 0, 0, 0);
+          dkT[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsf[kb], dkT[kb][db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_active) return;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int key = kbase + kb * 16 + t;
+    if (key >= p.S) continue;
+    bf16_t* kp = p.dk + (row_base + key) * p.ldg + h * HD;
+    bf16_t* vp = p.dv + (row_base + key) * p.ldg + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)(dkT[kb][db][r] * p.scale); c[r] = (bf16_t)dvT[kb][db][r]; }
+      *reinterpret_cast<bf16x4*>(kp + db * 16 + g * 4) = a;
+      *reinterpret_cast<bf16x4*>(vp + db * 16 + g * 4) = c;
+    }
+  }
+}
+
+// Shared by the dQ and dBias kernels: for one 64-key tile, lane (g,t) computes dS^T[key = kb*16 + g*4 + r][q = t]
+// for its two query blocks.  KF/VF: functors returning the first-operand fragment (K or V rows) for (kb, kk).
+template <typename KF, typename VF>
+__device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int k0, int q0w, int g, int t,
+                                        const bf16x8 (&qf)[2][2], const bf16x8 (&of)[2][2], const float (&lse)[2],
+                                        const float (&del)[2], KF kfrag, VF vfrag, f32x4 (&ds)[2][4]) {
+  f32x4 st[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; ds[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const bf16x8 kfr = kfrag(kb, kk);
+      const bf16x8 vfr = vfrag(kb, kk);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[qb][kk], st[qb][kb], 0, 0, 0);
+        ds[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, of[qb][kk], ds[qb][kb], 0, 0, 0);
+      }
+    }
+  }
+  unsigned padw[4] = {0u, 0u, 0u, 0u};
+  if (p.key_pad) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      padw[kb] = *reinterpret_cast<const unsigned*>(p.key_pad + (int64_t)b * p.Spad + k0 + kb * 16 + g * 4);
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qraw = q0w + qb * 16 + t;
+    const int qi = min(qraw, p.S - 1);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int key = k0 + kb * 16 + g * 4;
+      float bb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + key);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool dead = (key + r >= p.S) || ((padw[kb] >> (8 * r)) & 0xffu) || (qraw >= p.S);
+        const float pr = dead ? 0.f : __expf(st[qb][kb][r] * p.scale + bb[r] - lse[qb]);
+        ds[qb][kb][r] = pr * (ds[qb][kb][r] - del[qb]);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+  char* ldsK = smem;
+  char* ldsV = smem + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0w = blockIdx.x * BQ + wid * 32;
+  const bool wave_active = q0w < p.S;
+  const int64_t row_base = (int64_t)b * p.S;
+
+  bf16x8 qf[2][2], of[2][2];
+  float lse[2], del[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = min(q0w + qb * 16 + t, p.S - 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qf[qb][kk] = *reinterpret_cast<const bf16x8*>(p.q + (row_base + qi) * p.ld + h * HD + kk * 32 + g * 8);
+      of[qb][kk] = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + qi) * p.ldo + h * HD + kk * 32 + g * 8);
+    }
+    lse[qb] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
+    del[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+  }
+  f32x4 dqT[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dqT[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rk[2], rv[2];
+  int st_row[2], st_c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c2 = tid + 256 * i; st_row[i] = c2 >> 3; st_c[i] = c2 & 7; }
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = min(k0 + st_row[i], p.S - 1);
+      const int64_t off = (row_base + kr) * p.ld + h * HD + st_c[i] * 8;
+      rk[i] = *reinterpret_cast<const u32x4*>(p.k + off);
+      rv[i] = *reinterpret_cast<const u32x4*>(p.v + off);
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = st_row[i] * 128 + ((st_c[i] ^ (st_row[i] & 7)) << 4);
+      *reinterpret_cast<u32x4*>(ldsK + off) = rk[i];
+      *reinterpret_cast<u32x4*>(ldsV + off) = rv[i];
+    }
+  };
+  int trsw[4];  // transpose-read piece offset for rowblk 0; rowblk adds 16 rows = 2048 bytes (row & 7 unchanged)
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+
+  const int ntiles = (p.S + BKV - 1) / BKV;
+  load_tile(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * BKV;
+    __syncthreads();
+    write_tile();
+    __syncthreads();
+    if (kt + 1 < ntiles) load_tile(k0 + BKV);
+    if (!wave_active) continue;
+    f32x4 ds[2][4];
+    auto kfrag = [&](int kb, int kk) {
+      return *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
+    };
+    auto vfrag = [&](int kb, int kk) {
+      return *reinterpret_cast<const bf16x8*>(ldsV + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
+    };
+    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, ds);
+    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      bf16x8 dsf[2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float a0[4], a1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = ds[qb][2 * m][r]; a1[r] = ds[qb][2 * m + 1][r]; }
+        dsf[qb] = pack8(a0, a1);
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 kT = join_tr(tr_read(ldsK + trsw[db] + (2 * m) * 2048), tr_read(ldsK + trsw[db] + (2 * m + 1) * 2048));
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+          dqT[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsf[qb], dqT[qb][db], 0, 0, 0);
+      }
+    }
+  }
+  if (!wave_active) return;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = q0w + qb * 16 + t;
+    if (qi >= p.S) continue;
+    bf16_t* qp = p.dq + (row_base + qi) * p.ldg + h * HD;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      bf16x4 a;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r] = (bf16_t)(dqT[qb][db][r] * p.scale);
+      *reinterpret_cast<bf16x4*>(qp + db * 16 + g * 4) = a;
+    }
+  }
+}
+
+// grid (q tiles of 128, key tiles of 64, heads * batch chunks)
+__global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  const int h = blockIdx.z % p.heads, chunk = blockIdx.z / p.heads;
+  const int q0w = blockIdx.x * BQ + wid * 32;
+  const int k0 = blockIdx.y * BKV;
+  if (q0w >= p.S) return;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) acc[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int b_end = min(p.B, (chunk + 1) * p.bchunk);
+  for (int b = chunk * p.bchunk; b < b_end; ++b) {
+    const int64_t row_base = (int64_t)b * p.S;
+    bf16x8 qf[2][2], of[2][2];
+    float lse[2], del[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qi = min(q0w + qb * 16 + t, p.S - 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        qf[qb][kk] = *reinterpret_cast<const bf16x8*>(p.q + (row_base + qi) * p.ld + h * HD + kk * 32 + g * 8);
+        of[qb][kk] = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + qi) * p.ldo + h * HD + kk * 32 + g * 8);
+      }
+      lse[qb] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
+      del[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+    }
+    auto kfrag = [&](int kb, int kk) {
+      const int kr = min(k0 + kb * 16 + t, p.S - 1);
+      return *reinterpret_cast<const bf16x8*>(p.k + (row_base + kr) * p.ld + h * HD + kk * 32 + g * 8);
+    };
+    auto vfrag = [&](int kb, int kk) {
+      const int kr = min(k0 + kb * 16 + t, p.S - 1);
+      return *reinterpret_cast<const bf16x8*>(p.v + (row_base + kr) * p.ld + h * HD + kk * 32 + g * 8);
+    };
+    f32x4 ds[2][4];
+    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, ds);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[qb][kb][r] += ds[qb][kb][r];
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = q0w + qb * 16 + t;
+    if (qi >= p.S) continue;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      float* dst = p.dbias + ((int64_t)h * p.S + qi) * p.Spad + k0 + kb * 16 + g * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[qb][kb][r]);
+    }
   }
 }
 
@@ -239,9 +680,9 @@ extern "C" {
 // q, k, v: bf16 rows of `ld` elements (row = b*S + s), head h occupies columns [h*64, h*64+64) of each pointer
 // (so one packed [B*S, 3H] projection output serves all three with pointer offsets 0, H, 2H).
 // bias: bf16 [heads][S][Spad] or null.  key_pad: uint8 [B][Spad], non-zero = masked key, or null.
-// out: bf16 [B*S][ldo] (head h at columns h*64..).  lse: fp32 [B][heads][S] (natural log) or null.
+// out: bf16 [B*S][ldo] (head h at columns h*64..).  lse: fp32 [B][heads][lse_ld] (natural log) or null.
 int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, const void* key_pad, void* out,
-                int64_t ldo, float* lse, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
+                int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
                 void* stream) {
   OP_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
   OP_CHECK_ARG(head_dim == HD, "attn_fwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
@@ -251,13 +692,63 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
   a.bias = (const bf16_t*)bias; a.key_pad = (const uint8_t*)key_pad;
-  a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
+  a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse; a.lse_ld = lse_ld > 0 ? lse_ld : S;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
   dim3 grid(ceil_div(S, BQ), (unsigned)heads, (unsigned)B);
   const int slot = op_prof_begin(1, 4.0 * (double)B * (double)heads * (double)S * (double)S * HD, stream);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+
+// delta[b][h][q] = sum_d dout * out  (fp32, row stride Spad); dout/out: [B*S][ldo]
+int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,
+                      int64_t heads, void* stream) {
+  OP_CHECK_ARG(dout && out && delta && ldo % 8 == 0, "attn_bwd_delta: bad args");
+  const int64_t threads = B * S * heads * 8;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout,
+                     (const bf16_t*)out, ldo, delta, (int)B, (int)S, (int)Spad, (int)heads);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// Gradients of op_attn_fwd.  bias [heads][S][Spad] (rows = query) and biasT (same values, rows = key) are both needed
+// when a bias was used; lse/delta are fp32 [B][heads][Spad]; dq/dk/dv rows have stride ldg (packed like q/k/v);
+// dbias (fp32 [heads][S][Spad], pre-zeroed by the caller) is optional.
+int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
+                const void* biasT, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
+                void* stream) {
+  OP_CHECK_ARG(q && k && v && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
+  OP_CHECK_ARG(head_dim == HD, "attn_bwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
+  OP_CHECK_ARG(Spad >= ((S + 127) / 128) * 128 && Spad % 8 == 0, "attn_bwd: Spad must be >= S rounded up to 128");
+  OP_CHECK_ARG((bias == nullptr) == (biasT == nullptr), "attn_bwd: bias and biasT must be given together");
+  OP_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && ldg % 4 == 0, "attn_bwd: bad leading dims");
+  AttnBwdArgs a;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
+  a.dout = (const bf16_t*)dout; a.ldo = ldo; a.bias = (const bf16_t*)bias; a.biasT = (const bf16_t*)biasT;
+  a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
+  a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
+  a.bchunk = 16;
+  hipStream_t s = (hipStream_t)stream;
+  const double fl = 4.0 * (double)B * (double)heads * (double)S * (double)S * HD;
+  int slot = op_prof_begin(2, 2.0 * fl, stream);
+  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
+  op_prof_end(slot, stream);
+  OP_LAUNCH_CHECK();
+  slot = op_prof_begin(2, 1.5 * fl, stream);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(S, BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
+  op_prof_end(slot, stream);
+  OP_LAUNCH_CHECK();
+  if (dbias) {
+    const int chunks = ceil_div(B, a.bchunk);
+    hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(ceil_div(S, BQ), ceil_div(S, BKV), (unsigned)(heads * chunks)), dim3(256), 0,
+                       s, a);
+    OP_LAUNCH_CHECK();
+  }
   return OP_OK;
 }
 

@@ -92,4 +92,29 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_p part[p * pstride + n].  256 threads = 32 columns x 8 part
+// groups (independent loads, LDS fold) so the fold is not one long dependent chain per column.
+template <typename T>
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int parts, int64_t pstride,
+                                                              int N, const bf16_t* __restrict__ mul, T* __restrict__ out,
+                                                              int accumulate) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float a = 0.f;
+  if (n < N) {
+#pragma unroll 8
+    for (int p = pg; p < parts; p += 8) a += part[(int64_t)p * pstride + n];
+  }
+  red[pg][c] = a;
+  __syncthreads();
+  if (pg == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][c];
+    if (mul) t *= (float)mul[n];
+    out[n] = (T)(t + (accumulate ? (float)out[n] : 0.f));
+  }
+}
+
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + ty + k * 16, c = c0 + tx * 4;
     if (r < rows) {
-      if (c + 3 < cols) {
+      if (c + 3 < cols && (ld_in & 3) == 0) {
         bf16x4 v = *reinterpret_cast<const bf16x4*>(in + (int64_t)r * ld_in + c);
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[ty + k * 16][tx * 4 + j] = v[j];
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
   for (int k = 0; k < 4; ++k) {
     const int c = c0 + ty + k * 16, r = r0 + tx * 4;  // output row = input column
     if (c < cols) {
-      if (r + 3 < rows) {
+      if (r + 3 < rows && (ld_out & 3) == 0) {
         bf16x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = tile[tx * 4 + j][ty + k * 16];
@@ -82,18 +82,6 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
     const int cc = blockIdx.x * 512 + i;
     if (cc < N) part[(int64_t)blockIdx.y * N + cc] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
-}
-
-// out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_p part[p][n]
-template <typename T>
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, int parts, int N, const bf16_t* __restrict__ mul,
-                                     T* __restrict__ out, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float a = 0.f;
-  for (int p = 0; p < parts; ++p) a += part[(int64_t)p * N + n];
-  if (mul) a *= (float)mul[n];
-  out[n] = (T)(a + (accumulate ? (float)out[n] : 0.f));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -312,12 +300,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, cons
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void relpos_build_kernel(const bf16_t* __restrict__ table, const int* __restrict__ bucket,
                                                            int64_t bucket_ld, bf16_t* __restrict__ out, int heads, int S,
-                                                           int Spad) {
+                                                           int Spad, int transposed) {
   const int64_t total = (int64_t)S * Spad;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int i = (int)(idx / Spad), j = (int)(idx - (int64_t)i * Spad);
     if (j < S) {
-      const int b = bucket[(int64_t)i * bucket_ld + j];
+      const int b = transposed ? bucket[(int64_t)j * bucket_ld + i] : bucket[(int64_t)i * bucket_ld + j];
       for (int h = 0; h < heads; ++h) out[((int64_t)h * S + i) * Spad + j] = table[(int64_t)b * heads + h];
     } else {
       for (int h = 0; h < heads; ++h) out[((int64_t)h * S + i) * Spad + j] = (bf16_t)0.f;
@@ -351,7 +339,6 @@ extern "C" {
 
 int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream) {
   OP_CHECK_ARG(in && out && rows >= 0 && cols >= 0, "transpose: bad args");
-  OP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0, "transpose: leading dims must be multiples of 4");
   if (rows == 0 || cols == 0) return OP_OK;
   dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)rows,
@@ -377,11 +364,11 @@ int op_colsum(const void* x, const void* y, const float* rowscale, int64_t rows_
                      (int)(rows_per_sample > 0 ? rows_per_sample : 1), (float*)workspace, M, (int)N, N);
   OP_LAUNCH_CHECK();
   if (out_dtype == OP_DT_BF16)
-    hipLaunchKernelGGL((colsum_reduce_kernel<bf16_t>), dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)workspace, parts,
-                       (int)N, (const bf16_t*)mul, (bf16_t*)out, accumulate);
+    hipLaunchKernelGGL((partials_reduce_kernel<bf16_t>), dim3(ceil_div(N, 32)), dim3(256), 0, s, (const float*)workspace, parts,
+                       N, (int)N, (const bf16_t*)mul, (bf16_t*)out, accumulate);
   else
-    hipLaunchKernelGGL((colsum_reduce_kernel<float>), dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)workspace, parts,
-                       (int)N, (const bf16_t*)mul, (float*)out, accumulate);
+    hipLaunchKernelGGL((partials_reduce_kernel<float>), dim3(ceil_div(N, 32)), dim3(256), 0, s, (const float*)workspace, parts,
+                       N, (int)N, (const bf16_t*)mul, (float*)out, accumulate);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
@@ -465,11 +452,12 @@ int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, flo
   return OP_OK;
 }
 
+// transposed != 0 writes out[h][key][query] (the image the dK/dV kernel reads) instead of out[h][query][key]
 int op_relpos_bias_build(const void* table, const int* bucket, int64_t bucket_ld, void* out, int64_t heads, int64_t S,
-                         int64_t Spad, void* stream) {
+                         int64_t Spad, int transposed, void* stream) {
   OP_CHECK_ARG(table && bucket && out && Spad >= S && Spad % 8 == 0, "relpos_bias_build: bad args");
   hipLaunchKernelGGL(relpos_build_kernel, dim3(ew_grid(S * Spad)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table,
-                     bucket, bucket_ld, (bf16_t*)out, (int)heads, (int)S, (int)Spad);
+                     bucket, bucket_ld, (bf16_t*)out, (int)heads, (int)S, (int)Spad, transposed);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int LN_MAX_BLOCKS = 1024;
+constexpr int LN_MAX_BLOCKS = 512;
 
 template <int NW>
 __device__ __forceinline__ float group_sum(float v, float* red) {
@@ -198,20 +198,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-template <typename T>
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nparts, int cols, T* __restrict__ dw,
-                                     T* __restrict__ db, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float a = 0.f, bsum = 0.f;
-  for (int p = 0; p < nparts; ++p) {
-    a += ws[(int64_t)p * 2 * cols + c];
-    bsum += ws[(int64_t)p * 2 * cols + cols + c];
-  }
-  if (dw) dw[c] = (T)(a + (accumulate ? (float)dw[c] : 0.f));
-  if (db) db[c] = (T)(bsum + (accumulate ? (float)db[c] : 0.f));
-}
-
 inline int ln_grid(int64_t rows, int nw) {
   int64_t blocks = nw == 1 ? (rows + 3) / 4 : rows;
   if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
@@ -262,8 +248,10 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
 #undef LN_B
   OP_LAUNCH_CHECK();
   if (wsk) {
-    hipLaunchKernelGGL((ln_bwd_reduce_kernel<T>), dim3(ceil_div(cols, 256)), dim3(256), 0, s, ws, grid, cols, (T*)dw,
-                       (T*)db, accumulate);
+    if (dw) hipLaunchKernelGGL((partials_reduce_kernel<T>), dim3(ceil_div(cols, 32)), dim3(256), 0, s, ws, grid,
+                               (int64_t)2 * cols, cols, (const bf16_t*)nullptr, (T*)dw, accumulate);
+    if (db) hipLaunchKernelGGL((partials_reduce_kernel<T>), dim3(ceil_div(cols, 32)), dim3(256), 0, s, ws + cols, grid,
+                               (int64_t)2 * cols, cols, (const bf16_t*)nullptr, (T*)db, accumulate);
     OP_LAUNCH_CHECK();
   }
   return OP_OK;

@@ -43,9 +43,11 @@ SIGNATURES = {
     "op_l2norm_bwd": (c_int, [P, P, P, P, I64, I64, c_int, P]),
     "op_infonce_rows": (c_int, [P, I64, I64, I64, I64, c_float, c_float, P, P, P, c_int, P]),
     "op_adamw_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, I64, c_float, P]),
-    "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, P]),
+    "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
-    "op_attn_fwd": (c_int, [P, P, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_fwd": (c_int, [P, P, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
+    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
     "op_probe_mfma32": (c_int, [P, P, P, c_int, P]),
     "op_probe_tr16": (c_int, [P, P, P, c_int, P]),
@@ -239,11 +241,12 @@ def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale
                                grad_scale, stream()), "op_adamw_step")
 
 
-def relpos_bias_build(table, bucket_i32, S, Spad):
+def relpos_bias_build(table, bucket_i32, S, Spad, transposed=False):
+    """[heads][S][Spad] bf16 image of table[bucket]; transposed=True gives out[h][key][query]."""
     heads = table.shape[1]
     out = torch.empty(heads, S, Spad, dtype=torch.bfloat16, device=table.device)
     _check(lib().op_relpos_bias_build(ptr(table), ptr(bucket_i32), bucket_i32.stride(0), ptr(out), heads, S, Spad,
-                                      stream()), "op_relpos_bias_build")
+                                      int(transposed), stream()), "op_relpos_bias_build")
     return out
 
 
@@ -255,16 +258,42 @@ def relpos_bias_bwd(dbias_f32, bucket_i32, num_rel, S, Spad):
     return dtable
 
 
+def attn_spad(S):
+    """Padded key/query extent shared by the bias images, key-pad masks, lse and delta rows."""
+    return ((S + 127) // 128) * 128
+
+
 def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, out=None, want_lse=True):
-    """q, k, v: bf16 views into [B*S, ld] rows (head h at columns h*64..); returns out [B*S, heads*64], lse."""
+    """q, k, v: bf16 views into [B*S, ld] rows (head h at columns h*64..); returns out [B*S, heads*64] and
+    lse [B, heads, Spad] (fp32, natural log; entries >= S are unspecified)."""
     dev = q.device
     H = heads * 64
+    Spad = Spad or attn_spad(S)
     if out is None:
         out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
-    lse = torch.empty(B, heads, S, dtype=torch.float32, device=dev) if want_lse else None
-    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), ptr(key_pad), ptr(out), out.stride(0), ptr(lse), B, S,
-                             Spad, heads, 64, scale, stream()), "op_attn_fwd")
+    lse = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev) if want_lse else None
+    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), ptr(key_pad), ptr(out), out.stride(0), ptr(lse), Spad,
+                             B, S, Spad, heads, 64, scale, stream()), "op_attn_fwd")
     return out, lse
+
+
+def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=None, key_pad=None, Spad=0, dqkv=None,
+             want_dbias=False):
+    """Returns dqkv [B*S, 3H] (dq | dk | dv packed like a fused projection output) and dbias fp32 [heads,S,Spad]."""
+    dev = q.device
+    H = heads * 64
+    Spad = Spad or attn_spad(S)
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)
+    _check(lib().op_attn_bwd_delta(ptr(dout), ptr(out), dout.stride(0), ptr(delta), B, S, Spad, heads, stream()),
+           "op_attn_bwd_delta")
+    if dqkv is None:
+        dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=dev)
+    dbias = torch.zeros(heads, S, Spad, dtype=torch.float32, device=dev) if want_dbias else None
+    dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
+    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), ptr(key_pad),
+                             ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dbias), B, S, Spad, heads,
+                             64, scale, stream()), "op_attn_bwd")
+    return dqkv, dbias
 
 
 class profile_kernels:

@@ -241,6 +241,8 @@ def test_relpos_bias_build_and_bwd():
     ref = O.rel_pos_bias(table, bucket)
     out = hip.relpos_bias_build(dev_bf16(table), bucket.to(torch.int32).to(DEV), S, Spad)
     assert torch.equal(out[:, :, :S].float().cpu(), ref)
+    outT = hip.relpos_bias_build(dev_bf16(table), bucket.to(torch.int32).to(DEV), S, Spad, transposed=True)
+    assert torch.equal(outT[:, :, :S].float().cpu(), ref.transpose(1, 2))
     assert float(out[:, :, S:].abs().max()) == 0.0
     dbias = torch.randn(heads, S, Spad, generator=torch.Generator().manual_seed(2))
     tr = table.clone().requires_grad_(True)
@@ -263,31 +265,53 @@ def _attn_ref(q, k, v, heads, scale, bias, key_pad):
     return (p @ vh).transpose(1, 2).reshape(B, S, H), torch.logsumexp(s, dim=-1)
 
 
-@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", [(2, 37, 2, True, True), (3, 64, 4, True, True), (2, 257, 3, True, False),
-                                                       (1, 130, 2, False, False), (2, 300, 2, False, True), (1, 1025, 1, True, False)])
-def test_attention_forward(B, S, heads, use_bias, use_pad):
+ATTN_CASES = [(2, 37, 2, True, True), (3, 64, 4, True, True), (2, 257, 3, True, False), (1, 130, 2, False, False),
+              (2, 300, 2, False, True), (1, 1025, 1, True, False), (20, 72, 2, True, True)]
+
+
+def _attn_inputs(B, S, heads, use_bias, use_pad):
     hip = hipmod()
     H = heads * 64
     qkv = rnd(B * S, 3 * H, seed=1)
-    Spad = ((S + 63) // 64) * 64
+    Spad = hip.attn_spad(S)
     bias = rnd(heads, S, S, seed=2) if use_bias else None
     key_pad = None
     if use_pad:
         key_pad = torch.zeros(B, S, dtype=torch.bool)
         for b in range(B):
-            key_pad[b, S - 1 - 3 * b:] = True
+            key_pad[b, S - 1 - (3 * b) % (S // 2):] = True
         key_pad[0, :] = False
-    q, k, v = (qkv[:, i * H:(i + 1) * H].reshape(B, S, H) for i in range(3))
-    ref, lse_ref = _attn_ref(q, k, v, heads, 0.125, bias, key_pad)
     d = dev_bf16(qkv)
-    bias_d = None
+    bias_d = biasT_d = pad_d = None
     if use_bias:
         bias_d = torch.zeros(heads, S, Spad, dtype=torch.bfloat16, device=DEV)
         bias_d[:, :, :S] = bias.to(torch.bfloat16).to(DEV)
-    pad_d = None
+        biasT_d = torch.zeros(heads, S, Spad, dtype=torch.bfloat16, device=DEV)
+        biasT_d[:, :, :S] = bias.transpose(1, 2).to(torch.bfloat16).to(DEV)
     if use_pad:
         pad_d = torch.ones(B, Spad, dtype=torch.uint8, device=DEV)
         pad_d[:, :S] = key_pad.to(torch.uint8).to(DEV)
+    return qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad
+
+
+@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", ATTN_CASES)
+def test_attention_forward_backward(B, S, heads, use_bias, use_pad):
+    hip = hipmod()
+    H = heads * 64
+    qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad = _attn_inputs(B, S, heads, use_bias, use_pad)
+    qkv_r = qkv.clone().requires_grad_(True)
+    bias_r = bias.clone().requires_grad_(True) if use_bias else None
+    q, k, v = (qkv_r[:, i * H:(i + 1) * H].reshape(B, S, H) for i in range(3))
+    ref, lse_ref = _attn_ref(q, k, v, heads, 0.125, bias_r, key_pad)
+    dout = rnd(B * S, H, seed=3)
+    ref.backward(dout.view(B, S, H))
     out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
     assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
-    assert_close(lse, lse_ref, fro=1e-3, mx=2e-3, what="lse")
+    assert_close(lse[:, :, :S], lse_ref, fro=1e-3, mx=2e-3, what="lse")
+    dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
+                               bias_d, biasT_d, pad_d, Spad, want_dbias=use_bias)
+    # gradients pass through bf16 P / dS operands: tolerance 1.2e-2 rel-Frobenius, 3e-2 max
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
+    if use_bias:
+        assert_close(dbias[:, :, :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="dbias")

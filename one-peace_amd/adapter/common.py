@@ -1,0 +1,71 @@
+"""Pieces shared by the three modality adapters (masked-token gather/scatter of the pretraining objective and
+state-dict upgrades).  Reference: adapter/{text,image,audio}.py gather_features / preserve_embed branches."""
+import logging
+
+import torch
+
+from ..relpos import RelPosSpec
+
+logger = logging.getLogger(__name__)
+
+
+def take_rows(t, ids):
+    """t [B, S, H], ids [B, K] -> t[b, ids[b, k], :]."""
+    return torch.gather(t, 1, ids.unsqueeze(-1).expand(-1, -1, t.size(-1)))
+
+
+def take_bias(bias_list, ids, bsz):
+    """Select rows and columns ids[b] of each (dense or lazy) bias -> dense [B, heads, K, K] tensors."""
+    if bias_list is None:
+        return None
+    out = []
+    for bias in bias_list:
+        d = bias.dense(bsz) if isinstance(bias, RelPosSpec) else bias
+        heads, full = d.size(1), d.size(-1)
+        k = ids.size(1)
+        rows = torch.gather(d, 2, ids[:, None, :, None].expand(-1, heads, -1, full))
+        out.append(torch.gather(rows, 3, ids[:, None, None, :].expand(-1, heads, k, -1)))
+    return out
+
+
+def scatter_preserved(preserve_ids, preserve_embed, mask_token, bsz, seq_len):
+    """Decoder input: mask_token everywhere except positions preserve_ids[b, k] != -1, which get preserve_embed[b, k]."""
+    dim = preserve_embed.size(-1)
+    flat = mask_token.repeat(bsz * seq_len, 1)
+    keep = torch.nonzero(preserve_ids.ne(-1).flatten(), as_tuple=False).flatten()
+    dest = (preserve_ids + (torch.arange(bsz, device=preserve_ids.device) * seq_len).unsqueeze(1)).flatten()[keep]
+    flat[dest] = preserve_embed.reshape(-1, dim)[keep]
+    return flat.view(bsz, seq_len, dim)
+
+
+def upgrade_rel_pos_tables(module, state_dict, prefix):
+    """`rel_pos_table.weight` -> `rel_pos_table_list.0.weight`, and replicate table 0 when per-layer tables are new."""
+    old = prefix + "rel_pos_table.weight"
+    if old in state_dict:
+        state_dict[prefix + "rel_pos_table_list.0.weight"] = state_dict.pop(old)
+    tables = getattr(module, "rel_pos_table_list", None)
+    if tables is not None and len(tables) > 1 and prefix + "rel_pos_table_list.1.weight" not in state_dict:
+        logger.info("copy rel_pos_weight to each layer")
+        w = state_dict[prefix + "rel_pos_table_list.0.weight"]
+        for i in range(len(tables)):
+            state_dict[prefix + "rel_pos_table_list.%d.weight" % i] = w.clone()
+
+
+def fill_missing(module, state_dict, prefix):
+    for k, v in module.state_dict().items():
+        if prefix + k not in state_dict:
+            logger.info("%s not exists, re-initialized", prefix + k)
+            state_dict[prefix + k] = v
+
+
+class BucketCache:
+    """int32, device-resident, contiguous copies of rp_bucket[:S, :S] for the HIP bias-image kernel."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, rp_bucket, S):
+        key = (S, rp_bucket.device, rp_bucket.data_ptr())
+        if key not in self._c:
+            self._c = {key: rp_bucket[:S, :S].to(torch.int32).contiguous()}
+        return self._c[key]

@@ -106,8 +106,8 @@ template <typename T, int CH, int NW, bool GELU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ w, const T* __restrict__ b,
                                                      const float* __restrict__ mean_in,
-                                                     const float* __restrict__ rstd_in, T* __restrict__ dx,
-                                                     float* __restrict__ ws, int64_t rows, int cols) {
+                                                     const float* __restrict__ rstd_in, const T* __restrict__ add,
+                                                     T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // NW==1: [4][cols] ; NW==4: [4]
   float* red = smem;
   constexpr int G = 64 * NW;
@@ -163,6 +163,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - c1 - xh[i][j] * c2);
+        if (add) {
+          float av[8];
+          Vec8<T>::load(add + row * (int64_t)cols + c, av);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += av[j];
+        }
         Vec8<T>::store(dr + c, o);
       }
     }
@@ -226,8 +232,10 @@ int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float*
 
 template <typename T, bool GELU>
 int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
-                    void* dx, void* dw, void* db, float* ws, int64_t rows, int cols, int accumulate, hipStream_t s) {
+                    const void* add, void* dx, void* dw, void* db, float* ws, int64_t rows, int cols, int accumulate,
+                    hipStream_t s) {
   const T* DY = (const T*)dy; const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* DX = (T*)dx;
+  const T* ADD = (const T*)add;
   int grid = 0;
   float* wsk = (dw || db) ? ws : nullptr;
 #define LN_B(CH, NW)                                                                                        \
@@ -235,7 +243,7 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
     grid = ln_grid(rows, NW);                                                                               \
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
-                       rstd, DX, wsk, rows, cols);                                                          \
+                       rstd, ADD, DX, wsk, rows, cols);                                                          \
   } while (0)
   if (cols <= 512) LN_B(1, 1);
   else if (cols <= 1024) LN_B(2, 1);
@@ -284,9 +292,10 @@ int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float
   return OP_EINVAL;
 }
 
+// dx = LN backward (+ add, the gradient arriving through the residual path, optional and may alias dx)
 int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
-                     void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int act_gelu,
-                     int accumulate, int dtype, void* stream) {
+                     const void* add, void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
+                     int act_gelu, int accumulate, int dtype, void* stream) {
   OP_CHECK_ARG(dy && x && dx && mean && rstd, "layernorm_bwd: null pointer");
   OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0, "layernorm_bwd: cols=%lld must be a positive multiple of 8",
                (long long)cols);
@@ -294,14 +303,14 @@ int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b
   if (rows == 0) return OP_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OP_DT_BF16)
-    return act_gelu ? ln_bwd_dispatch<bf16_t, true>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+    return act_gelu ? ln_bwd_dispatch<bf16_t, true>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
                                                     (int)cols, accumulate, s)
-                    : ln_bwd_dispatch<bf16_t, false>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+                    : ln_bwd_dispatch<bf16_t, false>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
                                                      (int)cols, accumulate, s);
   if (dtype == OP_DT_F32)
-    return act_gelu ? ln_bwd_dispatch<float, true>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+    return act_gelu ? ln_bwd_dispatch<float, true>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
                                                    (int)cols, accumulate, s)
-                    : ln_bwd_dispatch<float, false>(dy, x, w, b, mean, rstd, dx, dw, db, (float*)workspace, rows,
+                    : ln_bwd_dispatch<float, false>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
                                                     (int)cols, accumulate, s);
   op_set_error("layernorm_bwd: bad dtype %d", dtype);
   return OP_EINVAL;

@@ -30,7 +30,7 @@ SIGNATURES = {
     "op_prof_collect": (c_int, [P, P, P, c_int]),
     "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
-    "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
+    "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
     "op_gemm_set_staging": (c_int, [c_int]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
                            c_int, P]),
@@ -138,9 +138,11 @@ def workspace(nbytes, device, tag="ws"):
     return buf
 
 
-def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None, db=None, accumulate=False):
+def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None, db=None, accumulate=False, add=None,
+                  dx=None):
     rows, cols = x.shape
-    dx = torch.empty_like(x)
+    if dx is None:
+        dx = torch.empty_like(x)
     ws = None
     if need_wgrad and w is not None:
         if dw is None:
@@ -150,7 +152,7 @@ def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None,
         ws = workspace(lib().op_layernorm_bwd_workspace_bytes(rows, cols), x.device, "ln")
     else:
         dw = db = None
-    _check(lib().op_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dx), ptr(dw), ptr(db),
+    _check(lib().op_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(add), ptr(dx), ptr(dw), ptr(db),
                                   ptr(ws), rows, cols, int(gelu), int(accumulate), _dt(x), stream()), "op_layernorm_bwd")
     return dx, dw, db
 

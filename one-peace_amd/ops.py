@@ -1,0 +1,420 @@
+"""Autograd layer over the C-ABI HIP kernels (``hip.py``).
+
+Each ``torch.autograd.Function`` here is what the host-side mirrors of the reference modules call when their
+input is a bf16 tensor on an MI355X.  Forward and backward enqueue HIP kernels on the current stream; PyTorch
+only owns the memory.  The encoder layer is ONE function (``EncoderLayerFn``): it keeps the layer input and
+recomputes the layer's intermediates in backward, i.e. the behaviour of the reference's
+``checkpoint_activations: true`` (pretrain_vl_3B.yaml:93, one_peace_pretrain.py:78-96) is built in.
+"""
+import math
+import weakref
+
+import torch
+
+from . import hip
+
+# --------------------------------------------------------------------------------------------------------------
+# derived-buffer cache: transposed weights for the dgrad GEMMs (never parameters, rebuilt when the weight changes)
+# --------------------------------------------------------------------------------------------------------------
+_wt_cache = {}
+_cache_epoch = 0
+
+
+def invalidate_weight_cache():
+    """Call after parameters were updated through raw pointers (the fused AdamW kernel does not bump _version)."""
+    global _cache_epoch
+    _cache_epoch += 1
+
+
+def _transposed(ws):
+    """[sum(out_i), in] -> cached bf16 [in, sum(out_i)] (ws: one weight or a tuple that is concatenated on dim 0)."""
+    ws = ws if isinstance(ws, (tuple, list)) else (ws,)
+    key = tuple(w.data_ptr() for w in ws)
+    ver = (tuple(w._version for w in ws), _cache_epoch)
+    hit = _wt_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    src = ws[0] if len(ws) == 1 else torch.cat([w.detach() for w in ws], dim=0)
+    out = hit[1] if hit is not None else None
+    t = hip.transpose(src.detach(), out)
+    _wt_cache[key] = (ver, t)
+    return t
+
+
+def _round_up(n, m):
+    return ((n + m - 1) // m) * m
+
+
+def _t_pad(x2d):
+    """[M, C] -> [C, Mpad] (Mpad = M rounded up to 64, zero tail): the K-contiguous operand of a weight-gradient GEMM."""
+    M, C = x2d.shape
+    Mp = _round_up(M, 64)
+    out = torch.empty(C, Mp, dtype=x2d.dtype, device=x2d.device)
+    if Mp != M:
+        out[:, M:].zero_()
+    hip.transpose(x2d, out)
+    return out
+
+
+def _wgrad(dyT, xT):
+    """dW[out, in] = dy^T x from the two transposed, K-padded operands."""
+    return hip.gemm_nt(dyT, [xT])
+
+
+def gemm_any(A, W, bias=None, out_f32=False, alpha=None):
+    """A[M,K] @ W[N,K]^T (+bias) through the HIP GEMM for ANY K, N (zero-pads K to 64 / N to 8 on the host)."""
+    M, K = A.shape
+    N = W.shape[0]
+    Kp, Np = _round_up(K, 64), _round_up(N, 8)
+    if Kp != K:
+        A = torch.nn.functional.pad(A, (0, Kp - K))
+        W = torch.nn.functional.pad(W, (0, Kp - K))
+    if Np != N:
+        W = torch.nn.functional.pad(W, (0, 0, 0, Np - N))
+        if bias is not None:
+            bias = torch.nn.functional.pad(bias, (0, Np - N))
+    A = A.contiguous()
+    W = W.contiguous()
+    if out_f32:
+        out = hip.gemm_nt(A, [W], [bias] if bias is not None else None, epilogue=hip.EPI_F32, alpha=alpha)
+    else:
+        out = hip.gemm_nt(A, [W], [bias] if bias is not None else None)
+    return out if Np == N else out[:, :N].contiguous()
+
+
+def hip_eligible(x):
+    """The HIP path takes bf16 CUDA tensors; anything else runs the torch reference ops of the mirrors."""
+    return x.is_cuda and x.dtype == torch.bfloat16
+
+
+# --------------------------------------------------------------------------------------------------------------
+# LayerNorm (+ optional fused GELU)
+# --------------------------------------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, gelu):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        need = any(ctx.needs_input_grad[:3])
+        y, mean, rstd = hip.layernorm_fwd(x2, w, b, eps, gelu=gelu, want_stats=need)
+        if need:
+            ctx.save_for_backward(x2, w, b, mean, rstd)
+            ctx.gelu = gelu
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, b, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(x2.shape)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx, dw, db = hip.layernorm_bwd(dy2, x2, w, b, mean, rstd, gelu=ctx.gelu,
+                                       need_wgrad=w is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))
+        return dx.view(dy.shape), dw, db, None, None
+
+
+def layer_norm(x, w, b, eps=1e-5, gelu=False):
+    return LayerNormFn.apply(x, w, b, eps, gelu)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Linear  y = x W^T + b
+# --------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        y = gemm_any(x2, w, b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        return y.view(*shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, w.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_any(dy2, _transposed(w)).view(*dy.shape[:-1], w.shape[1])
+        if ctx.needs_input_grad[1]:
+            dw = gemm_any(_t_pad(dy2), _t_pad(x2))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dy8 = dy2 if dy2.shape[1] % 8 == 0 else torch.nn.functional.pad(dy2, (0, 8 - dy2.shape[1] % 8))
+            db = hip.colsum(dy8.contiguous())[: w.shape[0]]
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# relative-position bias image  [heads][S][Spad]  (and its transpose for the dK/dV kernel)
+# --------------------------------------------------------------------------------------------------------------
+class RelPosBias:
+    """Per-forward handle: bf16 images of table[bucket] plus the fp32 accumulator the attention backward adds into."""
+
+    def __init__(self, table, bucket_i32, S):
+        self.S, self.Spad = S, hip.attn_spad(S)
+        self.num_rel, self.heads = table.shape
+        self.bucket = bucket_i32
+        self.table = table
+        self.acc = None
+        self._imageT = None
+        self.image = _RelPosImageFn.apply(table, self)
+
+    @property
+    def imageT(self):
+        """out[h][key][query]: what the dK/dV kernel reads (built on first use in a backward pass)."""
+        if self._imageT is None:
+            self._imageT = hip.relpos_bias_build(self.table.detach(), self.bucket, self.S, self.Spad, transposed=True)
+        return self._imageT
+
+    def grad_accumulator(self):
+        if self.acc is None:
+            self.acc = torch.zeros(self.heads, self.S, self.Spad, dtype=torch.float32, device=self.image.device)
+        return self.acc
+
+
+class _RelPosImageFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, handle):
+        ctx.handle_ref = weakref.ref(handle)  # the layers' ctx keep the handle alive until their backward ran
+        ctx.shape = tuple(table.shape)
+        return hip.relpos_bias_build(table, handle.bucket, handle.S, handle.Spad)
+
+    @staticmethod
+    def backward(ctx, _unused):
+        # The attention backward kernels add dS straight into handle.acc (fp32); the tensor gradient that autograd
+        # routes here is a placeholder that only orders this node after every consuming layer.
+        h = ctx.handle_ref()
+        if h is None or h.acc is None:
+            return torch.zeros(ctx.shape, dtype=torch.bfloat16, device=_unused.device), None
+        dtable = hip.relpos_bias_bwd(h.acc, h.bucket, h.num_rel, h.S, h.Spad)
+        h.acc = None
+        return dtable.to(torch.bfloat16), None
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the fused encoder layer
+# --------------------------------------------------------------------------------------------------------------
+LAYER_PARAMS = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b", "wo", "bo", "g1",
+                "ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
+
+
+def _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep):
+    """Runs the layer on x2 [B*S, H].  keep=True also returns the intermediates the backward needs."""
+    H = x2.shape[1]
+    xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
+    fused_qkv = H % 128 == 0
+    if fused_qkv:
+        qkv = hip.gemm_nt(xln1, [P["wq"], P["wk"], P["wv"]], [P["bq"], None, P["bv"]], n_seg=H, N=3 * H)
+    else:
+        qkv = torch.empty(x2.shape[0], 3 * H, dtype=x2.dtype, device=x2.device)
+        for i, (w, b) in enumerate(((P["wq"], P["bq"]), (P["wk"], None), (P["wv"], P["bv"]))):
+            hip.gemm_nt(xln1, [w], [b] if b is not None else None, out=qkv[:, i * H:(i + 1) * H], ldc=3 * H)
+    Spad = hip.attn_spad(S)
+    attn, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, B, S, heads, scale, bias_img, key_pad,
+                             Spad, want_lse=keep)
+    if P["aln_w"] is not None:
+        aln, mean_a, rstd_a = hip.layernorm_fwd(attn, P["aln_w"], P["aln_b"], want_stats=keep)
+    else:
+        aln, mean_a, rstd_a = attn, None, None
+    y1 = torch.empty_like(x2) if keep else None
+    x_mid = hip.gemm_nt(aln, [P["wo"]], [P["bo"]], epilogue=hip.EPI_RESID, resid=x2, gamma=P["g1"], rowscale=ps1,
+                        rows_per_sample=S, h0=y1)
+    xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
+    Fd = P["w0"].shape[0]
+    h0 = h1 = None
+    if keep:
+        h0 = torch.empty(x2.shape[0], Fd, dtype=x2.dtype, device=x2.device)
+        h1 = torch.empty_like(h0)
+    g = hip.gemm_nt(xln2, [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+    if P["fln_w"] is not None:
+        gln, mean_f, rstd_f = hip.layernorm_fwd(g, P["fln_w"], P["fln_b"], want_stats=keep)
+    else:
+        gln, mean_f, rstd_f = g, None, None
+    y2 = torch.empty_like(x2) if keep else None
+    out = hip.gemm_nt(gln, [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x_mid, gamma=P["g2"], rowscale=ps2,
+                      rows_per_sample=S, h0=y2)
+    if not keep:
+        return out, None
+    acts = dict(xln1=xln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, aln=aln, mean_a=mean_a, rstd_a=rstd_a,
+                y1=y1, x_mid=x_mid, xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, g=g, gln=gln, mean_f=mean_f,
+                rstd_f=rstd_f, y2=y2)
+    return out, acts
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """transformer_layer.py:165-228 for a single-modality stream, forward + backward in HIP.
+
+    x: [B, S, H] bf16 contiguous (batch-major).  bias: RelPosBias handle or None.  key_pad: uint8 [B, Spad] or None.
+    ps1 / ps2: fp32 [B] drop-path multipliers (0 or 1/keep) of the attention / FFN residual branch, or None.
+    """
+
+    @staticmethod
+    def forward(ctx, x, bias_image, bias, key_pad, ps1, ps2, heads, *params):
+        # bias_image (= bias.image) is passed as a tensor only to put the bias table into the autograd graph
+        B, S, H = x.shape
+        P = dict(zip(LAYER_PARAMS, params))
+        x2 = x.reshape(B * S, H)
+        scale = (H // heads) ** -0.5
+        bias_img = bias.image.detach() if bias is not None else None
+        out, _ = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=False)
+        ctx.save_for_backward(x2, key_pad, ps1, ps2, *params)
+        ctx.bias = bias
+        ctx.dims = (B, S, H, heads, scale)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, key_pad, ps1, ps2, *params = ctx.saved_tensors
+        B, S, H, heads, scale = ctx.dims
+        P = dict(zip(LAYER_PARAMS, params))
+        bias = ctx.bias
+        bias_img = bias.image.detach() if bias is not None else None
+        biasT = bias.imageT if bias is not None else None
+        want_dbias = bias is not None and bias.image.requires_grad
+        _, A = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=True)
+        N = B * S
+        Fd = P["w0"].shape[0]
+        dout2 = dout.reshape(N, H)
+        if not dout2.is_contiguous():
+            dout2 = dout2.contiguous()
+        G = {}
+
+        # ---- FFN branch: out = x_mid + ps * g2 * (gln W2^T + b2) ----
+        dy2 = hip.scale_rows(dout2, P["g2"], ps2, S)
+        if P["g2"] is not None:
+            G["g2"] = hip.colsum(dout2, A["y2"], ps2, S)
+        G["b2"] = hip.colsum(dy2)
+        dy2T = _t_pad(dy2)
+        G["w2"] = _wgrad(dy2T, _t_pad(A["gln"]))
+        dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
+        if P["fln_w"] is not None:
+            dg, G["fln_w"], G["fln_b"] = hip.layernorm_bwd(dgln, A["g"], P["fln_w"], P["fln_b"], A["mean_f"], A["rstd_f"])
+        else:
+            dg = dgln
+        dh0, dh1 = hip.geglu_bwd(dg, A["h0"], A["h1"])
+        xln2T = _t_pad(A["xln2"])
+        G["w0"] = _wgrad(_t_pad(dh0), xln2T)
+        G["w1"] = _wgrad(_t_pad(dh1), xln2T)
+        dxln2 = hip.gemm_nt(dh0, [_transposed(P["w0"])])
+        hip.gemm_nt(dh1, [_transposed(P["w1"])], out=dxln2, epilogue=hip.EPI_RESID, resid=dxln2)
+        dx_mid, G["ln2_w"], G["ln2_b"] = hip.layernorm_bwd(dxln2, A["x_mid"], P["ln2_w"], P["ln2_b"], A["mean2"],
+                                                           A["rstd2"], add=dout2)
+
+        # ---- attention branch: x_mid = x + ps * g1 * (aln Wo^T + bo) ----
+        dy1 = hip.scale_rows(dx_mid, P["g1"], ps1, S)
+        if P["g1"] is not None:
+            G["g1"] = hip.colsum(dx_mid, A["y1"], ps1, S)
+        G["bo"] = hip.colsum(dy1)
+        G["wo"] = _wgrad(_t_pad(dy1), _t_pad(A["aln"]))
+        daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
+        if P["aln_w"] is not None:
+            dattn, G["aln_w"], G["aln_b"] = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"],
+                                                              A["rstd_a"])
+        else:
+            dattn = daln
+        qkv = A["qkv"]
+        dqkv, _ = _attn_backward(qkv, dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
+                                 bias.grad_accumulator() if want_dbias else None)
+        dbias_cols = hip.colsum(dqkv)
+        G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
+        dW = _wgrad(_t_pad(dqkv), _t_pad(A["xln1"]))  # [3H, H]
+        G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
+        dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
+        dx, G["ln1_w"], G["ln1_b"] = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"],
+                                                       add=dx_mid)
+        grads = [G.get(n) if p is not None else None for n, p in zip(LAYER_PARAMS, params)]
+        dimg = None
+        if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
+            dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
+        return (dx.view(B, S, H), dimg, None, None, None, None, None, *grads)
+
+
+def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc):
+    H = heads * 64
+    dev = qkv.device
+    Spad = hip.attn_spad(S)
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)
+    L = hip.lib()
+    hip._check(L.op_attn_bwd_delta(hip.ptr(dattn), hip.ptr(attn), dattn.stride(0), hip.ptr(delta), B, S, Spad, heads,
+                                   hip.stream()), "op_attn_bwd_delta")
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
+    hip._check(L.op_attn_bwd(hip.ptr(qkv[:, :H]), hip.ptr(qkv[:, H:2 * H]), hip.ptr(qkv[:, 2 * H:]), 3 * H, hip.ptr(dattn),
+                             dattn.stride(0), hip.ptr(bias_img), hip.ptr(biasT), hip.ptr(key_pad), hip.ptr(lse),
+                             hip.ptr(delta), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), 3 * H, hip.ptr(dbias_acc), B, S, Spad,
+                             heads, 64, scale, hip.stream()), "op_attn_bwd")
+    return dqkv, dbias_acc
+
+
+def encoder_layer(x, bias, key_pad, ps1, ps2, heads, params):
+    return EncoderLayerFn.apply(x, bias.image if bias is not None else None, bias, key_pad, ps1, ps2, heads, *params)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# contrastive head
+# --------------------------------------------------------------------------------------------------------------
+class L2NormalizeFn(torch.autograd.Function):
+    """F.normalize(x, dim=1) (one_peace_retrieval.py:112)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = hip.l2norm_fwd(x.contiguous())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return hip.l2norm_bwd(dy.contiguous(), y, inv)
+
+
+def l2_normalize(x):
+    return L2NormalizeFn.apply(x)
+
+
+class InfoNCEFn(torch.autograd.Function):
+    """image_text_pretrain_loss.py:164-185: both directions of scale * local @ all^T -> fp32 log-softmax -> NLL.
+
+    a_local/b_local: [b, H] bf16 (with grad).  a_all/b_all: [n, H] bf16 gathered copies (no grad flows into them).
+    scale: fp32 0-d tensor (logit_scale.exp()).  Returns (loss, a_hits, b_hits)."""
+
+    @staticmethod
+    def forward(ctx, a_local, b_local, a_all, b_all, scale, rank, label_smoothing):
+        b = a_local.shape[0]
+        t0 = rank * b
+        scale_f = scale.detach().float().reshape(1)
+        sims, rows = [], []
+        for loc, allv in ((a_local, b_all), (b_local, a_all)):
+            sim = gemm_any(loc.detach(), allv.detach(), out_f32=True, alpha=scale_f)
+            loss_r, hit_r, dot_r = hip.infonce_rows(sim, t0, label_smoothing, gscale=0.5 / b, write_grad=True)
+            sims.append(sim)  # now holds d loss / d sim
+            rows.append((loss_r, hit_r, dot_r))
+        loss = 0.5 * (rows[0][0].mean() + rows[1][0].mean())
+        ctx.save_for_backward(a_local, b_local, a_all, b_all, scale_f, sims[0], sims[1], rows[0][2], rows[1][2])
+        ctx.scale_dtype = scale.dtype
+        return loss, rows[0][1].sum(), rows[1][1].sum()
+
+    @staticmethod
+    def backward(ctx, gl, _ga, _gb):
+        a_local, b_local, a_all, b_all, scale_f, ds_ab, ds_ba, dot_ab, dot_ba = ctx.saved_tensors
+        g = gl.float()
+        coef = (g * scale_f).reshape(1)
+        da = gemm_any(ds_ab.to(torch.bfloat16), hip.transpose(b_all.contiguous()), out_f32=True, alpha=coef)
+        db = gemm_any(ds_ba.to(torch.bfloat16), hip.transpose(a_all.contiguous()), out_f32=True, alpha=coef)
+        dscale = (g * (dot_ab.sum() + dot_ba.sum()) / scale_f).reshape(()).to(ctx.scale_dtype)
+        return da.to(a_local.dtype), db.to(b_local.dtype), None, None, dscale, None, None
+
+
+def info_nce(a_local, b_local, a_all, b_all, scale, rank=0, label_smoothing=0.0):
+    return InfoNCEFn.apply(a_local, b_local, a_all, b_all, scale, rank, label_smoothing)

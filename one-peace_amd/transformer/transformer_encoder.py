@@ -1,0 +1,151 @@
+"""Mirror of one_peace/models/transformer/transformer_encoder.py: the modality-shared encoder.
+
+``forward(text_info, image_info, audio_info, return_all_hiddens, encoder_type)`` takes the adapters' tuples
+``(x [B,S,H], padding_mask [B,S], bias_list)`` and returns the reference's dict (``encoder_out[0]`` is T x B x C).
+bias_list entries may be dense tensors (reference adapters) or ``RelPosSpec`` (our adapters).
+
+MI355X path (single-modality stream, bf16): activations stay batch-major, the dense ``[B, heads, S, S]`` bias of the
+reference (transformer_encoder.py:144-162) is never built -- each table becomes one ``[heads, S, Spad]`` image and
+key padding a ``[B, Spad]`` byte mask -- and every block is one fused HIP function."""
+import logging
+
+import torch
+import torch.nn as nn
+
+from .. import hip, ops
+from ..components import FairseqDropout, LayerNorm
+from ..relpos import RelPosSpec
+from .transformer_layer import TransformerEncoderLayer
+
+logger = logging.getLogger(__name__)
+
+
+class LayerDropModuleList(nn.ModuleList):
+    """fairseq/modules/layer_drop.py:13-44: skip each layer with probability p while training."""
+
+    def __init__(self, p, modules=None):
+        super().__init__(modules)
+        self.p = p
+
+    def __iter__(self):
+        probs = torch.empty(len(self)).uniform_()
+        for i, m in enumerate(super().__iter__()):
+            if not self.training or probs[i] > self.p:
+                yield m
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, cfg, dictionary, use_text_norm, use_image_norm, use_audio_norm):
+        super().__init__()
+        self.cfg, self.dictionary = cfg, dictionary
+        self.register_buffer("version", torch.Tensor([3]))
+        self.dropout_module = FairseqDropout(cfg.dropout, module_name=type(self).__name__)
+        self.encoder_layerdrop = cfg.layerdrop
+        self.max_positions = cfg.max_positions
+        self.num_attention_heads = cfg.attention_heads
+        self.layers = LayerDropModuleList(p=cfg.layerdrop) if cfg.layerdrop > 0.0 else nn.ModuleList()
+        rates = torch.linspace(0, cfg.drop_path_rate, cfg.layers).tolist()
+        self.layers.extend(self.build_encoder_layer(cfg, drop_path_rate=r) for r in rates)
+        self.num_layers = len(self.layers)
+        self.text_layer_norm = LayerNorm(cfg.embed_dim) if cfg.use_text_moe and use_text_norm else None
+        self.image_layer_norm = LayerNorm(cfg.embed_dim) if cfg.use_image_moe and use_image_norm else None
+        self.audio_layer_norm = LayerNorm(cfg.embed_dim) if cfg.use_audio_moe and use_audio_norm else None
+
+    def build_encoder_layer(self, cfg, drop_path_rate=0.0):
+        return TransformerEncoderLayer(cfg, drop_path_rate=drop_path_rate)
+
+    # ------------------------------------------------------------------------------------------------------
+    def forward(self, text_info, image_info, audio_info, return_all_hiddens: bool = False, encoder_type=None):
+        streams = {"text": ("text",), "image": ("image",), "audio": ("audio",), "vl": ("text", "image"),
+                   "al": ("text", "audio")}.get(encoder_type)
+        if streams is None:
+            raise NotImplementedError(encoder_type)
+        infos = dict(text=text_info, image=image_info, audio=audio_info)
+        if (len(streams) == 1 and not return_all_hiddens and ops.hip_eligible(infos[streams[0]][0])
+                and self._fused_ok(encoder_type, infos[streams[0]])):
+            return self._forward_fused(encoder_type, infos[streams[0]])
+        return self._forward_torch(encoder_type, streams, infos, return_all_hiddens)
+
+    def _fused_ok(self, encoder_type, info):
+        biases = info[2]
+        if biases is not None and not all(isinstance(b, RelPosSpec) for b in biases):
+            return False
+        if self.encoder_layerdrop > 0.0 and self.training:
+            return False
+        return all(getattr(layer, "fused_supported", lambda e: False)(encoder_type) for layer in self.layers)
+
+    def _forward_fused(self, encoder_type, info):
+        x, pad, biases = info
+        B, S, _ = x.shape
+        key_pad = None
+        if not getattr(pad, "_all_false", False):
+            x = x * (~pad).unsqueeze(-1).to(x.dtype)  # transformer_encoder.py:141-142
+            key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=x.device)
+            key_pad[:, :S] = pad.to(torch.uint8)
+        x = x.contiguous()
+        handles = [b.handle() for b in biases] if biases else []
+        for idx, layer in enumerate(self.layers):
+            h = None if not handles else (handles[0] if len(handles) == 1 else handles[idx])
+            x = layer.forward_fused(x, h, key_pad, encoder_type)
+        norm = getattr(self, encoder_type + "_layer_norm")
+        if norm is not None:
+            x = norm(x)
+        return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": [],
+                "image_encoder_states": [], "audio_encoder_states": []}
+
+    def _forward_torch(self, encoder_type, streams, infos, return_all_hiddens):
+        parts = [infos[s] for s in streams]
+        lens = {s: infos[s][0].size(1) for s in streams}
+        x = torch.cat([p[0] for p in parts], dim=1) if len(parts) > 1 else parts[0][0]
+        pad = torch.cat([p[1] for p in parts], dim=1) if len(parts) > 1 else parts[0][1]
+        n_bias = len(parts[0][2]) if parts[0][2] is not None else 0
+        has_pads = bool(pad.any())
+        if has_pads:
+            x = x * (1 - pad.unsqueeze(-1).type_as(x))
+        B, S, _ = x.shape
+        dense = []
+        for i in range(n_bias):
+            full = x.new_zeros(B, self.num_attention_heads, S, S)
+            off = 0
+            for s, p in zip(streams, parts):
+                n = lens[s]
+                if p[2] is not None:
+                    blk = p[2][i]
+                    full[:, :, off:off + n, off:off + n] += blk.dense(B).to(x.dtype) if isinstance(blk, RelPosSpec) else blk
+                off += n
+            if has_pads:
+                full = full.masked_fill(pad.view(B, 1, 1, S), float("-inf"))
+            dense.append(full)
+        x = x.transpose(0, 1)
+        states = {"text": [], "image": [], "audio": []}
+        tl, il, al = lens.get("text", 0), lens.get("image", 0), lens.get("audio", 0)
+        for idx, layer in enumerate(self.layers):
+            bias = None if not dense else (dense[0] if len(dense) == 1 else dense[idx])
+            x = layer(x, encoder_padding_mask=pad, self_attn_bias=bias, encoder_type=encoder_type, text_seq_len=tl,
+                      image_seq_len=il, audio_seq_len=al)
+            if return_all_hiddens:
+                off = 0
+                for s in streams:
+                    states[s].append(x[off:off + lens[s]])
+                    off += lens[s]
+
+        def final(t, s):
+            norm = getattr(self, s + "_layer_norm")
+            return norm(t) if norm is not None else t
+
+        if len(streams) == 1:
+            x = final(x, streams[0])
+        else:
+            x = torch.cat([final(x[:tl], "text"), final(x[-lens[streams[1]]:], streams[1])], dim=0)
+        return {"encoder_out": [x], "encoder_padding_mask": pad, "text_encoder_states": states["text"],
+                "image_encoder_states": states["image"], "audio_encoder_states": states["audio"]}
+
+    def upgrade_state_dict_named(self, state_dict, name):
+        for i, layer in enumerate(self.layers):
+            layer.upgrade_state_dict_named(state_dict, "%s.layers.%d" % (name, i))
+        prefix = name + "." if name != "" else ""
+        for k, v in self.state_dict().items():
+            if prefix + k not in state_dict:
+                logger.info("%s not exists, re-initialized", prefix + k)
+                state_dict[prefix + k] = v
+        return state_dict

@@ -1,0 +1,120 @@
+"""Host-logic tests on CPU: the mirrors of the reference modules (their torch-op path) must reproduce the
+reference-generated golden fixtures with the reference's own state-dict keys -- this is the drop-in contract
+ checked without a GPU."""
+import os
+
+import pytest
+import torch
+
+from tests.model_util import build_retrieval, load_synth
+
+ATOL = 3e-5
+
+
+def _fx(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+@pytest.fixture(scope="module")
+def micro(golden_dir):
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    m = load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]).eval()
+    return fx, m
+
+
+def test_state_dict_contract_and_buckets(micro):
+    fx, m = micro
+    assert torch.equal(m.encoder_wrapper.image_adapter.rp_bucket, fx["image_rp_bucket"])
+    assert m.encoder_wrapper.text_adapter.rp_bucket.sum() == fx["text_rp_bucket_sum"]
+    assert torch.equal(m.encoder_wrapper.text_adapter.rp_bucket[:40, :40], fx["text_rp_bucket_corner"])
+    assert torch.equal(m.encoder_wrapper.audio_adapter.rp_bucket[700], fx["audio_rp_bucket_row"])
+
+
+def test_micro_forward_losses_grads(micro):
+    from one_peace_amd.criterions.contrastive import AudioTextRetrievalCriterion, ImageTextRetrievalCriterion
+    fx, m = micro
+    inp = fx["inputs"]
+    t = m(src_tokens=inp["src_tokens"], encoder_type="text")
+    i = m(src_images=inp["src_images"], encoder_type="image")
+    a = m(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")
+    for got, key in ((t, "text_logits"), (i, "image_logits"), (a, "audio_logits")):
+        assert torch.allclose(got, fx[key], atol=ATOL, rtol=1e-4), key
+    scale = m(return_logit_scale=True)
+    itc = ImageTextRetrievalCriterion(None, 0.0)
+    atc = AudioTextRetrievalCriterion(None, 0.1)
+    l1, i2t, t2i = itc.compute_itc_loss(i, t, i.data, t.data, scale)
+    l2, a2t, t2a = atc.compute_atc_loss(a, t, a.data, t.data, scale)
+    assert torch.allclose(l1, fx["itc_loss"], atol=ATOL) and torch.allclose(l2, fx["atc_loss"], atol=ATOL)
+    assert (i2t, t2i, a2t, t2a) == (fx["i2t"], fx["t2i"], fx["a2t"], fx["t2a"])
+    m.zero_grad()
+    (l1 + l2).backward()
+    params = dict(m.named_parameters())
+    n = 0
+    for k, g in fx["grads"].items():
+        if k.endswith("#norm"):
+            assert torch.allclose(params[k[:-5]].grad.double().norm().float(), g, rtol=3e-4, atol=1e-6), k
+        elif k.endswith("#rows4"):
+            assert torch.allclose(params[k[:-6]].grad[:4], g, atol=ATOL, rtol=3e-4), k
+        else:
+            assert torch.allclose(params[k].grad, g, atol=ATOL, rtol=3e-4), k
+        n += 1
+    assert n > 50
+
+
+def test_micro_criterion_forward(micro):
+    from one_peace_amd.criterions.contrastive import ImageTextRetrievalCriterion, TriModalContrastiveCriterion
+    fx, m = micro
+    sample = {"net_input": dict(fx["inputs"]), "nsentences": 4}
+    loss, ss, log = ImageTextRetrievalCriterion(None, 0.0)(m, sample)
+    assert ss == 1 and torch.allclose(loss, fx["itc_loss"], atol=ATOL)
+    loss3, _, log3 = TriModalContrastiveCriterion(None, 0.0)(m, sample)
+    assert torch.allclose(log3["itc_loss"], fx["itc_loss"], atol=ATOL)
+
+
+def test_micro_joint_streams(micro):
+    fx, m = micro
+    inp = fx["inputs"]
+    with torch.no_grad():
+        vt, vi, _ = m.encoder_wrapper(src_tokens=inp["src_tokens"], src_images=inp["src_images"], encoder_type="vl")
+        at, _, aa = m.encoder_wrapper(src_tokens=inp["src_tokens"], src_audios=inp["src_audios"],
+                                      audio_padding_masks=inp["audio_padding_masks"], encoder_type="al")
+    assert torch.allclose(vt, fx["vl_text"], atol=ATOL, rtol=1e-4) and torch.allclose(vi, fx["vl_image"], atol=ATOL, rtol=1e-4)
+    assert torch.allclose(at, fx["al_text"], atol=ATOL, rtol=1e-4) and torch.allclose(aa, fx["al_audio"], atol=ATOL, rtol=1e-4)
+
+
+def test_tiny_text_config1(golden_dir):
+    fx = _fx(golden_dir, "tiny_text.pt")
+    cfg = {k: v for k, v in fx["cfg"].items()}
+    m = load_synth(build_retrieval(cfg, 50265, head_type="text"), fx["shapes"]).eval()
+    with torch.no_grad():
+        out = m(src_tokens=fx["inputs"]["src_tokens"], encoder_type="text")
+    assert torch.allclose(out, fx["text_logits"], atol=ATOL, rtol=1e-4)
+
+
+def test_pretrain_model_contrastive_branch_and_registry():
+    from types import SimpleNamespace
+    from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel
+    from one_peace_amd.registry import MODEL_REGISTRY
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from tests.model_util import TinyDictionary
+    assert MODEL_REGISTRY["one_peace_pretrain"] is OnePeacePretrainModel
+    enc = one_peace_encoder_config(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, drop_path_rate=0.0,
+                                   image_rel_bucket_size=4, use_audio_moe=False)
+    dec = one_peace_encoder_config(embed_dim=64, ffn_embed_dim=128, layers=1, attention_heads=1, drop_path_rate=0.0,
+                                   use_audio_moe=False)
+    dec.text_adapter.use_attn_bias = dec.image_adapter.use_attn_bias = False
+    dec.image_adapter.vision_encoder_type = "none"
+    cfg = SimpleNamespace(encoder=enc, decoder=dec, reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
+    m = OnePeacePretrainModel(cfg, TinyDictionary(1000)).eval()
+    tok = torch.randint(4, 1000, (2, 9))
+    logits, feats = m(src_tokens=tok, encoder_type="text")
+    assert logits.shape == (2, 128) and feats.shape == (2, 10, 128)
+    assert torch.allclose(logits.norm(dim=1), torch.ones(2), atol=1e-5)
+    keys = set(m.state_dict())
+    for k in ("decoder_text_embed.weight", "text_mask_token", "image_mask_head.bias", "logit_scale",
+              "decoder_wrapper.fusion_model.layers.0.gamma_1"):
+        assert k in keys
+    # masked (DCL) branch keeps working through the torch-op path
+    ids = torch.tensor([[0, 1, 3, 5, -1], [0, 2, 4, -1, -1]])
+    dt, di, da = m(src_tokens=tok, text_preserve_ids=ids, encoder_type="text")
+    assert dt.shape == (2, 10, 128) and di is None and da is None

@@ -1,0 +1,184 @@
+"""Model-level parity on MI355X: the HIP path (bf16) against the reference-generated golden fixtures / the fp32 oracle.
+
+Stated tolerance (north_star: "within a stated fp tolerance"): for every compared tensor
+    rel_fro(hip_bf16, fp32_reference) <= max(2 x rel_fro(torch_bf16_path, fp32_reference), floor)
+where torch_bf16_path is the reference algorithm executed op-by-op in bf16 (our mirrors' torch path = the numerics
+the reference itself has in bf16 training, trainer.py:86-88), and floor = 1.5e-2 for activations/embeddings,
+5e-2 for gradients.  The fused kernels keep fp32 accumulators across ops the reference rounds to bf16 in between, so
+they are normally *closer* to fp32 than the yardstick."""
+import os
+
+import pytest
+import torch
+
+from oracle import onepeace_oracle as O
+from oracle import synth
+from tests.model_util import build_retrieval, load_synth
+from tests.util import rel_fro
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _fx(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def _check(name, hip_val, torch_val, ref, floor, report):
+    e_hip, e_t = rel_fro(hip_val.float(), ref), rel_fro(torch_val.float(), ref)
+    report.append("%-60s hip %.3e  torch-bf16 %.3e" % (name, e_hip, e_t))
+    assert e_hip <= max(2 * e_t, floor), "%s: hip %.3e vs torch-bf16 %.3e (floor %.1e)" % (name, e_hip, e_t, floor)
+
+
+def _force_torch_path(model, flag):
+    """Disable/enable the HIP dispatch of the mirrors (yardstick run)."""
+    from one_peace_amd import ops
+    ops.hip_eligible = (lambda x: False) if flag else ops._hip_eligible_orig
+
+
+@pytest.fixture(autouse=True)
+def _save_eligible():
+    from one_peace_amd import ops
+    if not hasattr(ops, "_hip_eligible_orig"):
+        ops._hip_eligible_orig = ops.hip_eligible
+    yield
+    ops.hip_eligible = ops._hip_eligible_orig
+
+
+def _to_dev(inp):
+    return {k: (v.to(DEV).to(torch.bfloat16) if v.is_floating_point() else v.to(DEV)) for k, v in inp.items()}
+
+
+def test_micro_model_forward_backward(golden_dir):
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    report = []
+    results = {}
+    for mode in ("hip", "torch"):
+        m = load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]).to(DEV).to(torch.bfloat16).eval()
+        _force_torch_path(m, mode == "torch")
+        inp = _to_dev(fx["inputs"])
+        t = m(src_tokens=inp["src_tokens"], encoder_type="text")
+        i = m(src_images=inp["src_images"], encoder_type="image")
+        a = m(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")
+        crit = TriModalContrastiveCriterion(None, 0.0)
+        loss, _, log = crit(m, {"net_input": inp, "nsentences": 4})
+        m.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        results[mode] = dict(t=t.detach(), i=i.detach(), a=a.detach(), itc=log["itc_loss"].float(),
+                             grads={n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    h, tt = results["hip"], results["torch"]
+    for key, ref in (("t", "text_logits"), ("i", "image_logits"), ("a", "audio_logits")):
+        _check(ref, h[key], tt[key], fx[ref], 1.5e-2, report)
+    assert abs(float(h["itc"]) - float(fx["itc_loss"])) <= max(2 * abs(float(tt["itc"]) - float(fx["itc_loss"])), 2e-2)
+    # gradients: the golden file holds the ITC + ATC(label smoothing 0.1) objective; here the criterion uses 0.0 for both,
+    # so compare against the oracle's gradient of exactly this objective
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth.synth_state_dict(fx["shapes"]).items()}
+    sd["encoder_wrapper.text_adapter.rp_bucket"] = O.token_bucket_position(fx["cfg"]["text_bucket_size"])
+    sd["encoder_wrapper.audio_adapter.rp_bucket"] = O.token_bucket_position(fx["cfg"]["audio_bucket_size"])
+    rb = fx["cfg"]["image_rel_bucket_size"]
+    sd["encoder_wrapper.image_adapter.rp_bucket"] = O.image_bucket_position(rb, (2 * rb - 1) ** 2 + 3)
+    heads, L = fx["cfg"]["attention_heads"], fx["cfg"]["layers"]
+    inp = fx["inputs"]
+    to, _ = O.contrastive_embed(sd, heads, L, "text", src_tokens=inp["src_tokens"])
+    io, _ = O.contrastive_embed(sd, heads, L, "image", src_images=inp["src_images"])
+    ao, _ = O.contrastive_embed(sd, heads, L, "audio", src_audios=inp["src_audios"],
+                                audio_padding_masks=inp["audio_padding_masks"])
+    sc = O.logit_scale_exp(sd["logit_scale"])
+    (O.itc_loss(io, to, io, to, sc)[0] + O.itc_loss(ao, to, ao, to, sc)[0]).backward()
+    worst = 0.0
+    for n, g in h["grads"].items():
+        ref = sd[n].grad
+        if ref is None or float(ref.norm()) < 1e-7:
+            continue
+        _check("grad " + n, g, tt["grads"][n], ref, 5e-2, report)
+        worst = max(worst, rel_fro(g, ref))
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "model_parity_report.txt"), "w").write(
+        "\n".join(report) + "\nworst grad rel-fro %.3e\n" % worst)
+
+
+def test_tiny_text_config1_on_gpu(golden_dir):
+    fx = _fx(golden_dir, "tiny_text.pt")
+    m = load_synth(build_retrieval(dict(fx["cfg"]), 50265, head_type="text"), fx["shapes"]).to(DEV).to(torch.bfloat16).eval()
+    tok = fx["inputs"]["src_tokens"].to(DEV)
+    report = []
+    with torch.no_grad():
+        out_h = m(src_tokens=tok, encoder_type="text")
+        _force_torch_path(m, True)
+        out_t = m(src_tokens=tok, encoder_type="text")
+    _check("tiny text logits", out_h, out_t, fx["text_logits"], 1.5e-2, report)
+    cos = torch.nn.functional.cosine_similarity(out_h.float().cpu(), fx["text_logits"], dim=1)
+    assert float(cos.min()) > 0.9995
+
+
+def test_fused_layer_with_padding_and_drop_path():
+    """One 4B-aspect layer (hd=64, H=256) incl. key padding, per-sample drop-path and all gradients, vs the oracle."""
+    from one_peace_amd import ops
+    from one_peace_amd.relpos import RelPosSpec, make_token_bucket_position, add_cls_buckets
+    from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    import one_peace_amd.transformer.transformer_layer as TL
+    cfg = one_peace_encoder_config(embed_dim=256, ffn_embed_dim=512, layers=1, attention_heads=4, drop_path_rate=0.0)
+    torch.manual_seed(0)
+    layer = TransformerEncoderLayer(cfg, drop_path_rate=0.3)
+    shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
+    sd = synth.synth_state_dict(shapes)
+    layer.load_state_dict(sd)
+    layer = layer.to(DEV).to(torch.bfloat16).train()
+    B, S, H, heads = 5, 70, 256, 4
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, S, H, generator=g).to(torch.bfloat16).float()
+    table = (0.5 * torch.randn(2 * 32 - 1 + 3, heads, generator=g)).to(torch.bfloat16).float()
+    bucket = add_cls_buckets(make_token_bucket_position(32, 1024), 2 * 32 - 1)[:S, :S]
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[1, 60:] = True
+    pad[3, 33:] = True
+    ps1 = torch.tensor([1 / 0.7, 0.0, 1 / 0.7, 1 / 0.7, 0.0])
+    ps2 = torch.tensor([0.0, 1 / 0.7, 1 / 0.7, 0.0, 1 / 0.7])
+    dy = torch.randn(B, S, H, generator=g).to(torch.bfloat16).float()
+    # ---- oracle (fp32) ----
+    sdo = {"L." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    tab_o = table.clone().requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    bias = O.rel_pos_bias(tab_o, bucket).unsqueeze(0).expand(B, -1, -1, -1)
+    bias = bias.masked_fill(pad.view(B, 1, 1, S), float("-inf"))
+    # two different drop-path draws: oracle.encoder_layer takes one; apply through a small wrapper
+    import oracle.onepeace_oracle as OO
+    calls = {"n": 0}
+    orig = OO.residual_scale
+
+    def rs(xb, gamma, res, path_scale=None):
+        calls["n"] += 1
+        return orig(xb, gamma, res, ps1 if calls["n"] == 1 else ps2)
+    OO.residual_scale = rs
+    try:
+        yo = O.encoder_layer(xo.transpose(0, 1), sdo, "L", heads, "text", bias).transpose(0, 1)
+    finally:
+        OO.residual_scale = orig
+    (yo * dy).sum().backward()
+    # ---- HIP ----
+    seq = iter([ps1.to(DEV), ps2.to(DEV)])
+    orig_sample = TL.sample_path_scale
+    TL.sample_path_scale = lambda b, p, tr, dev: next(seq)
+    try:
+        xd = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        tab_d = table.to(DEV).to(torch.bfloat16).requires_grad_(True)
+        spec = RelPosSpec(tab_d, bucket.to(DEV))
+        key_pad = torch.ones(B, __import__("one_peace_amd").hip.attn_spad(S), dtype=torch.uint8, device=DEV)
+        key_pad[:, :S] = pad.to(torch.uint8).to(DEV)
+        yd = layer.forward_fused(xd, spec.handle(), key_pad, "text")
+        (yd.float() * dy.to(DEV)).sum().backward()
+    finally:
+        TL.sample_path_scale = orig_sample
+    torch.cuda.synchronize()
+    assert rel_fro(yd.float(), yo) < 6e-3
+    assert rel_fro(xd.grad.float(), xo.grad) < 2e-2
+    assert rel_fro(tab_d.grad.float(), tab_o.grad) < 3e-2
+    named = dict(layer.named_parameters())
+    for k, v in sdo.items():
+        n = k[2:]
+        if v.grad is None or n not in named or named[n].grad is None:
+            continue
+        e = rel_fro(named[n].grad.float(), v.grad)
+        assert e < 3e-2, (n, e)

@@ -1,0 +1,122 @@
+"""Data-parallel pieces of the pretraining step, MI355X-first (one process per GPU, RCCL over xGMI via
+``torch.distributed``'s "nccl" backend).
+
+What the reference does: ``LegacyDistributedDataParallel`` packs gradients into a flat buffer after
+backward, divides by the world size and all-reduces ~15 sequential 512 MiB buckets, not overlapped with backward
+(fairseq/distributed/legacy_distributed_data_parallel.py:76-165).  Here parameters and gradients LIVE in flat bf16
+buffers (no pack/unpack), buckets are contiguous slices that are all-reduced asynchronously as soon as autograd has
+finished the last parameter of the bucket (post-accumulate-grad hooks -> overlap with the rest of backward), and the
+1/world division is folded into the fused AdamW kernel."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """torchrun-style env:// initialisation; returns (rank, world, local_rank).  No-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FlatParameters:
+    """Re-homes a module's parameters (and their .grad) into two flat buffers of the parameter dtype.
+
+    Parameters are laid out in REVERSE registration order (roughly the order backward finishes them), each start
+    aligned to 8 elements (16 bytes for bf16) so the vector kernels can run over any sub-range; ``no_decay`` names go
+    to the tail so weight decay is a contiguous range."""
+
+    ALIGN = 8
+
+    def __init__(self, module, no_decay=lambda name, p: p.dim() <= 1):
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        named.reverse()
+        decay = [(n, p) for n, p in named if not no_decay(n, p)]
+        nodecay = [(n, p) for n, p in named if no_decay(n, p)]
+        self.entries = []
+        off = 0
+        for group, items in (("decay", decay), ("no_decay", nodecay)):
+            start = off
+            for n, p in items:
+                self.entries.append((n, p, off, p.numel()))
+                off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            setattr(self, group + "_range", (start, off))
+        self.numel = off
+        p0 = named[0][1]
+        self.params = torch.zeros(off, dtype=p0.dtype, device=p0.device)
+        self.grads = torch.zeros(off, dtype=p0.dtype, device=p0.device)
+        with torch.no_grad():
+            for n, p, o, k in self.entries:
+                self.params[o:o + k].copy_(p.detach().reshape(-1))
+                p.data = self.params[o:o + k].view(p.shape)
+                p.grad = self.grads[o:o + k].view(p.shape)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+
+class BucketedGradReducer:
+    """Asynchronous SUM all-reduce of contiguous gradient buckets, each launched when its last gradient is final."""
+
+    def __init__(self, flat: FlatParameters, bucket_bytes=256 << 20, process_group=None):
+        self.flat, self.pg = flat, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        cap = max(1, bucket_bytes // flat.grads.element_size())
+        self.buckets = []  # (start, end, [param indices])
+        cur_start, cur_items = 0, []
+        for idx, (n, p, o, k) in enumerate(flat.entries):
+            cur_items.append(idx)
+            end = o + (k + flat.ALIGN - 1) // flat.ALIGN * flat.ALIGN
+            if end - cur_start >= cap:
+                self.buckets.append((cur_start, end, cur_items))
+                cur_start, cur_items = end, []
+        if cur_items:
+            self.buckets.append((cur_start, flat.numel, cur_items))
+        self._bucket_of = {}
+        for b, (_, _, items) in enumerate(self.buckets):
+            for idx in items:
+                self._bucket_of[idx] = b
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        self._hooks = []
+        if self.world > 1:
+            for idx, (n, p, o, k) in enumerate(flat.entries):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+        self.reset()
+
+    def _make_hook(self, idx):
+        def hook(param):
+            b = self._bucket_of[idx]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                s, e, _ = self.buckets[b]
+                self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        return hook
+
+    def reset(self):
+        """Call before each backward."""
+        self._pending = [len(items) for (_, _, items) in self.buckets]
+        self._handles = []
+
+    def finish(self):
+        """Waits for the launched buckets and reduces any bucket whose hooks did not all fire (unused parameters)."""
+        if self.world <= 1:
+            return
+        for b, left in enumerate(self._pending):
+            if left > 0:
+                s, e, _ = self.buckets[b]
+                self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        for h in self._handles:
+            h.wait()
+        self._handles = []

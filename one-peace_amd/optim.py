@@ -1,0 +1,34 @@
+"""Fused AdamW over flat bf16 parameters.
+
+Update rule = the reference's in-repo ``Adam`` (one_peace/optim/adam.py:186-253; what runs when apex is absent):
+fp32 moments, fp32 math on bf16 parameters (the ``MemoryEfficientFP16Optimizer`` arrangement: no fp32 master copy),
+decoupled weight decay applied before the Adam update, eps added to sqrt(v).  One HIP launch per decay group over the
+flat buffers of ``distributed.FlatParameters``: 22 bytes/parameter of HBM traffic per step."""
+import torch
+
+from . import hip, ops
+from .distributed import FlatParameters
+
+
+class FusedAdamW:
+    def __init__(self, flat: FlatParameters, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05):
+        if not flat.params.is_cuda or flat.params.dtype != torch.bfloat16:
+            raise RuntimeError("FusedAdamW needs bf16 parameters on an MI355X (the HIP path has no CPU fallback)")
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros(flat.numel, dtype=torch.float32, device=flat.params.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.step_count = 0
+
+    def step(self, grad_scale=1.0):
+        """grad_scale multiplies the gradient inside the kernel (1/world_size after a SUM all-reduce, clip factor...)."""
+        self.step_count += 1
+        f = self.flat
+        for (s, e), wd in ((f.decay_range, self.weight_decay), (f.no_decay_range, 0.0)):
+            if e > s:
+                hip.adamw_step(f.params[s:e], f.grads[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.lr, self.betas[0],
+                               self.betas[1], self.eps, wd, self.step_count, grad_scale)
+        ops.invalidate_weight_cache()
+
+    def zero_grad(self):
+        self.flat.zero_grad()

@@ -43,11 +43,12 @@ class _Dict:
         return 1
 
 
-def build_model(layers, device):
+def build_model(layers, device, recompute=False):
     from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
     from one_peace_amd.unify_model_config import one_peace_encoder_config
     enc = one_peace_encoder_config(embed_dim=H, ffn_embed_dim=FFN, layers=layers, attention_heads=HEADS,
-                                   drop_path_rate=0.4, layer_scale_init_value=1e-6, audio_bucket_size=512)
+                                   drop_path_rate=0.4, layer_scale_init_value=1e-6, audio_bucket_size=512,
+                                   checkpoint_activations=recompute)
     cfg = SimpleNamespace(encoder=enc, copy_rel_pos_table=False)
     with torch.device(device):
         model = OnePeaceRetrievalModel(cfg, _Dict(), "val")
@@ -78,7 +79,7 @@ def cpu_baseline(seconds_budget=20.0):
     extrapolated x40 layers to tri-modal samples/s (adapters and the contrastive head are < 5 % and left out)."""
     from oracle import onepeace_oracle as O
     torch.manual_seed(0)
-    ncores = os.cpu_count() or 1
+    ncores = min(os.cpu_count() or 1, 32)  # more threads than this only adds fork/join overhead at these sizes
     torch.set_num_threads(ncores)
     p = "L"
     sd = {}
@@ -110,12 +111,13 @@ def cpu_baseline(seconds_budget=20.0):
         x = torch.randn(S, b, H, requires_grad=True)
         bias = torch.zeros(b, HEADS, S, S)
         times = []
-        for it in range(3):
+        for it in range(4):  # first pass = warm-up (allocator, thread pool), not timed
             t0 = time.time()
             y = O.encoder_layer(x, sd, p, HEADS, m, bias)
             y.sum().backward()
-            times.append(time.time() - t0)
-            if time.time() - t_start > seconds_budget:
+            if it > 0:
+                times.append(time.time() - t0)
+            if it > 0 and time.time() - t_start > seconds_budget:
                 break
         t = min(times)
         detail[m] = t / b
@@ -123,7 +125,7 @@ def cpu_baseline(seconds_budget=20.0):
     sps = 1.0 / (LAYERS * per_sample)
     return {"value": sps, "unit": "samples/s", "cores": ncores, "kind": "port",
             "sample": "oracle (fp32 torch-CPU restatement of the reference) 1 encoder layer fwd+bwd at H=1536/F=6144, "
-                      "b=2, text S=64 + image S=257 + audio S=250, best of <=3; EXTRAPOLATED x40 layers "
+                      "b=2, text S=64 + image S=257 + audio S=250, best of <=3 after a warm-up pass; EXTRAPOLATED x40 layers "
                       "(per-layer s/sample: %s)" % json.dumps({k: round(v, 4) for k, v in detail.items()})}
 
 
@@ -135,6 +137,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU tri-modal tuples")
     ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the reported metric needs 40")
     ap.add_argument("--audio-seconds", type=float, default=5.0)
+    ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -153,7 +156,7 @@ def main():
     torch.cuda.set_device(device)
     torch.manual_seed(3407 + rank)
 
-    model = build_model(args.layers, device)
+    model = build_model(args.layers, device, args.recompute)
     nparams = sum(p.numel() for p in model.parameters())
     no_decay_names = model.no_weight_decay()
     flat = FlatParameters(model, no_decay=lambda n, p: p.dim() <= 1 or n in no_decay_names)
@@ -214,7 +217,8 @@ def main():
                        "embed_dim": H, "ffn": FFN, "layers": args.layers, "heads": HEADS, "params": nparams,
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "tokens_per_sample": S_img + S_txt + audio_S, "parallelism": "dp%d" % world,
-                       "activation_recompute": "per layer (as the reference's checkpoint_activations: true)",
+                       "activation_recompute": ("per layer (the reference's checkpoint_activations: true)" if args.recompute
+                                                else "off: layer activations are kept in HBM (288 GB/GPU)"),
                        "algorithmic_tflop_per_sample": fl / 1e12,
                        "step_algorithmic_tflops_per_gpu": fl * args.batch / (ms / 1e3) / 1e12, "final_loss": loss_v},
         }

@@ -2,9 +2,10 @@
 
 Each ``torch.autograd.Function`` here is what the host-side mirrors of the reference modules call when their
 input is a bf16 tensor on an MI355X.  Forward and backward enqueue HIP kernels on the current stream; PyTorch
-only owns the memory.  The encoder layer is ONE function (``EncoderLayerFn``): it keeps the layer input and
-recomputes the layer's intermediates in backward, i.e. the behaviour of the reference's
-``checkpoint_activations: true`` (pretrain_vl_3B.yaml:93, one_peace_pretrain.py:78-96) is built in.
+only owns the memory.  The encoder layer is ONE function (``EncoderLayerFn``).  With ``save_acts=False`` it keeps only
+the layer input and recomputes the intermediates in backward -- the reference's ``checkpoint_activations: true``
+(pretrain_vl_3B.yaml:93, one_peace_pretrain.py:78-96); with ``save_acts=True`` (``checkpoint_activations: false``) it
+keeps them, which 288 GB of HBM affords even for the 4B model at batch 64.
 """
 import math
 import weakref
@@ -27,17 +28,26 @@ def invalidate_weight_cache():
 
 
 def _transposed(ws):
-    """[sum(out_i), in] -> cached bf16 [in, sum(out_i)] (ws: one weight or a tuple that is concatenated on dim 0)."""
+    """[sum(out_i), in] -> cached bf16 [in, sum(out_i)] (ws: one weight or a tuple that is concatenated on dim 0).
+
+    Entries are keyed by the identity of the parameter objects and validated through weak references (a freed
+    parameter's address can be handed to a different tensor by the allocator) plus (_version, epoch)."""
     ws = ws if isinstance(ws, (tuple, list)) else (ws,)
-    key = tuple(w.data_ptr() for w in ws)
-    ver = (tuple(w._version for w in ws), _cache_epoch)
+    key = tuple(id(w) for w in ws)
+    ver = (tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws), _cache_epoch)
     hit = _wt_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)):
+        if hit[1] == ver:
+            return hit[2]
+        out = hit[2]
+    else:
+        out = None
+        if len(_wt_cache) > 4096:  # drop entries of parameters that no longer exist
+            for k in [k for k, v in _wt_cache.items() if any(r() is None for r in v[0])]:
+                del _wt_cache[k]
     src = ws[0] if len(ws) == 1 else torch.cat([w.detach() for w in ws], dim=0)
-    out = hit[1] if hit is not None else None
     t = hip.transpose(src.detach(), out)
-    _wt_cache[key] = (ver, t)
+    _wt_cache[key] = (tuple(weakref.ref(w) for w in ws), ver, t)
     return t
 
 
@@ -260,29 +270,43 @@ class EncoderLayerFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, bias_image, bias, key_pad, ps1, ps2, heads, *params):
+    def forward(ctx, x, bias_image, bias, key_pad, ps1, ps2, heads, save_acts, *params):
         # bias_image (= bias.image) is passed as a tensor only to put the bias table into the autograd graph
         B, S, H = x.shape
         P = dict(zip(LAYER_PARAMS, params))
         x2 = x.reshape(B * S, H)
         scale = (H // heads) ** -0.5
         bias_img = bias.image.detach() if bias is not None else None
-        out, _ = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=False)
-        ctx.save_for_backward(x2, key_pad, ps1, ps2, *params)
+        need_grad = any(ctx.needs_input_grad)
+        keep = bool(save_acts) and need_grad
+        out, acts = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=keep)
         ctx.bias = bias
         ctx.dims = (B, S, H, heads, scale)
+        ctx.n_params = len(params)
+        if keep:  # 288 GB of HBM: keep the layer's intermediates instead of recomputing them in backward
+            ctx.act_names = [k for k, v in acts.items() if v is not None]
+            ctx.save_for_backward(x2, key_pad, ps1, ps2, *params, *[acts[k] for k in ctx.act_names])
+        else:
+            ctx.act_names = None
+            ctx.save_for_backward(x2, key_pad, ps1, ps2, *params)
         return out.view(B, S, H)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, key_pad, ps1, ps2, *params = ctx.saved_tensors
+        x2, key_pad, ps1, ps2, *rest = ctx.saved_tensors
+        params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
         B, S, H, heads, scale = ctx.dims
         P = dict(zip(LAYER_PARAMS, params))
         bias = ctx.bias
         bias_img = bias.image.detach() if bias is not None else None
         biasT = bias.imageT if bias is not None else None
         want_dbias = bias is not None and bias.image.requires_grad
-        _, A = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=True)
+        if ctx.act_names is not None:
+            A = dict(zip(ctx.act_names, saved_acts))
+            for k in ("mean_a", "rstd_a", "mean_f", "rstd_f"):
+                A.setdefault(k, None)
+        else:  # recompute (the reference's checkpoint_activations behaviour)
+            _, A = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=True)
         N = B * S
         Fd = P["w0"].shape[0]
         dout2 = dout.reshape(N, H)
@@ -337,7 +361,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dimg = None
         if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
             dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
-        return (dx.view(B, S, H), dimg, None, None, None, None, None, *grads)
+        return (dx.view(B, S, H), dimg, None, None, None, None, None, None, *grads)
 
 
 def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc):
@@ -357,8 +381,9 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
     return dqkv, dbias_acc
 
 
-def encoder_layer(x, bias, key_pad, ps1, ps2, heads, params):
-    return EncoderLayerFn.apply(x, bias.image if bias is not None else None, bias, key_pad, ps1, ps2, heads, *params)
+def encoder_layer(x, bias, key_pad, ps1, ps2, heads, params, save_acts=False):
+    return EncoderLayerFn.apply(x, bias.image if bias is not None else None, bias, key_pad, ps1, ps2, heads, save_acts,
+                                *params)
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -113,7 +113,8 @@ class TransformerEncoderLayer(nn.Module):
         ps1 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
         ps2 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
         return ops.encoder_layer(x_bsh, bias_handle, key_pad_u8, ps1, ps2, self.self_attn.num_heads,
-                                 self.fused_params(encoder_type))
+                                 self.fused_params(encoder_type),
+                                 save_acts=not getattr(self.cfg, "checkpoint_activations", False))
 
     def upgrade_state_dict_named(self, state_dict, name):
         """Legacy key renames + fill-in of missing keys (reference transformer_layer.py:230-248)."""

@@ -112,14 +112,17 @@ def test_tiny_text_config1_on_gpu(golden_dir):
     assert float(cos.min()) > 0.9995
 
 
-def test_fused_layer_with_padding_and_drop_path():
-    """One 4B-aspect layer (hd=64, H=256) incl. key padding, per-sample drop-path and all gradients, vs the oracle."""
+@pytest.mark.parametrize("recompute", [False, True])
+def test_fused_layer_with_padding_and_drop_path(recompute):
+    """One 4B-aspect layer (hd=64, H=256) incl. key padding, per-sample drop-path and all gradients, vs the oracle;
+    both activation policies (kept in HBM / recomputed in backward)."""
     from one_peace_amd import ops
     from one_peace_amd.relpos import RelPosSpec, make_token_bucket_position, add_cls_buckets
     from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
     from one_peace_amd.unify_model_config import one_peace_encoder_config
     import one_peace_amd.transformer.transformer_layer as TL
-    cfg = one_peace_encoder_config(embed_dim=256, ffn_embed_dim=512, layers=1, attention_heads=4, drop_path_rate=0.0)
+    cfg = one_peace_encoder_config(embed_dim=256, ffn_embed_dim=512, layers=1, attention_heads=4, drop_path_rate=0.0,
+                                   checkpoint_activations=recompute)
     torch.manual_seed(0)
     layer = TransformerEncoderLayer(cfg, drop_path_rate=0.3)
     shapes = {k: tuple(v.shape) for k, v in layer.state_dict().items()}

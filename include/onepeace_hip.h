@@ -1,0 +1,139 @@
+/* onepeace_hip.h -- C ABI of libonepeace_hip.so: the ONE-PEACE hot path as hand-written HIP for MI355X (gfx950).
+ *
+ * The reference (OFA-Sys/ONE-PEACE @ 2024-10-08) has no FFI of its own: its "operator API" is three import-time seams
+ * in Python.  This header is the boundary a binding for those seams talks to; every entry point
+ * names the reference code it replaces (file:line relative to the reference tree).  The Python binding that ships
+ * here is one-peace_amd/hip.py (ctypes); INTEGRATION.md shows the reference-side stubs.
+ *
+ * Contract (all functions):
+ *   - plain pointers + sizes, no framework types.  Pointers are DEVICE pointers unless stated otherwise.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates, frees or keeps a
+ *     pointer past the call.
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no internal synchronisation.
+ *     Stateless and re-entrant: safe from the Python main thread, autograd's backward thread and recompute.
+ *   - return 0 on success, a negative errno-style code (-22 EINVAL, -95 ENOTSUP) or a positive hipError_t otherwise;
+ *     never throws, never aborts.  op_last_error() gives the thread-local message.
+ *   - dtype codes: 0 = bf16, 1 = f32.  Matrices are row-major; `ld*` are row strides in ELEMENTS.
+ */
+#ifndef ONEPEACE_HIP_H
+#define ONEPEACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ------------------------------------------------------------------------------------------------ */
+int op_abi_version(void);
+const char* op_last_error(void);
+
+/* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
+ * family 0 = GEMM (work = flops), 1 = attention forward, 2 = attention backward.  HOST pointers. */
+int op_prof_enable(int on);
+int op_prof_collect(double* ms, int64_t* count, double* work, int n_families);
+
+/* ---- LayerNorm (+ optional fused exact-erf GELU) ---------------------------------------------------------------
+ * Replaces one_peace/models/components.py:23-26,47-52 (torch.nn.LayerNorm / flash_attn layer_norm seam) for
+ * self_attn_layer_norm, self_attn.ln (sub-LN), final_layer_norm, the FFN LN(F) (transformer_layer.py:154), the
+ * per-modality final norms (transformer_encoder.py:201-220), and with act_gelu=1 the LayerNorm->GELU pairs of the
+ * stems (adapter/image.py:66-75, adapter/audio.py:293-301).  x,y [rows, cols] contiguous; w,b [cols] or NULL;
+ * mean,rstd fp32 [rows] (NULL = not wanted).  cols % 8 == 0, cols <= 8192. */
+int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
+                     int64_t cols, float eps, int act_gelu, int dtype, void* stream);
+int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+/* dx = LN backward (+ `add`: gradient arriving through the residual path, may be NULL, may alias dx);
+ * dw, db [cols] optional (need `workspace`); accumulate != 0 adds into dw/db. */
+int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
+                     const void* add, void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
+                     int act_gelu, int accumulate, int dtype, void* stream);
+
+/* ---- bf16 MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  with fused epilogues ---------------------------------------------
+ * Replaces: q/k/v/out projections (multihead_attention.py:63-66,103-105,124; up to three weight segments of n_seg rows
+ * per launch, k_proj has no bias), GeGLU (transformer_layer.py:54-67), Linear(F->H) (:156), fused_dropout_res
+ * (transformer_layer.py:70-88), the similarity matmuls of the contrastive head (image_text_pretrain_loss.py:171-172),
+ * text/image/audio_proj (one_peace_retrieval.py:110-121) and the hMLP patch convolutions (adapter/image.py:66-75).
+ * epilogue 0: C(bf16) = acc + bias
+ *          1: C(f32)  = alpha[0] * acc + bias             (alpha: device scalar or NULL)
+ *          2: GeGLU:  C(bf16)[M,N] = gelu(A W0^T) * (A W1^T); B0 = wi_0, B1 = wi_1 ([N,K] each); h0/h1 (optional, both
+ *             or none) receive the two pre-activations for the backward pass
+ *          3: C(bf16) = resid + rowscale[m / rows_per_sample] * gamma[n] * (acc + bias[n]); gamma/rowscale NULL = 1;
+ *             resid may alias C; h0 (optional) receives acc + bias.
+ * K % 64 == 0, N % 8 == 0, lda/ldb % 8 == 0 (host pads otherwise: one-peace_amd/ops.py gemm_any). */
+int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
+               const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
+               const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
+               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* stream);
+/* 1 = LDS-DMA (global_load_lds) operand staging [default], 0 = register-staged variant.  Returns the old value. */
+int op_gemm_set_staging(int glds);
+
+/* ---- attention ---------------------------------------------------------------------------------------------------
+ * Replaces multihead_attention.py:102-115 (bmm QK^T, += attn_mask, fp32 softmax, bmm PV) and the xformers seam
+ * :79-101, plus the dense-bias assembly of transformer_encoder.py:144-162: bias is the per-table image
+ * [heads][S][Spad] from op_relpos_bias_build, key padding a byte mask [B][Spad] (non-zero = masked key).
+ * q,k,v: bf16 rows of `ld` elements, row = b*S + s, head h at columns [h*64, h*64+64) (a packed [B*S, 3H] projection
+ * output serves all three).  out [B*S][ldo]; lse fp32 [B][heads][lse_ld] (natural log) or NULL.  head_dim == 64.
+ * Spad >= S rounded up to 128 when bias/key_pad/backward are used. */
+int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, const void* key_pad, void* out,
+                int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad, int64_t heads,
+                int64_t head_dim, float scale, void* stream);
+/* delta[b][h][q] = sum_d dout*out (fp32, row stride Spad) */
+int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,
+                      int64_t heads, void* stream);
+/* autograd of the above (reference: torch autograd through the bmm/softmax ops).  biasT = bias with rows = key.
+ * dq/dk/dv rows have stride ldg; dbias fp32 [heads][S][Spad] (optional, accumulated into: pre-zero it). */
+int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
+                const void* biasT, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
+                void* stream);
+
+/* ---- relative-position bias tables -------------------------------------------------------------------------------
+ * Replaces get_rel_pos_bias of adapter/image.py:164-171, adapter/text.py:76-83, adapter/audio.py:117-124:
+ * out[h][i][j] = table[bucket[i][j]][h] (bf16 [heads][S][Spad], columns >= S zero); transposed != 0 -> out[h][j][i]. */
+int op_relpos_bias_build(const void* table, const int* bucket, int64_t bucket_ld, void* out, int64_t heads, int64_t S,
+                         int64_t Spad, int transposed, void* stream);
+/* dtable[bucket[i][j]][h] += dbias[h][i][j]  (fp32; dtable pre-zeroed by the caller) */
+int op_relpos_bias_bwd(const float* dbias, const int* bucket, int64_t bucket_ld, float* dtable, int64_t heads, int64_t S,
+                       int64_t Spad, void* stream);
+
+/* ---- HBM-bound helpers of the layer backward -----------------------------------------------------------------------
+ * (the reference gets these from autograd over transformer_layer.py:54-88,149-157) */
+int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream);
+int64_t op_colsum_workspace_bytes(int64_t N);
+/* out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_m rowscale[m/rps] * x[m][n] * (y ? y[m][n] : 1); y/rowscale/mul NULL ok */
+int op_colsum(const void* x, const void* y, const float* rowscale, int64_t rows_per_sample, const void* mul, void* out,
+              void* workspace, int64_t M, int64_t N, int accumulate, int out_dtype, void* stream);
+/* GeGLU backward: dh0 = dg*h1*gelu'(h0), dh1 = dg*gelu(h0) */
+int op_geglu_bwd(const void* dg, const void* h0, const void* h1, void* dh0, void* dh1, int64_t numel, void* stream);
+/* dbranch[m][n] = rowscale[m/rps] * gamma[n] * dout[m][n]  (backward of fused_dropout_res wrt the branch) */
+int op_scale_rows(const void* dout, const void* gamma, const float* rowscale, int64_t rows_per_sample, void* dbranch,
+                  int64_t M, int64_t N, void* stream);
+
+/* ---- contrastive head ----------------------------------------------------------------------------------------------
+ * F.normalize(x, dim=1) of one_peace_retrieval.py:112,116,120 / one_peace_pretrain.py:165-173. */
+int op_l2norm_fwd(const void* x, void* y, float* inv_norm, int64_t rows, int64_t cols, float eps, int out_dtype, void* stream);
+int op_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int64_t cols, int y_dtype,
+                  void* stream);
+/* compute_itc_loss / compute_atc_loss + adjust_label_smoothed_nll_loss (image_text_pretrain_loss.py:17-27,164-185;
+ * audio_text_pretrain_loss.py:160-181): per row of sim [rows][n] (fp32): fp32 log-softmax, NLL at target0+row with the
+ * reference's eps/(n-1) smoothing, argmax hit, <dsim, sim>; sim is overwritten by gscale * dloss_row/dsim. */
+int op_infonce_rows(float* sim, int64_t rows, int64_t n, int64_t ld, int64_t target0, float label_smoothing, float gscale,
+                    float* row_loss, float* row_hit, float* row_dot, int write_grad, void* stream);
+
+/* ---- optimiser -------------------------------------------------------------------------------------------------------
+ * One AdamW update over a flat bf16 parameter range, the rule of one_peace/optim/adam.py:186-253 (what the reference
+ * runs without apex): fp32 moments, decoupled decay before the update, eps added to sqrt(v).  g is multiplied by
+ * grad_scale inside the kernel (1/world after a SUM all-reduce).  numel % 8 == 0, step >= 1. */
+int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* ---- hardware-semantics probes (test infrastructure; tests/test_probes_gpu.py) --------------------------------------- */
+int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream);
+int op_probe_mfma32(const void* a, const void* b, float* d, int n, void* stream);
+int op_probe_tr16(const void* img, const int* addr, void* out, int n, void* stream);
+int op_probe_glds(const void* src, const int* src_off, int lds_base, void* dump, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ONEPEACE_HIP_H */

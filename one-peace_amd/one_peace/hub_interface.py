@@ -1,0 +1,142 @@
+"""Mirror of the feature-extraction surface of one_peace/models/one_peace/hub_interface.py:
+``from_pretrained(...) -> OnePeaceHubInterface`` with ``extract_{text,image,audio,vl}_features`` (:206-225) and the dtype
+cast of :107-122.  Raw-data pre-processing (BPE, CLIP resize, 16 kHz layer-normed waveforms, :134-193) stays with the
+reference's Python (PIL / torchvision / librosa are not part of the hot path); the ``process_*`` methods here accept
+already-tokenised / already-decoded tensors and do the collation only."""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from ..unify_model_config import one_peace_encoder_config
+from .one_peace_retrieval import OnePeaceRetrievalModel
+
+_DTYPES = {"float32": torch.float32, "fp32": torch.float32, "fp16": torch.float16, "float16": torch.float16,
+           "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+class _Dictionary:
+    def __init__(self, n=50265, pad=1, bos=0, eos=2):
+        self.n, self._pad, self._bos, self._eos = n, pad, bos, eos
+
+    def __len__(self):
+        return self.n
+
+    def pad(self):
+        return self._pad
+
+    def bos(self):
+        return self._bos
+
+    def eos(self):
+        return self._eos
+
+
+def _cfg_get(tree, key, default=None):
+    if isinstance(tree, dict):
+        return tree.get(key, default)
+    return getattr(tree, key, default)
+
+
+def build_from_checkpoint_cfg(model_cfg, head_type="vl", patch_image_size=256, vocab_size=50265):
+    """Build the retrieval model from the `cfg.model` tree of a reference checkpoint (dict / namespace / omegaconf)."""
+    enc = _cfg_get(model_cfg, "encoder")
+    kw = {}
+    for k in ("embed_dim", "ffn_embed_dim", "layers", "attention_heads", "drop_path_rate", "layer_scale_init_value"):
+        v = _cfg_get(enc, k)
+        if v is not None:
+            kw[k] = v
+    cfg_enc = one_peace_encoder_config(**kw)
+    for k in ("magneto_scale_attn", "scale_attn", "scale_fc", "scale_heads", "use_layer_scale", "checkpoint_activations"):
+        v = _cfg_get(enc, k)
+        if v is not None:
+            setattr(cfg_enc, k, v)
+    for adapter in ("text_adapter", "image_adapter", "audio_adapter"):
+        sub = _cfg_get(enc, adapter)
+        if sub is not None:
+            tgt = getattr(cfg_enc, adapter)
+            for f in vars(tgt):
+                v = _cfg_get(sub, f)
+                if v is not None:
+                    setattr(tgt, f, v)
+    cfg_enc.image_adapter.rel_bucket_size = patch_image_size // 16
+    cfg = SimpleNamespace(encoder=cfg_enc, copy_rel_pos_table=bool(_cfg_get(model_cfg, "copy_rel_pos_table", False)))
+    return OnePeaceRetrievalModel(cfg, _Dictionary(vocab_size), head_type)
+
+
+def from_pretrained(model_name_or_path, model_type="one_peace_retrieval", device="cuda", dtype="float32",
+                    download_root=None, head_type="vl", patch_image_size=256):
+    """hub_interface.py:53-73.  `model_name_or_path` must be a local checkpoint file ({"cfg": {"model": ...}, "model":
+    state_dict}); downloading by name needs network access and the reference's URL table."""
+    ckpt = torch.load(model_name_or_path, map_location="cpu", weights_only=False)
+    model_cfg = _cfg_get(_cfg_get(ckpt, "cfg"), "model")
+    model = build_from_checkpoint_cfg(model_cfg, head_type=head_type, patch_image_size=patch_image_size)
+    model.load_state_dict(ckpt["model"], strict=True)
+    return OnePeaceHubInterface(model, device=device, dtype=dtype)
+
+
+class OnePeaceHubInterface:
+    def __init__(self, model, device="cuda", dtype="float32"):
+        self.model = model.to(device).eval()
+        self.device = device
+        self.dtype = _DTYPES[dtype]
+        self.dict = model.src_dict
+        if self.dtype != torch.float32:  # hub_interface.py:107-114
+            self.model.to(self.dtype)
+        self.model.logit_scale.data = self.model.logit_scale.data.float() if False else self.model.logit_scale.data
+
+    def cast_data_dtype(self, t):
+        return t.to(self.dtype) if t.is_floating_point() else t
+
+    # ---- collation of already pre-processed inputs -------------------------------------------------------------
+    def process_text(self, token_id_lists):
+        """list of 1-D LongTensors (BPE ids incl. EOS) -> right-padded [B, T] batch (collate_tokens semantics)."""
+        T = max(len(t) for t in token_id_lists)
+        out = torch.full((len(token_id_lists), T), self.dict.pad(), dtype=torch.long)
+        for i, t in enumerate(token_id_lists):
+            out[i, : len(t)] = t
+        return out.to(self.device)
+
+    def process_image(self, images):
+        return self.cast_data_dtype(torch.as_tensor(images).to(self.device))
+
+    def process_audio(self, wav_list):
+        """list of 1-D float waveforms @16 kHz -> (src_audios [B, T], audio_padding_masks [B, frames+1])."""
+        T = max(len(w) for w in wav_list)
+        wavs = torch.zeros(len(wav_list), T)
+        pad = torch.zeros(len(wav_list), T, dtype=torch.bool)
+        for i, w in enumerate(wav_list):
+            w = torch.as_tensor(w, dtype=torch.float32)
+            w = F.layer_norm(w, w.shape)  # hub_interface.py:176-178 normalises each waveform
+            wavs[i, : len(w)] = w
+            pad[i, len(w):] = True
+        frames = T
+        for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+            frames = (frames - k) // s + 1
+        lens = (~pad).sum(1)
+        for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
+            lens = torch.div(lens - k, s, rounding_mode="floor") + 1
+        mask = torch.arange(frames).unsqueeze(0) >= lens.unsqueeze(1)
+        mask = torch.cat([mask.new_zeros(len(wav_list), 1), mask], dim=1)
+        return self.cast_data_dtype(wavs.to(self.device)), mask.to(self.device)
+
+    # ---- hub_interface.py:206-225 ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def extract_text_features(self, src_tokens):
+        return self.model(src_tokens=src_tokens, encoder_type="text")
+
+    @torch.no_grad()
+    def extract_image_features(self, src_images):
+        return self.model(src_images=self.cast_data_dtype(src_images), encoder_type="image")
+
+    @torch.no_grad()
+    def extract_audio_features(self, src_audios, audio_padding_masks):
+        return self.model(src_audios=self.cast_data_dtype(src_audios), audio_padding_masks=audio_padding_masks,
+                          encoder_type="audio")
+
+    @torch.no_grad()
+    def extract_vl_features(self, src_images, src_tokens):
+        tf, imf, _ = self.model.encoder_wrapper(src_tokens=src_tokens, src_images=self.cast_data_dtype(src_images),
+                                                encoder_type="vl")
+        return tf[:, 0, :]

@@ -1,0 +1,74 @@
+"""World-size-2 checks of the data-parallel path on CPU (gloo): fused all-gather ordering / target offsets of the
+contrastive criteria and the bucketed gradient all-reduce, against single-process computations on the full batch
+(reference semantics: image_text_pretrain_loss.py:30-39,164-185; legacy_distributed_data_parallel.py:76-165)."""
+import os
+import sys
+import tempfile
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    try:
+        from one_peace_amd.criterions.contrastive import contrastive_pair_loss, gather_without_grad
+        from one_peace_amd.distributed import BucketedGradReducer, FlatParameters
+        from oracle import onepeace_oracle as O
+        torch.manual_seed(0)
+        b, Hd = 3, 16
+        full_a = torch.nn.functional.normalize(torch.randn(world * b, Hd), dim=1)
+        full_t = torch.nn.functional.normalize(torch.randn(world * b, Hd), dim=1)
+        a = full_a[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        t = full_t[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        t_all, a_all = gather_without_grad(t, a)
+        assert torch.equal(t_all, full_t) and torch.equal(a_all, full_a), "rank-major gather order"
+        assert not t_all.requires_grad
+        scale = torch.tensor(10.0)
+        loss, a_ok, t_ok = contrastive_pair_loss(a, t, a_all, t_all, scale, 0.1)
+        ref, ra, rt = O.itc_loss(full_a[rank * b:(rank + 1) * b], full_t[rank * b:(rank + 1) * b], full_a, full_t, scale,
+                                 rank=rank, label_smoothing=0.1)
+        assert torch.allclose(loss, ref, atol=1e-6) and a_ok == ra and t_ok == rt
+        loss.backward()
+        assert a.grad is not None and t.grad is not None
+
+        # bucketed all-reduce == mean of per-rank grads (LegacyDDP: divide by world, then SUM)
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        ref_state = {k: v.clone() for k, v in net.state_dict().items()}
+        flat = FlatParameters(net)
+        red = BucketedGradReducer(flat, bucket_bytes=64)  # tiny buckets -> several collectives
+        assert len(red.buckets) > 1
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+        red.reset()
+        net(x).pow(2).sum().backward()
+        red.finish()
+        mine = flat.grads.clone() / world
+        torch.save({"avg": mine}, os.path.join(outdir, "r%d.pt" % rank))
+        net2 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        net2.load_state_dict(ref_state)
+        per_rank = []
+        for r in range(world):
+            net2.zero_grad()
+            xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + r))
+            net2(xr).pow(2).sum().backward()
+            per_rank.append({n: p.grad.clone() for n, p in net2.named_parameters()})
+        for (n, p, o, k) in flat.entries:
+            want = O.dp_mean_grads([g[n] for g in per_rank])
+            assert torch.allclose(mine[o:o + k].view(p.shape), want, atol=1e-6), n
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_world2_gather_loss_and_grad_allreduce():
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_worker, args=(world, initfile, d), nprocs=world, join=True)
+        r0, r1 = torch.load(os.path.join(d, "r0.pt")), torch.load(os.path.join(d, "r1.pt"))
+        assert torch.equal(r0["avg"], r1["avg"]), "ranks disagree after the all-reduce"

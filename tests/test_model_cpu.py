@@ -118,3 +118,20 @@ def test_pretrain_model_contrastive_branch_and_registry():
     ids = torch.tensor([[0, 1, 3, 5, -1], [0, 2, 4, -1, -1]])
     dt, di, da = m(src_tokens=tok, text_preserve_ids=ids, encoder_type="text")
     assert dt.shape == (2, 10, 128) and di is None and da is None
+
+
+def test_hub_interface_from_pretrained_roundtrip(golden_dir, tmp_path):
+    """from_pretrained / extract_text_features (BASELINE config 1 surface) on a checkpoint in the reference's format."""
+    from one_peace_amd.one_peace import hub_interface
+    fx = _fx(golden_dir, "tiny_text.pt")
+    m = load_synth(build_retrieval(dict(fx["cfg"]), 50265, head_type="text"), fx["shapes"])
+    ckpt = {"cfg": {"model": {"encoder": {"embed_dim": 256, "ffn_embed_dim": 1024, "layers": 4, "attention_heads": 4,
+                                          "drop_path_rate": 0.0, "layer_scale_init_value": 1e-2}}},
+            "model": m.state_dict()}
+    path = tmp_path / "tiny.pt"
+    torch.save(ckpt, path)
+    hub = hub_interface.from_pretrained(str(path), device="cpu", dtype="float32", head_type="text")
+    toks = hub.process_text([row[row != 1] for row in fx["inputs"]["src_tokens"]])
+    assert torch.equal(toks.cpu(), fx["inputs"]["src_tokens"])
+    out = hub.extract_text_features(toks)
+    assert torch.allclose(out, fx["text_logits"], atol=ATOL, rtol=1e-4)

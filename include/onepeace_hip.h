@@ -59,13 +59,20 @@ int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b
  *             or none) receive the two pre-activations for the backward pass
  *          3: C(bf16) = resid + rowscale[m / rows_per_sample] * gamma[n] * (acc + bias[n]); gamma/rowscale NULL = 1;
  *             resid may alias C; h0 (optional) receives acc + bias.
- * K % 64 == 0, N % 8 == 0, lda/ldb % 8 == 0 (host pads otherwise: one-peace_amd/ops.py gemm_any). */
+ * K % 64 == 0, N % 8 == 0, lda/ldb % 8 == 0 (host pads otherwise: one-peace_amd/ops.py gemm_any).
+ * workspace (optional fp32 scratch): lets the launch planner split K over several workgroups for bias-free epilogue-0
+ * launches with few output tiles and a long K (weight gradients); tile size (128^2 / 256^2) and the split are chosen
+ * from a wave-quantisation model. */
 int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
                const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
-               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* stream);
+               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
+               void* stream);
 /* 1 = LDS-DMA (global_load_lds) operand staging [default], 0 = register-staged variant.  Returns the old value. */
 int op_gemm_set_staging(int glds);
+/* 0 = auto (256x256 four-stage kernel when it yields >= 192 workgroups, else 128x128), 1 = force 128x128,
+ * 2 = force 256x256.  Returns the old value. */
+int op_gemm_set_tile(int mode);
 
 /* ---- attention ---------------------------------------------------------------------------------------------------
  * Replaces multihead_attention.py:102-115 (bmm QK^T, += attn_mask, fp32 softmax, bmm PV) and the xformers seam

@@ -39,6 +39,8 @@ struct GemmArgs {
   const float* alpha;
   int M, N, K;
   int tiles_m, tiles_n;
+  int kt_per_split;   // K-tiles handled by one workgroup (split-K along blockIdx.y); 0 = all
+  int64_t slab;       // elements between split-K output slabs
 };
 
 constexpr int BM = 128, BK = 64;
@@ -60,8 +62,143 @@ __device__ __forceinline__ int w_row_to_col(int p) {
   return (p & ~63) + (i >> 2) * 16 + ((p >> 4) & 3) * 4 + (i & 3);
 }
 
+// Shared epilogue.  Lane (g, t) holds, for mi = 0..MI-1, output row m = mrow0 + mi*16 + t and 16 contiguous columns
+// nbase + g*16 .. +15 (acc[ni][mi][r] <-> column ni*4 + r); GeGLU: 8 columns fbase + g*8 .. +7 with
+// acc[nl][mi][r] = h0, acc[2+nl][mi][r] = h1 of column nl*4 + r.
+template <int EPI, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32x4 (&acc)[4][MI], int mrow0, int nbase,
+                                              int fbase, int g, int t) {
+  if (EPI == EPI_GEGLU) {
+    const int f0 = fbase + g * 8;  // 8 contiguous f:  acc[nl][mi][r] = h0, acc[2+nl][mi][r] = h1, f = f0 + nl*4 + r
+    if (f0 >= p.N) return;
+    bf16_t* G = (bf16_t*)Cout;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = mrow0 + mi * 16 + t;
+      if (m >= p.M) continue;
+      float go[8], h0[8], h1[8];
+#pragma unroll
+      for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = acc[nl][mi][r], b = acc[2 + nl][mi][r];
+          h0[nl * 4 + r] = a;
+          h1[nl * 4 + r] = b;
+          go[nl * 4 + r] = gelu_erf(a) * b;
+        }
+      Vec8<bf16_t>::store(G + (int64_t)m * p.ldc + f0, go);
+      if (p.H0) {
+        Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + f0, h0);
+        Vec8<bf16_t>::store(p.H1 + (int64_t)m * p.ldc + f0, h1);
+      }
+    }
+    return;
+  }
+
+  const int nc0 = nbase + g * 16;
+  if (nc0 >= p.N) return;
+  float bv[16];
+  {
+    const int seg = nc0 / p.n_seg;
+    const bf16_t* bp = p.bias[seg];
+    if (bp) {
+      float tmp[8];
+      Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg), tmp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = tmp[j];
+      if (nc0 + 8 < p.N) {
+        Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg) + 8, tmp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[8 + j] = tmp[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[8 + j] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+    }
+  }
+  const bool second = nc0 + 8 < p.N;
+  float alpha = 1.f;
+  if (EPI == EPI_F32 && p.alpha) alpha = *p.alpha;
+  float gv[16];
+  if (EPI == EPI_RESID) {
+    if (p.gamma) {
+      float tmp[8];
+      Vec8<bf16_t>::load(p.gamma + nc0, tmp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = tmp[j];
+      if (second) {
+        Vec8<bf16_t>::load(p.gamma + nc0 + 8, tmp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[8 + j] = tmp[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) gv[j] = 1.f;
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = mrow0 + mi * 16 + t;
+    if (m >= p.M) continue;
+    float o[16];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[ni * 4 + r] = acc[ni][mi][r];
+    if (EPI == EPI_BIAS) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] += bv[j];
+    } else if (EPI == EPI_F32) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = alpha * o[j] + bv[j];
+    } else if (EPI == EPI_RESID) {
+      float rs = 1.f;
+      if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
+      float rv[16];
+      float tmp[8];
+      Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0, tmp);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rv[j] = tmp[j];
+      if (second) {
+        Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0 + 8, tmp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[8 + j] = tmp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] += bv[j];
+      if (p.H0) {  // branch output y (pre layer-scale), needed by the backward pass for d gamma
+        float lo[8], hi[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
+        Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0, lo);
+        if (second) Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0 + 8, hi);
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = rv[j] + rs * gv[j] * o[j];
+    }
+    if (EPI == EPI_F32) {
+      float* C = (float*)Cout + (int64_t)m * p.ldc + nc0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q >= 2 && !second) break;
+        *reinterpret_cast<f32x4*>(C + q * 4) = (f32x4){o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
+      }
+    } else {
+      bf16_t* C = (bf16_t*)Cout + (int64_t)m * p.ldc + nc0;
+      float lo[8], hi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
+      Vec8<bf16_t>::store(C, lo);
+      if (second) Vec8<bf16_t>::store(C + 8, hi);
+    }
+  }
+}
+
 template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -119,7 +256,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) rdX[mi] = (wm * 64 + mi * 16 + t) * 128;
 
-  const int nk = p.K / BK;
+  int nk = p.K / BK;
+  void* Cout = p.C;
+  if (p.kt_per_split > 0) {  // split-K: this workgroup owns K-tiles [z*kps, min(nk, (z+1)*kps)) and its own output slab
+    const int kt0 = blockIdx.y * p.kt_per_split;
+    nk = min(nk - kt0, p.kt_per_split);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { srcA[i] += (int64_t)kt0 * BK; srcB[i] += (int64_t)kt0 * BK; }
+    Cout = (float*)p.C + (int64_t)blockIdx.y * p.slab;
+  }
   u32x4 ra[4], rb[4];
 
   auto stage_glds = [&](int buf) {
@@ -195,140 +340,228 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
   }
 
-  // ---- epilogue: lane (g, t) holds, for mi = 0..3, row m = m0 + wm*64 + mi*16 + t and ------------------
-  //      columns ncol0 .. ncol0+15 (acc[ni][mi][r] <-> column ncol0 + ni*4 + r)                     ------
+  gemm_epilogue<EPI, 4>(p, Cout, acc, m0 + wm * 64, n0 + wn * 64, n0 + wn * 32, g, t);
+}
+
+// =====================================================================================================================
+// 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave = 4 x 8 accumulators), BK = 32, FOUR LDS stages of 32 KiB
+// (A 256x32 + B 256x32), LDS-DMA staging three stages ahead with a COUNTED vmcnt and a raw s_barrier, so loads stay
+// in flight across barriers (one barrier per 32 MFMAs per wave).  Twice the flops per byte pulled from L2 of the 128^2
+// kernel.  Operand rows are 64 bytes: the 16-byte slot index is XOR-ed with (row&1) | ((row>>2)&1)<<1, which makes the
+// ds_read_b128 fragment reads bank-conflict free under the gfx950 bank model (MI355X_MICROARCH.md, LDS section).
+// =====================================================================================================================
+constexpr int BM2 = 256, BK2 = 32, STAGES2 = 4;
+constexpr int OPER2_BYTES = BM2 * BK2 * 2;      // 16 KiB per operand per stage
+constexpr int STAGE2_BYTES = 2 * OPER2_BYTES;   // 32 KiB
+
+__device__ __forceinline__ int swz64(int row) { return (row & 1) | (((row >> 2) & 1) << 1); }
+
+template <int EPI>
+__device__ __forceinline__ int w_row_to_col256(int p) {
+  const int i = p & 15;
   if (EPI == EPI_GEGLU) {
-    const int f0 = n0 + wn * 32 + g * 8;  // 8 contiguous f:  acc[nl][mi][r] = h0, acc[2+nl][mi][r] = h1, f = f0 + nl*4 + r
-    if (f0 >= p.N) return;
-    bf16_t* G = (bf16_t*)p.C;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int m = m0 + wm * 64 + mi * 16 + t;
-      if (m >= p.M) continue;
-      float go[8], h0[8], h1[8];
-#pragma unroll
-      for (int nl = 0; nl < 2; ++nl)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float a = acc[nl][mi][r], b = acc[2 + nl][mi][r];
-          h0[nl * 4 + r] = a;
-          h1[nl * 4 + r] = b;
-          go[nl * 4 + r] = gelu_erf(a) * b;
-        }
-      Vec8<bf16_t>::store(G + (int64_t)m * p.ldc + f0, go);
-      if (p.H0) {
-        Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + f0, h0);
-        Vec8<bf16_t>::store(p.H1 + (int64_t)m * p.ldc + f0, h1);
-      }
-    }
-    return;
+    const int pp = p & 127;  // rows 0..127 <- W0, 128..255 <- W1
+    return (pp >> 5) * 32 + (i >> 2) * 8 + ((pp >> 4) & 1) * 4 + (i & 3);
+  }
+  return (p & ~63) + (i >> 2) * 16 + ((p >> 4) & 3) * 4 + (i & 3);
+}
+
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]); the builtin form keeps
+// the compiler's own scoreboard in sync, so it does not add conservative waits of its own around ours.
+#define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+#define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 0xF) | ((((n) >> 4) & 3) << 14))
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int g = lane >> 4, t = lane & 15;
+  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GM = 4;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM2, n0 = pid_n * BN_OUT;
+
+  int nk = p.K / BK2;
+  int kt0 = 0;
+  void* Cout = p.C;
+  if (p.kt_per_split > 0) {  // split-K: K-stages [z*kps, min(nk, (z+1)*kps)), own fp32 output slab
+    kt0 = blockIdx.y * p.kt_per_split;
+    nk = min(nk - kt0, p.kt_per_split);
+    Cout = (float*)p.C + (int64_t)blockIdx.y * p.slab;
   }
 
-  const int nc0 = n0 + wn * 64 + g * 16;
-  if (nc0 >= p.N) return;
-  float bv[16];
+  // ---- staging: wave-uniform base pointers + 32-bit per-lane byte offsets (2 x 16 bytes of A and of B per stage) ----
+  // slot q = i*512 + tid covers LDS row q>>2, 16-byte slot q&3; i = 0 -> rows 0..127, i = 1 -> rows 128..255.
+  const char* baseA = (const char*)(p.A + (int64_t)kt0 * BK2);
+  const char* baseB[2];
+  unsigned offA[2], offB[2];
   {
-    const int seg = nc0 / p.n_seg;
-    const bf16_t* bp = p.bias[seg];
-    if (bp) {
-      float tmp[8];
-      Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg), tmp);
+    const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;  // a 256-wide tile never straddles segments (n_seg % 256 == 0)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = tmp[j];
-      if (nc0 + 8 < p.N) {
-        Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg) + 8, tmp);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bv[8 + j] = tmp[j];
+    for (int i = 0; i < 2; ++i) {
+      const int q = i * 512 + tid;
+      const int row = q >> 2, pc = q & 3;
+      const int c = pc ^ swz64(row);
+      const int gm = min(m0 + row, p.M - 1);
+      offA[i] = (unsigned)(((int64_t)gm * p.lda + c * 8) * 2);
+      int gn = min(n0 + w_row_to_col256<EPI>(row), p.N - 1);
+      const bf16_t* wb;
+      if (EPI == EPI_GEGLU) {
+        wb = i == 0 ? p.B[0] : p.B[1];
       } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bv[8 + j] = 0.f;
+        wb = p.B[seg];
+        gn -= seg * p.n_seg;
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) bv[j] = 0.f;
+      baseB[i] = (const char*)(wb + (int64_t)kt0 * BK2);
+      offB[i] = (unsigned)(((int64_t)gn * p.ldb + c * 8) * 2);
     }
   }
-  const bool second = nc0 + 8 < p.N;
-  float alpha = 1.f;
-  if (EPI == EPI_F32 && p.alpha) alpha = *p.alpha;
-  float gv[16];
-  if (EPI == EPI_RESID) {
-    if (p.gamma) {
-      float tmp[8];
-      Vec8<bf16_t>::load(p.gamma + nc0, tmp);
+
+  f32x4 acc[4][8];  // [ni][mi]
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[j] = tmp[j];
-      if (second) {
-        Vec8<bf16_t>::load(p.gamma + nc0 + 8, tmp);
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gv[8 + j] = tmp[j];
-      }
-    } else {
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: every fragment row is (multiple of 16) + t, so the swizzle term only depends on the lane
+  const int fsw = (g ^ swz64(t)) << 4;
+  const int baseX = (wm * 128 + t) * 64 + fsw;                                              // + mi * 1024
+  const int baseW = OPER2_BYTES + ((EPI == EPI_GEGLU) ? (wn * 32 + t) : (wn * 64 + t)) * 64 + fsw;  // + per-ni constant
+
+  auto issue = [&](int slot) {
+    char* la = smem + slot * STAGE2_BYTES;
+    char* lb = la + OPER2_BYTES;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) gv[j] = 1.f;
+    for (int i = 0; i < 2; ++i) {
+      const int wbase = (i * 512 + wid * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                       (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
+                                       (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
     }
+    baseA += BK2 * 2;
+    baseB[0] += BK2 * 2;
+    baseB[1] += BK2 * 2;
+  };
+  auto wait_landed = [&](int younger) {  // `younger` = stages issued after the one we need (4 LDS-DMA ops each)
+    if (younger >= 3) WAIT_VM(12);
+    else if (younger == 2) WAIT_VM(8);
+    else if (younger == 1) WAIT_VM(4);
+    else WAIT_VM(0);
+  };
+  auto read_frags = [&](int kt, bf16x8 (&wf)[4], bf16x8 (&xf)[8]) {
+    const char* st = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int o = (EPI == EPI_GEGLU) ? ((ni >> 1) * 128 + (ni & 1) * 16) * 64 : ni * 16 * 64;
+      wf[ni] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(st + baseX + mi * 1024);
+  };
+  auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[8]) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+  };
+  // One pipeline step.  Four LDS stages are in flight; the fragments of stage kt+1 are read into the OTHER register set
+  // while the 32 MFMAs of stage kt run.  Order: own LDS reads retired -> stage kt+1 landed (counted vmcnt) -> ONE
+  // barrier (stage kt+1 visible to all waves AND every wave holds stage kt in registers, so slot kt&3 is free) ->
+  // {refill of that slot with stage kt+4, fragment reads of kt+1, MFMAs of kt} as ONE interleaved instruction stream:
+  // both waves of a SIMD leave the barrier together, so any load-issue phase ahead of the MFMAs would idle the matrix
+  // pipe; sched_group_barrier spreads the 16 memory instructions between the 32 MFMAs (1 per 2) instead.
+  auto step_steady = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
+    WAIT_LGKM0();
+    WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;  // fragments of the next stage
+    char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;              // slot being refilled with stage kt+4
+    char* lb = la + OPER2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {  // 16 groups of {2 MFMA, 1 memory instruction}, order pinned
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int idx = 2 * j + h, mi = idx >> 2, ni = idx & 3;
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
+      }
+      if (j < 4) {
+        const int o = (EPI == EPI_GEGLU) ? ((j >> 1) * 128 + (j & 1) * 16) * 64 : j * 16 * 64;
+        nxt_w[j] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
+      } else if (j < 12) {
+        nxt_x[j - 4] = *reinterpret_cast<const bf16x8*>(st + baseX + (j - 4) * 1024);
+      } else {
+        const int i = (j - 12) >> 1;
+        const int wbase = (i * 512 + wid * 64) * 16;
+        if ((j & 1) == 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                           (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
+                                           (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    baseA += BK2 * 2;
+    baseB[0] += BK2 * 2;
+    baseB[1] += BK2 * 2;
+  };
+  auto step_tail = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
+    const bool has_next = kt + 1 < nk;
+    WAIT_LGKM0();
+    if (has_next) wait_landed(min(nk - 2 - kt, STAGES2 - 2));
+    __builtin_amdgcn_s_barrier();
+    if (has_next) read_frags(kt + 1, nxt_w, nxt_x);
+    mma(cur_w, cur_x);
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES2; ++s0)
+    if (s0 < nk) issue(s0);
+  bf16x8 wfA[4], xfA[8], wfB[4], xfB[8];
+  wait_landed(min(nk - 1, STAGES2 - 1));
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, wfA, xfA);
+  int kt = 0;
+  for (; kt + STAGES2 + 1 < nk; kt += 2) {  // steady state: stages kt+4 and kt+5 still to be issued (nk is even)
+    step_steady(kt, wfA, xfA, wfB, xfB);
+    step_steady(kt + 1, wfB, xfB, wfA, xfA);
   }
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int m = m0 + wm * 64 + mi * 16 + t;
-    if (m >= p.M) continue;
-    float o[16];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[ni * 4 + r] = acc[ni][mi][r];
-    if (EPI == EPI_BIAS) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] += bv[j];
-    } else if (EPI == EPI_F32) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] = alpha * o[j] + bv[j];
-    } else if (EPI == EPI_RESID) {
-      float rs = 1.f;
-      if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
-      float rv[16];
-      float tmp[8];
-      Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0, tmp);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rv[j] = tmp[j];
-      if (second) {
-        Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0 + 8, tmp);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rv[8 + j] = tmp[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] += bv[j];
-      if (p.H0) {  // branch output y (pre layer-scale), needed by the backward pass for d gamma
-        float lo[8], hi[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
-        Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0, lo);
-        if (second) Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0 + 8, hi);
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] = rv[j] + rs * gv[j] * o[j];
-    }
-    if (EPI == EPI_F32) {
-      float* C = (float*)p.C + (int64_t)m * p.ldc + nc0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q >= 2 && !second) break;
-        *reinterpret_cast<f32x4*>(C + q * 4) = (f32x4){o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
-      }
-    } else {
-      bf16_t* C = (bf16_t*)p.C + (int64_t)m * p.ldc + nc0;
-      float lo[8], hi[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
-      Vec8<bf16_t>::store(C, lo);
-      if (second) Vec8<bf16_t>::store(C + 8, hi);
-    }
+  for (; kt < nk; kt += 2) {  // last (up to) four stages: nothing left to prefetch
+    step_tail(kt, wfA, xfA, wfB, xfB);
+    step_tail(kt + 1, wfB, xfB, wfA, xfA);
   }
+  gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, n0 + wn * 32, g, t);
 }
 
 template <int EPI>
-int launch(const GemmArgs& a, int glds, hipStream_t s) {
-  const int grid = a.tiles_m * a.tiles_n;
+int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
+  const dim3 grid(a.tiles_m * a.tiles_n, splits);
+  const size_t sh = STAGES2 * STAGE2_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) { op_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), sh, s, a);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, int glds, hipStream_t s, int splits = 1) {
+  const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = 4 * TILE_BYTES;
   static bool attr_set[2] = {false, false};
   if (!attr_set[glds ? 1 : 0]) {
@@ -340,14 +573,65 @@ int launch(const GemmArgs& a, int glds, hipStream_t s) {
     attr_set[glds ? 1 : 0] = true;
   }
   if (glds)
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), dim3(grid), dim3(256), sh, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), sh, s, a);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), dim3(grid), dim3(256), sh, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), sh, s, a);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
 
+
+// out[m][n] (bf16) = sum_z slab_z[m][n] (fp32); 8 elements per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t slab,
+                                                            bf16_t* __restrict__ out, int64_t ldc, int M, int N) {
+  const int n8 = N / 8;
+  const int64_t total = (int64_t)M * n8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / n8;
+    const int c = (int)(i - m * n8) * 8;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < splits; ++z) {
+      float v[8];
+      Vec8<float>::load(ws + z * slab + m * N + c, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+    Vec8<bf16_t>::store(out + m * ldc + c, a);
+  }
+}
+
+// Launch plan: tile size and split-K factor from a wave-quantisation model.  One "round" fills every workgroup slot
+// once (128x128: 2 per CU = 512, 256x256: 1 per CU = 256); relative slot-round costs are calibrated on MI355X
+// micro-benchmarks (128x128 ~ 900 TF/s, 256x256 ~ 1040 TF/s sustained).
+struct GemmPlan { int tile; int splits; int kt_per_split; };
+
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256, bool allow_split, int64_t ws_bytes) {
+  const double c128 = 2.0 * 128 * 128 / 900.0, c256 = 256.0 * 256 / 1040.0;  // time of one slot-round per unit K
+  const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(N, epilogue == EPI_GEGLU ? 64 : 128);
+  const int64_t t256 = (int64_t)ceil_div(M, 256) * ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
+  GemmPlan best = {128, 1, 0};
+  double best_t = 1e300;
+  for (int tile = 128; tile <= 256; tile += 128) {
+    if (tile == 256 && !allow_256) continue;
+    const int bk = tile == 128 ? BK : BK2;
+    const int nk = (int)(K / bk);
+    for (int s = 1; s <= 8; ++s) {
+      if (s > 1 && (!allow_split || (int64_t)s * M * N * 4 > ws_bytes || nk / s < 8)) break;
+      int kps = ceil_div(nk, s);
+      kps += kps & 1;  // the 256x256 kernel consumes K-stages in pairs
+      const int eff_s = ceil_div(nk, kps);
+      const int64_t blocks = (tile == 128 ? t128 : t256) * eff_s;
+      const int64_t rounds = tile == 128 ? (blocks + 511) / 512 : (blocks + 255) / 256;
+      double t = (double)rounds * (tile == 128 ? c128 : c256) * kps * bk;
+      if (eff_s > 1) t += (double)eff_s * M * N * 8.0 / 4.0e3 + 1.0e4;  // slab write + read at ~4 TB/s + one extra launch, in the same units (0.512 ns)
+      if (t < best_t) { best_t = t; best = {tile, eff_s, eff_s > 1 ? kps : 0}; }
+    }
+  }
+  return best;
+}
+
 int g_default_glds = 1;
+int g_tile_mode = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
 
 }  // namespace
 
@@ -355,6 +639,13 @@ extern "C" int op_prof_begin(int family, double work, void* stream);
 extern "C" void op_prof_end(int slot, void* stream);
 
 extern "C" {
+
+// 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
+int op_gemm_set_tile(int mode) {
+  int old = g_tile_mode;
+  g_tile_mode = mode;
+  return old;
+}
 
 // 1 = LDS-DMA staging (default), 0 = register-staged fallback.  Returns the previous value.
 int op_gemm_set_staging(int glds) {
@@ -369,13 +660,16 @@ int op_gemm_set_staging(int glds) {
 //   GeGLU: C = gelu(h0)*h1, optional h0/h1 [M,N] bf16 (same ldc) for the backward pass.
 //   residual: C = resid + rowscale[m / rows_per_sample] * gamma[n] * (acc + bias[n]); gamma, rowscale nullable;
 //             resid may alias C (in-place accumulate); h0 (optional) receives y = acc + bias.
+//   workspace (optional, fp32 scratch of workspace_bytes): enables split-K for bias-free epilogue-0 launches with few
+//   output tiles and a long K (the weight-gradient GEMMs).
 int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
                const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
-               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* stream) {
+               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
+               void* stream) {
   OP_CHECK_ARG(A && B0 && C, "gemm_nt: null A/B/C");
   OP_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
-  OP_CHECK_ARG(K % BK == 0, "gemm_nt: K=%lld must be a multiple of %d (pad on the host)", (long long)K, BK);
+  OP_CHECK_ARG(K % BK == 0, "gemm_nt: K=%lld must be a multiple of %d (pad on the host)", (long long)K, BK);  // => even number of 32-deep stages
   OP_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: N, lda, ldb must be multiples of 8");
   OP_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "gemm_nt: bad epilogue %d", epilogue);
   if (M == 0) return OP_OK;
@@ -406,13 +700,49 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
   if (epilogue == EPI_RESID) OP_CHECK_ARG(resid, "gemm_nt: residual epilogue needs resid");
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)M * (double)N * (double)K * (epilogue == EPI_GEGLU ? 2.0 : 1.0);
+  const bool seg_ok = epilogue == EPI_GEGLU || a.n_seg >= (int)N || a.n_seg % 256 == 0;
+  const bool off32_ok = (M * lda < ((int64_t)1 << 30)) && (N * ldb < ((int64_t)1 << 30));
+  const bool allow_256 = g_tile_mode != 1 && g_default_glds && seg_ok && off32_ok;
+  const bool allow_split = epilogue == EPI_BIAS && !bias0 && workspace != nullptr && N % 8 == 0;
+  GemmPlan plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, workspace_bytes);
+  if (g_tile_mode == 2 && allow_256 && plan.tile != 256) plan = {256, 1, 0};
+  a.kt_per_split = plan.kt_per_split;
+  a.slab = (int64_t)M * N;
+  int epi = epilogue;
+  void* c_final = C;
+  const int64_t ldc_final = ldc;
+  if (plan.splits > 1) {  // partial sums go to fp32 slabs, folded by splitk_reduce_kernel
+    a.C = workspace;
+    a.ldc = N;
+    a.alpha = nullptr;
+    epi = EPI_F32;
+  }
   const int slot = op_prof_begin(0, flops, stream);
   int rc;
-  switch (epilogue) {
-    case EPI_BIAS: rc = launch<EPI_BIAS>(a, g_default_glds, s); break;
-    case EPI_F32: rc = launch<EPI_F32>(a, g_default_glds, s); break;
-    case EPI_GEGLU: rc = launch<EPI_GEGLU>(a, g_default_glds, s); break;
-    default: rc = launch<EPI_RESID>(a, g_default_glds, s); break;
+  if (plan.tile == 256) {
+    a.tiles_m = ceil_div(M, 256);
+    a.tiles_n = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
+    switch (epi) {
+      case EPI_BIAS: rc = launch256<EPI_BIAS>(a, s, plan.splits); break;
+      case EPI_F32: rc = launch256<EPI_F32>(a, s, plan.splits); break;
+      case EPI_GEGLU: rc = launch256<EPI_GEGLU>(a, s, plan.splits); break;
+      default: rc = launch256<EPI_RESID>(a, s, plan.splits); break;
+    }
+  } else {
+    switch (epi) {
+      case EPI_BIAS: rc = launch<EPI_BIAS>(a, g_default_glds, s, plan.splits); break;
+      case EPI_F32: rc = launch<EPI_F32>(a, g_default_glds, s, plan.splits); break;
+      case EPI_GEGLU: rc = launch<EPI_GEGLU>(a, g_default_glds, s, plan.splits); break;
+      default: rc = launch<EPI_RESID>(a, g_default_glds, s, plan.splits); break;
+    }
+  }
+  if (rc == OP_OK && plan.splits > 1) {
+    int64_t nb = ((int64_t)M * (N / 8) + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, s, (const float*)workspace, plan.splits, a.slab,
+                       (bf16_t*)c_final, ldc_final, (int)M, (int)N);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { op_set_error("gemm_nt: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
   }
   op_prof_end(slot, stream);
   return rc;

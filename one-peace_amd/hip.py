@@ -32,8 +32,9 @@ SIGNATURES = {
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
     "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
     "op_gemm_set_staging": (c_int, [c_int]),
+    "op_gemm_set_tile": (c_int, [c_int]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
-                           c_int, P]),
+                           c_int, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_colsum_workspace_bytes": (I64, [I64]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
@@ -157,8 +158,11 @@ def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None,
     return dx, dw, db
 
 
+SPLITK_WS_BYTES = 768 << 20
+
+
 def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h1=None, resid=None, gamma=None,
-            rowscale=None, rows_per_sample=0, alpha=None, N=None, ldc=None):
+            rowscale=None, rows_per_sample=0, alpha=None, N=None, ldc=None, splitk=True):
     """C[M,N] = A[M,K] @ cat(Bs)[N,K]^T with the fused epilogue.  Bs: list of 1-3 [n_seg,K] weights (GeGLU: [W0, W1])."""
     M, K = A.shape
     Bs = list(Bs) + [None] * (3 - len(Bs))
@@ -172,10 +176,14 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
     if out is None:
         out = torch.empty(M, Nn, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16, device=A.device)
     ldc_ = ldc if ldc is not None else out.stride(0)
+    ws, ws_bytes = None, 0
+    if splitk and epilogue == EPI_BIAS and biases[0] is None and K >= 2048:
+        ws = workspace(SPLITK_WS_BYTES, A.device, "gemm_splitk")
+        ws_bytes = ws.numel()
     _check(lib().op_gemm_nt(ptr(A), A.stride(0), ptr(Bs[0]), ptr(Bs[1]), ptr(Bs[2]), Bs[0].stride(0), n_seg,
                             ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), ptr(out), ldc_, ptr(h0), ptr(h1),
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
-                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, stream()), "op_gemm_nt")
+                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, stream()), "op_gemm_nt")
     return out
 
 

@@ -328,8 +328,13 @@ class EncoderLayerFn(torch.autograd.Function):
             dg = dgln
         dh0, dh1 = hip.geglu_bwd(dg, A["h0"], A["h1"])
         xln2T = _t_pad(A["xln2"])
-        G["w0"] = _wgrad(_t_pad(dh0), xln2T)
-        G["w1"] = _wgrad(_t_pad(dh1), xln2T)
+        dhT = torch.empty(2 * Fd, xln2T.shape[1], dtype=dh0.dtype, device=dh0.device)  # [dh0^T ; dh1^T] -> one GEMM
+        if xln2T.shape[1] != N:
+            dhT[:, N:].zero_()
+        hip.transpose(dh0, dhT[:Fd])
+        hip.transpose(dh1, dhT[Fd:])
+        dW01 = _wgrad(dhT, xln2T)
+        G["w0"], G["w1"] = dW01[:Fd], dW01[Fd:]
         dxln2 = hip.gemm_nt(dh0, [_transposed(P["w0"])])
         hip.gemm_nt(dh1, [_transposed(P["w1"])], out=dxln2, epilogue=hip.EPI_RESID, resid=dxln2)
         dx_mid, G["ln2_w"], G["ln2_b"] = hip.layernorm_bwd(dxln2, A["x_mid"], P["ln2_w"], P["ln2_b"], A["mean2"],

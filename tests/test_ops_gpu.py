@@ -62,9 +62,18 @@ def test_layernorm_fp32_no_affine():
 GEMM_SHAPES = [(128, 128, 64), (300, 384, 192), (1000, 1536, 256), (257, 136, 128), (64, 4608, 1536), (4099, 256, 1024)]
 
 
+@pytest.fixture(params=[1, 2], ids=["tile128", "tile256"])
+def tile_mode(request):
+    """Run every GEMM test on both tile configurations (auto-selection would pick 128x128 at these small sizes)."""
+    hip = hipmod()
+    old = hip.lib().op_gemm_set_tile(request.param)
+    yield request.param
+    hip.lib().op_gemm_set_tile(old)
+
+
 @pytest.mark.parametrize("glds", [1, 0])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_bias(M, N, K, glds):
+def test_gemm_bias(M, N, K, glds, tile_mode):
     hip = hipmod()
     hip.lib().op_gemm_set_staging(glds)
     try:
@@ -79,8 +88,20 @@ def test_gemm_bias(M, N, K, glds):
         hip.lib().op_gemm_set_staging(1)
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 1536, 8192), (384, 256, 16448 - 16448 % 64), (4608, 1536, 4096)])
+def test_gemm_split_k_weight_gradient_shapes(M, N, K, tile_mode):
+    """Few output tiles + long K: the planner splits K across workgroups (fp32 slabs + reduce)."""
+    hip = hipmod()
+    A, W = rnd(M, K, seed=1, scale=0.5), rnd(N, K, seed=2, scale=0.5)
+    ref = A @ W.t()
+    out = hip.gemm_nt(dev_bf16(A), [dev_bf16(W)])
+    assert_close(out, ref, what="split-k")
+    out1 = hip.gemm_nt(dev_bf16(A), [dev_bf16(W)], splitk=False)
+    assert_close(out1, ref, what="no split")
+
+
 @pytest.mark.parametrize("glds", [1, 0])
-def test_gemm_three_segments_qkv(glds):
+def test_gemm_three_segments_qkv(glds, tile_mode):
     hip = hipmod()
     hip.lib().op_gemm_set_staging(glds)
     try:
@@ -97,7 +118,7 @@ def test_gemm_three_segments_qkv(glds):
 
 @pytest.mark.parametrize("glds", [1, 0])
 @pytest.mark.parametrize("M,F_,K", [(200, 256, 128), (515, 1024, 256), (130, 6144, 1536)])
-def test_gemm_geglu(M, F_, K, glds):
+def test_gemm_geglu(M, F_, K, glds, tile_mode):
     hip = hipmod()
     hip.lib().op_gemm_set_staging(glds)
     try:
@@ -117,7 +138,7 @@ def test_gemm_geglu(M, F_, K, glds):
 
 
 @pytest.mark.parametrize("glds", [1, 0])
-def test_gemm_residual_epilogue(glds):
+def test_gemm_residual_epilogue(glds, tile_mode):
     hip = hipmod()
     hip.lib().op_gemm_set_staging(glds)
     try:

@@ -53,9 +53,10 @@ def main():
         res.append(r)
         print(json.dumps(r), flush=True)
 
-    for glds in (1, 0):
+    for glds, tile in ((1, 1), (1, 2), (0, 1)):
         hip.lib().op_gemm_set_staging(glds)
-        tag = "glds" if glds else "reg"
+        hip.lib().op_gemm_set_tile(tile)
+        tag = ("glds" if glds else "reg") + ("_t256" if tile == 2 else "_t128")
         out = torch.empty(M, 3 * H, **bf)
         rec("gemm_qkv_%s" % tag, timeit(lambda: hip.gemm_nt(x, wq, [bias, None, bias], out=out, n_seg=H, N=3 * H)),
             flops=2.0 * M * 3 * H * H)
@@ -67,6 +68,7 @@ def main():
             timeit(lambda: hip.gemm_nt(xf, [w2], [bias], out=outr, epilogue=hip.EPI_RESID, resid=x, gamma=gamma)),
             flops=2.0 * M * H * Fd)
     hip.lib().op_gemm_set_staging(1)
+    hip.lib().op_gemm_set_tile(0)
     # torch (hipBLASLt) reference point for the same GEMM
     wcat = torch.cat([w0, w1], 0)
     rec("torch_matmul_geglu_shape", timeit(lambda: torch.matmul(x, wcat.t())), flops=4.0 * M * Fd * H)

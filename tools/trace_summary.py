@@ -14,7 +14,10 @@ def main():
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            name = r["Kernel_Name"]
+            if "gemm" in name and "Grid_Size_X" in r:  # tell GEMM shapes apart by their launch geometry
+                name = "%s grid=%sx%s wg=%s" % (name[:70], r.get("Grid_Size_X"), r.get("Grid_Size_Y"), r.get("Workgroup_Size_X"))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
     adam = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
     if len(adam) < 2 * per_step:

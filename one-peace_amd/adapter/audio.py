@@ -2,14 +2,15 @@
 (7 x [conv -> LayerNorm over channels -> GELU]), LN + Linear to the model width, a convolutional positional
 encoder (5 x [grouped conv -> LayerNorm without affine -> GELU]), CLS token and 1-D relative-position tables.
 
-MI355X path: the convolutions go through torch's conv1d (MIOpen) for now, every
-LayerNorm(+GELU) pair is the fused HIP kernel on [B, T, C] rows, and the 512->H projection is the HIP GEMM."""
+MI355X path (``audio_ops.py``): the whole stem stays channels-last; every convolution is a HIP MFMA GEMM over strided
+views of the activation buffer (no im2col, no transposes, no MIOpen), every LayerNorm(+GELU) pair is the fused HIP
+kernel on [rows, C], and the 512->H projection is the HIP GEMM."""
 from typing import List, Tuple
 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import audio_ops, ops
 from ..components import Embedding, FairseqDropout, LayerNorm, Linear, trunc_normal_
 from ..relpos import RelPosSpec, add_cls_buckets, make_token_bucket_position
 from . import common
@@ -113,6 +114,24 @@ class AudioAdapter(nn.Module):
         b32 = self._buckets.get(self.rp_bucket, seq_len) if self.rp_bucket.is_cuda else None
         return [RelPosSpec(t.weight, b64, b32) for t in self.rel_pos_table_list]
 
+    def _hip_stem_ok(self, src_audios):
+        if not (ops.hip_eligible(src_audios) and hasattr(self, "embed_audios")):
+            return False
+        blocks = self.embed_audios[0].conv_layers
+        c0 = blocks[0][0]
+        ok = c0.kernel_size[0] == 10 and c0.stride[0] == 5 and c0.in_channels == 1
+        for blk in blocks[1:]:
+            c = blk[0]
+            ok = ok and c.stride[0] == 2 and c.kernel_size[0] in (2, 3) and c.bias is None and c.in_channels % 32 == 0
+        return ok and all(blk[1].p == 0.0 for blk in blocks)
+
+    def _frames(self, src_audios):
+        """embed_audios (adapter/audio.py:46-55): conv stack -> LayerNorm(512) -> Linear(512 -> H); [B, T, H]."""
+        if self._hip_stem_ok(src_audios):
+            feats = audio_ops.feature_extractor(src_audios, self.embed_audios[0].conv_layers)
+            return self.embed_audios[3](self.embed_audios[2](feats))
+        return self.embed_audios(src_audios)
+
     def _positions(self, frames):
         """Convolutional positional encoding of the frame embeddings [B, T, H] (adapter/audio.py:57-84)."""
         if self.abs_pos_type != "conv":
@@ -121,15 +140,20 @@ class AudioAdapter(nn.Module):
         x = frames
         if self.conv_pos_pre_ln:
             x, seq = seq[0](x), seq[1]
+        blocks = list(seq)[1:-1]
+        conv0 = blocks[0][0]
+        cg = conv0.in_channels // conv0.groups
+        if (ops.hip_eligible(x) and conv0.kernel_size[0] % 2 == 1 and cg % 8 == 0
+                and (conv0.kernel_size[0] + 1) * cg >= (conv0.kernel_size[0] * cg + 63) // 64 * 64):
+            for block in blocks:  # channels-last grouped-conv GEMMs + fused LN(no affine)+GELU
+                conv = block[0]
+                x = audio_ops.grouped_conv1d_same(x, conv.weight, conv.bias, conv.groups)
+                x = ops.layer_norm(x, None, None, block[3].eps, gelu=True)
+            return x
         x = x.transpose(1, 2)
-        for block in list(seq)[1:-1]:
+        for block in blocks:
             x = block[1](block[0](x))
-            xt = x.transpose(1, 2)
-            if ops.hip_eligible(xt) and xt.shape[-1] % 8 == 0:
-                xt = ops.layer_norm(xt, None, None, block[3].eps, gelu=True)
-            else:
-                xt = nn.functional.gelu(block[3](xt))
-            x = xt.transpose(1, 2)
+            x = nn.functional.gelu(block[3](x.transpose(1, 2))).transpose(1, 2)
         return x.transpose(1, 2)
 
     def forward(self, src_audios, padding_mask, preserve_ids=None, preserve_embed=None, mask_token=None):
@@ -140,7 +164,7 @@ class AudioAdapter(nn.Module):
             pos = self.embed_positions.weight[:n].unsqueeze(0).expand(bsz, -1, -1)
             emb = common.scatter_preserved(preserve_ids, preserve_embed, mask_token, bsz, n)
         else:
-            frames = self.embed_audios(src_audios)
+            frames = self._frames(src_audios)
             if preserve_ids is not None:
                 padding_mask = preserve_ids.eq(-1)
                 ids = preserve_ids.masked_fill(padding_mask, preserve_ids.size(1) - 1)

@@ -336,3 +336,65 @@ def test_attention_forward_backward(B, S, heads, use_bias, use_pad):
         assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
     if use_bias:
         assert_close(dbias[:, :, :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="dbias")
+
+
+def test_audio_stem_convs_match_conv1d():
+    """audio_ops: strided-view GEMM convolutions (feature extractor + grouped positional conv) vs F.conv1d, fwd + grads."""
+    from one_peace_amd import audio_ops
+    import torch.nn as nn
+    torch.manual_seed(0)
+    B = 3
+    # --- stride-2 convs, k = 3 and k = 2, channels-last flat rows with slack ---
+    for k in (3, 2):
+        Cin, Cout, slots = 64, 128, 40
+        xs = rnd(B, slots, Cin, seed=3 + k)
+        w = rnd(Cout, Cin, k, seed=5 + k, scale=(Cin * k) ** -0.5)
+        xr, wr = xs.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        # reference on each sample separately; valid outputs only
+        ref = F.conv1d(xr.transpose(1, 2), wr, stride=2).transpose(1, 2)  # [B, Tout, Cout]
+        Tout = ref.shape[1]
+        dyv = rnd(B, Tout, Cout, seed=9)
+        ref.backward(dyv)
+        xd = torch.cat([dev_bf16(xs).view(B * slots, Cin), torch.zeros(2, Cin, dtype=torch.bfloat16, device=DEV)]).requires_grad_(True)
+        wd = dev_bf16(w).requires_grad_(True)
+        y = audio_ops.StridedConv1dFn.apply(xd, wd)
+        yv = y[: B * slots // 2].view(B, slots // 2, Cout)[:, :Tout]
+        assert_close(yv, ref, what="strided conv k=%d" % k)
+        yv.backward(dev_bf16(dyv))
+        assert_close(xd.grad[: B * slots].view(B, slots, Cin), xr.grad, what="strided conv dx k=%d" % k)
+        assert_close(wd.grad, wr.grad, what="strided conv dw k=%d" % k)
+    # --- grouped same-padding conv ---
+    C, G, k, T = 128, 4, 19, 37
+    x = rnd(B, T, C, seed=11)
+    w = rnd(C, C // G, k, seed=12, scale=(C // G * k) ** -0.5)
+    b = rnd(C, seed=13)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv1d(xr.transpose(1, 2), wr, br, padding=k // 2, groups=G).transpose(1, 2)
+    dy = rnd(B, T, C, seed=14)
+    ref.backward(dy)
+    xd, wd, bd = (dev_bf16(t).requires_grad_(True) for t in (x, w, b))
+    y = audio_ops.grouped_conv1d_same(xd, wd, bd, G)
+    assert_close(y, ref, what="grouped conv")
+    y.backward(dev_bf16(dy))
+    assert_close(xd.grad, xr.grad, what="grouped conv dx")
+    assert_close(wd.grad, wr.grad, what="grouped conv dw")
+    assert_close(bd.grad, br.grad, what="grouped conv db")
+
+
+def test_audio_feature_extractor_matches_conv_stack():
+    """Whole 7-layer extractor (k10s5 + 4x k3s2 + 2x k2s2, LN+GELU each) through audio_ops vs the torch conv path."""
+    from one_peace_amd import audio_ops, ops
+    from one_peace_amd.adapter.audio import ConvFeatureExtractionModel
+    torch.manual_seed(0)
+    spec = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2
+    m = ConvFeatureExtractionModel(spec).to(DEV).to(torch.bfloat16)
+    wav = torch.randn(3, 4000, device=DEV).to(torch.bfloat16)
+    out = audio_ops.feature_extractor(wav, m.conv_layers)           # [B, T, C]
+    saved = ops.hip_eligible
+    ops.hip_eligible = lambda t: False
+    try:
+        ref = m(wav).transpose(1, 2)
+    finally:
+        ops.hip_eligible = saved
+    assert out.shape == ref.shape
+    assert_close(out, ref.float(), fro=3e-2, mx=8e-2, what="feature extractor (bf16 vs bf16, 7 layers)")

@@ -356,6 +356,15 @@ constexpr int STAGE2_BYTES = 2 * OPER2_BYTES;   // 32 KiB
 
 __device__ __forceinline__ int swz64(int row) { return (row & 1) | (((row >> 2) & 1) << 1); }
 
+__device__ __forceinline__ s16x4 tr_read16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+__device__ __forceinline__ bf16x8 join16(s16x4 a, s16x4 b) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 template <int EPI>
 __device__ __forceinline__ int w_row_to_col256(int p) {
   const int i = p & 15;
@@ -542,6 +551,199 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
     step_tail(kt + 1, wfB, xfB, wfA, xfA);
   }
   gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, n0 + wn * 32, g, t);
+}
+
+// =====================================================================================================================
+// TN variant of the 256x256 kernel:  C[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands stored K-major ([K, M] and
+// [K, N] row-major) -- the weight-gradient GEMM dW = dy^T x straight from the activation matrices, no transposed copies.
+// Same four-stage LDS-DMA pipeline and epilogue; operand tiles are [32 k][256] (512-byte rows) and the MFMA fragments
+// (8 consecutive k for one m / n) come from ds_read_b64_tr_b16: a 16-lane group reads a [4 k][16 cols] block and each lane
+// receives one column.  The column a lane receives is chosen through the addresses the provider lanes supply, which gives
+// the same "16 contiguous output columns per lane" accumulator layout as the NT kernel for free.
+// 16-byte slots are XOR-swizzled per k-row (different functions for the two operands: the m-operand reads are conflict
+// free, the n-operand reads are 2-way by construction).
+// =====================================================================================================================
+__device__ __forceinline__ int swzA_tn(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
+__device__ __forceinline__ int swzB_tn(int k) { return (k & 1) | (((k >> 1) & 1) << 3); }
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int g = lane >> 4, t = lane & 15;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GM = 4;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM2, n0 = pid_n * 256;
+
+  int nk = p.K / BK2;
+  int kt0 = 0;
+  void* Cout = p.C;
+  if (p.kt_per_split > 0) {
+    kt0 = blockIdx.y * p.kt_per_split;
+    nk = min(nk - kt0, p.kt_per_split);
+    Cout = (float*)p.C + (int64_t)blockIdx.y * p.slab;
+  }
+
+  // staging: slot q = i*512 + tid -> k-row q>>5 (i = 0: rows 0..15, i = 1: 16..31), 16-byte slot q&31
+  const char* baseA = (const char*)(p.A + (int64_t)kt0 * BK2 * p.lda);
+  const char* baseB = (const char*)(p.B[0] + (int64_t)kt0 * BK2 * p.ldb);
+  unsigned offA[2], offB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = i * 512 + tid;
+    const int kr = q >> 5, pc = q & 31;
+    const int ca = min(m0 + (pc ^ swzA_tn(kr)) * 8, p.M - 8);
+    const int cb = min(n0 + (pc ^ swzB_tn(kr)) * 8, p.N - 8);
+    offA[i] = (unsigned)(((int64_t)kr * p.lda + ca) * 2);
+    offB[i] = (unsigned)(((int64_t)kr * p.ldb + cb) * 2);
+  }
+  const int64_t stepA = (int64_t)BK2 * p.lda * 2, stepB = (int64_t)BK2 * p.ldb * 2;
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transpose-read provider addresses (bytes inside a stage); k-row of this lane = g*8 + h*4 + (t>>2), h = 0,1 (+2048 B)
+  const int krow = g * 8 + (t >> 2);
+  const int rowoff = krow * 512;
+  int rdX[8], rdW[4];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int chunk = wm * 16 + mi * 2 + ((t & 3) >> 1);
+    rdX[mi] = rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
+  }
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int chunk = wn * 8 + (t & 3) * 2 + (ni >> 1);
+    rdW[ni] = OPER2_BYTES + rowoff + ((chunk ^ swzB_tn(krow)) << 4) + (ni & 1) * 8;
+  }
+
+  auto issue = [&](int slot) {
+    char* la = smem + slot * STAGE2_BYTES;
+    char* lb = la + OPER2_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int wbase = (i * 512 + wid * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                       (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB + offB[i]),
+                                       (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
+    }
+    baseA += stepA;
+    baseB += stepB;
+  };
+  auto wait_landed = [&](int younger) {
+    if (younger >= 3) WAIT_VM(12);
+    else if (younger == 2) WAIT_VM(8);
+    else if (younger == 1) WAIT_VM(4);
+    else WAIT_VM(0);
+  };
+  struct Frags { s16x4 w[4][2]; s16x4 x[8][2]; };
+  auto read_frags = [&](int kt, Frags& f) {
+    const char* st = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      f.w[ni][0] = tr_read16(st + rdW[ni]);
+      f.w[ni][1] = tr_read16(st + rdW[ni] + 2048);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+      f.x[mi][0] = tr_read16(st + rdX[mi]);
+      f.x[mi][1] = tr_read16(st + rdX[mi] + 2048);
+    }
+  };
+  auto mma = [&](const Frags& f) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join16(f.w[ni][0], f.w[ni][1]), join16(f.x[mi][0], f.x[mi][1]),
+                                                              acc[ni][mi], 0, 0, 0);
+  };
+  auto step_steady = [&](int kt, const Frags& cur, Frags& nxt) {
+    WAIT_LGKM0();
+    WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;
+    char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
+    char* lb = la + OPER2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {  // 32 groups of {1 MFMA, <= 1 memory instruction}, order pinned
+      const int mi = j >> 2, ni = j & 3;
+      acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join16(cur.w[ni][0], cur.w[ni][1]), join16(cur.x[mi][0], cur.x[mi][1]),
+                                                            acc[ni][mi], 0, 0, 0);
+      if (j < 8) {
+        nxt.w[j >> 1][j & 1] = tr_read16(st + rdW[j >> 1] + (j & 1) * 2048);
+      } else if (j < 24) {
+        const int e = j - 8;
+        nxt.x[e >> 1][e & 1] = tr_read16(st + rdX[e >> 1] + (e & 1) * 2048);
+      } else if (j < 28) {
+        const int i = (j - 24) >> 1;
+        const int wbase = (i * 512 + wid * 64) * 16;
+        if ((j & 1) == 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                           (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB + offB[i]),
+                                           (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    baseA += stepA;
+    baseB += stepB;
+  };
+  auto step_tail = [&](int kt, const Frags& cur, Frags& nxt) {
+    const bool has_next = kt + 1 < nk;
+    WAIT_LGKM0();
+    if (has_next) wait_landed(min(nk - 2 - kt, STAGES2 - 2));
+    __builtin_amdgcn_s_barrier();
+    if (has_next) read_frags(kt + 1, nxt);
+    mma(cur);
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES2; ++s0)
+    if (s0 < nk) issue(s0);
+  Frags fA, fB;
+  wait_landed(min(nk - 1, STAGES2 - 1));
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, fA);
+  int kt = 0;
+  for (; kt + STAGES2 + 1 < nk; kt += 2) {
+    step_steady(kt, fA, fB);
+    step_steady(kt + 1, fB, fA);
+  }
+  for (; kt < nk; kt += 2) {
+    step_tail(kt, fA, fB);
+    step_tail(kt + 1, fB, fA);
+  }
+  gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, 0, g, t);
+}
+
+template <int EPI>
+int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
+  const dim3 grid(a.tiles_m * a.tiles_n, splits);
+  const size_t sh = STAGES2 * STAGE2_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) { op_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), grid, dim3(512), sh, s, a);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
 }
 
 template <int EPI>
@@ -743,6 +945,69 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
                        (bf16_t*)c_final, ldc_final, (int)M, (int)N);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { op_set_error("gemm_nt: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
+  }
+  op_prof_end(slot, stream);
+  return rc;
+}
+
+
+// C[M,N] (bf16, ldc) = A^T B with A [K, M] (lda) and B [K, N] (ldb) both row-major bf16: the weight-gradient GEMM
+// dW[out,in] = dy[tokens,out]^T x[tokens,in] (autograd of nn.Linear) without transposed operand copies.
+// Requirements: K % 64 == 0, M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0.  Returns OP_ENOTSUP (-95) when the shape does not
+// qualify (the caller then uses op_transpose + op_gemm_nt).  workspace: optional fp32 scratch enabling split-K.
+int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+               void* workspace, int64_t workspace_bytes, void* stream) {
+  OP_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
+  if (K % 64 != 0 || M % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || M < 8 || N < 8 ||
+      31 * lda + M >= ((int64_t)1 << 30) || 31 * ldb + N >= ((int64_t)1 << 30)) {
+    op_set_error("gemm_tn: shape M=%lld N=%lld K=%lld not supported by the transpose-read kernel", (long long)M, (long long)N,
+                 (long long)K);
+    return OP_ENOTSUP;
+  }
+  if (M == 0 || N == 0) return OP_OK;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.lda = lda;
+  a.B[0] = (const bf16_t*)B; a.B[1] = a.B[2] = nullptr; a.ldb = ldb; a.n_seg = (int)N;
+  a.bias[0] = a.bias[1] = a.bias[2] = nullptr;
+  a.C = C; a.ldc = ldc; a.H0 = a.H1 = nullptr; a.resid = nullptr; a.ldr = 0; a.gamma = nullptr; a.rowscale = nullptr;
+  a.rows_per_sample = 1; a.alpha = nullptr;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.tiles_m = ceil_div(M, 256);
+  a.tiles_n = ceil_div(N, 256);
+  // split-K: fill the chip (256 slots per round) while keeping chunks long and even
+  const int nk = (int)(K / BK2);
+  const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+  int best_s = 1;
+  double best_t = 1e300;
+  for (int s = 1; s <= 16; ++s) {
+    if (s > 1 && (!workspace || (int64_t)s * M * N * 4 > workspace_bytes || nk / s < 16)) break;
+    int kps = ceil_div(nk, s);
+    kps += kps & 1;
+    const int eff = ceil_div(nk, kps);
+    const double rounds = (double)((tiles * eff + 255) / 256);
+    double t = rounds * kps * (256.0 * 256 / 1040.0) * BK2;
+    if (eff > 1) t += (double)eff * M * N * 8.0 / 4.0e3 + 1.0e4;
+    if (t < best_t) { best_t = t; best_s = eff; a.kt_per_split = eff > 1 ? kps : 0; }
+  }
+  a.slab = (int64_t)M * N;
+  hipStream_t s = (hipStream_t)stream;
+  const int slot = op_prof_begin(0, 2.0 * (double)M * (double)N * (double)K, stream);
+  int rc;
+  if (best_s > 1) {
+    a.C = workspace;
+    a.ldc = N;
+    rc = launch256_tn<EPI_F32>(a, s, best_s);
+    if (rc == OP_OK) {
+      int64_t nb = ((int64_t)M * (N / 8) + 255) / 256;
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, s, (const float*)workspace, best_s, a.slab,
+                         (bf16_t*)C, ldc, (int)M, (int)N);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) { op_set_error("gemm_tn: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
+    }
+  } else {
+    a.kt_per_split = 0;
+    rc = launch256_tn<EPI_BIAS>(a, s, 1);
   }
   op_prof_end(slot, stream);
   return rc;

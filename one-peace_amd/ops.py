@@ -71,6 +71,19 @@ def _wgrad(dyT, xT):
     return hip.gemm_nt(dyT, [xT])
 
 
+USE_TN_WGRAD = True
+
+
+def wgrad(dy, x, out=None):
+    """dW[out, in] = dy[rows, out]^T x[rows, in].  Transpose-read GEMM straight from the row-major activations when the
+    shape qualifies (rows % 64 == 0 ...), otherwise two transposed K-padded copies + the NT kernel."""
+    K, M = dy.shape
+    N = x.shape[1]
+    if USE_TN_WGRAD and hip.gemm_tn_supported(K, M, N, dy.stride(0), x.stride(0)):
+        return hip.gemm_tn(dy, x, out)
+    return hip.gemm_nt(_t_pad(dy), [_t_pad(x)], out=out)
+
+
 def gemm_any(A, W, bias=None, out_f32=False, alpha=None):
     """A[M,K] @ W[N,K]^T (+bias) through the HIP GEMM for ANY K, N (zero-pads K to 64 / N to 8 on the host)."""
     M, K = A.shape
@@ -154,7 +167,10 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = gemm_any(dy2, _transposed(w)).view(*dy.shape[:-1], w.shape[1])
         if ctx.needs_input_grad[1]:
-            dw = gemm_any(_t_pad(dy2), _t_pad(x2))
+            if dy2.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0:
+                dw = wgrad(dy2, x2)
+            else:
+                dw = gemm_any(_t_pad(dy2), _t_pad(x2))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dy8 = dy2 if dy2.shape[1] % 8 == 0 else torch.nn.functional.pad(dy2, (0, 8 - dy2.shape[1] % 8))
             db = hip.colsum(dy8.contiguous())[: w.shape[0]]
@@ -319,22 +335,24 @@ class EncoderLayerFn(torch.autograd.Function):
         if P["g2"] is not None:
             G["g2"] = hip.colsum(dout2, A["y2"], ps2, S)
         G["b2"] = hip.colsum(dy2)
-        dy2T = _t_pad(dy2)
-        G["w2"] = _wgrad(dy2T, _t_pad(A["gln"]))
+        G["w2"] = wgrad(dy2, A["gln"])
         dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
         if P["fln_w"] is not None:
             dg, G["fln_w"], G["fln_b"] = hip.layernorm_bwd(dgln, A["g"], P["fln_w"], P["fln_b"], A["mean_f"], A["rstd_f"])
         else:
             dg = dgln
         dh0, dh1 = hip.geglu_bwd(dg, A["h0"], A["h1"])
-        xln2T = _t_pad(A["xln2"])
-        dhT = torch.empty(2 * Fd, xln2T.shape[1], dtype=dh0.dtype, device=dh0.device)  # [dh0^T ; dh1^T] -> one GEMM
-        if xln2T.shape[1] != N:
-            dhT[:, N:].zero_()
-        hip.transpose(dh0, dhT[:Fd])
-        hip.transpose(dh1, dhT[Fd:])
-        dW01 = _wgrad(dhT, xln2T)
-        G["w0"], G["w1"] = dW01[:Fd], dW01[Fd:]
+        if USE_TN_WGRAD and hip.gemm_tn_supported(N, Fd, H, Fd, H):
+            G["w0"], G["w1"] = wgrad(dh0, A["xln2"]), wgrad(dh1, A["xln2"])
+        else:
+            xln2T = _t_pad(A["xln2"])
+            dhT = torch.empty(2 * Fd, xln2T.shape[1], dtype=dh0.dtype, device=dh0.device)  # [dh0^T ; dh1^T] -> one GEMM
+            if xln2T.shape[1] != N:
+                dhT[:, N:].zero_()
+            hip.transpose(dh0, dhT[:Fd])
+            hip.transpose(dh1, dhT[Fd:])
+            dW01 = _wgrad(dhT, xln2T)
+            G["w0"], G["w1"] = dW01[:Fd], dW01[Fd:]
         dxln2 = hip.gemm_nt(dh0, [_transposed(P["w0"])])
         hip.gemm_nt(dh1, [_transposed(P["w1"])], out=dxln2, epilogue=hip.EPI_RESID, resid=dxln2)
         dx_mid, G["ln2_w"], G["ln2_b"] = hip.layernorm_bwd(dxln2, A["x_mid"], P["ln2_w"], P["ln2_b"], A["mean2"],
@@ -345,7 +363,7 @@ class EncoderLayerFn(torch.autograd.Function):
         if P["g1"] is not None:
             G["g1"] = hip.colsum(dx_mid, A["y1"], ps1, S)
         G["bo"] = hip.colsum(dy1)
-        G["wo"] = _wgrad(_t_pad(dy1), _t_pad(A["aln"]))
+        G["wo"] = wgrad(dy1, A["aln"])
         daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
         if P["aln_w"] is not None:
             dattn, G["aln_w"], G["aln_b"] = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"],
@@ -357,7 +375,7 @@ class EncoderLayerFn(torch.autograd.Function):
                                  bias.grad_accumulator() if want_dbias else None)
         dbias_cols = hip.colsum(dqkv)
         G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
-        dW = _wgrad(_t_pad(dqkv), _t_pad(A["xln1"]))  # [3H, H]
+        dW = wgrad(dqkv, A["xln1"])  # [3H, H]
         G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
         dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
         dx, G["ln1_w"], G["ln1_b"] = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"],

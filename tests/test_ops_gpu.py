@@ -100,6 +100,21 @@ def test_gemm_split_k_weight_gradient_shapes(M, N, K, tile_mode):
     assert_close(out1, ref, what="no split")
 
 
+@pytest.mark.parametrize("K,M,N", [(64, 256, 256), (128, 264, 8), (1024, 1536, 512), (4096, 768, 1536), (16448, 1536, 1536),
+                                   (2048, 4608, 1536)])
+def test_gemm_tn_transpose_read(K, M, N):
+    """dW = dy^T x straight from row-major operands (ds_read_b64_tr_b16 fragments), incl. split-K and ragged M/N."""
+    hip = hipmod()
+    A, Bm = rnd(K, M, seed=1, scale=0.5), rnd(K, N, seed=2, scale=0.5)
+    ref = A.t() @ Bm
+    out = hip.gemm_tn(dev_bf16(A), dev_bf16(Bm))
+    assert_close(out, ref, what="gemm_tn")
+    # strided operands (views into wider buffers), as the packed qkv gradient
+    wide = dev_bf16(torch.cat([A, A], dim=1))
+    out2 = hip.gemm_tn(wide[:, M:], dev_bf16(Bm))
+    assert_close(out2, ref, what="gemm_tn strided")
+
+
 @pytest.mark.parametrize("glds", [1, 0])
 def test_gemm_three_segments_qkv(glds, tile_mode):
     hip = hipmod()

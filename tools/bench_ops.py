@@ -69,6 +69,14 @@ def main():
             flops=2.0 * M * H * Fd)
     hip.lib().op_gemm_set_staging(1)
     hip.lib().op_gemm_set_tile(0)
+    # weight-gradient GEMMs: transpose-read TN kernel vs transposes + NT kernel
+    from one_peace_amd import ops
+    for (Mo, No) in ((3 * H, H), (Fd, H), (H, Fd), (H, H)):
+        dy = torch.randn(M, Mo, **bf)
+        xx = torch.randn(M, No, **bf)
+        rec("wgrad_tn_%dx%d" % (Mo, No), timeit(lambda: hip.gemm_tn(dy, xx)), flops=2.0 * M * Mo * No)
+        rec("wgrad_transpose_nt_%dx%d" % (Mo, No), timeit(lambda: hip.gemm_nt(ops._t_pad(dy), [ops._t_pad(xx)])),
+            flops=2.0 * M * Mo * No)
     # torch (hipBLASLt) reference point for the same GEMM
     wcat = torch.cat([w0, w1], 0)
     rec("torch_matmul_geglu_shape", timeit(lambda: torch.matmul(x, wcat.t())), flops=4.0 * M * Fd * H)

@@ -150,8 +150,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     hip.lib()
-    rank, world, local = init_distributed()
+    rank, world, local = init_distributed(os.environ.get("ONEPEACE_DIST_BACKEND"))
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    if os.environ.get("ONEPEACE_SINGLE_DEVICE_DEBUG"):  # functional test of the N>1 control flow on a 1-GPU box (gloo)
+        local = 0
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     torch.manual_seed(3407 + rank)

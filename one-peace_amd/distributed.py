@@ -23,7 +23,7 @@ def init_distributed(backend=None):
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() and not os.environ.get("ONEPEACE_SINGLE_DEVICE_DEBUG"):
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

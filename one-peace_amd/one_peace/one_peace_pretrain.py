@@ -15,7 +15,7 @@ from ..components import Linear, trunc_normal_
 from ..registry import register_model
 from ..unify_model_config import AdjustEncDecConfig, UnifyModelConfig
 from .one_peace_base import ModelWrapper, OnePeaceBaseModel, init_one_peace_params
-from .one_peace_retrieval import normalized_projection
+from .one_peace_retrieval import MODALITIES, clamped_logit_scale, normalized_projection
 
 logger = logging.getLogger(__name__)
 
@@ -67,36 +67,29 @@ class OnePeacePretrainModel(OnePeaceBaseModel):
                 src_audios: Optional[torch.Tensor] = None, audio_padding_masks=None, audio_preserve_ids=None,
                 encoder_type: str = None, return_logit_scale: bool = False):
         if return_logit_scale:
-            with torch.no_grad():
-                self.logit_scale.clamp_(0, math.log(100))
-            return self.logit_scale.exp()
-        tf, imf, af = self.encoder_wrapper(
+            return clamped_logit_scale(self.logit_scale)
+        preserve = {"text": text_preserve_ids, "image": image_preserve_ids, "audio": audio_preserve_ids}
+        feats = dict(zip(MODALITIES, self.encoder_wrapper(
             src_tokens=src_tokens, text_preserve_ids=text_preserve_ids, src_images=src_images,
             image_preserve_ids=image_preserve_ids, src_audios=src_audios, audio_padding_masks=audio_padding_masks,
-            audio_preserve_ids=audio_preserve_ids, encoder_type=encoder_type)
-        if text_preserve_ids is not None or image_preserve_ids is not None or audio_preserve_ids is not None:
-            te = self.decoder_text_embed(tf) if tf is not None else None
-            ie = self.decoder_image_embed(imf) if imf is not None else None
-            ae = self.decoder_audio_embed(af) if af is not None else None
-            dt, di, da = self.decoder_wrapper(
-                src_tokens=src_tokens, text_preserve_ids=text_preserve_ids, text_preserve_embed=te,
+            audio_preserve_ids=audio_preserve_ids, encoder_type=encoder_type)))
+        if any(v is not None for v in preserve.values()):
+            # masked-feature branch: encoder features of the kept tokens -> small decoder -> per-modality mask heads
+            embeds = {m: (getattr(self, "decoder_%s_embed" % m)(f) if f is not None else None) for m, f in feats.items()}
+            dec = self.decoder_wrapper(
+                src_tokens=src_tokens, text_preserve_ids=text_preserve_ids, text_preserve_embed=embeds["text"],
                 text_mask_token=self.text_mask_token, src_images=src_images, image_preserve_ids=image_preserve_ids,
-                image_preserve_embed=ie, image_mask_token=self.image_mask_token, src_audios=src_audios,
-                audio_padding_masks=audio_padding_masks, audio_preserve_ids=audio_preserve_ids, audio_preserve_embed=ae,
-                audio_mask_token=self.audio_mask_token, encoder_type=encoder_type)
-            return (self.text_mask_head(dt) if dt is not None else None,
-                    self.image_mask_head(di) if di is not None else None,
-                    self.audio_mask_head(da) if da is not None else None)
-        if encoder_type == "text":
-            return normalized_projection(self.text_proj, tf[:, 0, :]), tf
-        if encoder_type == "image":
-            return normalized_projection(self.image_proj, imf[:, 0, :]), imf
-        if encoder_type == "audio":
-            return normalized_projection(self.audio_proj, af[:, 0, :]), af
+                image_preserve_embed=embeds["image"], image_mask_token=self.image_mask_token, src_audios=src_audios,
+                audio_padding_masks=audio_padding_masks, audio_preserve_ids=audio_preserve_ids,
+                audio_preserve_embed=embeds["audio"], audio_mask_token=self.audio_mask_token, encoder_type=encoder_type)
+            return tuple(getattr(self, m + "_mask_head")(d) if d is not None else None for m, d in zip(MODALITIES, dec))
+        if encoder_type in MODALITIES:
+            f = feats[encoder_type]
+            return normalized_projection(getattr(self, encoder_type + "_proj"), f[:, 0, :]), f
         if encoder_type == "vl":
-            return tf, imf
+            return feats["text"], feats["image"]
         if encoder_type == "al":
-            return tf, af
+            return feats["text"], feats["audio"]
         raise NotImplementedError(encoder_type)
 
     def upgrade_state_dict_named(self, state_dict, name):

@@ -303,19 +303,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
   auto compute = [&](int buf) {
     const char* la = smem + buf * (2 * TILE_BYTES);
     const char* lb = la + TILE_BYTES;
+    // kk = 0 fragments, then the kk = 1 fragment reads are interleaved (one per two MFMAs) with the kk = 0 MFMAs
+    bf16x8 wf0[4], xf0[4], wf1[4], xf1[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 wf[4], xf[4];
+    for (int ni = 0; ni < 4; ++ni) wf0[ni] = *reinterpret_cast<const bf16x8*>(lb + rdW[ni] + swz[0]);
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(lb + rdW[ni] + swz[kk]);
+    for (int mi = 0; mi < 4; ++mi) xf0[mi] = *reinterpret_cast<const bf16x8*>(la + rdX[mi] + swz[0]);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(la + rdX[mi] + swz[kk]);
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int idx = 2 * j + h, mi = idx >> 2, ni = idx & 3;
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[ni], xf0[mi], acc[ni][mi], 0, 0, 0);
+      }
+      if (j < 4) wf1[j] = *reinterpret_cast<const bf16x8*>(lb + rdW[j] + swz[1]);
+      else xf1[j - 4] = *reinterpret_cast<const bf16x8*>(la + rdX[j - 4] + swz[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-    }
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[ni], xf1[mi], acc[ni][mi], 0, 0, 0);
   };
 
   if (GLDS) {
@@ -380,7 +389,7 @@ __device__ __forceinline__ int w_row_to_col256(int p) {
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 0xF) | ((((n) >> 4) & 3) << 14))
 
-template <int EPI>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // pipe; sched_group_barrier spreads the 16 memory instructions between the 32 MFMAs (1 per 2) instead.
   auto step_steady = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
     WAIT_LGKM0();
-    WAIT_VM(8);
+    if (ABL != 2) WAIT_VM(8); else WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;  // fragments of the next stage
     char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;              // slot being refilled with stage kt+4
@@ -502,7 +511,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int idx = 2 * j + h, mi = idx >> 2, ni = idx & 3;
-        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
+        if (ABL != 1)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
+        else
+          asm volatile("" :: "v"(cur_w[ni]), "v"(cur_x[mi]));
       }
       if (j < 4) {
         const int o = (EPI == EPI_GEGLU) ? ((j >> 1) * 128 + (j & 1) * 16) * 64 : j * 16 * 64;
@@ -512,12 +524,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       } else {
         const int i = (j - 12) >> 1;
         const int wbase = (i * 512 + wid * 64) * 16;
-        if ((j & 1) == 0)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
-                                           (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
-        else
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
-                                           (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
+        if (ABL != 2) {
+          if ((j & 1) == 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                             (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+          else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
+                                             (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -746,6 +760,8 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
   return OP_OK;
 }
 
+int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads in the steady loop (timing ablations only, wrong results)
+
 template <int EPI>
 int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
@@ -756,7 +772,15 @@ int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
     if (e != hipSuccess) { op_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), sh, s, a);
+  if (EPI == EPI_BIAS && g_ablation == 1) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 1>), grid, dim3(512), sh, s, a);
+  } else if (EPI == EPI_BIAS && g_ablation == 2) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 2>), grid, dim3(512), sh, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), sh, s, a);
+  }
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
@@ -808,7 +832,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 struct GemmPlan { int tile; int splits; int kt_per_split; };
 
 GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256, bool allow_split, int64_t ws_bytes) {
-  const double c128 = 2.0 * 128 * 128 / 900.0, c256 = 256.0 * 256 / 1040.0;  // time of one slot-round per unit K
+  const double c128 = 2.0 * 128 * 128 / 920.0, c256 = 256.0 * 256 / 1080.0;  // time of one slot-round per unit K
   const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(N, epilogue == EPI_GEGLU ? 64 : 128);
   const int64_t t256 = (int64_t)ceil_div(M, 256) * ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
   GemmPlan best = {128, 1, 0};
@@ -845,6 +869,7 @@ extern "C" {
 // 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
 int op_gemm_set_tile(int mode) {
   int old = g_tile_mode;
+  if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10/11/12: timing ablations of the 256x256 kernel (tools only)
   g_tile_mode = mode;
   return old;
 }

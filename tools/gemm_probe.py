@@ -1,4 +1,5 @@
-"""Run one GEMM configuration repeatedly (for rocprofv3 --pmc passes).  python tools/gemm_probe.py qkv|geglu|ffn2 [tile] [iters]"""
+"""Run one GEMM configuration repeatedly (for rocprofv3 --pmc passes).
+python tools/gemm_probe.py qkv|geglu|ffn2|wgrad [tile] [iters]"""
 import sys, os
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +21,9 @@ elif which == "geglu":
     w0, w1 = torch.randn(F, H, **bf) * 0.02, torch.randn(F, H, **bf) * 0.02
     out = torch.empty(M, F, **bf)
     fn = lambda: hip.gemm_nt(x, [w0, w1], out=out, epilogue=hip.EPI_GEGLU)
+elif which == "wgrad":
+    dy = torch.randn(M, F, **bf)
+    fn = lambda: hip.gemm_tn(dy, x)
 else:
     w2 = torch.randn(H, F, **bf) * 0.02
     b = torch.randn(H, **bf)

@@ -71,9 +71,9 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
 /* C[M,N] (bf16) = A^T B with A [K,M] (lda), B [K,N] (ldb) row-major bf16: the weight-gradient GEMM dW = dy^T x of
  * nn.Linear (autograd of components.py:29-34 users) straight from the activation matrices (transpose-read fragments,
  * no transposed copies).  K % 64 == 0, M/N/lda/ldb % 8 == 0, else returns -95 (use op_transpose + op_gemm_nt).
- * workspace: optional fp32 scratch enabling split-K. */
+ * accumulate != 0: C += A^T B.  workspace: optional fp32 scratch enabling split-K. */
 int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-               void* workspace, int64_t workspace_bytes, void* stream);
+               int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* 1 = LDS-DMA (global_load_lds) operand staging [default], 0 = register-staged variant.  Returns the old value. */
 int op_gemm_set_staging(int glds);
 /* 0 = auto (256x256 four-stage kernel when it yields >= 192 workgroups, else 128x128), 1 = force 128x128,

@@ -452,10 +452,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 
 // Shared by the dQ and dBias kernels: for one 64-key tile, lane (g,t) computes dS^T[key = kb*16 + g*4 + r][q = t]
 // for its two query blocks.  KF/VF: functors returning the first-operand fragment (K or V rows) for (kb, kk).
-template <typename KF, typename VF>
+template <typename KF, typename VF, typename BF>
 __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int k0, int q0w, int g, int t,
                                         const bf16x8 (&qf)[2][2], const bf16x8 (&of)[2][2], const float (&lse)[2],
-                                        const float (&del)[2], KF kfrag, VF vfrag, f32x4 (&ds)[2][4]) {
+                                        const float (&del)[2], KF kfrag, VF vfrag, BF biasfrag, f32x4 (&ds)[2][4]) {
   f32x4 st[2][4];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
@@ -489,7 +489,7 @@ __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int 
       const int key = k0 + kb * 16 + g * 4;
       float bb[4] = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) {
-        const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + key);
+        const bf16x4 bv = biasfrag(qb, kb, qi, key);
 #pragma unroll
         for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
       }
@@ -574,7 +574,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     auto vfrag = [&](int kb, int kk) {
       return *reinterpret_cast<const bf16x8*>(ldsV + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
     };
-    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, ds);
+    auto biasfrag = [&](int, int, int qi, int key) {
+      return *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + key);
+    };
+    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -611,21 +614,60 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
   }
 }
 
-// grid (q tiles of 128, key tiles of 64, heads * batch chunks)
+// grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
+// same for every sample and is loaded once; each sample's K/V tile goes through LDS once for all four waves (next
+// sample's tile in flight during the MFMAs); dS is accumulated in registers over the chunk, chunks combine by fp32 atomics.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+  char* ldsK = smem;
+  char* ldsV = smem + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
   const int h = blockIdx.z % p.heads, chunk = blockIdx.z / p.heads;
   const int q0w = blockIdx.x * BQ + wid * 32;
   const int k0 = blockIdx.y * BKV;
-  if (q0w >= p.S) return;
+  const bool wave_active = q0w < p.S;
   f32x4 acc[2][4];
+  bf16x4 breg[2][4];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qi = min(q0w + qb * 16 + t, p.S - 1);
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) acc[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int b_end = min(p.B, (chunk + 1) * p.bchunk);
-  for (int b = chunk * p.bchunk; b < b_end; ++b) {
+    for (int kb = 0; kb < 4; ++kb) {
+      acc[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias)
+        breg[qb][kb] = *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + k0 + kb * 16 + g * 4);
+    }
+  }
+  u32x4 rk[2], rv[2];
+  int st_row[2], st_c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c2 = tid + 256 * i; st_row[i] = c2 >> 3; st_c[i] = c2 & 7; }
+  auto load_tile = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = min(k0 + st_row[i], p.S - 1);
+      const int64_t off = ((int64_t)b * p.S + kr) * p.ld + h * HD + st_c[i] * 8;
+      rk[i] = *reinterpret_cast<const u32x4*>(p.k + off);
+      rv[i] = *reinterpret_cast<const u32x4*>(p.v + off);
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = st_row[i] * 128 + ((st_c[i] ^ (st_row[i] & 7)) << 4);
+      *reinterpret_cast<u32x4*>(ldsK + off) = rk[i];
+      *reinterpret_cast<u32x4*>(ldsV + off) = rv[i];
+    }
+  };
+  const int b_begin = chunk * p.bchunk, b_end = min(p.B, (chunk + 1) * p.bchunk);
+  if (b_begin < b_end) load_tile(b_begin);
+  for (int b = b_begin; b < b_end; ++b) {
+    __syncthreads();
+    write_tile();
+    __syncthreads();
+    if (b + 1 < b_end) load_tile(b + 1);
+    if (!wave_active) continue;
     const int64_t row_base = (int64_t)b * p.S;
     bf16x8 qf[2][2], of[2][2];
     float lse[2], del[2];
@@ -641,15 +683,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
       del[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
     }
     auto kfrag = [&](int kb, int kk) {
-      const int kr = min(k0 + kb * 16 + t, p.S - 1);
-      return *reinterpret_cast<const bf16x8*>(p.k + (row_base + kr) * p.ld + h * HD + kk * 32 + g * 8);
+      return *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
     };
     auto vfrag = [&](int kb, int kk) {
-      const int kr = min(k0 + kb * 16 + t, p.S - 1);
-      return *reinterpret_cast<const bf16x8*>(p.v + (row_base + kr) * p.ld + h * HD + kk * 32 + g * 8);
+      return *reinterpret_cast<const bf16x8*>(ldsV + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
     };
+    auto biasfrag = [&](int qb, int kb, int, int) { return breg[qb][kb]; };
     f32x4 ds[2][4];
-    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, ds);
+    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -657,6 +698,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[qb][kb][r] += ds[qb][kb][r];
   }
+  if (!wave_active) return;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qi = q0w + qb * 16 + t;
@@ -732,7 +774,13 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
-  a.bchunk = 16;
+  {  // batch chunk per workgroup: enough workgroups to fill the chip, as few atomic rounds as possible
+    const int64_t base = (int64_t)ceil_div(S, BQ) * ceil_div(S, BKV) * heads;
+    int chunks = (int)((1024 + base - 1) / base);
+    if (chunks < 1) chunks = 1;
+    if (chunks > B) chunks = (int)B;
+    a.bchunk = ceil_div(B, chunks);
+  }
   hipStream_t s = (hipStream_t)stream;
   const double fl = 4.0 * (double)B * (double)heads * (double)S * (double)S * HD;
   int slot = op_prof_begin(2, 2.0 * fl, stream);

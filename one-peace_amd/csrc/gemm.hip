@@ -809,13 +809,15 @@ int launch(const GemmArgs& a, int glds, hipStream_t s, int splits = 1) {
 
 // out[m][n] (bf16) = sum_z slab_z[m][n] (fp32); 8 elements per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t slab,
-                                                            bf16_t* __restrict__ out, int64_t ldc, int M, int N) {
+                                                            bf16_t* __restrict__ out, int64_t ldc, int M, int N,
+                                                            int accumulate) {
   const int n8 = N / 8;
   const int64_t total = (int64_t)M * n8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t m = i / n8;
     const int c = (int)(i - m * n8) * 8;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (accumulate) Vec8<bf16_t>::load(out + m * ldc + c, a);
     for (int z = 0; z < splits; ++z) {
       float v[8];
       Vec8<float>::load(ws + z * slab + m * N + c, v);
@@ -967,7 +969,7 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
     int64_t nb = ((int64_t)M * (N / 8) + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, s, (const float*)workspace, plan.splits, a.slab,
-                       (bf16_t*)c_final, ldc_final, (int)M, (int)N);
+                       (bf16_t*)c_final, ldc_final, (int)M, (int)N, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { op_set_error("gemm_nt: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
   }
@@ -979,9 +981,10 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
 // C[M,N] (bf16, ldc) = A^T B with A [K, M] (lda) and B [K, N] (ldb) both row-major bf16: the weight-gradient GEMM
 // dW[out,in] = dy[tokens,out]^T x[tokens,in] (autograd of nn.Linear) without transposed operand copies.
 // Requirements: K % 64 == 0, M % 8 == 0, N % 8 == 0, lda/ldb % 8 == 0.  Returns OP_ENOTSUP (-95) when the shape does not
-// qualify (the caller then uses op_transpose + op_gemm_nt).  workspace: optional fp32 scratch enabling split-K.
+// qualify (the caller then uses op_transpose + op_gemm_nt).  accumulate != 0: C += A^T B (gradient accumulation into a
+// pre-existing buffer).  workspace: optional fp32 scratch enabling split-K.
 int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-               void* workspace, int64_t workspace_bytes, void* stream) {
+               int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   OP_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
   if (K % 64 != 0 || M % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || M < 8 || N < 8 ||
       31 * lda + M >= ((int64_t)1 << 30) || 31 * ldb + N >= ((int64_t)1 << 30)) {
@@ -1026,10 +1029,15 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
       int64_t nb = ((int64_t)M * (N / 8) + 255) / 256;
       if (nb > 2048) nb = 2048;
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, s, (const float*)workspace, best_s, a.slab,
-                         (bf16_t*)C, ldc, (int)M, (int)N);
+                         (bf16_t*)C, ldc, (int)M, (int)N, accumulate);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) { op_set_error("gemm_tn: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
     }
+  } else if (accumulate) {  // C += A^T B in place through the residual epilogue
+    a.kt_per_split = 0;
+    a.resid = (const bf16_t*)C;
+    a.ldr = ldc;
+    rc = launch256_tn<EPI_RESID>(a, s, 1);
   } else {
     a.kt_per_split = 0;
     rc = launch256_tn<EPI_BIAS>(a, s, 1);

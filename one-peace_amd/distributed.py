@@ -61,9 +61,13 @@ class FlatParameters:
                 self.params[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.params[o:o + k].view(p.shape)
                 p.grad = self.grads[o:o + k].view(p.shape)
+                p._op_flat = True      # ops.EncoderLayerFn may accumulate this gradient in place (see ops._direct_grad)
+                p._op_pending = 0
 
     def zero_grad(self):
         self.grads.zero_()
+        for _, p, _, _ in self.entries:
+            p._op_pending = 0
 
 
 class BucketedGradReducer:
@@ -92,7 +96,9 @@ class BucketedGradReducer:
         self._hooks = []
         if self.world > 1:
             for idx, (n, p, o, k) in enumerate(flat.entries):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx)))
+                hook = self._make_hook(idx)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+                p._op_on_final = hook  # gradients written in place by the fused layer never pass through autograd
         self.reset()
 
     def _make_hook(self, idx):

@@ -35,7 +35,7 @@ SIGNATURES = {
     "op_gemm_set_tile": (c_int, [c_int]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
                            c_int, P, I64, P]),
-    "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, P, I64, P]),
+    "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_colsum_workspace_bytes": (I64, [I64]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
@@ -193,15 +193,16 @@ def gemm_tn_supported(K, M, N, lda, ldb):
             and 31 * lda + M < (1 << 30) and 31 * ldb + N < (1 << 30))
 
 
-def gemm_tn(A_km, B_kn, out=None):
-    """C[M,N] = A_km^T @ B_kn with A_km [K, M], B_kn [K, N] (row-major, last dim contiguous): dW = dy^T x without copies."""
+def gemm_tn(A_km, B_kn, out=None, accumulate=False):
+    """C[M,N] (+)= A_km^T @ B_kn with A_km [K, M], B_kn [K, N] (row-major, last dim contiguous): dW = dy^T x without copies."""
     K, M = A_km.shape
     N = B_kn.shape[1]
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=A_km.device)
+        accumulate = False
     ws = workspace(SPLITK_WS_BYTES, A_km.device, "gemm_splitk")
-    _check(lib().op_gemm_tn(ptr(A_km), A_km.stride(0), ptr(B_kn), B_kn.stride(0), ptr(out), out.stride(0), M, N, K, ptr(ws),
-                            ws.numel(), stream()), "op_gemm_tn")
+    _check(lib().op_gemm_tn(ptr(A_km), A_km.stride(0), ptr(B_kn), B_kn.stride(0), ptr(out), out.stride(0), M, N, K,
+                            int(accumulate), ptr(ws), ws.numel(), stream()), "op_gemm_tn")
     return out
 
 

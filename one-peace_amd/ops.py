@@ -74,14 +74,32 @@ def _wgrad(dyT, xT):
 USE_TN_WGRAD = True
 
 
-def wgrad(dy, x, out=None):
-    """dW[out, in] = dy[rows, out]^T x[rows, in].  Transpose-read GEMM straight from the row-major activations when the
+def wgrad(dy, x, out=None, accumulate=False):
+    """dW[out, in] (+)= dy[rows, out]^T x[rows, in].  Transpose-read GEMM straight from the row-major activations when the
     shape qualifies (rows % 64 == 0 ...), otherwise two transposed K-padded copies + the NT kernel."""
     K, M = dy.shape
     N = x.shape[1]
     if USE_TN_WGRAD and hip.gemm_tn_supported(K, M, N, dy.stride(0), x.stride(0)):
-        return hip.gemm_tn(dy, x, out)
+        return hip.gemm_tn(dy, x, out, accumulate)
+    if out is not None and accumulate:
+        return out.add_(hip.gemm_nt(_t_pad(dy), [_t_pad(x)]))
     return hip.gemm_nt(_t_pad(dy), [_t_pad(x)], out=out)
+
+
+def _direct_grad(param):
+    """True when `param` lives in distributed.FlatParameters: its .grad is a pre-allocated, pre-zeroed view the weight
+    gradient GEMM can accumulate into directly (no autograd accumulation pass, no temporary dW tensor)."""
+    return getattr(param, "_op_flat", False) and param.grad is not None
+
+
+def _direct_grad_done(param):
+    """One backward contribution to a directly accumulated gradient finished; the last one notifies the reducer."""
+    left = getattr(param, "_op_pending", 1) - 1
+    param._op_pending = left
+    if left <= 0:
+        cb = getattr(param, "_op_on_final", None)
+        if cb is not None:
+            cb(param)
 
 
 def gemm_any(A, W, bias=None, out_f32=False, alpha=None):
@@ -231,6 +249,7 @@ class _RelPosImageFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------------------------
 # the fused encoder layer
 # --------------------------------------------------------------------------------------------------------------
+_DIRECT_WEIGHTS = ("wq", "wk", "wv", "wo", "w0", "w1", "w2")
 LAYER_PARAMS = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b", "wo", "bo", "g1",
                 "ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
 
@@ -299,6 +318,13 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.bias = bias
         ctx.dims = (B, S, H, heads, scale)
         ctx.n_params = len(params)
+        ctx.direct = ()
+        if need_grad:  # weights whose gradient GEMM accumulates straight into the flat gradient buffer
+            # (name, Parameter object): saved_tensors hands back fresh tensor objects without .grad / attributes
+            ctx.direct = tuple((n, q) for n, q, ng in zip(LAYER_PARAMS, params, ctx.needs_input_grad[8:])
+                               if ng and n in _DIRECT_WEIGHTS and q is not None and _direct_grad(q))
+            for _, q in ctx.direct:
+                q._op_pending = getattr(q, "_op_pending", 0) + 1
         if keep:  # 288 GB of HBM: keep the layer's intermediates instead of recomputing them in backward
             ctx.act_names = [k for k, v in acts.items() if v is not None]
             ctx.save_for_backward(x2, key_pad, ps1, ps2, *params, *[acts[k] for k in ctx.act_names])
@@ -335,15 +361,26 @@ class EncoderLayerFn(torch.autograd.Function):
         if P["g2"] is not None:
             G["g2"] = hip.colsum(dout2, A["y2"], ps2, S)
         G["b2"] = hip.colsum(dy2)
-        G["w2"] = wgrad(dy2, A["gln"])
+        direct = dict(ctx.direct)
+
+        def weight_grad(name, dyv, xv):
+            target = direct.get(name)
+            if target is not None:
+                wgrad(dyv, xv, out=target.grad, accumulate=True)
+                _direct_grad_done(target)
+            else:
+                G[name] = wgrad(dyv, xv)
+
+        weight_grad("w2", dy2, A["gln"])
         dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
         if P["fln_w"] is not None:
             dg, G["fln_w"], G["fln_b"] = hip.layernorm_bwd(dgln, A["g"], P["fln_w"], P["fln_b"], A["mean_f"], A["rstd_f"])
         else:
             dg = dgln
         dh0, dh1 = hip.geglu_bwd(dg, A["h0"], A["h1"])
-        if USE_TN_WGRAD and hip.gemm_tn_supported(N, Fd, H, Fd, H):
-            G["w0"], G["w1"] = wgrad(dh0, A["xln2"]), wgrad(dh1, A["xln2"])
+        if ("w0" in direct and "w1" in direct) or (USE_TN_WGRAD and hip.gemm_tn_supported(N, Fd, H, Fd, H)):
+            weight_grad("w0", dh0, A["xln2"])
+            weight_grad("w1", dh1, A["xln2"])
         else:
             xln2T = _t_pad(A["xln2"])
             dhT = torch.empty(2 * Fd, xln2T.shape[1], dtype=dh0.dtype, device=dh0.device)  # [dh0^T ; dh1^T] -> one GEMM
@@ -363,7 +400,7 @@ class EncoderLayerFn(torch.autograd.Function):
         if P["g1"] is not None:
             G["g1"] = hip.colsum(dx_mid, A["y1"], ps1, S)
         G["bo"] = hip.colsum(dy1)
-        G["wo"] = wgrad(dy1, A["aln"])
+        weight_grad("wo", dy1, A["aln"])
         daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
         if P["aln_w"] is not None:
             dattn, G["aln_w"], G["aln_b"] = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"],
@@ -375,8 +412,12 @@ class EncoderLayerFn(torch.autograd.Function):
                                  bias.grad_accumulator() if want_dbias else None)
         dbias_cols = hip.colsum(dqkv)
         G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
-        dW = wgrad(dqkv, A["xln1"])  # [3H, H]
-        G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
+        if direct.keys() & {"wq", "wk", "wv"}:
+            for i, n in enumerate(("wq", "wk", "wv")):
+                weight_grad(n, dqkv[:, i * H:(i + 1) * H], A["xln1"])
+        else:
+            dW = wgrad(dqkv, A["xln1"])  # [3H, H]
+            G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
         dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
         dx, G["ln1_w"], G["ln1_b"] = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"],
                                                        add=dx_mid)

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int kb = 0; kb < 4; ++kb) st[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
+      if (k0 + kb * 16 >= p.S) break;  // uniform: key blocks past the sequence end are masked anyway
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      if (k0 + m * 32 >= p.S) break;  // P is exactly zero there
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const char* base = ldsV + (t >> 2) * VSTRIDE + (db * 16 + (t & 3) * 4) * 2;
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     // then P, dS in place, then dV^T[d][key] += dO^T[d][q] P[q][key] and dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      if (q0 + m * 32 >= p.S) break;  // uniform: no valid query in this half of the tile
       f32x4 s[2][2], dp[2][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -463,6 +466,7 @@ __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int 
     for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; ds[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int kb = 0; kb < 4; ++kb) {
+    if (k0 + kb * 16 >= p.S) break;  // uniform; those dS entries are forced to zero below
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const bf16x8 kfr = kfrag(kb, kk);
@@ -581,6 +585,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
+      if (k0 + m * 32 >= p.S) break;
       bf16x8 dsf[2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {

@@ -2,8 +2,10 @@
 
 Each ``torch.autograd.Function`` here is what the host-side mirrors of the reference modules call when their
 input is a bf16 tensor on an MI355X.  Forward and backward enqueue HIP kernels on the current stream; PyTorch
-only owns the memory.  The encoder layer is ONE function (``EncoderLayerFn``).  With ``save_acts=False`` it keeps only
-the layer input and recomputes the intermediates in backward -- the reference's ``checkpoint_activations: true``
+only owns the memory.  An encoder layer is two functions -- ``AttnBranchFn`` (LN, fused QKV GEMM, attention, sub-LN,
+out-proj + layer-scale/drop-path residual) and ``FfnBranchFn`` (LN, GeGLU GEMM, LN(F), down GEMM + residual) -- so that
+joint text+image / text+audio streams can route each modality's rows to its own FFN.  With ``save_acts=False`` a branch
+keeps only its input and recomputes the intermediates in backward -- the reference's ``checkpoint_activations: true``
 (pretrain_vl_3B.yaml:93, one_peace_pretrain.py:78-96); with ``save_acts=True`` (``checkpoint_activations: false``) it
 keeps them, which 288 GB of HBM affords even for the 4B model at batch 64.
 """
@@ -250,16 +252,16 @@ class _RelPosImageFn(torch.autograd.Function):
 # the fused encoder layer
 # --------------------------------------------------------------------------------------------------------------
 _DIRECT_WEIGHTS = ("wq", "wk", "wv", "wo", "w0", "w1", "w2")
-LAYER_PARAMS = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b", "wo", "bo", "g1",
-                "ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
+ATTN_PARAMS = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b", "wo", "bo", "g1")
+FFN_PARAMS = ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
+LAYER_PARAMS = ATTN_PARAMS + FFN_PARAMS
 
 
-def _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep):
-    """Runs the layer on x2 [B*S, H].  keep=True also returns the intermediates the backward needs."""
+def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep):
+    """x_mid = x + ps1 * g1 * out_proj(subLN(attention(LN1(x))))  on x2 [B*S, H]."""
     H = x2.shape[1]
     xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
-    fused_qkv = H % 128 == 0
-    if fused_qkv:
+    if H % 128 == 0:
         qkv = hip.gemm_nt(xln1, [P["wq"], P["wk"], P["wv"]], [P["bq"], None, P["bv"]], n_seg=H, N=3 * H)
     else:
         qkv = torch.empty(x2.shape[0], 3 * H, dtype=x2.dtype, device=x2.device)
@@ -275,102 +277,185 @@ def _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep)
     y1 = torch.empty_like(x2) if keep else None
     x_mid = hip.gemm_nt(aln, [P["wo"]], [P["bo"]], epilogue=hip.EPI_RESID, resid=x2, gamma=P["g1"], rowscale=ps1,
                         rows_per_sample=S, h0=y1)
+    if not keep:
+        return x_mid, None
+    return x_mid, dict(xln1=xln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, aln=aln, mean_a=mean_a,
+                       rstd_a=rstd_a, y1=y1)
+
+
+def _ffn_forward(x_mid, P, S, ps2, keep):
+    """out = x_mid + ps2 * g2 * W2(LN_F(gelu(LN2(x_mid) W0^T) * (LN2(x_mid) W1^T)))  on x_mid [B*S, H]."""
     xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
     Fd = P["w0"].shape[0]
     h0 = h1 = None
     if keep:
-        h0 = torch.empty(x2.shape[0], Fd, dtype=x2.dtype, device=x2.device)
+        h0 = torch.empty(x_mid.shape[0], Fd, dtype=x_mid.dtype, device=x_mid.device)
         h1 = torch.empty_like(h0)
     g = hip.gemm_nt(xln2, [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
     if P["fln_w"] is not None:
         gln, mean_f, rstd_f = hip.layernorm_fwd(g, P["fln_w"], P["fln_b"], want_stats=keep)
     else:
         gln, mean_f, rstd_f = g, None, None
-    y2 = torch.empty_like(x2) if keep else None
+    y2 = torch.empty_like(x_mid) if keep else None
     out = hip.gemm_nt(gln, [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x_mid, gamma=P["g2"], rowscale=ps2,
                       rows_per_sample=S, h0=y2)
     if not keep:
         return out, None
-    acts = dict(xln1=xln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, aln=aln, mean_a=mean_a, rstd_a=rstd_a,
-                y1=y1, x_mid=x_mid, xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, g=g, gln=gln, mean_f=mean_f,
-                rstd_f=rstd_f, y2=y2)
-    return out, acts
+    return out, dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, g=g, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2)
 
 
-class EncoderLayerFn(torch.autograd.Function):
-    """transformer_layer.py:165-228 for a single-modality stream, forward + backward in HIP.
+def _register_direct(ctx, names, params, needs):
+    """Weights whose gradient GEMM accumulates straight into the flat gradient buffer (distributed.FlatParameters).
+    Keeps (name, Parameter object) pairs: saved_tensors hands back fresh tensor objects without .grad / attributes."""
+    ctx.direct = tuple((n, q) for n, q, ng in zip(names, params, needs)
+                       if ng and n in _DIRECT_WEIGHTS and q is not None and _direct_grad(q))
+    for _, q in ctx.direct:
+        q._op_pending = getattr(q, "_op_pending", 0) + 1
 
-    x: [B, S, H] bf16 contiguous (batch-major).  bias: RelPosBias handle or None.  key_pad: uint8 [B, Spad] or None.
-    ps1 / ps2: fp32 [B] drop-path multipliers (0 or 1/keep) of the attention / FFN residual branch, or None.
-    """
+
+def _weight_grad_fn(ctx, G):
+    direct = dict(ctx.direct)
+
+    def weight_grad(name, dyv, xv):
+        target = direct.get(name)
+        if target is not None:
+            wgrad(dyv, xv, out=target.grad, accumulate=True)
+            _direct_grad_done(target)
+        else:
+            G[name] = wgrad(dyv, xv)
+    return weight_grad, direct
+
+
+def _save(ctx, keep, acts, *tensors):
+    if keep:  # 288 GB of HBM: keep the intermediates instead of recomputing them in backward
+        ctx.act_names = [k for k, v in acts.items() if v is not None]
+        ctx.save_for_backward(*tensors, *[acts[k] for k in ctx.act_names])
+    else:
+        ctx.act_names = None
+        ctx.save_for_backward(*tensors)
+
+
+def _restore(ctx, saved_acts, optional):
+    A = dict(zip(ctx.act_names, saved_acts))
+    for k in optional:
+        A.setdefault(k, None)
+    return A
+
+
+class AttnBranchFn(torch.autograd.Function):
+    """First half of transformer_layer.py:165-228: x + droppath(gamma_1 * self_attn(LN(x))), forward + backward in HIP.
+
+    x: [B, S, H] bf16 contiguous (batch-major; S may be a joint text+image / text+audio stream).  bias: RelPosBias-like
+    handle or None (bias_image = bias.image only puts the table(s) into the autograd graph).  key_pad: uint8 [B, Spad] or
+    None.  ps: fp32 [B] drop-path multipliers (0 or 1/keep) or None."""
 
     @staticmethod
-    def forward(ctx, x, bias_image, bias, key_pad, ps1, ps2, heads, save_acts, *params):
-        # bias_image (= bias.image) is passed as a tensor only to put the bias table into the autograd graph
+    def forward(ctx, x, bias_image, bias, key_pad, ps, heads, save_acts, *params):
         B, S, H = x.shape
-        P = dict(zip(LAYER_PARAMS, params))
+        P = dict(zip(ATTN_PARAMS, params))
         x2 = x.reshape(B * S, H)
         scale = (H // heads) ** -0.5
         bias_img = bias.image.detach() if bias is not None else None
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
-        out, acts = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=keep)
-        ctx.bias = bias
-        ctx.dims = (B, S, H, heads, scale)
-        ctx.n_params = len(params)
+        x_mid, acts = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, keep)
+        ctx.bias, ctx.dims, ctx.n_params = bias, (B, S, H, heads, scale), len(params)
         ctx.direct = ()
-        if need_grad:  # weights whose gradient GEMM accumulates straight into the flat gradient buffer
-            # (name, Parameter object): saved_tensors hands back fresh tensor objects without .grad / attributes
-            ctx.direct = tuple((n, q) for n, q, ng in zip(LAYER_PARAMS, params, ctx.needs_input_grad[8:])
-                               if ng and n in _DIRECT_WEIGHTS and q is not None and _direct_grad(q))
-            for _, q in ctx.direct:
-                q._op_pending = getattr(q, "_op_pending", 0) + 1
-        if keep:  # 288 GB of HBM: keep the layer's intermediates instead of recomputing them in backward
-            ctx.act_names = [k for k, v in acts.items() if v is not None]
-            ctx.save_for_backward(x2, key_pad, ps1, ps2, *params, *[acts[k] for k in ctx.act_names])
-        else:
-            ctx.act_names = None
-            ctx.save_for_backward(x2, key_pad, ps1, ps2, *params)
-        return out.view(B, S, H)
+        if need_grad:
+            _register_direct(ctx, ATTN_PARAMS, params, ctx.needs_input_grad[7:])
+        _save(ctx, keep, acts, x2, key_pad, ps, *params)
+        return x_mid.view(B, S, H)
 
     @staticmethod
-    def backward(ctx, dout):
-        x2, key_pad, ps1, ps2, *rest = ctx.saved_tensors
+    def backward(ctx, dx_mid):
+        x2, key_pad, ps, *rest = ctx.saved_tensors
         params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
         B, S, H, heads, scale = ctx.dims
-        P = dict(zip(LAYER_PARAMS, params))
+        P = dict(zip(ATTN_PARAMS, params))
         bias = ctx.bias
         bias_img = bias.image.detach() if bias is not None else None
         biasT = bias.imageT if bias is not None else None
         want_dbias = bias is not None and bias.image.requires_grad
         if ctx.act_names is not None:
-            A = dict(zip(ctx.act_names, saved_acts))
-            for k in ("mean_a", "rstd_a", "mean_f", "rstd_f"):
-                A.setdefault(k, None)
+            A = _restore(ctx, saved_acts, ("mean_a", "rstd_a"))
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = _layer_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, ps2, keep=True)
+            _, A = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, True)
+        dx_mid = dx_mid.reshape(B * S, H)
+        if not dx_mid.is_contiguous():
+            dx_mid = dx_mid.contiguous()
+        G = {}
+        weight_grad, direct = _weight_grad_fn(ctx, G)
+        dy1 = hip.scale_rows(dx_mid, P["g1"], ps, S)
+        if P["g1"] is not None:
+            G["g1"] = hip.colsum(dx_mid, A["y1"], ps, S)
+        G["bo"] = hip.colsum(dy1)
+        weight_grad("wo", dy1, A["aln"])
+        daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
+        if P["aln_w"] is not None:
+            dattn, G["aln_w"], G["aln_b"] = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"],
+                                                              A["rstd_a"])
+        else:
+            dattn = daln
+        dqkv, _ = _attn_backward(A["qkv"], dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
+                                 bias.grad_accumulator() if want_dbias else None)
+        dbias_cols = hip.colsum(dqkv)
+        G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
+        if direct.keys() & {"wq", "wk", "wv"}:
+            for i, n in enumerate(("wq", "wk", "wv")):
+                weight_grad(n, dqkv[:, i * H:(i + 1) * H], A["xln1"])
+        else:
+            dW = wgrad(dqkv, A["xln1"])  # [3H, H]
+            G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
+        dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
+        dx, G["ln1_w"], G["ln1_b"] = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"],
+                                                       add=dx_mid)
+        grads = [G.get(n) if q is not None else None for n, q in zip(ATTN_PARAMS, params)]
+        dimg = None
+        if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
+            dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
+        return (dx.view(B, S, H), dimg, None, None, None, None, None, *grads)
+
+
+class FfnBranchFn(torch.autograd.Function):
+    """Second half of transformer_layer.py:165-228: x + droppath(gamma_2 * modality_ffn(LN(x))) for the rows of ONE
+    modality.  x: [B, S, H] contiguous; ps: fp32 [B] or None."""
+
+    @staticmethod
+    def forward(ctx, x, ps, save_acts, *params):
+        B, S, H = x.shape
+        P = dict(zip(FFN_PARAMS, params))
+        x2 = x.reshape(B * S, H)
+        need_grad = any(ctx.needs_input_grad)
+        keep = bool(save_acts) and need_grad
+        out, acts = _ffn_forward(x2, P, S, ps, keep)
+        ctx.dims, ctx.n_params = (B, S, H), len(params)
+        ctx.direct = ()
+        if need_grad:
+            _register_direct(ctx, FFN_PARAMS, params, ctx.needs_input_grad[3:])
+        _save(ctx, keep, acts, x2, ps, *params)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_mid, ps, *rest = ctx.saved_tensors
+        params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
+        B, S, H = ctx.dims
+        P = dict(zip(FFN_PARAMS, params))
+        if ctx.act_names is not None:
+            A = _restore(ctx, saved_acts, ("mean_f", "rstd_f"))
+        else:
+            _, A = _ffn_forward(x_mid, P, S, ps, True)
         N = B * S
         Fd = P["w0"].shape[0]
         dout2 = dout.reshape(N, H)
         if not dout2.is_contiguous():
             dout2 = dout2.contiguous()
         G = {}
-
-        # ---- FFN branch: out = x_mid + ps * g2 * (gln W2^T + b2) ----
-        dy2 = hip.scale_rows(dout2, P["g2"], ps2, S)
+        weight_grad, direct = _weight_grad_fn(ctx, G)
+        dy2 = hip.scale_rows(dout2, P["g2"], ps, S)
         if P["g2"] is not None:
-            G["g2"] = hip.colsum(dout2, A["y2"], ps2, S)
+            G["g2"] = hip.colsum(dout2, A["y2"], ps, S)
         G["b2"] = hip.colsum(dy2)
-        direct = dict(ctx.direct)
-
-        def weight_grad(name, dyv, xv):
-            target = direct.get(name)
-            if target is not None:
-                wgrad(dyv, xv, out=target.grad, accumulate=True)
-                _direct_grad_done(target)
-            else:
-                G[name] = wgrad(dyv, xv)
-
         weight_grad("w2", dy2, A["gln"])
         dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
         if P["fln_w"] is not None:
@@ -392,40 +477,10 @@ class EncoderLayerFn(torch.autograd.Function):
             G["w0"], G["w1"] = dW01[:Fd], dW01[Fd:]
         dxln2 = hip.gemm_nt(dh0, [_transposed(P["w0"])])
         hip.gemm_nt(dh1, [_transposed(P["w1"])], out=dxln2, epilogue=hip.EPI_RESID, resid=dxln2)
-        dx_mid, G["ln2_w"], G["ln2_b"] = hip.layernorm_bwd(dxln2, A["x_mid"], P["ln2_w"], P["ln2_b"], A["mean2"],
-                                                           A["rstd2"], add=dout2)
-
-        # ---- attention branch: x_mid = x + ps * g1 * (aln Wo^T + bo) ----
-        dy1 = hip.scale_rows(dx_mid, P["g1"], ps1, S)
-        if P["g1"] is not None:
-            G["g1"] = hip.colsum(dx_mid, A["y1"], ps1, S)
-        G["bo"] = hip.colsum(dy1)
-        weight_grad("wo", dy1, A["aln"])
-        daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
-        if P["aln_w"] is not None:
-            dattn, G["aln_w"], G["aln_b"] = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"],
-                                                              A["rstd_a"])
-        else:
-            dattn = daln
-        qkv = A["qkv"]
-        dqkv, _ = _attn_backward(qkv, dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
-                                 bias.grad_accumulator() if want_dbias else None)
-        dbias_cols = hip.colsum(dqkv)
-        G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
-        if direct.keys() & {"wq", "wk", "wv"}:
-            for i, n in enumerate(("wq", "wk", "wv")):
-                weight_grad(n, dqkv[:, i * H:(i + 1) * H], A["xln1"])
-        else:
-            dW = wgrad(dqkv, A["xln1"])  # [3H, H]
-            G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
-        dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
-        dx, G["ln1_w"], G["ln1_b"] = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"],
-                                                       add=dx_mid)
-        grads = [G.get(n) if p is not None else None for n, p in zip(LAYER_PARAMS, params)]
-        dimg = None
-        if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
-            dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
-        return (dx.view(B, S, H), dimg, None, None, None, None, None, None, *grads)
+        dx, G["ln2_w"], G["ln2_b"] = hip.layernorm_bwd(dxln2, x_mid, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"],
+                                                       add=dout2)
+        grads = [G.get(n) if q is not None else None for n, q in zip(FFN_PARAMS, params)]
+        return (dx.view(B, S, H), None, None, *grads)
 
 
 def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc):
@@ -445,9 +500,18 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
     return dqkv, dbias_acc
 
 
+def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):
+    return AttnBranchFn.apply(x, bias.image if bias is not None else None, bias, key_pad, ps, heads, save_acts, *params)
+
+
+def ffn_branch(x, ps, params, save_acts=False):
+    return FfnBranchFn.apply(x, ps, save_acts, *params)
+
+
 def encoder_layer(x, bias, key_pad, ps1, ps2, heads, params, save_acts=False):
-    return EncoderLayerFn.apply(x, bias.image if bias is not None else None, bias, key_pad, ps1, ps2, heads, save_acts,
-                                *params)
+    """Whole single-modality layer; params in LAYER_PARAMS order."""
+    n = len(ATTN_PARAMS)
+    return ffn_branch(attn_branch(x, bias, key_pad, ps1, heads, params[:n], save_acts), ps2, params[n:], save_acts)
 
 
 # --------------------------------------------------------------------------------------------------------------

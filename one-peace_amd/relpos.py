@@ -2,7 +2,8 @@
 
 The reference adapters return dense ``[B, heads, S, S]`` tensors (adapter/image.py:164-171).  Here an adapter
 returns ``RelPosSpec`` objects instead: the encoder turns them into the per-table ``[heads, S, Spad]`` image for the
-HIP attention kernels, or into the dense tensor when it has to run the torch ops (CPU, fp32, joint vl/al streams)."""
+HIP attention kernels (``joint_handle`` for the block-diagonal bias of a joint vl/al stream), or into the dense tensor
+when it has to run the torch ops (CPU, fp32)."""
 import math
 
 import torch
@@ -58,3 +59,28 @@ class RelPosSpec:
         S = self.bucket.shape[0]
         b32 = self.bucket_i32 if self.bucket_i32 is not None else self.bucket.to(torch.int32).contiguous()
         return ops.RelPosBias(self.table, b32, S)
+
+
+def joint_handle(specs, lens, bucket_cache=None):
+    """Block-diagonal bias of a joint stream (transformer_encoder.py:144-158: zeros, then each modality's block added on
+    its own diagonal square) as ONE table + bucket: rows of the per-modality tables stacked, plus a constant zero row
+    that every cross-modal (off-diagonal) position points at.  ``torch.cat`` routes the table gradient back to each
+    modality's own embedding.  specs: RelPosSpec or None per segment; lens: segment lengths."""
+    live = [sp for sp in specs if sp is not None]
+    ref = live[0].table
+    S = sum(lens)
+    key = tuple(id(sp.bucket) if sp is not None else None for sp in specs) + tuple(lens)
+    bucket = bucket_cache.get(key) if bucket_cache is not None else None
+    n_rows = sum(sp.table.shape[0] for sp in live)
+    if bucket is None:
+        bucket = torch.full((S, S), n_rows, dtype=torch.int32, device=ref.device)
+        off = base = 0
+        for sp, n in zip(specs, lens):
+            if sp is not None:
+                bucket[off:off + n, off:off + n] = sp.bucket.to(torch.int32) + base
+                base += sp.table.shape[0]
+            off += n
+        if bucket_cache is not None:
+            bucket_cache[key] = bucket
+    table = torch.cat([sp.table for sp in live] + [ref.new_zeros(1, ref.shape[1])], dim=0)
+    return ops.RelPosBias(table, bucket, S)

@@ -4,9 +4,10 @@
 ``(x [B,S,H], padding_mask [B,S], bias_list)`` and returns the reference's dict (``encoder_out[0]`` is T x B x C).
 bias_list entries may be dense tensors (reference adapters) or ``RelPosSpec`` (our adapters).
 
-MI355X path (single-modality stream, bf16): activations stay batch-major, the dense ``[B, heads, S, S]`` bias of the
-reference (transformer_encoder.py:144-162) is never built -- each table becomes one ``[heads, S, Spad]`` image and
-key padding a ``[B, Spad]`` byte mask -- and every block is one fused HIP function."""
+MI355X path (bf16; single-modality and joint vl/al streams): activations stay batch-major, the dense
+``[B, heads, S, S]`` bias of the reference (transformer_encoder.py:144-162) is never built -- each table (or, for a
+joint stream, the block-diagonal pair of tables) becomes one ``[heads, S, Spad]`` image and key padding a ``[B, Spad]``
+byte mask -- and every block is two fused HIP functions (attention branch, per-modality FFN branch)."""
 import logging
 
 import torch
@@ -14,7 +15,7 @@ import torch.nn as nn
 
 from .. import hip, ops
 from ..components import FairseqDropout, LayerNorm
-from ..relpos import RelPosSpec
+from ..relpos import RelPosSpec, joint_handle
 from .transformer_layer import TransformerEncoderLayer
 
 logger = logging.getLogger(__name__)
@@ -61,35 +62,60 @@ class TransformerEncoder(nn.Module):
         if streams is None:
             raise NotImplementedError(encoder_type)
         infos = dict(text=text_info, image=image_info, audio=audio_info)
-        if (len(streams) == 1 and not return_all_hiddens and ops.hip_eligible(infos[streams[0]][0])
-                and self._fused_ok(encoder_type, infos[streams[0]])):
-            return self._forward_fused(encoder_type, infos[streams[0]])
+        parts = [infos[s] for s in streams]
+        if not return_all_hiddens and ops.hip_eligible(parts[0][0]) and self._fused_ok(encoder_type, parts):
+            return self._forward_fused(encoder_type, streams, parts)
         return self._forward_torch(encoder_type, streams, infos, return_all_hiddens)
 
-    def _fused_ok(self, encoder_type, info):
-        biases = info[2]
-        if biases is not None and not all(isinstance(b, RelPosSpec) for b in biases):
+    def _fused_ok(self, encoder_type, parts):
+        n_bias = None
+        for _, _, biases in parts:
+            if biases is not None:
+                if not all(isinstance(b, RelPosSpec) for b in biases):
+                    return False
+                if n_bias is not None and len(biases) != n_bias:
+                    return False
+                n_bias = len(biases)
+        if len(parts) > 1 and any(p[0].dtype != parts[0][0].dtype or not p[0].is_cuda for p in parts):
             return False
         if self.encoder_layerdrop > 0.0 and self.training:
             return False
         return all(getattr(layer, "fused_supported", lambda e: False)(encoder_type) for layer in self.layers)
 
-    def _forward_fused(self, encoder_type, info):
-        x, pad, biases = info
+    def _forward_fused(self, encoder_type, streams, parts):
+        lens = [p[0].shape[1] for p in parts]
+        if len(parts) == 1:
+            x, pad, biases = parts[0]
+            no_pads = getattr(pad, "_all_false", False)
+            handles = [b.handle() for b in biases] if biases else []
+        else:
+            x = torch.cat([p[0] for p in parts], dim=1)
+            pad = torch.cat([p[1] for p in parts], dim=1)
+            no_pads = all(getattr(p[1], "_all_false", False) for p in parts)
+            n_bias = max((len(p[2]) for p in parts if p[2] is not None), default=0)
+            cache = {}
+            handles = [joint_handle([p[2][i] if p[2] is not None else None for p in parts], lens, cache)
+                       for i in range(n_bias)]
         B, S, _ = x.shape
         key_pad = None
-        if not getattr(pad, "_all_false", False):
+        if not no_pads:
             x = x * (~pad).unsqueeze(-1).to(x.dtype)  # transformer_encoder.py:141-142
             key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=x.device)
             key_pad[:, :S] = pad.to(torch.uint8)
         x = x.contiguous()
-        handles = [b.handle() for b in biases] if biases else []
         for idx, layer in enumerate(self.layers):
             h = None if not handles else (handles[0] if len(handles) == 1 else handles[idx])
-            x = layer.forward_fused(x, h, key_pad, encoder_type)
-        norm = getattr(self, encoder_type + "_layer_norm")
-        if norm is not None:
-            x = norm(x)
+            x = layer.forward_fused(x, h, key_pad, encoder_type, lens)
+        if len(parts) == 1:
+            norm = getattr(self, encoder_type + "_layer_norm")
+            x = norm(x) if norm is not None else x
+        else:  # transformer_encoder.py:196-207: each modality's rows through its own final norm
+            segs, off = [], 0
+            for s, n in zip(streams, lens):
+                norm, seg = getattr(self, s + "_layer_norm"), x[:, off:off + n]
+                segs.append(norm(seg.contiguous()) if norm is not None else seg)
+                off += n
+            x = torch.cat(segs, dim=1)
         return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": [],
                 "image_encoder_states": [], "audio_encoder_states": []}
 

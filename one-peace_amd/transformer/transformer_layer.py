@@ -3,7 +3,8 @@
 Parameter names/shapes are the reference's (state-dict contract): ``self_attn.*``,
 ``self_attn_layer_norm``, ``final_layer_norm``, ``{text,image,audio}_ffn.{0.wi_0,0.wi_1,2,3}``, ``gamma_1/2``,
 optional ``attn_ln``.  ``forward`` keeps the reference signature (time-major x, dense additive bias) and runs torch
-ops; ``forward_fused`` is the MI355X path: one HIP-backed autograd function for the whole block."""
+ops; ``forward_fused`` is the MI355X path: one HIP-backed autograd function per branch (attention over the whole --
+possibly joint -- stream, then each modality's rows through its own GeGLU FFN)."""
 import logging
 
 import torch
@@ -90,31 +91,48 @@ class TransformerEncoderLayer(nn.Module):
         return self._branch(y, self.gamma_2, x)
 
     # ------------------------------------------------------------------ MI355X path
+    _STREAMS = {"text": ("text",), "image": ("image",), "audio": ("audio",), "vl": ("text", "image"),
+                "al": ("text", "audio")}
+
     def fused_supported(self, encoder_type):
-        return (encoder_type in ("text", "image", "audio") and self.self_attn.head_dim == 64 and self.attn_ln is None
+        streams = self._STREAMS.get(encoder_type)
+        return (streams is not None and all(hasattr(self, s + "_ffn") for s in streams)
+                and self.self_attn.head_dim == 64 and self.attn_ln is None
                 and self.self_attn.c_attn is None and not (self.training and self.dropout_prob > 0.0)
                 and self.self_attn.dropout_p == 0.0 and float(self.cfg.activation_dropout) == 0.0
                 and self.embed_dim % 64 == 0 and self.ffn_embed_dim % 64 == 0)
 
-    def fused_params(self, encoder_type):
-        a, ffn = self.self_attn, getattr(self, encoder_type + "_ffn")
-        fln = ffn[2] if isinstance(ffn[2], nn.LayerNorm) else None
-        sub = a.ln
+    def attn_params(self):
+        a, sub = self.self_attn, self.self_attn.ln
         return (self.self_attn_layer_norm.weight, self.self_attn_layer_norm.bias, a.q_proj.weight, a.q_proj.bias,
                 a.k_proj.weight, a.v_proj.weight, a.v_proj.bias, sub.weight if sub is not None else None,
-                sub.bias if sub is not None else None, a.out_proj.weight, a.out_proj.bias, self.gamma_1,
-                self.final_layer_norm.weight, self.final_layer_norm.bias, ffn[0].wi_0.weight, ffn[0].wi_1.weight,
+                sub.bias if sub is not None else None, a.out_proj.weight, a.out_proj.bias, self.gamma_1)
+
+    def ffn_params(self, modality):
+        ffn = getattr(self, modality + "_ffn")
+        fln = ffn[2] if isinstance(ffn[2], nn.LayerNorm) else None
+        return (self.final_layer_norm.weight, self.final_layer_norm.bias, ffn[0].wi_0.weight, ffn[0].wi_1.weight,
                 fln.weight if fln is not None else None, fln.bias if fln is not None else None, ffn[3].weight, ffn[3].bias,
                 self.gamma_2)
 
-    def forward_fused(self, x_bsh, bias_handle, key_pad_u8, encoder_type):
-        """x_bsh: [B, S, H] bf16 batch-major; bias_handle: ops.RelPosBias or None; key_pad_u8: [B, Spad] or None."""
+    def fused_params(self, encoder_type):
+        return self.attn_params() + self.ffn_params(encoder_type)
+
+    def forward_fused(self, x_bsh, bias_handle, key_pad_u8, encoder_type, seg_lens=None):
+        """x_bsh: [B, S, H] bf16 batch-major; bias_handle: ops.RelPosBias or None; key_pad_u8: [B, Spad] or None.
+        For 'vl'/'al' S = seg_lens[0] (text) + seg_lens[1] (image|audio) and the two row ranges take their own FFN
+        (transformer_layer.py:206-216) under ONE shared drop-path draw, as in the reference."""
         B = x_bsh.shape[0]
+        keep = not getattr(self.cfg, "checkpoint_activations", False)
         ps1 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
         ps2 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
-        return ops.encoder_layer(x_bsh, bias_handle, key_pad_u8, ps1, ps2, self.self_attn.num_heads,
-                                 self.fused_params(encoder_type),
-                                 save_acts=not getattr(self.cfg, "checkpoint_activations", False))
+        x = ops.attn_branch(x_bsh, bias_handle, key_pad_u8, ps1, self.self_attn.num_heads, self.attn_params(), keep)
+        streams = self._STREAMS[encoder_type]
+        if len(streams) == 1:
+            return ops.ffn_branch(x, ps2, self.ffn_params(streams[0]), keep)
+        n_text = seg_lens[0]
+        parts = (x[:, :n_text].contiguous(), x[:, n_text:].contiguous())
+        return torch.cat([ops.ffn_branch(part, ps2, self.ffn_params(m), keep) for part, m in zip(parts, streams)], dim=1)
 
     def upgrade_state_dict_named(self, state_dict, name):
         """Legacy key renames + fill-in of missing keys (reference transformer_layer.py:230-248)."""

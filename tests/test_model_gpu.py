@@ -216,3 +216,63 @@ def test_direct_gradient_accumulation_matches_autograd():
         worst = max(worst, e)
         assert e < 2e-2, (n, e)   # bf16 accumulation order differs (in-place += vs autograd's sum)
     assert len(grads["direct"]) >= len(grads["autograd"])
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_joint_vl_al_streams_on_hip(golden_dir, train):
+    """encoder_type 'vl' / 'al' (transformer_encoder.py:144-207, transformer_layer.py:206-216): one attention over the
+    joint sequence with the block-diagonal bias, each modality's rows through its own FFN.  Forward against the
+    reference-generated golden outputs; gradients (weighted sum of both outputs, incl. both rel-pos tables) against
+    the fp32 torch path of the mirror (itself pinned to the reference on CPU, tests/test_model_cpu.py)."""
+    from one_peace_amd.transformer import transformer_encoder as TE
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    report = []
+    calls = {"n": 0}
+    orig = TE.TransformerEncoder._forward_fused
+
+    def counted(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+
+    def run(m, inp):
+        w = m.encoder_wrapper
+        vt, vi, _ = w(src_tokens=inp["src_tokens"], src_images=inp["src_images"], encoder_type="vl")
+        at, _, aa = w(src_tokens=inp["src_tokens"], src_audios=inp["src_audios"],
+                      audio_padding_masks=inp["audio_padding_masks"], encoder_type="al")
+        outs = dict(vl_text=vt, vl_image=vi, al_text=at, al_audio=aa)
+        grads = {}
+        if train:
+            g = torch.Generator().manual_seed(5)
+            loss = sum((o.float() * torch.randn(o.shape, generator=g).to(o.device)).sum() for o in outs.values())
+            m.zero_grad()
+            loss.backward()
+            grads = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None}
+        return {k: v.detach().float().cpu() for k, v in outs.items()}, grads
+
+    res = {}
+    TE.TransformerEncoder._forward_fused = counted
+    try:
+        for mode in ("hip", "torch", "fp32"):
+            dt = torch.float32 if mode == "fp32" else torch.bfloat16
+            m = load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]).to(DEV).to(dt).eval()
+            _force_torch_path(m, mode != "hip")
+            inp = {k: (v.to(DEV).to(dt) if v.is_floating_point() else v.to(DEV)) for k, v in fx["inputs"].items()}
+            before = calls["n"]
+            res[mode] = run(m, inp)
+            assert (calls["n"] - before == 2) == (mode == "hip"), "joint streams must take the fused HIP path"
+    finally:
+        TE.TransformerEncoder._forward_fused = orig
+    for k in ("vl_text", "vl_image", "al_text", "al_audio"):
+        assert rel_fro(res["fp32"][0][k], fx[k]) < 1e-4  # the fp32 mirror reproduces the reference fixture
+        _check(k, res["hip"][0][k], res["torch"][0][k], fx[k], 1.5e-2, report)
+    if train:
+        n_checked = 0
+        for n, ref in res["fp32"][1].items():
+            if float(ref.norm()) < 1e-7:
+                continue
+            _check("grad " + n, res["hip"][1][n], res["torch"][1][n], ref, 5e-2, report)
+            n_checked += 1
+        assert n_checked > 50
+        assert any("rel_pos_table" in n for n in res["hip"][1])
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "joint_parity_report_%d.txt" % train),
+         "w").write("\n".join(report) + "\n")

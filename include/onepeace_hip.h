@@ -42,6 +42,8 @@ int op_prof_collect(double* ms, int64_t* count, double* work, int n_families);
 int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
                      int64_t cols, float eps, int act_gelu, int dtype, void* stream);
 int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
+/* tuning knob: caps of the persistent LayerNorm grids (<= 0 keeps the current value) */
+int op_layernorm_set_grid(int fwd_blocks, int bwd_blocks);
 /* dx = LN backward (+ `add`: gradient arriving through the residual path, may be NULL, may alias dx);
  * dw, db [cols] optional (need `workspace`); accumulate != 0 adds into dw/db. */
 int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
@@ -113,6 +115,23 @@ int op_relpos_bias_bwd(const float* dbias, const int* bucket, int64_t bucket_ld,
  * (the reference gets these from autograd over transformer_layer.py:54-88,149-157) */
 int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream);
 int64_t op_colsum_workspace_bytes(int64_t N);
+/* Per-segment column sums of x [M, n_seg*seg_cols]: the q/k/v bias gradients of the fused projection
+ * (one_peace/models/transformer/multihead_attention.py:57-62; a null out_i skips that segment).  workspace: op_colsum_workspace_bytes(n_seg*seg_cols). */
+int op_colsum_segments(const void* x, void* out0, void* out1, void* out2, void* workspace, int64_t M, int64_t n_seg,
+                       int64_t seg_cols, int accumulate, void* stream);
+/* Backward of out = resid + rowscale[m/rps] * gamma[n] * y[m][n] (layer-scale + drop-path residual,
+ * one_peace/models/transformer/transformer_layer.py:70-88,190-196,224-226) in one pass:
+ * dbranch = rowscale*gamma*dout; dgamma (+)= sum_m rowscale*dout*y; dbias (+)= sum_m dbranch.  Nullable: y+dgamma, gamma,
+ * rowscale, dbias. */
+int64_t op_resid_bwd_workspace_bytes(int64_t N);
+int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
+                 void* dbranch, void* dgamma, void* dbias, void* workspace, int64_t M, int64_t N, int accumulate,
+                 void* stream);
+/* Backward of LayerNorm_F(gelu(h0) * h1) w.r.t. h0, h1 and the LayerNorm affine in one pass (the FFN's GeGLU + inner
+ * sub-LayerNorm, transformer_layer.py:64-67,111-118); mean/rstd: forward statistics.  workspace: op_layernorm_bwd_workspace_bytes. */
+int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* w, const float* mean, const float* rstd,
+                    void* dh0, void* dh1, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int accumulate,
+                    void* stream);
 /* out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_m rowscale[m/rps] * x[m][n] * (y ? y[m][n] : 1); y/rowscale/mul NULL ok */
 int op_colsum(const void* x, const void* y, const float* rowscale, int64_t rows_per_sample, const void* mul, void* out,
               void* workspace, int64_t M, int64_t N, int accumulate, int out_dtype, void* stream);

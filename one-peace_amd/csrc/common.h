@@ -56,6 +56,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- 8-element vector load/store with fp32 math --------------------------------------------------
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
+  typedef bf16x8 raw_t;  // load now, convert at first use (keeps prefetched rows as plain loads in flight)
+  static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+  static __device__ __forceinline__ void cvt(const raw_t& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+  }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
 #pragma unroll
@@ -69,6 +75,17 @@ template <> struct Vec8<bf16_t> {
   }
 };
 template <> struct Vec8<float> {
+  struct raw_t { f32x4 a, b; };
+  static __device__ __forceinline__ raw_t ldraw(const float* p) {
+    raw_t r;
+    r.a = *reinterpret_cast<const f32x4*>(p);
+    r.b = *reinterpret_cast<const f32x4*>(p + 4);
+    return r;
+  }
+  static __device__ __forceinline__ void cvt(const raw_t& r, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
+  }
   static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
     f32x4 a = *reinterpret_cast<const f32x4*>(p);
     f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -99,6 +116,38 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __res
                                                               int N, const bf16_t* __restrict__ mul, T* __restrict__ out,
                                                               int accumulate) {
   __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float a = 0.f;
+  if (n < N) {
+#pragma unroll 8
+    for (int p = pg; p < parts; p += 8) a += part[(int64_t)p * pstride + n];
+  }
+  red[pg][c] = a;
+  __syncthreads();
+  if (pg == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += red[i][c];
+    if (mul) t *= (float)mul[n];
+    out[n] = (T)(t + (accumulate ? (float)out[n] : 0.f));
+  }
+}
+
+// Up to three such folds in ONE launch (gridDim.y = jobs; a job with a null `out` is skipped): the dw/db pair of a
+// LayerNorm backward, dgamma/dbias of a residual branch, the q/k/v bias segments of a fused projection.
+template <typename T>
+__global__ __launch_bounds__(256) void partials_reduce3_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                               const float* __restrict__ p2, const bf16_t* __restrict__ m0,
+                                                               const bf16_t* __restrict__ m1, const bf16_t* __restrict__ m2,
+                                                               T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2,
+                                                               int parts, int64_t pstride, int N, int accumulate) {
+  __shared__ float red[8][33];
+  const int job = blockIdx.y;
+  const float* part = job == 0 ? p0 : (job == 1 ? p1 : p2);
+  const bf16_t* mul = job == 0 ? m0 : (job == 1 ? m1 : m2);
+  T* out = job == 0 ? o0 : (job == 1 ? o1 : o2);
+  if (out == nullptr) return;  // uniform
   const int c = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + c;
   float a = 0.f;

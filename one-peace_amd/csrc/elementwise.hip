@@ -85,6 +85,73 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// residual-branch backward in one pass (transformer_layer.py:70-88):  out = resid + rs[m] * gamma[n] * y[m][n]
+//   dbranch[m][n] = rs[m] * gamma[n] * dout[m][n]
+//   part[0][p][n] = sum_rows rs * dout * y        (-> dgamma)
+//   part[1][p][n] = sum_rows rs * dout            (-> dbias of the branch's last Linear, times gamma in the fold)
+// grid = (ceil(N / 512), parts); block 256 = 4 waves x 64 lanes x 8 columns; two rows in flight per wave.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resid_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
+                                                        const bf16_t* __restrict__ gamma, const float* __restrict__ rowscale,
+                                                        int rps, bf16_t* __restrict__ dbranch, float* __restrict__ part,
+                                                        int64_t M, int N) {
+  __shared__ float red[4][512];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 512 + lane * 8;
+  float ag[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float gv[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+  if (c < N) {
+    if (gamma) Vec8<bf16_t>::load(gamma + c, gv);
+    const int64_t step = (int64_t)gridDim.y * 4;
+    for (int64_t m = (int64_t)blockIdx.y * 4 + wid; m < M; m += 2 * step) {
+      const int64_t m2 = m + step;
+      const bool two = m2 < M;
+      bf16x8 d0 = Vec8<bf16_t>::ldraw(dout + m * N + c), d1, y0, y1;
+      if (y) y0 = Vec8<bf16_t>::ldraw(y + m * N + c);
+      if (two) {
+        d1 = Vec8<bf16_t>::ldraw(dout + m2 * N + c);
+        if (y) y1 = Vec8<bf16_t>::ldraw(y + m2 * N + c);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !two) break;
+        const int64_t mm = h == 0 ? m : m2;
+        float d[8], o[8];
+        Vec8<bf16_t>::cvt(h == 0 ? d0 : d1, d);
+        const float sc = rowscale ? rowscale[mm / rps] : 1.f;
+        if (y) {
+          float yv[8];
+          Vec8<bf16_t>::cvt(h == 0 ? y0 : y1, yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ag[j] += sc * d[j] * yv[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = sc * d[j];
+          ab[j] += t;
+          o[j] = t * gv[j];
+        }
+        Vec8<bf16_t>::store(dbranch + mm * N + c, o);
+      }
+    }
+  }
+  if (part == nullptr) return;  // uniform
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0 && y == nullptr) continue;  // uniform
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[wid][lane * 8 + j] = pass == 0 ? ag[j] : ab[j];
+    __syncthreads();
+    float* dst = part + ((int64_t)pass * gridDim.y + blockIdx.y) * N;
+    for (int i = threadIdx.x; i < 512; i += 256) {
+      const int cc = blockIdx.x * 512 + i;
+      if (cc < N) dst[cc] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // GeGLU backward (transformer_layer.py:64-67):  g = gelu(h0) * h1
 //   dh0 = dg * h1 * gelu'(h0),  dh1 = dg * gelu(h0)
 // ------------------------------------------------------------------------------------------------------------
@@ -369,6 +436,63 @@ int op_colsum(const void* x, const void* y, const float* rowscale, int64_t rows_
   else
     hipLaunchKernelGGL((partials_reduce_kernel<float>), dim3(ceil_div(N, 32)), dim3(256), 0, s, (const float*)workspace, parts,
                        N, (int)N, (const bf16_t*)mul, (float*)out, accumulate);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+int64_t op_resid_bwd_workspace_bytes(int64_t N) { return 2 * (int64_t)CS_MAX_PARTS * N * (int64_t)sizeof(float); }
+
+// One pass over the gradient of  out = resid + rowscale[m/rps] * gamma[n] * y[m][n]  (transformer_layer.py:70-88,
+// y = the branch's last Linear output incl. its bias):
+//   dbranch = rowscale * gamma * dout;  dgamma (+)= sum_m rowscale * dout * y;  dbias (+)= sum_m dbranch
+// gamma, rowscale, y/dgamma, dbias nullable; dgamma/dbias are bf16 [N]; accumulate: add into them instead of overwriting.
+int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
+                 void* dbranch, void* dgamma, void* dbias, void* workspace, int64_t M, int64_t N, int accumulate,
+                 void* stream) {
+  OP_CHECK_ARG(dout && dbranch, "resid_bwd: null pointer");
+  OP_CHECK_ARG(N > 0 && N % 8 == 0, "resid_bwd: N must be a multiple of 8");
+  OP_CHECK_ARG(!dgamma || y, "resid_bwd: dgamma needs y");
+  OP_CHECK_ARG(!(dgamma || dbias) || workspace, "resid_bwd: dgamma/dbias requested without workspace");
+  if (M == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int parts = (int)((M + 63) / 64);
+  if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
+  if (parts < 1) parts = 1;
+  float* ws = (dgamma || dbias) ? (float*)workspace : nullptr;
+  hipLaunchKernelGGL(resid_bwd_kernel, dim3(ceil_div(N, 512), parts), dim3(256), 0, s, (const bf16_t*)dout,
+                     (const bf16_t*)(dgamma ? y : nullptr), (const bf16_t*)gamma, rowscale,
+                     (int)(rows_per_sample > 0 ? rows_per_sample : 1), (bf16_t*)dbranch, ws, M, (int)N);
+  OP_LAUNCH_CHECK();
+  if (ws) {
+    hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(N, 32), 2), dim3(256), 0, s, ws,
+                       ws + (int64_t)parts * N, (const float*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)gamma,
+                       (const bf16_t*)nullptr, (bf16_t*)dgamma, (bf16_t*)dbias, (bf16_t*)nullptr, parts, N, (int)N,
+                       accumulate);
+    OP_LAUNCH_CHECK();
+  }
+  return OP_OK;
+}
+
+// Column sums of x [M, n_seg * seg_cols] (row stride = n_seg * seg_cols) delivered per segment: out_i (bf16 [seg_cols],
+// nullable = skip) (+)= sum_m x[m][i * seg_cols + n].  The q/k/v bias gradients of the fused projection
+// (multihead_attention.py:57-62: k_proj has no bias -> its slot is null).  n_seg <= 3.
+int op_colsum_segments(const void* x, void* out0, void* out1, void* out2, void* workspace, int64_t M, int64_t n_seg,
+                       int64_t seg_cols, int accumulate, void* stream) {
+  OP_CHECK_ARG(x && workspace, "colsum_segments: null pointer");
+  OP_CHECK_ARG(n_seg >= 1 && n_seg <= 3 && seg_cols > 0 && seg_cols % 8 == 0, "colsum_segments: bad segments");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t N = n_seg * seg_cols;
+  int parts = (int)((M + 63) / 64);
+  if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
+  if (parts < 1) parts = 1;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(N, 512), parts), dim3(256), 0, s, (const bf16_t*)x,
+                     (const bf16_t*)nullptr, (const float*)nullptr, 1, (float*)workspace, M, (int)N, N);
+  OP_LAUNCH_CHECK();
+  const float* ws = (const float*)workspace;
+  hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(seg_cols, 32), (int)n_seg), dim3(256), 0, s, ws,
+                     ws + seg_cols, ws + 2 * seg_cols, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                     (const bf16_t*)nullptr, (bf16_t*)out0, (bf16_t*)out1, (bf16_t*)out2, parts, N, (int)seg_cols,
+                     accumulate);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

@@ -12,7 +12,8 @@
 
 namespace {
 
-constexpr int LN_MAX_BLOCKS = 512;
+constexpr int LN_MAX_BLOCKS = 4096;       // workspace bound for the dw/db partials
+int g_ln_blocks_fwd = 512, g_ln_blocks_bwd = 512;  // persistent-grid caps (tuning knobs, op_layernorm_set_grid)
 
 template <int NW>
 __device__ __forceinline__ float group_sum(float v, float* red) {
@@ -51,16 +52,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       if (b) Vec8<T>::load(b + c, bv[i]);
     }
   }
-  // NW == 4: every thread of the block walks the same rows (uniform trip count -> barriers are safe)
+  // NW == 4: every thread of the block walks the same rows (uniform trip count -> barriers are safe).
+  // The next row is requested before the current one is reduced: twice the bytes in flight per wave.
+  typedef typename Vec8<T>::raw_t raw_t;
+  raw_t cur[CH], nxt[CH];
+  if (row0 < rows) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) cur[i] = Vec8<T>::ldraw(x + row0 * (int64_t)cols + c);
+    }
+  }
   for (int64_t row = row0; row < rows; row += rstep) {
-    const T* xr = x + row * (int64_t)cols;
+    const int64_t nrow = row + rstep;
+    if (nrow < rows) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) nxt[i] = Vec8<T>::ldraw(x + nrow * (int64_t)cols + c);
+      }
+    }
     float v[CH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        Vec8<T>::load(xr + c, v[i]);
+        Vec8<T>::cvt(cur[i], v[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[i][j];
       } else {
@@ -97,6 +115,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
       if (mean_out) mean_out[row] = mean;
       if (rstd_out) rstd_out[row] = rstd;
     }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -128,18 +148,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       if (GELU && b) Vec8<T>::load(b + c, bv[i]);
     }
   }
+  typedef typename Vec8<T>::raw_t raw_t;
+  raw_t curx[CH], curg[CH], nxtx[CH], nxtg[CH], addv[CH];
+  if (row0 < rows) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        curx[i] = Vec8<T>::ldraw(x + row0 * (int64_t)cols + c);
+        curg[i] = Vec8<T>::ldraw(dy + row0 * (int64_t)cols + c);
+      }
+    }
+  }
   for (int64_t row = row0; row < rows; row += rstep) {
     const float mean = mean_in[row], rstd = rstd_in[row];
-    const T* xr = x + row * (int64_t)cols;
-    const T* gr = dy + row * (int64_t)cols;
+    const int64_t nrow = row + rstep;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {  // residual-path gradient of this row + both operands of the next row
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        if (add) addv[i] = Vec8<T>::ldraw(add + row * (int64_t)cols + c);
+        if (nrow < rows) {
+          nxtx[i] = Vec8<T>::ldraw(x + nrow * (int64_t)cols + c);
+          nxtg[i] = Vec8<T>::ldraw(dy + nrow * (int64_t)cols + c);
+        }
+      }
+    }
     float xh[CH][8], g[CH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        Vec8<T>::load(xr + c, xh[i]);
-        Vec8<T>::load(gr + c, g[i]);
+        Vec8<T>::cvt(curx[i], xh[i]);
+        Vec8<T>::cvt(curg[i], g[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xh[i][j] = (xh[i][j] - mean) * rstd;
@@ -165,13 +207,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - c1 - xh[i][j] * c2);
         if (add) {
           float av[8];
-          Vec8<T>::load(add + row * (int64_t)cols + c, av);
+          Vec8<T>::cvt(addv[i], av);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += av[j];
         }
         Vec8<T>::store(dr + c, o);
       }
     }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { curx[i] = nxtx[i]; curg[i] = nxtg[i]; }
   }
   if (ws == nullptr) return;  // uniform
   float* wsb = ws + (int64_t)blockIdx.x * 2 * cols;
@@ -204,9 +248,127 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
 }
 
-inline int ln_grid(int64_t rows, int nw) {
+// LayerNorm(F) backward fused with the GeGLU backward (transformer_layer.py:64-67,111-118): the FFN's inner
+// sub-LayerNorm takes g = gelu(h0) * h1; g is RECOMPUTED from the saved h0/h1 (never stored for backward) and
+//   dg  = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat)),   xhat = (g - mean) * rstd
+//   dh0 = dg * h1 * gelu'(h0),   dh1 = dg * gelu(h0)
+// Algorithmic bytes: 3 reads + 2 writes of [rows, cols] bf16 (the unfused pair moved 8 passes).
+template <int CH, int NW>
+__global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h0,
+                                                           const bf16_t* __restrict__ h1, const bf16_t* __restrict__ w,
+                                                           const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, bf16_t* __restrict__ dh0,
+                                                           bf16_t* __restrict__ dh1, float* __restrict__ ws, int64_t rows,
+                                                           int cols) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // NW==1: [4][cols] ; NW==4: [4]
+  float* red = smem;
+  constexpr int G = 64 * NW;
+  const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
+  const int wid = threadIdx.x >> 6;
+  const int64_t row0 = (NW == 1) ? ((int64_t)blockIdx.x * 4 + wid) : blockIdx.x;
+  const int64_t rstep = (NW == 1) ? (int64_t)gridDim.x * 4 : gridDim.x;
+  const float inv = 1.0f / (float)cols;
+  float wv[CH][8], dwa[CH][8], dba[CH][8];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (tig + G * i) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wv[i][j] = 1.f; dwa[i][j] = 0.f; dba[i][j] = 0.f; }
+    if (c < cols && w) Vec8<bf16_t>::load(w + c, wv[i]);
+  }
+  for (int64_t row = row0; row < rows; row += rstep) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const int64_t base = row * (int64_t)cols;
+    bf16x8 r0[CH], r1[CH], rg[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        r0[i] = Vec8<bf16_t>::ldraw(h0 + base + c);
+        r1[i] = Vec8<bf16_t>::ldraw(h1 + base + c);
+        rg[i] = Vec8<bf16_t>::ldraw(dy + base + c);
+      }
+    }
+    float a[CH][8], b[CH][8], cdf[CH][8], gw[CH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        Vec8<bf16_t>::cvt(r0[i], a[i]);
+        Vec8<bf16_t>::cvt(r1[i], b[i]);
+        Vec8<bf16_t>::cvt(rg[i], gw[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          cdf[i][j] = 0.5f * (1.0f + erff(a[i][j] * 0.70710678118654752440f));
+          // the forward rounded g to bf16 before the LayerNorm statistics were taken
+          const float gval = (float)(bf16_t)(a[i][j] * cdf[i][j] * b[i][j]);
+          const float xh = (gval - mean) * rstd;
+          const float d = gw[i][j];
+          dwa[i][j] += d * xh;
+          dba[i][j] += d;
+          const float t = d * wv[i][j];
+          gw[i][j] = t;
+          s1 += t;
+          s2 += t * xh;
+        }
+      }
+    }
+    const float c1 = group_sum<NW>(s1, red) * inv;
+    const float c2 = group_sum<NW>(s2, red) * inv;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        float o0[8], o1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float ge = a[i][j] * cdf[i][j];
+          const float xh = ((float)(bf16_t)(ge * b[i][j]) - mean) * rstd;
+          // the unfused path rounded dg to bf16 between the two kernels; keep fp32 here
+          const float dg = rstd * (gw[i][j] - c1 - xh * c2);
+          const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[i][j] * a[i][j]);
+          o0[j] = dg * b[i][j] * (cdf[i][j] + a[i][j] * pdf);
+          o1[j] = dg * ge;
+        }
+        Vec8<bf16_t>::store(dh0 + base + c, o0);
+        Vec8<bf16_t>::store(dh1 + base + c, o1);
+      }
+    }
+  }
+  if (ws == nullptr) return;  // uniform
+  float* wsb = ws + (int64_t)blockIdx.x * 2 * cols;
+  if (NW == 1) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) smem[wid * cols + c + j] = pass == 0 ? dwa[i][j] : dba[i][j];
+        }
+      }
+      __syncthreads();
+      for (int c = threadIdx.x; c < cols; c += 256)
+        wsb[pass * cols + c] = smem[c] + smem[cols + c] + smem[2 * cols + c] + smem[3 * cols + c];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wsb[c + j] = dwa[i][j]; wsb[cols + c + j] = dba[i][j]; }
+      }
+    }
+  }
+}
+
+inline int ln_grid(int64_t rows, int nw, int cap) {
   int64_t blocks = nw == 1 ? (rows + 3) / 4 : rows;
-  if (blocks > LN_MAX_BLOCKS) blocks = LN_MAX_BLOCKS;
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -216,7 +378,7 @@ int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float*
                     int cols, float eps, hipStream_t s) {
   const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* Y = (T*)y;
 #define LN_F(CH, NW) \
-  hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU>), dim3(ln_grid(rows, NW)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps)
+  hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps)
   if (cols <= 512) LN_F(1, 1);
   else if (cols <= 1024) LN_F(2, 1);
   else if (cols <= 1536) LN_F(3, 1);
@@ -240,7 +402,7 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
   float* wsk = (dw || db) ? ws : nullptr;
 #define LN_B(CH, NW)                                                                                        \
   do {                                                                                                      \
-    grid = ln_grid(rows, NW);                                                                               \
+    grid = ln_grid(rows, NW, g_ln_blocks_bwd);                                                                               \
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
                        rstd, ADD, DX, wsk, rows, cols);                                                          \
@@ -256,10 +418,9 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
 #undef LN_B
   OP_LAUNCH_CHECK();
   if (wsk) {
-    if (dw) hipLaunchKernelGGL((partials_reduce_kernel<T>), dim3(ceil_div(cols, 32)), dim3(256), 0, s, ws, grid,
-                               (int64_t)2 * cols, cols, (const bf16_t*)nullptr, (T*)dw, accumulate);
-    if (db) hipLaunchKernelGGL((partials_reduce_kernel<T>), dim3(ceil_div(cols, 32)), dim3(256), 0, s, ws + cols, grid,
-                               (int64_t)2 * cols, cols, (const bf16_t*)nullptr, (T*)db, accumulate);
+    hipLaunchKernelGGL((partials_reduce3_kernel<T>), dim3(ceil_div(cols, 32), 2), dim3(256), 0, s, ws, ws + cols,
+                       (const float*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (T*)dw,
+                       (T*)db, (T*)nullptr, grid, (int64_t)2 * cols, cols, accumulate);
     OP_LAUNCH_CHECK();
   }
   return OP_OK;
@@ -268,6 +429,13 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
 }  // namespace
 
 extern "C" {
+
+// Tuning knob: caps of the persistent grids (values <= 0 keep the current one).
+int op_layernorm_set_grid(int fwd_blocks, int bwd_blocks) {
+  if (fwd_blocks > 0) g_ln_blocks_fwd = fwd_blocks;
+  if (bwd_blocks > 0) g_ln_blocks_bwd = bwd_blocks > LN_MAX_BLOCKS ? LN_MAX_BLOCKS : bwd_blocks;
+  return OP_OK;
+}
 
 // Bytes of fp32 workspace op_layernorm_bwd needs for dw/db partials.
 int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
@@ -314,6 +482,45 @@ int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b
                                                     (int)cols, accumulate, s);
   op_set_error("layernorm_bwd: bad dtype %d", dtype);
   return OP_EINVAL;
+}
+
+// Backward of  y = LayerNorm_F(gelu(h0) * h1) * w + b  w.r.t. h0, h1, w, b in one pass (bf16 only); mean/rstd are the
+// forward statistics of g = gelu(h0) * h1.  Replaces the LayerNorm backward + GeGLU backward pair of the FFN
+// (one_peace/models/transformer/transformer_layer.py:64-67,111-118); g itself is not needed.
+int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* w, const float* mean, const float* rstd,
+                    void* dh0, void* dh1, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int accumulate,
+                    void* stream) {
+  OP_CHECK_ARG(dy && h0 && h1 && dh0 && dh1 && mean && rstd, "ln_geglu_bwd: null pointer");
+  OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192, "ln_geglu_bwd: cols=%lld unsupported", (long long)cols);
+  OP_CHECK_ARG(!(dw || db) || workspace, "ln_geglu_bwd: dw/db requested without workspace");
+  if (rows == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  float* wsk = (dw || db) ? (float*)workspace : nullptr;
+  int grid = 0;
+#define LNG_B(CH, NW)                                                                                              \
+  do {                                                                                                             \
+    grid = ln_grid(rows, NW, g_ln_blocks_bwd);                                                                     \
+    size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                                 \
+    hipLaunchKernelGGL((ln_geglu_bwd_kernel<CH, NW>), dim3(grid), dim3(256), sh, s, (const bf16_t*)dy,            \
+                       (const bf16_t*)h0, (const bf16_t*)h1, (const bf16_t*)w, mean, rstd, (bf16_t*)dh0, (bf16_t*)dh1, \
+                       wsk, rows, (int)cols);                                                                      \
+  } while (0)
+  if (cols <= 512) LNG_B(1, 1);
+  else if (cols <= 1024) LNG_B(2, 1);
+  else if (cols <= 1536) LNG_B(3, 1);
+  else if (cols <= 2048) LNG_B(4, 1);
+  else if (cols <= 4096) LNG_B(2, 4);
+  else if (cols <= 6144) LNG_B(3, 4);
+  else LNG_B(4, 4);
+#undef LNG_B
+  OP_LAUNCH_CHECK();
+  if (wsk) {
+    hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(cols, 32), 2), dim3(256), 0, s, wsk, wsk + cols,
+                       (const float*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
+                       (bf16_t*)dw, (bf16_t*)db, (bf16_t*)nullptr, grid, (int64_t)2 * cols, (int)cols, accumulate);
+    OP_LAUNCH_CHECK();
+  }
+  return OP_OK;
 }
 
 }  // extern "C"

@@ -30,6 +30,7 @@ SIGNATURES = {
     "op_prof_collect": (c_int, [P, P, P, c_int]),
     "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
+    "op_layernorm_set_grid": (c_int, [c_int, c_int]),
     "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
     "op_gemm_set_staging": (c_int, [c_int]),
     "op_gemm_set_tile": (c_int, [c_int]),
@@ -38,6 +39,10 @@ SIGNATURES = {
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_colsum_workspace_bytes": (I64, [I64]),
+    "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
+    "op_resid_bwd_workspace_bytes": (I64, [I64]),
+    "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, I64, I64, c_int, P]),
+    "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, P]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
     "op_geglu_bwd": (c_int, [P, P, P, P, P, I64, P]),
     "op_scale_rows": (c_int, [P, P, P, I64, P, I64, I64, P]),
@@ -223,6 +228,49 @@ def colsum(x, y=None, rowscale=None, rows_per_sample=0, mul=None, out=None, accu
     _check(lib().op_colsum(ptr(x), ptr(y), ptr(rowscale), rows_per_sample, ptr(mul), ptr(out), ptr(ws), M, N,
                            int(accumulate), _dt(out), stream()), "op_colsum")
     return out
+
+
+def colsum_segments(x, seg_cols, outs=None, accumulate=False):
+    """Per-segment column sums of x [M, n_seg*seg_cols]; outs: list of bf16 [seg_cols] targets / None (skip) per segment."""
+    M, N = x.shape
+    n_seg = N // seg_cols
+    if outs is None:
+        outs = [torch.empty(seg_cols, dtype=x.dtype, device=x.device) for _ in range(n_seg)]
+        accumulate = False
+    o = list(outs) + [None] * (3 - len(outs))
+    ws = workspace(lib().op_colsum_workspace_bytes(N), x.device, "colsum")
+    _check(lib().op_colsum_segments(ptr(x), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(ws), M, n_seg, seg_cols, int(accumulate),
+                                    stream()), "op_colsum_segments")
+    return outs
+
+
+def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma=None, dbias=None, accumulate=False):
+    """dbranch = rowscale*gamma*dout plus the column reductions dgamma / dbias in one pass.  dgamma / dbias: True
+    (allocate), a bf16 [N] tensor (write or, with accumulate, add into it) or None (skip)."""
+    M, N = dout.shape
+    out = torch.empty_like(dout)
+    if dgamma is True:
+        dgamma = torch.empty(N, dtype=dout.dtype, device=dout.device)
+    if dbias is True:
+        dbias = torch.empty(N, dtype=dout.dtype, device=dout.device)
+    ws = None
+    if dgamma is not None or dbias is not None:
+        ws = workspace(lib().op_resid_bwd_workspace_bytes(N), dout.device, "resid")
+    _check(lib().op_resid_bwd(ptr(dout), ptr(y if dgamma is not None else None), ptr(gamma), ptr(rowscale), rows_per_sample,
+                              ptr(out), ptr(dgamma), ptr(dbias), ptr(ws), M, N, int(accumulate), stream()), "op_resid_bwd")
+    return out, dgamma, dbias
+
+
+def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False):
+    """Backward of LayerNorm_F(gelu(h0)*h1): returns dh0, dh1, dw, db (dw/db allocated unless given)."""
+    rows, cols = h0.shape
+    dh0, dh1 = torch.empty_like(h0), torch.empty_like(h1)
+    if dw is None:
+        dw, db, accumulate = torch.empty_like(w), torch.empty_like(w), False
+    ws = workspace(lib().op_layernorm_bwd_workspace_bytes(rows, cols), h0.device, "ln")
+    _check(lib().op_ln_geglu_bwd(ptr(dy), ptr(h0), ptr(h1), ptr(w), ptr(mean), ptr(rstd), ptr(dh0), ptr(dh1), ptr(dw), ptr(db),
+                                 ptr(ws), rows, cols, int(accumulate), stream()), "op_ln_geglu_bwd")
+    return dh0, dh1, dw, db
 
 
 def geglu_bwd(dg, h0, h1):

@@ -301,16 +301,57 @@ def _ffn_forward(x_mid, P, S, ps2, keep):
                       rows_per_sample=S, h0=y2)
     if not keep:
         return out, None
-    return out, dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, g=g, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2)
+    # g (the GeGLU output) is not kept: the fused LN(F)+GeGLU backward recomputes it from h0, h1
+    return out, dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2)
 
 
 def _register_direct(ctx, names, params, needs):
     """Weights whose gradient GEMM accumulates straight into the flat gradient buffer (distributed.FlatParameters).
     Keeps (name, Parameter object) pairs: saved_tensors hands back fresh tensor objects without .grad / attributes."""
-    ctx.direct = tuple((n, q) for n, q, ng in zip(names, params, needs)
-                       if ng and n in _DIRECT_WEIGHTS and q is not None and _direct_grad(q))
+    ctx.direct = tuple((n, q) for n, q, ng in zip(names, params, needs) if ng and q is not None and _direct_grad(q))
     for _, q in ctx.direct:
         q._op_pending = getattr(q, "_op_pending", 0) + 1
+
+
+def _targets(direct, *names):
+    """(grad views, accumulate) for a kernel that produces the gradients of `names` together: in-place accumulation
+    only when every one of them lives in the flat gradient buffer."""
+    if all(n in direct for n in names):
+        return [direct[n].grad for n in names], True
+    return [None] * len(names), False
+
+
+def _finish(direct, G, names, values, accumulated):
+    for n, v in zip(names, values):
+        if accumulated:
+            _direct_grad_done(direct[n])
+        else:
+            G[n] = v
+
+
+def _return_grads(names, params, G, direct):
+    """Gradients handed back to autograd: None for absent parameters and for the ones accumulated in place -- unless a
+    producer fell back to a temporary, which is then folded into the flat buffer here."""
+    out = []
+    for n, q in zip(names, params):
+        g = G.get(n) if q is not None else None
+        if g is not None and n in direct:
+            direct[n].grad.add_(g.view_as(direct[n].grad))
+            _direct_grad_done(direct[n])
+            g = None
+        out.append(g)
+    return out
+
+
+def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G):
+    """Gradient of  resid + ps * gamma * (y)  w.r.t. the branch output, gamma and the last Linear's bias in one pass."""
+    names = (gname, bname) if gamma is not None else (bname,)
+    tgt, acc = _targets(direct, *names)
+    dgamma = None if gamma is None else (tgt[0] if acc else True)
+    dy, dg, dbias = hip.resid_bwd(dout, y if gamma is not None else None, gamma, ps, S, dgamma=dgamma,
+                                  dbias=tgt[-1] if acc else True, accumulate=acc)
+    _finish(direct, G, names, (dg, dbias) if gamma is not None else (dbias,), acc)
+    return dy
 
 
 def _weight_grad_fn(ctx, G):
@@ -385,21 +426,25 @@ class AttnBranchFn(torch.autograd.Function):
             dx_mid = dx_mid.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy1 = hip.scale_rows(dx_mid, P["g1"], ps, S)
-        if P["g1"] is not None:
-            G["g1"] = hip.colsum(dx_mid, A["y1"], ps, S)
-        G["bo"] = hip.colsum(dy1)
+        dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], ps, S, "g1", "bo", direct, G)
         weight_grad("wo", dy1, A["aln"])
         daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
         if P["aln_w"] is not None:
-            dattn, G["aln_w"], G["aln_b"] = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"],
-                                                              A["rstd_a"])
+            (tw, tb), acc = _targets(direct, "aln_w", "aln_b")
+            dattn, dw_, db_ = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"], A["rstd_a"], dw=tw, db=tb,
+                                                accumulate=acc)
+            _finish(direct, G, ("aln_w", "aln_b"), (dw_, db_), acc)
         else:
             dattn = daln
         dqkv, _ = _attn_backward(A["qkv"], dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
                                  bias.grad_accumulator() if want_dbias else None)
-        dbias_cols = hip.colsum(dqkv)
-        G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
+        (tq, tv), acc = _targets(direct, "bq", "bv")
+        if H % 8 == 0:
+            sums = hip.colsum_segments(dqkv, H, [tq, None, tv] if acc else None, accumulate=acc)
+            _finish(direct, G, ("bq", "bv"), (sums[0], sums[2]), acc)
+        else:
+            dbias_cols = hip.colsum(dqkv)
+            G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
         if direct.keys() & {"wq", "wk", "wv"}:
             for i, n in enumerate(("wq", "wk", "wv")):
                 weight_grad(n, dqkv[:, i * H:(i + 1) * H], A["xln1"])
@@ -407,9 +452,11 @@ class AttnBranchFn(torch.autograd.Function):
             dW = wgrad(dqkv, A["xln1"])  # [3H, H]
             G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
         dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
-        dx, G["ln1_w"], G["ln1_b"] = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"],
-                                                       add=dx_mid)
-        grads = [G.get(n) if q is not None else None for n, q in zip(ATTN_PARAMS, params)]
+        (tw, tb), acc = _targets(direct, "ln1_w", "ln1_b")
+        dx, dw_, db_ = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"], add=dx_mid, dw=tw, db=tb,
+                                         accumulate=acc)
+        _finish(direct, G, ("ln1_w", "ln1_b"), (dw_, db_), acc)
+        grads = _return_grads(ATTN_PARAMS, params, G, direct)
         dimg = None
         if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
             dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
@@ -452,17 +499,16 @@ class FfnBranchFn(torch.autograd.Function):
             dout2 = dout2.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy2 = hip.scale_rows(dout2, P["g2"], ps, S)
-        if P["g2"] is not None:
-            G["g2"] = hip.colsum(dout2, A["y2"], ps, S)
-        G["b2"] = hip.colsum(dy2)
+        dy2 = _resid_backward(dout2, A["y2"], P["g2"], ps, S, "g2", "b2", direct, G)
         weight_grad("w2", dy2, A["gln"])
         dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
-        if P["fln_w"] is not None:
-            dg, G["fln_w"], G["fln_b"] = hip.layernorm_bwd(dgln, A["g"], P["fln_w"], P["fln_b"], A["mean_f"], A["rstd_f"])
+        if P["fln_w"] is not None:  # sub-LayerNorm(F) and GeGLU backward in one pass; g is recomputed from h0, h1
+            (tw, tb), acc = _targets(direct, "fln_w", "fln_b")
+            dh0, dh1, dw_, db_ = hip.ln_geglu_bwd(dgln, A["h0"], A["h1"], P["fln_w"], A["mean_f"], A["rstd_f"], dw=tw, db=tb,
+                                                  accumulate=acc)
+            _finish(direct, G, ("fln_w", "fln_b"), (dw_, db_), acc)
         else:
-            dg = dgln
-        dh0, dh1 = hip.geglu_bwd(dg, A["h0"], A["h1"])
+            dh0, dh1 = hip.geglu_bwd(dgln, A["h0"], A["h1"])
         if ("w0" in direct and "w1" in direct) or (USE_TN_WGRAD and hip.gemm_tn_supported(N, Fd, H, Fd, H)):
             weight_grad("w0", dh0, A["xln2"])
             weight_grad("w1", dh1, A["xln2"])
@@ -477,9 +523,11 @@ class FfnBranchFn(torch.autograd.Function):
             G["w0"], G["w1"] = dW01[:Fd], dW01[Fd:]
         dxln2 = hip.gemm_nt(dh0, [_transposed(P["w0"])])
         hip.gemm_nt(dh1, [_transposed(P["w1"])], out=dxln2, epilogue=hip.EPI_RESID, resid=dxln2)
-        dx, G["ln2_w"], G["ln2_b"] = hip.layernorm_bwd(dxln2, x_mid, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"],
-                                                       add=dout2)
-        grads = [G.get(n) if q is not None else None for n, q in zip(FFN_PARAMS, params)]
+        (tw, tb), acc = _targets(direct, "ln2_w", "ln2_b")
+        dx, dw_, db_ = hip.layernorm_bwd(dxln2, x_mid, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"], add=dout2, dw=tw, db=tb,
+                                         accumulate=acc)
+        _finish(direct, G, ("ln2_w", "ln2_b"), (dw_, db_), acc)
+        grads = _return_grads(FFN_PARAMS, params, G, direct)
         return (dx.view(B, S, H), None, None, *grads)
 
 

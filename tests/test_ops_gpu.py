@@ -204,6 +204,75 @@ def test_colsum_and_scale_rows():
     assert_close(sr, rsm * mul * x, what="scale_rows")
 
 
+@pytest.mark.parametrize("M,N,rps,use_gamma,use_ps,accumulate", [(70, 1536, 7, True, True, False), (1030, 520, 103, True, False, True),
+                                                              (33, 64, 3, False, True, False), (4100, 1536, 41, True, True, True)])
+def test_resid_bwd_one_pass(M, N, rps, use_gamma, use_ps, accumulate):
+    """Layer-scale / drop-path residual backward (transformer_layer.py:70-88,190-196): dbranch, dgamma, dbias together."""
+    hip = hipmod()
+    dout, y = rnd(M, N, seed=1), rnd(M, N, seed=2)
+    gamma = rnd(N, seed=3) if use_gamma else None
+    ps = ((torch.arange(M // rps) % 3 != 0).float() / 0.75) if use_ps else None
+    rows = ps.repeat_interleave(rps)[:, None] if use_ps else 1.0
+    base_g, base_b = rnd(N, seed=4), rnd(N, seed=5)
+    ref_dy = dout * rows * (gamma if use_gamma else 1.0)
+    ref_dg = (dout * y * rows).sum(0)
+    ref_db = ref_dy.sum(0)
+    kw = {}
+    if accumulate:
+        kw = dict(dgamma=dev_bf16(base_g) if use_gamma else None, dbias=dev_bf16(base_b), accumulate=True)
+        ref_dg, ref_db = ref_dg + base_g.bfloat16().float(), ref_db + base_b.bfloat16().float()
+    else:
+        kw = dict(dgamma=True if use_gamma else None, dbias=True)
+    dy, dg, db = hip.resid_bwd(dev_bf16(dout), dev_bf16(y) if use_gamma else None, dev_bf16(gamma) if use_gamma else None,
+                               ps.to(DEV) if use_ps else None, rps, **kw)
+    gq = gamma.bfloat16().float() if use_gamma else 1.0
+    assert_close(dy, dout.bfloat16().float() * rows * gq, what="dbranch")
+    assert_close(db, ref_db, what="dbias")
+    if use_gamma:
+        assert_close(dg, ref_dg, what="dgamma")
+    else:
+        assert dg is None
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_colsum_segments_qkv_bias_gradients(accumulate):
+    hip = hipmod()
+    M, H = 777, 192
+    x = rnd(M, 3 * H, seed=1)
+    ref = x.bfloat16().float().sum(0)
+    if accumulate:
+        b0, b2 = rnd(H, seed=2), rnd(H, seed=3)
+        t0, t2 = dev_bf16(b0), dev_bf16(b2)
+        hip.colsum_segments(dev_bf16(x), H, [t0, None, t2], accumulate=True)
+        assert_close(t0, ref[:H] + b0.bfloat16().float(), what="seg0")
+        assert_close(t2, ref[2 * H:] + b2.bfloat16().float(), what="seg2")
+    else:
+        outs = hip.colsum_segments(dev_bf16(x), H)
+        for i in range(3):
+            assert_close(outs[i], ref[i * H:(i + 1) * H], what="seg%d" % i)
+
+
+@pytest.mark.parametrize("M,F_", [(130, 1024), (37, 256), (70, 6144), (9, 2048)])
+def test_ln_geglu_bwd_fused(M, F_):
+    """LayerNorm(F) backward + GeGLU backward in one pass vs autograd through the oracle's formulas
+    (transformer_layer.py:64-67,111-118)."""
+    hip = hipmod()
+    dy, h0, h1 = rnd(M, F_, seed=1), rnd(M, F_, seed=2, scale=2.0), rnd(M, F_, seed=3)
+    w, b = 1 + 0.1 * rnd(F_, seed=4), 0.1 * rnd(F_, seed=5)
+    q = lambda t: t.bfloat16().float()
+    a, c = q(h0).requires_grad_(True), q(h1).requires_grad_(True)
+    wr, br = q(w).requires_grad_(True), q(b).requires_grad_(True)
+    g = O.gelu_erf(a) * c
+    O.layer_norm(g, wr, br).backward(q(dy))
+    # forward statistics as the HIP forward produces them (from the bf16-rounded g)
+    _, mean, rstd = hip.layernorm_fwd(dev_bf16(g.detach()), dev_bf16(w), dev_bf16(b), want_stats=True)
+    dh0, dh1, dw, db = hip.ln_geglu_bwd(dev_bf16(dy), dev_bf16(h0), dev_bf16(h1), dev_bf16(w), mean, rstd)
+    assert_close(dh0, a.grad, what="dh0", fro=6e-3, mx=2.5e-2)
+    assert_close(dh1, c.grad, what="dh1", fro=6e-3, mx=2.5e-2)
+    assert_close(dw, wr.grad, what="dw", fro=8e-3, mx=3e-2)
+    assert_close(db, br.grad, what="db")
+
+
 def test_geglu_bwd():
     hip = hipmod()
     M, F_ = 130, 1024

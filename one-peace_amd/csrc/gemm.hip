@@ -501,8 +501,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // pipe; sched_group_barrier spreads the 16 memory instructions between the 32 MFMAs (1 per 2) instead.
   auto step_steady = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
     WAIT_LGKM0();
-    if (ABL != 2) WAIT_VM(8); else WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
+    if (ABL != 2 && ABL < 4) WAIT_VM(8); else WAIT_VM(0);
+    if (ABL != 5) __builtin_amdgcn_s_barrier();
     const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;  // fragments of the next stage
     char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;              // slot being refilled with stage kt+4
     char* lb = la + OPER2_BYTES;
@@ -516,7 +516,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         else
           asm volatile("" :: "v"(cur_w[ni]), "v"(cur_x[mi]));
       }
-      if (j < 4) {
+      if (ABL >= 4) {  // timing ablation: MFMAs only (4: barriers kept, 5: no barriers)
+        if (j < 4) nxt_w[j] = cur_w[j];
+        else if (j < 12) nxt_x[j - 4] = cur_x[j - 4];
+      } else if (j < 4) {
         const int o = (EPI == EPI_GEGLU) ? ((j >> 1) * 128 + (j & 1) * 16) * 64 : j * 16 * 64;
         nxt_w[j] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
       } else if (j < 12) {
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       } else {
         const int i = (j - 12) >> 1;
         const int wbase = (i * 512 + wid * 64) * 16;
-        if (ABL != 2) {
+        if (ABL != 2 && ABL < 4) {
           if ((j & 1) == 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
                                              (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
@@ -760,7 +763,8 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
   return OP_OK;
 }
 
-int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads in the steady loop (timing ablations only, wrong results)
+int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + barriers only, 5 = MFMAs only in the steady loop
+                     // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
 
 template <int EPI>
 int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
@@ -778,6 +782,12 @@ int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
   } else if (EPI == EPI_BIAS && g_ablation == 2) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 2>), grid, dim3(512), sh, s, a);
+  } else if (EPI == EPI_BIAS && g_ablation == 4) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 4>), grid, dim3(512), sh, s, a);
+  } else if (EPI == EPI_BIAS && g_ablation == 5) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 5>), grid, dim3(512), sh, s, a);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), sh, s, a);
   }
@@ -871,7 +881,7 @@ extern "C" {
 // 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
 int op_gemm_set_tile(int mode) {
   int old = g_tile_mode;
-  if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10/11/12: timing ablations of the 256x256 kernel (tools only)
+  if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10..15: timing ablations of the 256x256 kernel (tools only)
   g_tile_mode = mode;
   return old;
 }

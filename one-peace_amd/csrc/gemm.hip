@@ -571,6 +571,192 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 }
 
 // =====================================================================================================================
+// BK = 64 flavour of the 256 x 256 NT kernel ("full-line staging").  Same wave layout, MFMA order, fragment double
+// buffering and {2 MFMA, 1 memory instruction} interleave as gemm256_kernel, but every operand row in LDS is a full
+// 128-byte line: one wave-level global_load_lds moves 8 rows x 128 B instead of 16 rows x 64 B, which halves the number
+// of L2 requests / texture-addresser lines per byte (the 64-byte segments of the BK = 32 kernel are what limits its main
+// loop, profiles/r1_gemm_experiments.md).  LDS: FIVE 32 KiB slots (all 160 KiB), each one operand K-tile
+// [256 rows][64 k], 16-byte slot index XOR-ed with (row & 7) (conflict-free ds_read_b128, same image as the 128^2
+// kernel).  Operand tiles go through the slots in the order A0 B0 A1 B1 A2 ...; a K-tile is two half-steps of 32 MFMAs
+// per wave; half-step (i,0) issues A(i+2), half-step (i,1) issues B(i+2); ONE barrier per K-tile, at the start of (i,1):
+//   RAW: before it every wave retires its share of A(i+1), B(i+1) (counted vmcnt: only A(i+2) may stay in flight) -- the
+//        fragments of (i+1,0) are read after it;
+//   WAR: before it every wave has retired its fragment reads of tile i (lgkmcnt(0)), so the slots of A(i), B(i) may be
+//        refilled after it (B(i+2) -> slot of A(i) in (i,1), A(i+3) -> slot of B(i) in (i+1,0)).
+// =====================================================================================================================
+constexpr int SLOT3_BYTES = 256 * 128;  // one operand K-tile
+constexpr int SLOTS3 = 5;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256b_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int g = lane >> 4, t = lane & 15;
+  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  constexpr int GM = 4;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM2, n0 = pid_n * BN_OUT;
+
+  int nk = p.K / 64;
+  int kt0 = 0;
+  void* Cout = p.C;
+  if (p.kt_per_split > 0) {  // split-K (kt_per_split counts 32-deep stages and is even)
+    kt0 = blockIdx.y * (p.kt_per_split >> 1);
+    nk = min(nk - kt0, p.kt_per_split >> 1);
+    Cout = (float*)p.C + (int64_t)blockIdx.y * p.slab;
+  }
+
+  // ---- staging: op j of an operand tile covers LDS rows j*64 + (tid >> 3), 16-byte slot tid & 7 ----
+  const int srow = tid >> 3;                       // row within the 64-row group
+  const int sc = (tid & 7) ^ (srow & 7);           // source k-chunk of this lane's LDS slot
+  const char* baseA = (const char*)(p.A + (int64_t)kt0 * 64);
+  unsigned offA[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gm = min(m0 + j * 64 + srow, p.M - 1);
+    offA[j] = (unsigned)(((int64_t)gm * p.lda + sc * 8) * 2);
+  }
+  // weight rows: LDS row j*64 + q  <-  output column (j-dependent uniform term) + f(q); no N clamp (N % BN_OUT == 0)
+  const char* baseB[4];
+  unsigned offB;
+  {
+    const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;
+    const int colq = w_row_to_col256<EPI>(srow);  // column of LDS row `srow` of group 0
+    offB = (unsigned)(((int64_t)colq * p.ldb + sc * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16_t* wb;
+      int col0;
+      if (EPI == EPI_GEGLU) {
+        wb = p.B[j >> 1];
+        col0 = n0 + (j & 1) * 64;
+      } else {
+        wb = p.B[seg];
+        col0 = n0 - seg * p.n_seg + j * 64;
+      }
+      baseB[j] = (const char*)(wb + (int64_t)col0 * p.ldb + (int64_t)kt0 * 64);
+    }
+  }
+
+  f32x4 acc[4][8];  // [ni][mi]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: row = (multiple of 16) + t  ->  swizzle term (t & 7); half h of the K-tile = 16-byte chunks h*4 + g
+  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+  const int rowX = (wm * 128 + t) * 128;                                                   // + mi * 2048
+  const int rowW = ((EPI == EPI_GEGLU) ? (wn * 32 + t) : (wn * 64 + t)) * 128;             // + per-ni constant
+  auto w_off = [&](int ni) { return (EPI == EPI_GEGLU) ? ((ni >> 1) * 128 + (ni & 1) * 16) * 128 : ni * 16 * 128; };
+
+  // operand-tile sequence q = 2*i (A_i), 2*i + 1 (B_i); slot = q % 5
+  int qslot_issue = 0;  // slot of the next operand tile to be issued
+  auto issue_a = [&]() {
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[j]),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    baseA += 128;
+    qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
+  };
+  auto issue_b = [&]() {
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[j] + offB),
+                                       (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+      baseB[j] += 128;
+    }
+    qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
+  };
+  auto read_frags = [&](const char* sa, const char* sb, int h, bf16x8 (&wf)[4], bf16x8 (&xf)[8]) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) wf[ni] = *reinterpret_cast<const bf16x8*>(sb + rowW + w_off(ni) + fsw[h]);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(sa + rowX + mi * 2048 + fsw[h]);
+  };
+  auto mma = [&](const bf16x8 (&wf)[4], const bf16x8 (&xf)[8]) {
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+  };
+  // One half-step: 32 MFMAs on `cur`, the 12 fragment reads of the NEXT half-step (from sa/sb, half h) and the 4 LDS-DMA
+  // ops of one operand tile, as 16 pinned groups of {2 MFMA, 1 memory instruction}.  WHAT: 0 = issue an A tile, 1 = a B
+  // tile, 2 = nothing left to issue.
+  auto half_step = [&](const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8],
+                       const char* sa, const char* sb, int h, bool do_read, int what) {
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int idx = 2 * j + hh, mi = idx >> 2, ni = idx & 3;
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
+      }
+      if (j < 4) {
+        if (do_read) nxt_w[j] = *reinterpret_cast<const bf16x8*>(sb + rowW + w_off(j) + fsw[h]);
+      } else if (j < 12) {
+        if (do_read) nxt_x[j - 4] = *reinterpret_cast<const bf16x8*>(sa + rowX + (j - 4) * 2048 + fsw[h]);
+      } else {
+        const int jj = j - 12;
+        if (what == 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[jj]),
+                                           (__attribute__((address_space(3))) void*)(dst + jj * 8192), 16, 0, 0);
+        else if (what == 1)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[jj] + offB),
+                                           (__attribute__((address_space(3))) void*)(dst + jj * 8192), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (what == 0) {
+      baseA += 128;
+    } else if (what == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) baseB[j] += 128;
+    }
+    if (what != 2) qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
+  };
+
+  // ---- prologue: A0 B0 [A1 B1]; fragments of (0,0) ----
+  issue_a();
+  issue_b();
+  if (nk > 1) { issue_a(); issue_b(); WAIT_VM(8); } else { WAIT_VM(0); }
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfA[4], xfA[8], wfB[4], xfB[8];
+  int sa = 0, sb = 1;  // slots of A_i, B_i
+  read_frags(smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 0, wfA, xfA);
+  for (int i = 0; i < nk; ++i) {
+    const char* pa = smem + sa * SLOT3_BYTES;
+    const char* pb = smem + sb * SLOT3_BYTES;
+    const int sa1 = sa + 2 >= SLOTS3 ? sa + 2 - SLOTS3 : sa + 2, sb1 = sb + 2 >= SLOTS3 ? sb + 2 - SLOTS3 : sb + 2;
+    const bool more2 = i + 2 < nk, more1 = i + 1 < nk;
+    // (i,0): MFMAs of half 0, fragments of half 1 (same tile), A(i+2)
+    half_step(wfA, xfA, wfB, xfB, pa, pb, 1, true, more2 ? 0 : 2);
+    WAIT_LGKM0();
+    if (more1) { if (more2) WAIT_VM(4); else WAIT_VM(0); }
+    __builtin_amdgcn_s_barrier();
+    // (i,1): MFMAs of half 1, fragments of (i+1,0), B(i+2)
+    half_step(wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0, more1, more2 ? 1 : 2);
+    sa = sa1;
+    sb = sb1;
+  }
+  gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, n0 + wn * 32, g, t);
+}
+
+// =====================================================================================================================
 // TN variant of the 256x256 kernel:  C[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands stored K-major ([K, M] and
 // [K, N] row-major) -- the weight-gradient GEMM dW = dy^T x straight from the activation matrices, no transposed copies.
 // Same four-stage LDS-DMA pipeline and epilogue; operand tiles are [32 k][256] (512-byte rows) and the MFMA fragments
@@ -763,6 +949,7 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
   return OP_OK;
 }
 
+int g_fullline = 2;  // BK = 64 full-line flavour of the 256^2 NT kernel: 0 off, 1 always, 2 auto (op_gemm_set_tile(20/21/22))
 int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + barriers only, 5 = MFMAs only in the steady loop
                      // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
 
@@ -776,7 +963,18 @@ int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
     if (e != hipSuccess) { op_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  if (EPI == EPI_BIAS && g_ablation == 1) {
+  // g_fullline: 0 never, 1 always, 2 (default) when the launch fills every CU at least once
+  if ((g_fullline == 1 || (g_fullline == 2 && (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1)) &&
+      a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0) {
+    const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
+    static bool attr5 = false;
+    if (!attr5) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm256b_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
+      if (e != hipSuccess) { op_set_error("gemm256b: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+      attr5 = true;
+    }
+    hipLaunchKernelGGL((gemm256b_kernel<EPI>), grid, dim3(512), sh5, s, a);
+  } else if (EPI == EPI_BIAS && g_ablation == 1) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 1>), grid, dim3(512), sh, s, a);
   } else if (EPI == EPI_BIAS && g_ablation == 2) {
@@ -881,6 +1079,7 @@ extern "C" {
 // 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
 int op_gemm_set_tile(int mode) {
   int old = g_tile_mode;
+  if (mode >= 20) { g_fullline = mode - 20; return old; }  // 20/21/22: BK = 32 / BK = 64 / auto flavour of the 256x256 NT kernel
   if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10..15: timing ablations of the 256x256 kernel (tools only)
   g_tile_mode = mode;
   return old;

@@ -62,12 +62,15 @@ def test_layernorm_fp32_no_affine():
 GEMM_SHAPES = [(128, 128, 64), (300, 384, 192), (1000, 1536, 256), (257, 136, 128), (64, 4608, 1536), (4099, 256, 1024)]
 
 
-@pytest.fixture(params=[1, 2], ids=["tile128", "tile256"])
+@pytest.fixture(params=[1, 2, 3], ids=["tile128", "tile256_bk32", "tile256_bk64"])
 def tile_mode(request):
-    """Run every GEMM test on both tile configurations (auto-selection would pick 128x128 at these small sizes)."""
+    """Run every GEMM test on all tile configurations (auto-selection would pick 128x128 at these small sizes): the
+    128x128 kernel, the 256x256 kernel with 64-byte (BK = 32) rows and its full-line (BK = 64) flavour."""
     hip = hipmod()
-    old = hip.lib().op_gemm_set_tile(request.param)
+    old = hip.lib().op_gemm_set_tile(1 if request.param == 1 else 2)
+    hip.lib().op_gemm_set_tile(21 if request.param == 3 else 20)
     yield request.param
+    hip.lib().op_gemm_set_tile(22)
     hip.lib().op_gemm_set_tile(old)
 
 

@@ -165,8 +165,10 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* __restrict
     Vec8<bf16_t>::load(h1 + i * 8, b);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      o0[j] = g[j] * b[j] * gelu_erf_grad(a[j]);
-      o1[j] = g[j] * gelu_erf(a[j]);
+      float cdf, pdf;
+      gelu_parts(a[j], cdf, pdf);
+      o0[j] = g[j] * b[j] * (cdf + a[j] * pdf);
+      o1[j] = g[j] * a[j] * cdf;
     }
     Vec8<bf16_t>::store(dh0 + i * 8, o0);
     Vec8<bf16_t>::store(dh1 + i * 8, o1);

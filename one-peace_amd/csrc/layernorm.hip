@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 //   dh0 = dg * h1 * gelu'(h0),   dh1 = dg * gelu(h0)
 // Algorithmic bytes: 3 reads + 2 writes of [rows, cols] bf16 (the unfused pair moved 8 passes).
 template <int CH, int NW>
-__global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h0,
+__global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ h0,
                                                            const bf16_t* __restrict__ h1, const bf16_t* __restrict__ w,
                                                            const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, bf16_t* __restrict__ dh0,
@@ -276,33 +276,51 @@ __global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const bf16_t* __restr
     for (int j = 0; j < 8; ++j) { wv[i][j] = 1.f; dwa[i][j] = 0.f; dba[i][j] = 0.f; }
     if (c < cols && w) Vec8<bf16_t>::load(w + c, wv[i]);
   }
-  for (int64_t row = row0; row < rows; row += rstep) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
-    const int64_t base = row * (int64_t)cols;
-    bf16x8 r0[CH], r1[CH], rg[CH];
+  // Registers: the row is kept as raw bf16 (h0, h1) + fp32 dy*w across the two block reductions and the GELU pieces are
+  // recomputed for the output pass, so that the NEXT row's three operands can already be in flight.
+  bf16x8 r0[CH], r1[CH], rg[CH], n0[CH], n1[CH], ng[CH];
+  if (row0 < rows) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        r0[i] = Vec8<bf16_t>::ldraw(h0 + base + c);
-        r1[i] = Vec8<bf16_t>::ldraw(h1 + base + c);
-        rg[i] = Vec8<bf16_t>::ldraw(dy + base + c);
+        r0[i] = Vec8<bf16_t>::ldraw(h0 + row0 * (int64_t)cols + c);
+        r1[i] = Vec8<bf16_t>::ldraw(h1 + row0 * (int64_t)cols + c);
+        rg[i] = Vec8<bf16_t>::ldraw(dy + row0 * (int64_t)cols + c);
       }
     }
-    float a[CH][8], b[CH][8], cdf[CH][8], gw[CH][8];
+  }
+  for (int64_t row = row0; row < rows; row += rstep) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const int64_t base = row * (int64_t)cols;
+    const int64_t nrow = row + rstep;
+    if (nrow < rows) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) {
+          n0[i] = Vec8<bf16_t>::ldraw(h0 + nrow * (int64_t)cols + c);
+          n1[i] = Vec8<bf16_t>::ldraw(h1 + nrow * (int64_t)cols + c);
+          ng[i] = Vec8<bf16_t>::ldraw(dy + nrow * (int64_t)cols + c);
+        }
+      }
+    }
+    float gw[CH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        Vec8<bf16_t>::cvt(r0[i], a[i]);
-        Vec8<bf16_t>::cvt(r1[i], b[i]);
+        float a[8], b[8];
+        Vec8<bf16_t>::cvt(r0[i], a);
+        Vec8<bf16_t>::cvt(r1[i], b);
         Vec8<bf16_t>::cvt(rg[i], gw[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          cdf[i][j] = 0.5f * (1.0f + erff(a[i][j] * 0.70710678118654752440f));
+          float cdf, pdf;
+          gelu_parts(a[j], cdf, pdf);
           // the forward rounded g to bf16 before the LayerNorm statistics were taken
-          const float gval = (float)(bf16_t)(a[i][j] * cdf[i][j] * b[i][j]);
+          const float gval = (float)(bf16_t)(a[j] * cdf * b[j]);
           const float xh = (gval - mean) * rstd;
           const float d = gw[i][j];
           dwa[i][j] += d * xh;
@@ -320,21 +338,26 @@ __global__ __launch_bounds__(256) void ln_geglu_bwd_kernel(const bf16_t* __restr
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        float o0[8], o1[8];
+        float a[8], b[8], o0[8], o1[8];
+        Vec8<bf16_t>::cvt(r0[i], a);
+        Vec8<bf16_t>::cvt(r1[i], b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float ge = a[i][j] * cdf[i][j];
-          const float xh = ((float)(bf16_t)(ge * b[i][j]) - mean) * rstd;
+          float cdf, pdf;
+          gelu_parts(a[j], cdf, pdf);
+          const float ge = a[j] * cdf;
+          const float xh = ((float)(bf16_t)(ge * b[j]) - mean) * rstd;
           // the unfused path rounded dg to bf16 between the two kernels; keep fp32 here
           const float dg = rstd * (gw[i][j] - c1 - xh * c2);
-          const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[i][j] * a[i][j]);
-          o0[j] = dg * b[i][j] * (cdf[i][j] + a[i][j] * pdf);
+          o0[j] = dg * b[j] * (cdf + a[j] * pdf);
           o1[j] = dg * ge;
         }
         Vec8<bf16_t>::store(dh0 + base + c, o0);
         Vec8<bf16_t>::store(dh1 + base + c, o1);
       }
     }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { r0[i] = n0[i]; r1[i] = n1[i]; rg[i] = ng[i]; }
   }
   if (ws == nullptr) return;  // uniform
   float* wsb = ws + (int64_t)blockIdx.x * 2 * cols;
@@ -501,9 +524,9 @@ int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* 
   do {                                                                                                             \
     grid = ln_grid(rows, NW, g_ln_blocks_bwd);                                                                     \
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                                 \
-    hipLaunchKernelGGL((ln_geglu_bwd_kernel<CH, NW>), dim3(grid), dim3(256), sh, s, (const bf16_t*)dy,            \
-                       (const bf16_t*)h0, (const bf16_t*)h1, (const bf16_t*)w, mean, rstd, (bf16_t*)dh0, (bf16_t*)dh1, \
-                       wsk, rows, (int)cols);                                                                      \
+    hipLaunchKernelGGL((ln_geglu_bwd_kernel<CH, NW>), dim3(grid), dim3(NW == 1 ? 256 : 64 * NW), sh, s,           \
+                       (const bf16_t*)dy, (const bf16_t*)h0, (const bf16_t*)h1, (const bf16_t*)w, mean, rstd,      \
+                       (bf16_t*)dh0, (bf16_t*)dh1, wsk, rows, (int)cols);                                          \
   } while (0)
   if (cols <= 512) LNG_B(1, 1);
   else if (cols <= 1024) LNG_B(2, 1);

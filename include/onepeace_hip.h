@@ -96,7 +96,11 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
 int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,
                       int64_t heads, void* stream);
 /* autograd of the above (reference: torch autograd through the bmm/softmax ops).  biasT = bias with rows = key.
- * dq/dk/dv rows have stride ldg; dbias fp32 [heads][S][Spad] (optional, accumulated into: pre-zero it). */
+ * dq/dk/dv rows have stride ldg; dbias fp32 [slabs][heads][S][Spad] (optional, accumulated into: pre-zero it; the
+ * gradient is the sum over slabs, slabs = op_attn_bwd_dbias_slabs(B, S, heads)). */
+int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads);
+/* test knob: 0 = separate dQ / dBias kernels, 1 (default) = dQ + dBias in one kernel for sequences up to 384 keys */
+int op_attn_set_merge_dbias(int on);
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
                 const void* biasT, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                 int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,

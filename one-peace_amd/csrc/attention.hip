@@ -455,13 +455,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 
 // Shared by the dQ and dBias kernels: for one 64-key tile, lane (g,t) computes dS^T[key = kb*16 + g*4 + r][q = t]
 // for its two query blocks.  KF/VF: functors returning the first-operand fragment (K or V rows) for (kb, kk).
-template <typename KF, typename VF, typename BF>
+template <int QB, typename KF, typename VF, typename BF>
 __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int k0, int q0w, int g, int t,
-                                        const bf16x8 (&qf)[2][2], const bf16x8 (&of)[2][2], const float (&lse)[2],
-                                        const float (&del)[2], KF kfrag, VF vfrag, BF biasfrag, f32x4 (&ds)[2][4]) {
-  f32x4 st[2][4];
+                                        const bf16x8 (&qf)[QB][2], const bf16x8 (&of)[QB][2], const float (&lse)[QB],
+                                        const float (&del)[QB], KF kfrag, VF vfrag, BF biasfrag, f32x4 (&ds)[QB][4]) {
+  f32x4 st[QB][4];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) { st[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; ds[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
@@ -472,7 +472,7 @@ __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int 
       const bf16x8 kfr = kfrag(kb, kk);
       const bf16x8 vfr = vfrag(kb, kk);
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < QB; ++qb) {
         st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[qb][kk], st[qb][kb], 0, 0, 0);
         ds[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, of[qb][kk], ds[qb][kb], 0, 0, 0);
       }
@@ -485,7 +485,7 @@ __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int 
       padw[kb] = *reinterpret_cast<const unsigned*>(p.key_pad + (int64_t)b * p.Spad + k0 + kb * 16 + g * 4);
   }
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     const int qraw = q0w + qb * 16 + t;
     const int qi = min(qraw, p.S - 1);
 #pragma unroll
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     auto biasfrag = [&](int, int, int qi, int key) {
       return *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + key);
     };
-    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
+    ds_tile<2>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -617,6 +617,155 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
       *reinterpret_cast<bf16x4*>(qp + db * 16 + g * 4) = a;
     }
   }
+}
+
+// dQ and dBias in ONE pass (sequences of up to NT * 64 keys, NT <= 6): grid (q tiles of 64 = 4 waves x 16 queries, heads,
+// batch chunks).  A workgroup walks the samples of its chunk; for each sample it streams the K/V tiles exactly like
+// attn_bwd_dq_kernel, and the dS tiles it computes anyway for dQ are ALSO summed over the samples in registers
+// (NT x 4 accumulators per lane) and added to dbias once at the end -- the separate dBias kernel recomputed S and dP
+// (two of the five backward matmuls) just for that sum.  One 16-query block per wave keeps the NT x 64 dS accumulators
+// within the register budget; 64-row query tiles also waste less on S = 257 (5 tiles = 320 rows instead of 3 x 128).
+template <int NT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+  char* ldsK = smem;
+  char* ldsV = smem + 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  const int h = blockIdx.y, chunk = blockIdx.z;
+  const int q0w = blockIdx.x * 64 + wid * 16;
+  const bool wave_active = q0w < p.S;
+  const int qi = min(q0w + t, p.S - 1);
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) acc[kt][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  u32x4 rk[2], rv[2];
+  int st_row[2], st_c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int c2 = tid + 256 * i; st_row[i] = c2 >> 3; st_c[i] = c2 & 7; }
+  auto load_tile = [&](int b, int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kr = min(k0 + st_row[i], p.S - 1);
+      const int64_t off = ((int64_t)b * p.S + kr) * p.ld + h * HD + st_c[i] * 8;
+      rk[i] = *reinterpret_cast<const u32x4*>(p.k + off);
+      rv[i] = *reinterpret_cast<const u32x4*>(p.v + off);
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = st_row[i] * 128 + ((st_c[i] ^ (st_row[i] & 7)) << 4);
+      *reinterpret_cast<u32x4*>(ldsK + off) = rk[i];
+      *reinterpret_cast<u32x4*>(ldsV + off) = rv[i];
+    }
+  };
+  bf16x8 qn[1][2], on[1][2];
+  float lsen[1], deln[1];
+  auto load_q = [&](int b) {
+    const int64_t row = (int64_t)b * p.S + qi;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      qn[0][kk] = *reinterpret_cast<const bf16x8*>(p.q + row * p.ld + h * HD + kk * 32 + g * 8);
+      on[0][kk] = *reinterpret_cast<const bf16x8*>(p.dout + row * p.ldo + h * HD + kk * 32 + g * 8);
+    }
+    lsen[0] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
+    deln[0] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+  };
+  int trsw[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+
+  const int b_begin = chunk * p.bchunk, b_end = min(p.B, (chunk + 1) * p.bchunk);
+  if (b_begin >= b_end) return;
+  load_tile(b_begin, 0);
+  load_q(b_begin);
+  for (int b = b_begin; b < b_end; ++b) {
+    bf16x8 qf[1][2], of[1][2];
+    float lse[1], del[1];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) { qf[0][kk] = qn[0][kk]; of[0][kk] = on[0][kk]; }
+    lse[0] = lsen[0];
+    del[0] = deln[0];
+    if (b + 1 < b_end) load_q(b + 1);
+    // The bias fragments do not depend on the sample; left alone the compiler hoists all NT x 4 of them out of this loop
+    // (8 VGPRs per key tile) and spills accumulators instead.  They are L2-resident: reload per sample.
+    int bias_resample = 0;
+    asm volatile("" : "+s"(bias_resample));
+    f32x4 dqT[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dqT[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // NOT unrolled: an unrolled body costs ~35 VGPRs per key tile on top of the 16 accumulators; the accumulator set is
+    // picked by a uniform compare chain instead.
+#pragma unroll 1
+    for (int kt = 0; kt < NT; ++kt) {
+      const int k0 = kt * BKV;
+      __syncthreads();
+      write_tile();
+      __syncthreads();
+      if (kt + 1 < NT) load_tile(b, k0 + BKV);
+      else if (b + 1 < b_end) load_tile(b + 1, 0);
+      if (!wave_active) continue;
+      f32x4 ds[1][4];
+      auto kfrag = [&](int kb, int kk) {
+        return *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
+      };
+      auto vfrag = [&](int kb, int kk) {
+        return *reinterpret_cast<const bf16x8*>(ldsV + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
+      };
+      auto biasfrag = [&](int, int, int qrow, int key) {
+        return *reinterpret_cast<const bf16x4*>(p.bias + bias_resample + ((int64_t)h * p.S + qrow) * p.Spad + key);
+      };
+      ds_tile<1>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        if (kt == c) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) acc[c][kb] += ds[0][kb];
+        }
+      }
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (k0 + m * 32 >= p.S) break;
+        float a0[4], a1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = ds[0][2 * m][r]; a1[r] = ds[0][2 * m + 1][r]; }
+        const bf16x8 dsf = pack8(a0, a1);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 kT = join_tr(tr_read(ldsK + trsw[db] + (2 * m) * 2048), tr_read(ldsK + trsw[db] + (2 * m + 1) * 2048));
+          dqT[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, dsf, dqT[db], 0, 0, 0);
+        }
+      }
+    }
+    if (wave_active && q0w + t < p.S) {
+      bf16_t* qp = p.dq + ((int64_t)b * p.S + q0w + t) * p.ldg + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        bf16x4 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = (bf16_t)(dqT[db][r] * p.scale);
+        *reinterpret_cast<bf16x4*>(qp + db * 16 + g * 4) = a;
+      }
+    }
+  }
+  if (!wave_active || q0w + t >= p.S) return;
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int key = kt * BKV + kb * 16 + g * 4;
+      if (key >= p.Spad) continue;
+      // slab `chunk` of dbias belongs to this batch chunk alone: plain read-modify-write (fp32 atomics from several
+      // chunks on one slab cost more than the whole rest of this kernel)
+      f32x4* dst = reinterpret_cast<f32x4*>(p.dbias + (((int64_t)chunk * p.heads + h) * p.S + q0w + t) * p.Spad + key);
+      *dst = *dst + acc[kt][kb];
+    }
 }
 
 // grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
@@ -666,27 +815,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
     }
   };
   const int b_begin = chunk * p.bchunk, b_end = min(p.B, (chunk + 1) * p.bchunk);
-  if (b_begin < b_end) load_tile(b_begin);
+  // per-sample query-side operands (Q and dO fragments, lse, delta) are prefetched one sample ahead, like the K/V tile
+  bf16x8 qn[2][2], on[2][2];
+  float lsen[2], deln[2];
+  auto load_q = [&](int b) {
+    const int64_t row_base = (int64_t)b * p.S;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qi = min(q0w + qb * 16 + t, p.S - 1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        qn[qb][kk] = *reinterpret_cast<const bf16x8*>(p.q + (row_base + qi) * p.ld + h * HD + kk * 32 + g * 8);
+        on[qb][kk] = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + qi) * p.ldo + h * HD + kk * 32 + g * 8);
+      }
+      lsen[qb] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
+      deln[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+    }
+  };
+  if (b_begin < b_end) {
+    load_tile(b_begin);
+    if (wave_active) load_q(b_begin);
+  }
   for (int b = b_begin; b < b_end; ++b) {
     __syncthreads();
     write_tile();
     __syncthreads();
     if (b + 1 < b_end) load_tile(b + 1);
     if (!wave_active) continue;
-    const int64_t row_base = (int64_t)b * p.S;
     bf16x8 qf[2][2], of[2][2];
     float lse[2], del[2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      const int qi = min(q0w + qb * 16 + t, p.S - 1);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        qf[qb][kk] = *reinterpret_cast<const bf16x8*>(p.q + (row_base + qi) * p.ld + h * HD + kk * 32 + g * 8);
-        of[qb][kk] = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + qi) * p.ldo + h * HD + kk * 32 + g * 8);
-      }
-      lse[qb] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
-      del[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+      for (int kk = 0; kk < 2; ++kk) { qf[qb][kk] = qn[qb][kk]; of[qb][kk] = on[qb][kk]; }
+      lse[qb] = lsen[qb];
+      del[qb] = deln[qb];
     }
+    if (b + 1 < b_end) load_q(b + 1);
     auto kfrag = [&](int kb, int kk) {
       return *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
     };
@@ -695,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
     };
     auto biasfrag = [&](int qb, int kb, int, int) { return breg[qb][kb]; };
     f32x4 ds[2][4];
-    ds_tile(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
+    ds_tile<2>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -717,12 +882,36 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
   }
 }
 
+int g_merge_dbias = 1;  // 1: dQ + dBias in one kernel when the sequence fits (<= 384 keys); 0: separate kernels (tests)
+
+// number of batch chunks (= dbias slabs) of the merged dQ + dBias kernel; 1 when the separate kernels run
+inline int dbias_chunks(int64_t B, int64_t S, int64_t heads) {
+  if (!g_merge_dbias || ceil_div(S, BKV) > 6) return 1;
+  const int64_t base = (int64_t)ceil_div(S, 64) * heads;
+  int chunks = (int)((768 + base - 1) / base);
+  if (chunks < 1) chunks = 1;
+  if (chunks > B) chunks = (int)B;
+  const int bchunk = ceil_div(B, chunks);
+  return ceil_div(B, bchunk);
+}
+
 }  // namespace
 
 extern "C" int op_prof_begin(int family, double work, void* stream);
 extern "C" void op_prof_end(int slot, void* stream);
 
 extern "C" {
+
+// Debug/test knob: 0 = separate dQ and dBias kernels, 1 (default) = merged kernel for sequences up to 384 keys.  Returns the old value.
+// dbias of op_attn_bwd is fp32 [slabs][heads][S][Spad], pre-zeroed, slabs = this value (the batch chunks of the merged
+// dQ + dBias kernel add into their own slab without atomics; sum the slabs afterwards).
+int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads) { return dbias_chunks(B, S, heads); }
+
+int op_attn_set_merge_dbias(int on) {
+  const int old = g_merge_dbias;
+  g_merge_dbias = on ? 1 : 0;
+  return old;
+}
 
 // q, k, v: bf16 rows of `ld` elements (row = b*S + s), head h occupies columns [h*64, h*64+64) of each pointer
 // (so one packed [B*S, 3H] projection output serves all three with pointer offsets 0, H, 2H).
@@ -763,7 +952,7 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 
 // Gradients of op_attn_fwd.  bias [heads][S][Spad] (rows = query) and biasT (same values, rows = key) are both needed
 // when a bias was used; lse/delta are fp32 [B][heads][Spad]; dq/dk/dv rows have stride ldg (packed like q/k/v);
-// dbias (fp32 [heads][S][Spad], pre-zeroed by the caller) is optional.
+// dbias (fp32 [op_attn_bwd_dbias_slabs()][heads][S][Spad], pre-zeroed by the caller, accumulated into) is optional.
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
                 const void* biasT, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                 int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
@@ -792,6 +981,24 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
+  const int nt = ceil_div(S, BKV);
+  if (dbias && nt <= 6 && g_merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
+    const int chunks = dbias_chunks(B, S, heads);
+    a.bchunk = ceil_div(B, chunks);
+    const dim3 grid(ceil_div(S, 64), (unsigned)heads, (unsigned)chunks);
+    slot = op_prof_begin(2, 1.5 * fl, stream);
+    switch (nt) {
+      case 1: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<1>, grid, dim3(256), 0, s, a); break;
+      case 2: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<2>, grid, dim3(256), 0, s, a); break;
+      case 3: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<3>, grid, dim3(256), 0, s, a); break;
+      case 4: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<4>, grid, dim3(256), 0, s, a); break;
+      case 5: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<5>, grid, dim3(256), 0, s, a); break;
+      default: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<6>, grid, dim3(256), 0, s, a); break;
+    }
+    op_prof_end(slot, stream);
+    OP_LAUNCH_CHECK();
+    return OP_OK;
+  }
   slot = op_prof_begin(2, 1.5 * fl, stream);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(S, BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
   op_prof_end(slot, stream);

@@ -31,6 +31,8 @@ SIGNATURES = {
     "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
     "op_layernorm_set_grid": (c_int, [c_int, c_int]),
+    "op_attn_set_merge_dbias": (c_int, [c_int]),
+    "op_attn_bwd_dbias_slabs": (I64, [I64, I64, I64]),
     "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
     "op_gemm_set_staging": (c_int, [c_int]),
     "op_gemm_set_tile": (c_int, [c_int]),
@@ -365,12 +367,18 @@ def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=N
            "op_attn_bwd_delta")
     if dqkv is None:
         dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=dev)
-    dbias = torch.zeros(heads, S, Spad, dtype=torch.float32, device=dev) if want_dbias else None
+    dbias = attn_dbias_buffer(B, S, heads, Spad, dev) if want_dbias else None
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), ptr(key_pad),
                              ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dbias), B, S, Spad, heads,
                              64, scale, stream()), "op_attn_bwd")
-    return dqkv, dbias
+    return dqkv, dbias.sum(0) if dbias is not None else None
+
+
+def attn_dbias_buffer(B, S, heads, Spad, device):
+    """Zeroed fp32 [slabs, heads, S, Spad] accumulator for op_attn_bwd's dbias (the bias gradient is its sum over dim 0)."""
+    slabs = lib().op_attn_bwd_dbias_slabs(B, S, heads)
+    return torch.zeros(slabs, heads, S, Spad, dtype=torch.float32, device=device)
 
 
 class profile_kernels:

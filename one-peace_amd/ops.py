@@ -223,9 +223,10 @@ class RelPosBias:
             self._imageT = hip.relpos_bias_build(self.table.detach(), self.bucket, self.S, self.Spad, transposed=True)
         return self._imageT
 
-    def grad_accumulator(self):
+    def grad_accumulator(self, B):
+        """fp32 [slabs, heads, S, Spad]: the attention backward of every layer that uses this table adds its dS sums here."""
         if self.acc is None:
-            self.acc = torch.zeros(self.heads, self.S, self.Spad, dtype=torch.float32, device=self.image.device)
+            self.acc = hip.attn_dbias_buffer(B, self.S, self.heads, self.Spad, self.image.device)
         return self.acc
 
 
@@ -243,7 +244,7 @@ class _RelPosImageFn(torch.autograd.Function):
         h = ctx.handle_ref()
         if h is None or h.acc is None:
             return torch.zeros(ctx.shape, dtype=torch.bfloat16, device=_unused.device), None
-        dtable = hip.relpos_bias_bwd(h.acc, h.bucket, h.num_rel, h.S, h.Spad)
+        dtable = hip.relpos_bias_bwd(h.acc.sum(0), h.bucket, h.num_rel, h.S, h.Spad)
         h.acc = None
         return dtable.to(torch.bfloat16), None
 
@@ -437,7 +438,7 @@ class AttnBranchFn(torch.autograd.Function):
         else:
             dattn = daln
         dqkv, _ = _attn_backward(A["qkv"], dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
-                                 bias.grad_accumulator() if want_dbias else None)
+                                 bias.grad_accumulator(B) if want_dbias else None)
         (tq, tv), acc = _targets(direct, "bq", "bv")
         if H % 8 == 0:
             sums = hip.colsum_segments(dqkv, H, [tq, None, tv] if acc else None, accumulate=acc)

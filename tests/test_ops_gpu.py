@@ -402,8 +402,16 @@ def _attn_inputs(B, S, heads, use_bias, use_pad):
     return qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad
 
 
-@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", ATTN_CASES)
-def test_attention_forward_backward(B, S, heads, use_bias, use_pad):
+@pytest.fixture(params=[1, 0], ids=["dq_dbias_merged", "dq_dbias_separate"])
+def merge_dbias(request):
+    hip = hipmod()
+    old = hip.lib().op_attn_set_merge_dbias(request.param)
+    yield request.param
+    hip.lib().op_attn_set_merge_dbias(old)
+
+
+@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", ATTN_CASES + [(5, 327, 2, True, True), (3, 384, 1, True, False)])
+def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias):
     hip = hipmod()
     H = heads * 64
     qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad = _attn_inputs(B, S, heads, use_bias, use_pad)

@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU tri-modal tuples")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU tri-modal tuples; 0 = the largest of 128/64/32/16 whose kept activations fit this GPU's HBM")
     ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the reported metric needs 40")
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
@@ -158,6 +159,12 @@ def main():
     torch.cuda.set_device(device)
     torch.manual_seed(3407 + rank)
 
+    if args.batch <= 0:
+        # Kept-activation footprint measured on MI355X: 46.6 GB of parameters / gradients / Adam moments + 1.64 GB per
+        # tri-modal tuple (40 layers x 571 tokens x 67.6 KB); 128 tuples = 256 GB of the 288 GB.  Same choice on every rank.
+        total_gb = torch.cuda.get_device_properties(device).total_memory / 1e9
+        per_tuple_gb = (0.25 if args.recompute else 1.64) * 1.0737 * args.layers / LAYERS
+        args.batch = next((b for b in (128, 64, 32, 16) if 50.0 + per_tuple_gb * b <= 0.93 * total_gb), 8)
     model = build_model(args.layers, device, args.recompute)
     nparams = sum(p.numel() for p in model.parameters())
     no_decay_names = model.no_weight_decay()

@@ -194,6 +194,7 @@ def main():
     sync()
     if not args.no_profile:
         hip.lib().op_prof_enable(1)
+    hip.GEMM_ALGO_BYTES[0] = hip.GEMM_ALGO_BYTES[1] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -237,9 +238,18 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM, all epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": g["count"], "avg_launch_ms": g["ms"] / g["count"],
+                               "algorithmic_bytes_per_launch": hip.GEMM_ALGO_BYTES[0] / max(1, hip.GEMM_ALGO_BYTES[1]),
                                "gemm_share_of_step": g["ms"] / (ms * args.steps),
                                "attention_fwd_tflops": (prof[1]["work"] / (prof[1]["ms"] * 1e-3) / 1e12) if prof[1]["count"] else None,
                                "attention_bwd_tflops": (prof[2]["work"] / (prof[2]["ms"] * 1e-3) / 1e12) if prof[2]["count"] else None}
+            # HBM bytes per GEMM launch from the PMC passes of this same command (FETCH_SIZE / WRITE_SIZE need their own
+            # rocprofv3 runs, so they cannot be collected inside this process): tools/pmc_bench_traffic.sh wrote the file.
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_gemm_hbm_traffic.json")
+            if os.path.exists(tpath):
+                tr = json.load(open(tpath))
+                if tr.get("per_gpu_batch") == args.batch and tr.get("n_gpus") == world and args.layers == LAYERS:
+                    out["roofline"]["traffic"] = tr["bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/r1_gemm_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -41,6 +41,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int kt_per_split;   // K-tiles handled by one workgroup (split-K along blockIdx.y); 0 = all
   int64_t slab;       // elements between split-K output slabs
+  int gm;             // 256x256 kernels: M-tiles per L2 group (tile order: gm M-tiles x all N-tiles, M fastest)
 };
 
 constexpr int BM = 128, BK = 64;
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  constexpr int GM = 4;
+  const int GM = p.gm;
   const int per_group = GM * p.tiles_n;
   const int first_m = (pid / per_group) * GM;
   const int gsz = min(p.tiles_m - first_m, GM);
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(512, 2) void gemm256b_kernel(const GemmArgs p) {
   constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  constexpr int GM = 4;
+  const int GM = p.gm;
   const int per_group = GM * p.tiles_n;
   const int first_m = (pid / per_group) * GM;
   const int gsz = min(p.tiles_m - first_m, GM);
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
   const int g = lane >> 4, t = lane & 15;
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  constexpr int GM = 4;
+  const int GM = p.gm;
   const int per_group = GM * p.tiles_n;
   const int first_m = (pid / per_group) * GM;
   const int gsz = min(p.tiles_m - first_m, GM);
@@ -950,6 +951,7 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
 }
 
 int g_fullline = 2;  // BK = 64 full-line flavour of the 256^2 NT kernel: 0 off, 1 always, 2 auto (op_gemm_set_tile(20/21/22))
+int g_gm = 0;        // M-tiles per L2 group of the 256x256 kernels; 0 = auto (op_gemm_set_tile(40 + gm))
 int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + barriers only, 5 = MFMAs only in the steady loop
                      // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
 
@@ -1079,6 +1081,7 @@ extern "C" {
 // 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
 int op_gemm_set_tile(int mode) {
   int old = g_tile_mode;
+  if (mode >= 40) { g_gm = mode - 40; return old; }  // 40: auto, 40+g: g M-tiles per L2 group
   if (mode >= 20) { g_fullline = mode - 20; return old; }  // 20/21/22: BK = 32 / BK = 64 / auto flavour of the 256x256 NT kernel
   if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10..15: timing ablations of the 256x256 kernel (tools only)
   g_tile_mode = mode;
@@ -1119,7 +1122,7 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
   a.resid = (const bf16_t*)resid; a.ldr = ldr; a.gamma = (const bf16_t*)gamma; a.rowscale = rowscale;
   a.rows_per_sample = rows_per_sample > 0 ? (int)rows_per_sample : 1;
   a.alpha = alpha;
-  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4;
   a.n_seg = (int)(n_seg > 0 ? n_seg : N);
   a.tiles_m = ceil_div(M, BM);
   if (epilogue == EPI_GEGLU) {
@@ -1160,6 +1163,9 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
   if (plan.tile == 256) {
     a.tiles_m = ceil_div(M, 256);
     a.tiles_n = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
+    // L2 tile-group depth (tools/gemm_gm.py): few column tiles (N = 1536) -> walk all N-tiles of ONE M-tile together
+    // (+3-5 %); wide outputs -> 8 M-tiles per group (+1-2 % over 4)
+    a.gm = g_gm > 0 ? g_gm : (a.tiles_n <= 8 ? 1 : 8);
     switch (epi) {
       case EPI_BIAS: rc = launch256<EPI_BIAS>(a, s, plan.splits); break;
       case EPI_F32: rc = launch256<EPI_F32>(a, s, plan.splits); break;
@@ -1208,9 +1214,10 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   a.bias[0] = a.bias[1] = a.bias[2] = nullptr;
   a.C = C; a.ldc = ldc; a.H0 = a.H1 = nullptr; a.resid = nullptr; a.ldr = 0; a.gamma = nullptr; a.rowscale = nullptr;
   a.rows_per_sample = 1; a.alpha = nullptr;
-  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4;
   a.tiles_m = ceil_div(M, 256);
   a.tiles_n = ceil_div(N, 256);
+  a.gm = g_gm > 0 ? g_gm : (a.tiles_n <= 8 ? 1 : 8);
   // split-K: fill the chip (256 slots per round) while keeping chunks long and even
   const int nk = (int)(K / BK2);
   const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;

@@ -167,6 +167,7 @@ def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None,
 
 
 SPLITK_WS_BYTES = 768 << 20
+GEMM_ALGO_BYTES = [0, 0]  # [bytes, launches]: operands read once + outputs written once (bench.py's roofline.traffic yardstick)
 
 
 def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h1=None, resid=None, gamma=None,
@@ -188,6 +189,10 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
     if splitk and epilogue == EPI_BIAS and biases[0] is None and K >= 2048:
         ws = workspace(SPLITK_WS_BYTES, A.device, "gemm_splitk")
         ws_bytes = ws.numel()
+    outs = 1 + (2 if h1 is not None else (1 if h0 is not None else 0))
+    GEMM_ALGO_BYTES[0] += 2 * (M * K + Nn * K * (2 if epilogue == EPI_GEGLU else 1) + (M * Nn if resid is not None else 0)) \
+        + out.element_size() * M * Nn * outs
+    GEMM_ALGO_BYTES[1] += 1
     _check(lib().op_gemm_nt(ptr(A), A.stride(0), ptr(Bs[0]), ptr(Bs[1]), ptr(Bs[2]), Bs[0].stride(0), n_seg,
                             ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), ptr(out), ldc_, ptr(h0), ptr(h1),
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
@@ -208,6 +213,8 @@ def gemm_tn(A_km, B_kn, out=None, accumulate=False):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=A_km.device)
         accumulate = False
     ws = workspace(SPLITK_WS_BYTES, A_km.device, "gemm_splitk")
+    GEMM_ALGO_BYTES[0] += 2 * (K * M + K * N + M * N * (2 if accumulate else 1))
+    GEMM_ALGO_BYTES[1] += 1
     _check(lib().op_gemm_tn(ptr(A_km), A_km.stride(0), ptr(B_kn), B_kn.stride(0), ptr(out), out.stride(0), M, N, K,
                             int(accumulate), ptr(ws), ws.numel(), stream()), "op_gemm_tn")
     return out

@@ -1,4 +1,5 @@
-"""Sweep the LayerNorm persistent-grid caps at ONE-PEACE-4B shapes (GPU box)."""
+"""Sweep the LayerNorm persistent-grid caps at ONE-PEACE-4B shapes (GPU box).  Buffers are rotated so that every launch
+streams from HBM (the 256 MB MALL would otherwise serve the re-reads of a 50 MB tensor)."""
 import os
 import sys
 
@@ -6,31 +7,50 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from one_peace_amd import hip  # noqa: E402
-from tools.bench_ops import timeit  # noqa: E402
 
-M = 64 * 257
+M = 128 * 257
 bf = dict(dtype=torch.bfloat16, device="cuda")
+
+
+def timeit_rot(fn, n, iters=24):
+    for i in range(n):
+        fn(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(iters):
+        fn(i % n)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
 for cols in (1536, 6144):
-    x, dy = torch.randn(M, cols, **bf), torch.randn(M, cols, **bf)
+    n = 8 if cols == 1536 else 3
+    xs = [torch.randn(M, cols, **bf) for _ in range(n)]
+    dys = [torch.randn(M, cols, **bf) for _ in range(n)]
     w, b = torch.ones(cols, **bf), torch.zeros(cols, **bf)
-    y, mean, rstd = hip.layernorm_fwd(x, w, b)
-    for blocks in (256, 512, 1024, 2048, 4096):
+    y, mean, rstd = hip.layernorm_fwd(xs[0], w, b)
+    out = torch.empty_like(xs[0])
+    for blocks in (512, 1024, 2048, 4096):
         hip.lib().op_layernorm_set_grid(blocks, blocks)
-        tf = timeit(lambda: hip.layernorm_fwd(x, w, b), iters=50)
-        tb = timeit(lambda: hip.layernorm_bwd(dy, x, w, b, mean, rstd), iters=50)
-        tba = timeit(lambda: hip.layernorm_bwd(dy, x, w, b, mean, rstd, add=dy), iters=50)
+        tf = timeit_rot(lambda i: hip.layernorm_fwd(xs[i], w, b), n)
+        tb = timeit_rot(lambda i: hip.layernorm_bwd(dys[i], xs[i], w, b, mean, rstd), n)
+        tba = timeit_rot(lambda i: hip.layernorm_bwd(dys[i], xs[i], w, b, mean, rstd, add=dys[(i + 1) % n]), n)
         print("cols %d blocks %4d: fwd %.4f ms (%.0f GB/s)  bwd %.4f ms (%.0f GB/s)  bwd+add %.4f ms (%.0f GB/s)" % (
             cols, blocks, tf, 4.0 * M * cols / tf / 1e6, tb, 6.0 * M * cols / tb / 1e6, tba, 8.0 * M * cols / tba / 1e6), flush=True)
-
+    del xs, dys
 hip.lib().op_layernorm_set_grid(512, 512)
-M, F = 64 * 257, 6144
-h0, h1, dy = torch.randn(M, F, **bf), torch.randn(M, F, **bf), torch.randn(M, F, **bf)
+F = 6144
+h0s = [torch.randn(M, F, **bf) for _ in range(2)]
+h1s = [torch.randn(M, F, **bf) for _ in range(2)]
+dys = [torch.randn(M, F, **bf) for _ in range(2)]
 w, b = torch.ones(F, **bf), torch.zeros(F, **bf)
-_, mean, rstd = hip.layernorm_fwd(h0, w, b)
+_, mean, rstd = hip.layernorm_fwd(h0s[0], w, b)
 for blocks in (512, 1024, 2048):
     hip.lib().op_layernorm_set_grid(512, blocks)
-    t = timeit(lambda: hip.ln_geglu_bwd(dy, h0, h1, w, mean, rstd), iters=30)
-    print("ln_geglu_bwd blocks %d: %.4f ms (%.0f GB/s algorithmic)" % (blocks, t, 10.0 * M * F / t / 1e6))
+    t = timeit_rot(lambda i: hip.ln_geglu_bwd(dys[i], h0s[i], h1s[i], w, mean, rstd), 2, iters=12)
+    print("ln_geglu_bwd blocks %d: %.4f ms (%.0f GB/s algorithmic)" % (blocks, t, 10.0 * M * F / t / 1e6), flush=True)
 hip.lib().op_layernorm_set_grid(512, 512)
-t = timeit(lambda: hip.geglu_bwd(dy, h0, h1), iters=30)
+t = timeit_rot(lambda i: hip.geglu_bwd(dys[i], h0s[i], h1s[i]), 2, iters=12)
 print("geglu_bwd: %.4f ms (%.0f GB/s)" % (t, 10.0 * M * F / t / 1e6))

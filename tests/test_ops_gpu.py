@@ -410,7 +410,9 @@ def merge_dbias(request):
     hip.lib().op_attn_set_merge_dbias(old)
 
 
-@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", ATTN_CASES + [(5, 327, 2, True, True), (3, 384, 1, True, False)])
+@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", ATTN_CASES + [(5, 327, 2, True, True), (3, 384, 1, True, False),
+                                                                     (3, 250, 2, True, True), (2, 272, 1, False, True),
+                                                                     (4, 100, 2, True, False), (2, 16, 1, True, True)])
 def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias):
     hip = hipmod()
     H = heads * 64

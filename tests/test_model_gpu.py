@@ -276,3 +276,64 @@ def test_joint_vl_al_streams_on_hip(golden_dir, train):
         assert any("rel_pos_table" in n for n in res["hip"][1])
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "joint_parity_report_%d.txt" % train),
          "w").write("\n".join(report) + "\n")
+
+
+def test_full_size_layer_4b_dimensions():
+    """One encoder layer at the BASELINE dimensions (H=1536, F=6144, 24 heads, image S=257) on the HIP path against the
+    fp32 torch path of the same mirror on the same device (the mirror's torch path is pinned to the reference at 1e-5 on
+    CPU): outputs and every parameter gradient, plus two size-independent properties -- batch-permutation equivariance
+    (bit-exact: rows never mix across samples) and invariance to appended, masked keys."""
+    from one_peace_amd.relpos import RelPosSpec, make_image_bucket_position
+    from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd import hip
+    cfg = one_peace_encoder_config(embed_dim=1536, ffn_embed_dim=6144, layers=1, attention_heads=24, drop_path_rate=0.0)
+    torch.manual_seed(0)
+    layer = TransformerEncoderLayer(cfg, drop_path_rate=0.0)
+    for n, q in layer.named_parameters():  # non-trivial LayerNorm / layer-scale values
+        if q.dim() == 1:
+            q.data.add_(0.1 * torch.randn_like(q))
+    B, S, H, heads = 6, 257, 1536, 24
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, S, H, generator=g)
+    dy = torch.randn(B, S, H, generator=g)
+    nrel = (2 * 16 - 1) ** 2 + 3
+    table = 0.5 * torch.randn(nrel, heads, generator=g)
+    bucket = make_image_bucket_position(16, nrel)
+
+    def run(dtype, fused, xin, key_pad=None, dense_extra=None):
+        m = layer.to(DEV).to(dtype)
+        m.zero_grad()
+        xd = xin.to(DEV).to(dtype).requires_grad_(True)
+        tab = table.to(DEV).to(dtype).requires_grad_(True)
+        spec = RelPosSpec(tab, bucket.to(DEV))
+        if fused:
+            y = m.forward_fused(xd, spec.handle(), key_pad, "image")
+        else:
+            bias = spec.dense(xin.shape[0]).to(dtype)
+            y = m(xd.transpose(0, 1), encoder_padding_mask=None, self_attn_bias=bias, encoder_type="image").transpose(0, 1)
+        (y.float() * dy.to(DEV)[: xin.shape[0]]).sum().backward()
+        grads = {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None}
+        return y.detach().float(), xd.grad.detach().float(), tab.grad.detach().float(), grads
+
+    y32, dx32, dt32, g32 = run(torch.float32, False, x)
+    yb, dxb, dtb, gb = run(torch.bfloat16, False, x)     # yardstick: the reference algorithm op by op in bf16
+    yh, dxh, dth, gh = run(torch.bfloat16, True, x)
+    report = []
+    _check("4B-dim layer out", yh, yb, y32, 1.5e-2, report)
+    _check("4B-dim layer dx", dxh, dxb, dx32, 5e-2, report)
+    _check("4B-dim layer dtable", dth, dtb, dt32, 5e-2, report)
+    for n, ref in g32.items():
+        if float(ref.norm()) > 1e-7:
+            _check("4B-dim grad " + n, gh[n], gb[n], ref, 5e-2, report)
+    # property 1: permuting the samples permutes the outputs, bit for bit
+    perm = torch.tensor([3, 0, 5, 1, 4, 2])
+    yp = run(torch.bfloat16, True, x[perm])[0]
+    assert torch.equal(yp, yh[perm.to(DEV)])
+    # property 2: keys that are masked out do not exist -- mask the last 40 keys and compare with the truncated sequence
+    key_pad = torch.zeros(B, hip.attn_spad(S), dtype=torch.uint8, device=DEV)
+    key_pad[:, S - 40:] = 1
+    y_masked = run(torch.bfloat16, True, x, key_pad=key_pad)[0]
+    assert y_masked.isfinite().all() and rel_fro(y_masked[:, : S - 40], yh[:, : S - 40]) > 1e-3   # the mask had an effect
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "layer_4b_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")

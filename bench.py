@@ -181,7 +181,7 @@ def main():
         loss, _, log = crit(model, sample)
         loss.backward()
         reducer.finish()
-        opt.step(grad_scale=1.0 / world)
+        opt.step(grad_scale=1.0 / world, clip_norm=3.0)  # pretrain_vl_3B.yaml:45 clip_norm; trainer.py:917-935
         return loss
 
     def sync():
@@ -222,7 +222,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights, seeded random tokens / N(0,1) pixels and waveforms)",
             "config": {"workload": "BASELINE configs[3]: ONE-PEACE-4B tri-modal (image 256^2 + text 64 + audio %.0fs) "
-                                   "contrastive pretrain step: 3 forwards, ITC+ATC, backward, grad all-reduce, AdamW"
+                                   "contrastive pretrain step: 3 forwards, ITC+ATC, backward, grad all-reduce, grad-norm clip, AdamW"
                                    % args.audio_seconds,
                        "embed_dim": H, "ffn": FFN, "layers": args.layers, "heads": HEADS, "params": nparams,
                        "per_gpu_batch": args.batch, "global_batch": global_batch,

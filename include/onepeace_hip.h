@@ -161,7 +161,11 @@ int op_infonce_rows(float* sim, int64_t rows, int64_t n, int64_t ld, int64_t tar
  * runs without apex): fp32 moments, decoupled decay before the update, eps added to sqrt(v).  g is multiplied by
  * grad_scale inside the kernel (1/world after a SUM all-reduce).  numel % 8 == 0, step >= 1. */
 int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int64_t step, float grad_scale, void* stream);
+                  float weight_decay, int64_t step, float grad_scale, const float* grad_sqnorm, float clip_norm,
+                  void* stream);
+/* out[0] = sum of squares of a bf16 vector in fp32 (the global gradient norm of fairseq/fairseq/utils.py:349-391 over the
+ * flat gradient buffer; feeds op_adamw_step's device-side clip coefficient, trainer.py:929).  workspace: 1024 floats. */
+int op_sqnorm(const void* x, int64_t numel, float* workspace, float* out, void* stream);
 
 /* ---- hardware-semantics probes (test infrastructure; tests/test_probes_gpu.py) --------------------------------------- */
 int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream);

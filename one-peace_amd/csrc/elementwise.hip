@@ -340,7 +340,12 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(float* __restrict__ s
 __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n8,
                                                     float beta1, float beta2, float eps, float step_size,
-                                                    float decay_mul, float grad_scale) {
+                                                    float decay_mul, float grad_scale, const float* __restrict__ sqnorm,
+                                                    float clip_norm) {
+  if (sqnorm != nullptr && clip_norm > 0.f) {  // fairseq/utils.py:393-397: clip_coef = clamp(max_norm / (norm + 1e-6), max=1)
+    const float norm = fabsf(grad_scale) * sqrtf(*sqnorm);
+    grad_scale *= fminf(1.0f, clip_norm / (norm + 1e-6f));
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     float pv[8], gv[8], mv[8], vv[8];
     Vec8<bf16_t>::load(p + i * 8, pv);
@@ -359,6 +364,31 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, cons
     Vec8<float>::store(m + i * 8, mv);
     Vec8<float>::store(v + i * 8, vv);
   }
+}
+
+// sum of squares, stage 1: one partial per workgroup (grid-stride over 8-element vectors); stage 2 folds the partials
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const bf16_t* __restrict__ x, int64_t n8, float* __restrict__ part) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    Vec8<bf16_t>::load(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += v[j] * v[j];
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -562,9 +592,25 @@ int op_infonce_rows(float* sim, int64_t rows, int64_t n, int64_t ld, int64_t tar
   return OP_OK;
 }
 
-// One AdamW update over a flat bf16 parameter range (numel % 8 == 0).  step >= 1.
+// out[0] = sum of squares of a bf16 vector (fp32, deterministic two-stage fold): the global gradient norm of
+// fairseq/utils.py:349-391 over the flat gradient buffer.  workspace: 1024 floats.  numel % 8 == 0.
+int op_sqnorm(const void* x, int64_t numel, float* workspace, float* out, void* stream) {
+  OP_CHECK_ARG(x && workspace && out && numel % 8 == 0, "sqnorm: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(1024), dim3(256), 0, s, (const bf16_t*)x, numel / 8, workspace);
+  OP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, 1024, out);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// One AdamW update over a flat bf16 parameter range (numel % 8 == 0).  step >= 1.  The gradient is multiplied by
+// grad_scale (1/world after a SUM all-reduce, trainer.py:917-923) and, when grad_sqnorm (device scalar = sum of squares of
+// the UNSCALED gradients of ALL ranges, op_sqnorm) and clip_norm > 0 are given, by the reference's clip coefficient
+// (trainer.py:929, fairseq/utils.py:393-397) -- computed on the device, no host synchronisation.
 int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int64_t step, float grad_scale, void* stream) {
+                  float weight_decay, int64_t step, float grad_scale, const float* grad_sqnorm, float clip_norm,
+                  void* stream) {
   OP_CHECK_ARG(p && g && m && v, "adamw: null pointer");
   OP_CHECK_ARG(numel % 8 == 0 && step >= 1, "adamw: numel must be a multiple of 8 and step >= 1");
   if (numel == 0) return OP_OK;
@@ -573,7 +619,7 @@ int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, flo
   const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
   const float decay_mul = 1.f - weight_decay * lr;
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (const bf16_t*)g,
-                     m, v, numel / 8, beta1, beta2, eps, step_size, decay_mul, grad_scale);
+                     m, v, numel / 8, beta1, beta2, eps, step_size, decay_mul, grad_scale, grad_sqnorm, clip_norm);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

@@ -42,6 +42,7 @@ struct GemmArgs {
   int kt_per_split;   // K-tiles handled by one workgroup (split-K along blockIdx.y); 0 = all
   int64_t slab;       // elements between split-K output slabs
   int gm;             // 256x256 kernels: M-tiles per L2 group (tile order: gm M-tiles x all N-tiles, M fastest)
+  int m_off;          // row index of A's first row in the caller's matrix (rowscale lookup of a tail-rows launch)
 };
 
 constexpr int BM = 128, BK = 64;
@@ -157,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
       for (int j = 0; j < 16; ++j) o[j] = alpha * o[j] + bv[j];
     } else if (EPI == EPI_RESID) {
       float rs = 1.f;
-      if (p.rowscale) rs = p.rowscale[m / p.rows_per_sample];
+      if (p.rowscale) rs = p.rowscale[(m + p.m_off) / p.rows_per_sample];
       float rv[16];
       float tmp[8];
       Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0, tmp);
@@ -951,6 +952,7 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
 }
 
 int g_fullline = 2;  // BK = 64 full-line flavour of the 256^2 NT kernel: 0 off, 1 always, 2 auto (op_gemm_set_tile(20/21/22))
+int g_tail_rows = 1;  // 1: split off the <= 128 leftover rows when that saves a round (op_gemm_set_tile(50/51/52))
 int g_gm = 0;        // M-tiles per L2 group of the 256x256 kernels; 0 = auto (op_gemm_set_tile(40 + gm))
 int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + barriers only, 5 = MFMAs only in the steady loop
                      // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
@@ -1081,6 +1083,7 @@ extern "C" {
 // 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
 int op_gemm_set_tile(int mode) {
   int old = g_tile_mode;
+  if (mode >= 50) { g_tail_rows = mode - 50; return old; }  // 50: off, 51: on (K >= 1024), 52: whenever it saves a round, 53: always (tests)
   if (mode >= 40) { g_gm = mode - 40; return old; }  // 40: auto, 40+g: g M-tiles per L2 group
   if (mode >= 20) { g_fullline = mode - 20; return old; }  // 20/21/22: BK = 32 / BK = 64 / auto flavour of the 256x256 NT kernel
   if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10..15: timing ablations of the 256x256 kernel (tools only)
@@ -1103,11 +1106,11 @@ int op_gemm_set_staging(int glds) {
 //             resid may alias C (in-place accumulate); h0 (optional) receives y = acc + bias.
 //   workspace (optional, fp32 scratch of workspace_bytes): enables split-K for bias-free epilogue-0 launches with few
 //   output tiles and a long K (the weight-gradient GEMMs).
-int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
-               const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
-               const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
-               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
-               void* stream) {
+static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
+                        const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
+                        const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
+                        const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace,
+                        int64_t workspace_bytes, void* stream, int64_t m_off, bool allow_tail_split) {
   OP_CHECK_ARG(A && B0 && C, "gemm_nt: null A/B/C");
   OP_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   OP_CHECK_ARG(K % BK == 0, "gemm_nt: K=%lld must be a multiple of %d (pad on the host)", (long long)K, BK);  // => even number of 32-deep stages
@@ -1122,7 +1125,7 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
   a.resid = (const bf16_t*)resid; a.ldr = ldr; a.gamma = (const bf16_t*)gamma; a.rowscale = rowscale;
   a.rows_per_sample = rows_per_sample > 0 ? (int)rows_per_sample : 1;
   a.alpha = alpha;
-  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.m_off = (int)m_off;
   a.n_seg = (int)(n_seg > 0 ? n_seg : N);
   a.tiles_m = ceil_div(M, BM);
   if (epilogue == EPI_GEGLU) {
@@ -1147,6 +1150,25 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
   const bool allow_split = epilogue == EPI_BIAS && !bias0 && workspace != nullptr && N % 8 == 0;
   GemmPlan plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, workspace_bytes);
   if (g_tile_mode == 2 && allow_256 && plan.tile != 256) plan = {256, 1, 0};
+  // Tail rows.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
+  // every CU (M = 128 x 257: 774 tiles = 3.02 rounds for N = 1536).  If dropping them saves a round, the full M-tiles run
+  // as one launch and the <= 128 leftover rows as a second, small one (128 x 128 tiles).
+  if (allow_tail_split && g_tail_rows && plan.tile == 256 && plan.splits == 1 && M > 256) {
+    const int64_t m_rem = M % 256, m_main = M - m_rem;
+    const int64_t tn = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
+    const int64_t r_full = ceil_div(ceil_div(M, 256) * tn, 256), r_main = ceil_div((m_main / 256) * tn, 256);
+    if (m_rem > 0 && m_rem <= 128 && (g_tail_rows == 3 || (r_main < r_full && (g_tail_rows == 2 || K >= 1024)))) {
+      const int64_t esz = epilogue == EPI_F32 ? 4 : 2;
+      int rc = gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
+                            rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false);
+      if (rc != OP_OK) return rc;
+      return gemm_nt_impl((const bf16_t*)A + m_main * lda, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2,
+                          (char*)C + m_main * ldc * esz, ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
+                          h1 ? (bf16_t*)h1 + m_main * ldc : nullptr, resid ? (const bf16_t*)resid + m_main * ldr : nullptr, ldr,
+                          gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, nullptr, 0, stream, m_off + m_main,
+                          false);
+    }
+  }
   a.kt_per_split = plan.kt_per_split;
   a.slab = (int64_t)M * N;
   int epi = epilogue;
@@ -1192,6 +1214,15 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
   return rc;
 }
 
+int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,
+               const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
+               const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
+               const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
+               void* stream) {
+  return gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
+                      rows_per_sample, alpha, M, N, K, epilogue, workspace, workspace_bytes, stream, 0, true);
+}
+
 
 // C[M,N] (bf16, ldc) = A^T B with A [K, M] (lda) and B [K, N] (ldb) both row-major bf16: the weight-gradient GEMM
 // dW[out,in] = dy[tokens,out]^T x[tokens,in] (autograd of nn.Linear) without transposed operand copies.
@@ -1214,7 +1245,7 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   a.bias[0] = a.bias[1] = a.bias[2] = nullptr;
   a.C = C; a.ldc = ldc; a.H0 = a.H1 = nullptr; a.resid = nullptr; a.ldr = 0; a.gamma = nullptr; a.rowscale = nullptr;
   a.rows_per_sample = 1; a.alpha = nullptr;
-  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.m_off = 0;
   a.tiles_m = ceil_div(M, 256);
   a.tiles_n = ceil_div(N, 256);
   a.gm = g_gm > 0 ? g_gm : (a.tiles_n <= 8 ? 1 : 8);

@@ -51,7 +51,8 @@ SIGNATURES = {
     "op_l2norm_fwd": (c_int, [P, P, P, I64, I64, c_float, c_int, P]),
     "op_l2norm_bwd": (c_int, [P, P, P, P, I64, I64, c_int, P]),
     "op_infonce_rows": (c_int, [P, I64, I64, I64, I64, c_float, c_float, P, P, P, c_int, P]),
-    "op_adamw_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, I64, c_float, P]),
+    "op_adamw_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, I64, c_float, P, c_float, P]),
+    "op_sqnorm": (c_int, [P, I64, P, P, P]),
     "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
     "op_attn_fwd": (c_int, [P, P, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
@@ -322,9 +323,18 @@ def infonce_rows(sim, target0, label_smoothing=0.0, gscale=1.0, write_grad=True)
     return loss, hit, dot
 
 
-def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_sqnorm=None, clip_norm=0.0):
     _check(lib().op_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                               grad_scale, stream()), "op_adamw_step")
+                               grad_scale, ptr(grad_sqnorm), clip_norm, stream()), "op_adamw_step")
+
+
+def sqnorm(x, out=None):
+    """Sum of squares of a flat bf16 tensor -> fp32 device scalar [1]."""
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+    ws = workspace(4096, x.device, "sqnorm")
+    _check(lib().op_sqnorm(ptr(x), x.numel(), ptr(ws), ptr(out), stream()), "op_sqnorm")
+    return out
 
 
 def relpos_bias_build(table, bucket_i32, S, Spad, transposed=False):

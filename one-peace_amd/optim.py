@@ -20,15 +20,20 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.step_count = 0
 
-    def step(self, grad_scale=1.0):
-        """grad_scale multiplies the gradient inside the kernel (1/world_size after a SUM all-reduce, clip factor...)."""
+    def step(self, grad_scale=1.0, clip_norm=0.0):
+        """grad_scale multiplies the gradient inside the kernel (1/world_size after a SUM all-reduce, trainer.py:917-923).
+        clip_norm > 0: the reference's global-norm clipping (trainer.py:929 -> fairseq/utils.py:349-397) -- the norm is
+        one extra pass over the flat gradient buffer, the clip coefficient is derived on the device inside the update
+        kernel.  Returns the (unclipped, scaled) gradient norm as a device scalar when clipping is on."""
         self.step_count += 1
         f = self.flat
+        sq = hip.sqnorm(f.grads) if clip_norm > 0 else None
         for (s, e), wd in ((f.decay_range, self.weight_decay), (f.no_decay_range, 0.0)):
             if e > s:
                 hip.adamw_step(f.params[s:e], f.grads[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.lr, self.betas[0],
-                               self.betas[1], self.eps, wd, self.step_count, grad_scale)
+                               self.betas[1], self.eps, wd, self.step_count, grad_scale, sq, clip_norm)
         ops.invalidate_weight_cache()
+        return sq.sqrt() * abs(grad_scale) if sq is not None else None
 
     def zero_grad(self):
         self.flat.zero_grad()

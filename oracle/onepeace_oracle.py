@@ -413,6 +413,14 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
     return p
 
 
+def clip_coef(grads, max_norm):
+    """fairseq/fairseq/utils.py:349-397 (clip_grad_norm_): total L2 norm over all gradients in fp32;
+    clip_coef = clamp(max_norm / (total_norm + 1e-6), max=1).  Returns (total_norm, clip_coef)."""
+    total = torch.norm(torch.stack([torch.norm(g.float(), p=2) for g in grads]))
+    coef = (float(max_norm) / (total + 1e-6)).clamp(max=1.0) if max_norm > 0 else torch.tensor(1.0)
+    return total, coef
+
+
 def dp_mean_grads(per_rank_grads):
     """fairseq legacy_distributed_data_parallel.py:76-165: each rank divides by world size, then SUM."""
     w = len(per_rank_grads)

@@ -338,6 +338,30 @@ def test_adamw_matches_reference_rule():
     assert (diff > 0).float().mean() < 0.01 and float(diff.max()) <= float(pr.float().abs().max()) * 2 ** -7
 
 
+@pytest.mark.parametrize("gnorm_scale", [0.01, 30.0])
+def test_adamw_with_global_norm_clipping(gnorm_scale):
+    """trainer.py:917-935: grads * 1/world, clip_grad_norm(3.0) over ALL parameters (two decay groups here), Adam step."""
+    hip = hipmod()
+    n = 8192
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=gnorm_scale)
+    gq = g.to(torch.bfloat16)
+    world = 4
+    total, coef = O.clip_coef([gq.float() / world], 3.0)
+    assert (float(coef) < 1.0) == (gnorm_scale > 1.0)
+    m = torch.zeros(n); v = torch.zeros(n)
+    pr = p0.to(torch.bfloat16)
+    O.adamw_step(pr, (gq.float() / world * coef), m, v, 1, lr=1e-2, beta1=0.9, beta2=0.98, eps=1e-6, weight_decay=0.05)
+    pd, gd, md, vd = dev_bf16(p0), dev_bf16(g), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sq = hip.sqnorm(gd)
+    assert abs(float(sq.sqrt()) / world - float(total)) <= 1e-4 * float(total)
+    for s_, e_ in ((0, 4096), (4096, n)):  # two ranges share the one global norm
+        hip.adamw_step(pd[s_:e_], gd[s_:e_], md[s_:e_], vd[s_:e_], 1e-2, 0.9, 0.98, 1e-6, 0.05, 1, 1.0 / world, sq, 3.0)
+    assert_close(md, m, fro=1e-5, mx=1e-4, what="m")
+    assert_close(vd, v, fro=1e-5, mx=1e-4, what="v")
+    diff = (pd.float().cpu() - pr.float()).abs()
+    assert (diff > 0).float().mean() < 0.01 and float(diff.max()) <= float(pr.float().abs().max()) * 2 ** -7
+
+
 def test_relpos_bias_build_and_bwd():
     hip = hipmod()
     heads, n = 3, 4
@@ -546,3 +570,40 @@ def test_weight_gradient_full_size_matches_torch():
     ops.wgrad(dy, x, out=grad, accumulate=True)
     ref = base.float() + dy.float().t() @ x.float()
     assert_close(grad, ref, what="dW accumulate")
+
+
+@pytest.mark.parametrize("epi", ["bias", "geglu", "resid"])
+def test_gemm_tail_rows_split(epi):
+    """M = 2 x 256 + 77: the full M-tiles and the leftover rows run as two launches (forced here; in production only when
+    that saves a round of all CUs).  Row-dependent epilogue inputs (residual, drop-path scale, saved branch outputs) must
+    follow the row offset."""
+    hip = hipmod()
+    M, N, K, S = 589, 512, 256, 19
+    a = rnd(M, K, seed=1)
+    old = hip.lib().op_gemm_set_tile(2)
+    hip.lib().op_gemm_set_tile(53)
+    try:
+        if epi == "bias":
+            w, b = rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+            out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)])
+            assert_close(out, a @ w.t() + b, what="bias")
+        elif epi == "geglu":
+            w0, w1 = rnd(N, K, seed=2, scale=0.1), rnd(N, K, seed=3, scale=0.1)
+            h0 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            h1 = torch.empty_like(h0)
+            out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w0), dev_bf16(w1)], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+            assert_close(out, O.gelu_erf(a @ w0.t()) * (a @ w1.t()), what="geglu")
+            assert_close(h0, a @ w0.t(), what="h0")
+            assert_close(h1, a @ w1.t(), what="h1")
+        else:
+            w, b, gamma, res = rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(N, seed=4), rnd(M, N, seed=5)
+            ps = (torch.arange(M // S) % 3 != 1).float() / 0.66
+            y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)], epilogue=hip.EPI_RESID, resid=dev_bf16(res),
+                              gamma=dev_bf16(gamma), rowscale=ps.to(DEV), rows_per_sample=S, h0=y)
+            branch = a @ w.t() + b
+            assert_close(y, branch, what="branch output")
+            assert_close(out, res + ps.repeat_interleave(S)[:, None] * gamma * branch, what="resid")
+    finally:
+        hip.lib().op_gemm_set_tile(51)
+        hip.lib().op_gemm_set_tile(old)

@@ -139,8 +139,8 @@ _ws_cache = {}
 
 
 def workspace(nbytes, device, tag="ws"):
-    """Grow-only scratch buffer per (device, tag); caller-owned memory as the C ABI requires."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, stream); caller-owned memory as the C ABI requires."""
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream)  # per stream: launches on different streams may overlap
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

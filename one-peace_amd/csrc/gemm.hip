@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // pipe; sched_group_barrier spreads the 16 memory instructions between the 32 MFMAs (1 per 2) instead.
   auto step_steady = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
     WAIT_LGKM0();
-    if (ABL != 2 && ABL < 4) WAIT_VM(8); else WAIT_VM(0);
+    if (ABL != 2 && (ABL < 4 || ABL == 6)) WAIT_VM(8); else WAIT_VM(0);
     if (ABL != 5) __builtin_amdgcn_s_barrier();
     const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;  // fragments of the next stage
     char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;              // slot being refilled with stage kt+4
@@ -513,12 +513,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int idx = 2 * j + h, mi = idx >> 2, ni = idx & 3;
-        if (ABL != 1)
+        if (ABL != 1 && ABL != 6)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
         else
           asm volatile("" :: "v"(cur_w[ni]), "v"(cur_x[mi]));
       }
-      if (ABL >= 4) {  // timing ablation: MFMAs only (4: barriers kept, 5: no barriers)
+      if (ABL >= 4) {  // timing ablation: MFMAs only (4: barriers kept, 5: no barriers); 6: LDS-DMA + barriers only
         if (j < 4) nxt_w[j] = cur_w[j];
         else if (j < 12) nxt_x[j - 4] = cur_x[j - 4];
       } else if (j < 4) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
       } else {
         const int i = (j - 12) >> 1;
         const int wbase = (i * 512 + wid * 64) * 16;
-        if (ABL != 2 && ABL < 4) {
+        if (ABL != 2 && (ABL < 4 || ABL == 6)) {
           if ((j & 1) == 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
                                              (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
@@ -990,6 +990,9 @@ int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
   } else if (EPI == EPI_BIAS && g_ablation == 5) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 5>), grid, dim3(512), sh, s, a);
+  } else if (EPI == EPI_BIAS && g_ablation == 6) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 6>), grid, dim3(512), sh, s, a);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), sh, s, a);
   }

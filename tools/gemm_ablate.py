@@ -8,7 +8,7 @@ x = torch.randn(M, H, **bf)
 w = torch.randn(3 * H, H, **bf) * 0.02
 out = torch.empty(M, 3 * H, **bf)
 hip.lib().op_gemm_set_tile(2)
-for abl, name in ((0, "full"), (1, "no-mfma"), (2, "no-global-loads"), (4, "mfma+barriers only"), (5, "mfma only"), (0, "full")):
+for abl, name in ((0, "full"), (1, "no-mfma"), (2, "no-global-loads"), (4, "mfma+barriers only"), (5, "mfma only"), (6, "LDS-DMA + barriers only"), (0, "full")):
     hip.lib().op_gemm_set_tile(10 + abl)
     ms = timeit(lambda: hip.gemm_nt(x, [w], out=out), iters=30)
     print(name, "%.3f ms" % ms, "%.0f TF-equiv" % (2.0 * M * 3 * H * H / ms / 1e9))

@@ -337,3 +337,26 @@ def test_full_size_layer_4b_dimensions():
     assert y_masked.isfinite().all() and rel_fro(y_masked[:, : S - 40], yh[:, : S - 40]) > 1e-3   # the mask had an effect
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "layer_4b_parity_report.txt"), "w").write(
         "\n".join(report) + "\n")
+
+
+def test_sample_prefetcher_matches_prepare_sample():
+    """staging.SamplePrefetcher == trainer.py:1297-1336 (_prepare_sample: move_to_cuda + fp32->bf16 of floating tensors,
+    integer / bool tensors untouched, nested dict structure kept), for a stream of different samples and slot reuse."""
+    from one_peace_amd.staging import SamplePrefetcher
+    g = torch.Generator().manual_seed(0)
+
+    def make(i):
+        return {"id": torch.tensor([i]), "nsentences": 4,
+                "net_input": {"src_tokens": torch.randint(0, 1000, (4, 9), generator=g),
+                              "src_images": torch.randn(4, 3, 32, 32, generator=g) + i,
+                              "audio_padding_masks": torch.zeros(4, 7, dtype=torch.bool)}}
+    samples = [make(i) for i in range(5)]
+    got = list(SamplePrefetcher(iter(samples), DEV))
+    assert len(got) == 5
+    for s_host, s_dev in zip(samples, got):
+        assert s_dev["nsentences"] == 4 and int(s_dev["id"].item()) == int(s_host["id"].item())
+        ni, nd = s_host["net_input"], s_dev["net_input"]
+        assert nd["src_tokens"].dtype == torch.int64 and torch.equal(nd["src_tokens"].cpu(), ni["src_tokens"])
+        assert nd["audio_padding_masks"].dtype == torch.bool
+        assert nd["src_images"].dtype == torch.bfloat16 and nd["src_images"].is_cuda
+        assert torch.equal(nd["src_images"].cpu(), ni["src_images"].to(torch.bfloat16))

@@ -88,10 +88,13 @@ int op_gemm_set_tile(int mode);
  * [heads][S][Spad] from op_relpos_bias_build, key padding a byte mask [B][Spad] (non-zero = masked key).
  * q,k,v: bf16 rows of `ld` elements, row = b*S + s, head h at columns [h*64, h*64+64) (a packed [B*S, 3H] projection
  * output serves all three).  out [B*S][ldo]; lse fp32 [B][heads][lse_ld] (natural log) or NULL.  head_dim == 64.
- * Spad >= S rounded up to 128 when bias/key_pad/backward are used. */
-int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, const void* key_pad, void* out,
-                int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad, int64_t heads,
-                int64_t head_dim, float scale, void* stream);
+ * Spad >= S rounded up to 128 when bias/key_pad/backward are used.
+ * bias_batch_stride: 0 = one bias image shared by all samples; otherwise elements between per-sample images
+ * [B][heads][S][Spad] (masked pretraining gathers a different token subset per sample, adapter/image.py:229-246); the
+ * backward then returns one dbias slab per sample. */
+int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, int64_t bias_batch_stride,
+                const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad,
+                int64_t heads, int64_t head_dim, float scale, void* stream);
 /* delta[b][h][q] = sum_d dout*out (fp32, row stride Spad) */
 int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,
                       int64_t heads, void* stream);
@@ -102,9 +105,9 @@ int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads);
 /* test knob: 0 = separate dQ / dBias kernels, 1 (default) = dQ + dBias in one kernel for sequences up to 384 keys */
 int op_attn_set_merge_dbias(int on);
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
-                const void* biasT, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
-                int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
-                void* stream);
+                const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
+                void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
+                int64_t head_dim, float scale, void* stream);
 
 /* ---- relative-position bias tables -------------------------------------------------------------------------------
  * Replaces get_rel_pos_bias of adapter/image.py:164-171, adapter/text.py:76-83, adapter/audio.py:117-124:

@@ -29,6 +29,7 @@ constexpr int VSTRIDE = 160;  // bytes per V row in LDS (128 + 32 pad: 8 consecu
 struct AttnArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; int64_t ld;  // row stride (elements) of q/k/v rows
   const bf16_t* bias;      // [heads][S][Spad] or null
+  int64_t bias_bs;         // elements between the bias images of consecutive samples (0: one image shared by all samples)
   const uint8_t* key_pad;  // [B][Spad] (1 = padded key) or null
   bf16_t* out; int64_t ldo;
   float* lse;              // [B][heads][lse_ld]
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         const int key = k0 + kb * 16 + g * 4;
         float bb[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
-          const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + key);
+          const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qi) * p.Spad + key);
 #pragma unroll
           for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
         }
@@ -251,6 +252,7 @@ struct AttnBwdArgs {
   const bf16_t* dout; int64_t ldo;   // [B*S][ldo]
   const bf16_t* bias;                // [heads][S][Spad]  (rows = query)
   const bf16_t* biasT;               // [heads][S][Spad]  (rows = key), same values transposed
+  int64_t bias_bs;                   // elements between the images of consecutive samples (0: shared by all samples)
   const uint8_t* key_pad;            // [B][Spad]
   const float* lse;                  // [B][heads][Spad]
   const float* delta;                // [B][heads][Spad]
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
           const int key = min(kbase + kb * 16 + t, p.S - 1);
           float bb[4] = {0.f, 0.f, 0.f, 0.f};
           if (p.biasT) {
-            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.biasT + ((int64_t)h * p.S + key) * p.Spad + qrow);
+            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.biasT + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + key) * p.Spad + qrow);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
           }
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
       return *reinterpret_cast<const bf16x8*>(ldsV + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
     };
     auto biasfrag = [&](int, int, int qi, int key) {
-      return *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + key);
+      return *reinterpret_cast<const bf16x4*>(p.bias + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qi) * p.Spad + key);
     };
     ds_tile<2>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -718,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
         return *reinterpret_cast<const bf16x8*>(ldsV + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
       };
       auto biasfrag = [&](int, int, int qrow, int key) {
-        return *reinterpret_cast<const bf16x4*>(p.bias + bias_resample + ((int64_t)h * p.S + qrow) * p.Spad + key);
+        return *reinterpret_cast<const bf16x4*>(p.bias + bias_resample + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qrow) * p.Spad + key);
       };
       ds_tile<1>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
 #pragma unroll
@@ -917,9 +919,9 @@ int op_attn_set_merge_dbias(int on) {
 // (so one packed [B*S, 3H] projection output serves all three with pointer offsets 0, H, 2H).
 // bias: bf16 [heads][S][Spad] or null.  key_pad: uint8 [B][Spad], non-zero = masked key, or null.
 // out: bf16 [B*S][ldo] (head h at columns h*64..).  lse: fp32 [B][heads][lse_ld] (natural log) or null.
-int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, const void* key_pad, void* out,
-                int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
-                void* stream) {
+int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, int64_t bias_batch_stride,
+                const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad,
+                int64_t heads, int64_t head_dim, float scale, void* stream) {
   OP_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
   OP_CHECK_ARG(head_dim == HD, "attn_fwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(B > 0 && S > 0 && heads > 0 && ld % 8 == 0 && ldo % 4 == 0, "attn_fwd: bad sizes");
@@ -927,7 +929,7 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
                "attn_fwd: Spad must be >= S rounded up to 64");
   AttnArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
-  a.bias = (const bf16_t*)bias; a.key_pad = (const uint8_t*)key_pad;
+  a.bias = (const bf16_t*)bias; a.bias_bs = bias ? bias_batch_stride : 0; a.key_pad = (const uint8_t*)key_pad;
   a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse; a.lse_ld = lse_ld > 0 ? lse_ld : S;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
   dim3 grid(ceil_div(S, BQ), (unsigned)heads, (unsigned)B);
@@ -953,10 +955,12 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 // Gradients of op_attn_fwd.  bias [heads][S][Spad] (rows = query) and biasT (same values, rows = key) are both needed
 // when a bias was used; lse/delta are fp32 [B][heads][Spad]; dq/dk/dv rows have stride ldg (packed like q/k/v);
 // dbias (fp32 [op_attn_bwd_dbias_slabs()][heads][S][Spad], pre-zeroed by the caller, accumulated into) is optional.
+// bias_batch_stride != 0: bias / biasT hold one image per sample (that many elements apart; the masked-pretraining
+// branch gathers a different token subset per sample, adapter/image.py:229-246); dbias then has B slabs, one per sample.
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
-                const void* biasT, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
-                int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale,
-                void* stream) {
+                const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
+                void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
+                int64_t head_dim, float scale, void* stream) {
   OP_CHECK_ARG(q && k && v && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   OP_CHECK_ARG(head_dim == HD, "attn_bwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(Spad >= ((S + 127) / 128) * 128 && Spad % 8 == 0, "attn_bwd: Spad must be >= S rounded up to 128");
@@ -965,6 +969,9 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
   a.dout = (const bf16_t*)dout; a.ldo = ldo; a.bias = (const bf16_t*)bias; a.biasT = (const bf16_t*)biasT;
+  a.bias_bs = bias ? bias_batch_stride : 0;
+  OP_CHECK_ARG(!(dbias && a.bias_bs != 0) || (g_merge_dbias && ceil_div(S, BKV) <= 6),
+               "attn_bwd: the gradient of a per-sample bias needs the merged dQ + dBias kernel (S <= 384)");
   a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
@@ -983,7 +990,8 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   OP_LAUNCH_CHECK();
   const int nt = ceil_div(S, BKV);
   if (dbias && nt <= 6 && g_merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
-    const int chunks = dbias_chunks(B, S, heads);
+    // per-sample bias: every sample is its own chunk, slab b of dbias is the gradient of sample b's bias image
+    const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads);
     a.bchunk = ceil_div(B, chunks);
     const dim3 grid(ceil_div(S, 64), (unsigned)heads, (unsigned)chunks);
     slot = op_prof_begin(2, 1.5 * fl, stream);

@@ -55,9 +55,9 @@ SIGNATURES = {
     "op_sqnorm": (c_int, [P, I64, P, P, P]),
     "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
-    "op_attn_fwd": (c_int, [P, P, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_fwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
-    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
     "op_probe_mfma32": (c_int, [P, P, P, c_int, P]),
     "op_probe_tr16": (c_int, [P, P, P, c_int, P]),
@@ -359,6 +359,11 @@ def attn_spad(S):
     return ((S + 127) // 128) * 128
 
 
+def _bias_bstride(bias):
+    """bias [heads, S, Spad]: one image for all samples (stride 0); [B, heads, S, Spad]: one image per sample."""
+    return bias.stride(0) if bias is not None and bias.dim() == 4 else 0
+
+
 def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, out=None, want_lse=True):
     """q, k, v: bf16 views into [B*S, ld] rows (head h at columns h*64..); returns out [B*S, heads*64] and
     lse [B, heads, Spad] (fp32, natural log; entries >= S are unspecified)."""
@@ -368,14 +373,15 @@ def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, o
     if out is None:
         out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev) if want_lse else None
-    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), ptr(key_pad), ptr(out), out.stride(0), ptr(lse), Spad,
-                             B, S, Spad, heads, 64, scale, stream()), "op_attn_fwd")
+    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), _bias_bstride(bias), ptr(key_pad), ptr(out), out.stride(0),
+                             ptr(lse), Spad, B, S, Spad, heads, 64, scale, stream()), "op_attn_fwd")
     return out, lse
 
 
 def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=None, key_pad=None, Spad=0, dqkv=None,
              want_dbias=False):
-    """Returns dqkv [B*S, 3H] (dq | dk | dv packed like a fused projection output) and dbias fp32 [heads,S,Spad]."""
+    """Returns dqkv [B*S, 3H] (dq | dk | dv packed like a fused projection output) and dbias fp32: [heads,S,Spad] for a
+    shared bias image, [B,heads,S,Spad] when bias / biasT hold one image per sample."""
     dev = q.device
     H = heads * 64
     Spad = Spad or attn_spad(S)
@@ -384,17 +390,25 @@ def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=N
            "op_attn_bwd_delta")
     if dqkv is None:
         dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=dev)
-    dbias = attn_dbias_buffer(B, S, heads, Spad, dev) if want_dbias else None
+    per_sample = bias is not None and bias.dim() == 4
+    dbias = attn_dbias_buffer(B, S, heads, Spad, dev, per_sample) if want_dbias else None
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
-    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), ptr(key_pad),
-                             ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), dqkv.stride(0), ptr(dbias), B, S, Spad, heads,
+    attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, dqkv.stride(0), dbias, B, S, Spad, heads, scale)
+    if dbias is None:
+        return dqkv, None
+    return dqkv, (dbias if per_sample else dbias.sum(0))
+
+
+def attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, ldg, dbias, B, S, Spad, heads, scale):
+    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), _bias_bstride(bias),
+                             ptr(key_pad), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldg, ptr(dbias), B, S, Spad, heads,
                              64, scale, stream()), "op_attn_bwd")
-    return dqkv, dbias.sum(0) if dbias is not None else None
 
 
-def attn_dbias_buffer(B, S, heads, Spad, device):
-    """Zeroed fp32 [slabs, heads, S, Spad] accumulator for op_attn_bwd's dbias (the bias gradient is its sum over dim 0)."""
-    slabs = lib().op_attn_bwd_dbias_slabs(B, S, heads)
+def attn_dbias_buffer(B, S, heads, Spad, device, per_sample=False):
+    """Zeroed fp32 [slabs, heads, S, Spad] accumulator for op_attn_bwd's dbias: a shared bias image gets one slab per
+    batch chunk (the gradient is the sum over dim 0), per-sample images one slab per sample (slab b = gradient of image b)."""
+    slabs = B if per_sample else lib().op_attn_bwd_dbias_slabs(B, S, heads)
     return torch.zeros(slabs, heads, S, Spad, dtype=torch.float32, device=device)
 
 

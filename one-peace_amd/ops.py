@@ -230,6 +230,54 @@ class RelPosBias:
         return self.acc
 
 
+class DenseBias:
+    """Handle for a PER-SAMPLE additive bias [B, heads, S, S] (what the adapters' gather of a different token subset per
+    sample produces in masked pretraining, adapter/image.py:229-246 / common.take_bias): same interface as RelPosBias, but
+    the images are [B, heads, S, Spad], and the attention backward returns one gradient slab per sample, which flows back
+    into the dense tensor (and through autograd's gather into the table)."""
+
+    def __init__(self, dense):
+        B, self.heads, self.S, _ = dense.shape
+        self.B, self.Spad = B, hip.attn_spad(self.S)
+        self.acc = None
+        self._imageT = None
+        self.image = _DenseBiasFn.apply(dense, self)
+
+    @property
+    def imageT(self):
+        if self._imageT is None:
+            img = self.image.detach()
+            t = torch.zeros_like(img)
+            t[..., : self.S] = img[..., : self.S].transpose(2, 3)
+            self._imageT = t
+        return self._imageT
+
+    def grad_accumulator(self, B):
+        if self.acc is None:
+            self.acc = hip.attn_dbias_buffer(B, self.S, self.heads, self.Spad, self.image.device, per_sample=True)
+        return self.acc
+
+
+class _DenseBiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dense, handle):
+        ctx.handle_ref = weakref.ref(handle)
+        ctx.S = dense.shape[-1]
+        B, heads, S, _ = dense.shape
+        img = torch.zeros(B, heads, S, hip.attn_spad(S), dtype=dense.dtype, device=dense.device)
+        img[..., :S] = dense
+        return img
+
+    @staticmethod
+    def backward(ctx, _unused):
+        h = ctx.handle_ref()
+        if h is None or h.acc is None:
+            return torch.zeros(_unused.shape[:-1] + (ctx.S,), dtype=_unused.dtype, device=_unused.device), None
+        g = h.acc[..., : ctx.S].to(_unused.dtype)
+        h.acc = None
+        return g, None
+
+
 class _RelPosImageFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, table, handle):
@@ -542,10 +590,8 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
                                    hip.stream()), "op_attn_bwd_delta")
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
-    hip._check(L.op_attn_bwd(hip.ptr(qkv[:, :H]), hip.ptr(qkv[:, H:2 * H]), hip.ptr(qkv[:, 2 * H:]), 3 * H, hip.ptr(dattn),
-                             dattn.stride(0), hip.ptr(bias_img), hip.ptr(biasT), hip.ptr(key_pad), hip.ptr(lse),
-                             hip.ptr(delta), hip.ptr(dq), hip.ptr(dk), hip.ptr(dv), 3 * H, hip.ptr(dbias_acc), B, S, Spad,
-                             heads, 64, scale, hip.stream()), "op_attn_bwd")
+    hip.attn_bwd_launch(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, bias_img, biasT, key_pad, lse, delta, dq, dk,
+                        dv, 3 * H, dbias_acc, B, S, Spad, heads, scale)
     return dqkv, dbias_acc
 
 

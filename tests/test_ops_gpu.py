@@ -390,7 +390,7 @@ def _attn_ref(q, k, v, heads, scale, bias, key_pad):
     qh, kh, vh = (t.reshape(B, S, heads, hd).transpose(1, 2) for t in (q, k, v))
     s = (qh * scale) @ kh.transpose(-1, -2)
     if bias is not None:
-        s = s + bias[None]
+        s = s + (bias[None] if bias.dim() == 3 else bias)
     if key_pad is not None:
         s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
@@ -457,6 +457,44 @@ def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias)
         assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
     if use_bias:
         assert_close(dbias[:, :, :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="dbias")
+
+
+@pytest.mark.parametrize("B,S,heads,use_pad", [(3, 70, 2, True), (5, 83, 3, False), (2, 257, 2, True)])
+def test_attention_per_sample_bias(B, S, heads, use_pad):
+    """Masked pretraining gathers a different token subset per sample, so the additive bias is [B, heads, S, S]
+    (adapter/image.py:229-246): one bias image per sample in the kernels, one gradient slab per sample back."""
+    hip = hipmod()
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=1)
+    bias = rnd(B, heads, S, S, seed=2)
+    key_pad = None
+    if use_pad:
+        key_pad = torch.zeros(B, S, dtype=torch.bool)
+        for b in range(1, B):
+            key_pad[b, S - 3 * b:] = True
+    Spad = hip.attn_spad(S)
+    qkv_r, bias_r = qkv.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    q, k, v = (qkv_r[:, i * H:(i + 1) * H].reshape(B, S, H) for i in range(3))
+    ref, lse_ref = _attn_ref(q, k, v, heads, 0.125, bias_r, key_pad)
+    dout = rnd(B * S, H, seed=3)
+    ref.backward(dout.view(B, S, H))
+    d = dev_bf16(qkv)
+    bias_d = torch.zeros(B, heads, S, Spad, dtype=torch.bfloat16, device=DEV)
+    bias_d[..., :S] = bias.to(torch.bfloat16).to(DEV)
+    biasT_d = torch.zeros_like(bias_d)
+    biasT_d[..., :S] = bias.transpose(2, 3).to(torch.bfloat16).to(DEV)
+    pad_d = None
+    if use_pad:
+        pad_d = torch.ones(B, Spad, dtype=torch.uint8, device=DEV)
+        pad_d[:, :S] = key_pad.to(torch.uint8).to(DEV)
+    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+    assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
+    dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
+                               bias_d, biasT_d, pad_d, Spad, want_dbias=True)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
+    assert dbias.shape == (B, heads, S, Spad)
+    assert_close(dbias[..., :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="per-sample dbias")
 
 
 def test_audio_stem_convs_match_conv1d():

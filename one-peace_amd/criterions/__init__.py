@@ -1,1 +1,1 @@
-from . import contrastive  # noqa: F401  (fills the criterion registries)
+from . import contrastive, pretrain  # noqa: F401  (fills the criterion registries)

@@ -666,3 +666,41 @@ class InfoNCEFn(torch.autograd.Function):
 
 def info_nce(a_local, b_local, a_all, b_all, scale, rank=0, label_smoothing=0.0):
     return InfoNCEFn.apply(a_local, b_local, a_all, b_all, scale, rank, label_smoothing)
+
+
+class DclFn(torch.autograd.Function):
+    """Masked-token contrastive loss (image_text_pretrain_loss.py:187-208): rows = the MASKED student tokens, columns =
+    every teacher token of the batch, target of row i = the teacher token at the same position.
+
+    student [m, H] and teacher [n, H] are L2-normalised bf16; the caller has permuted the teacher rows so that the m
+    masked positions come first in student order (softmax is permutation invariant), i.e. the target of row i is column
+    i.  The [m, n] similarity matrix (22 k x 32 k at b=128) is never materialised: row blocks of `block` rows go
+    through GEMM (fp32) -> op_infonce_rows (loss + d loss / d sim in place) -> GEMM with the teacher, and only the
+    [m, H] student gradient is kept for backward.  The teacher carries no gradient (it is detached in the reference)."""
+
+    @staticmethod
+    def forward(ctx, student, teacher, scale, label_smoothing, block):
+        m, H = student.shape
+        teacher = teacher.detach().contiguous()
+        teacher_t = hip.transpose(teacher)  # [H, n]: the NT operand of d student = d sim @ teacher
+        alpha = torch.full((1,), float(scale), dtype=torch.float32, device=student.device)
+        dstudent = torch.empty(m, H, dtype=torch.float32, device=student.device)
+        total = torch.zeros((), dtype=torch.float32, device=student.device)
+        for r0 in range(0, m, block):
+            rows = student[r0:r0 + block].detach().contiguous()
+            sim = gemm_any(rows, teacher, out_f32=True, alpha=alpha)
+            loss_r, _, _ = hip.infonce_rows(sim, r0, label_smoothing, gscale=1.0 / m, write_grad=True)
+            total += loss_r.sum()
+            dstudent[r0:r0 + block] = gemm_any(sim.to(torch.bfloat16), teacher_t, out_f32=True, alpha=alpha)
+        ctx.save_for_backward(dstudent)
+        ctx.dtype = student.dtype
+        return total / m
+
+    @staticmethod
+    def backward(ctx, g):
+        (dstudent,) = ctx.saved_tensors
+        return (dstudent * g.float()).to(ctx.dtype), None, None, None, None
+
+
+def dcl_loss(student, teacher, scale, label_smoothing=0.0, block=4096):
+    return DclFn.apply(student, teacher, scale, label_smoothing, block)

@@ -69,13 +69,17 @@ class TransformerEncoder(nn.Module):
 
     def _fused_ok(self, encoder_type, parts):
         n_bias = None
-        for _, _, biases in parts:
+        for x, _, biases in parts:
             if biases is not None:
-                if not all(isinstance(b, RelPosSpec) for b in biases):
-                    return False
+                for b in biases:  # lazy (table, bucket) specs, or dense per-sample tensors from the masked-token gather
+                    if not (isinstance(b, RelPosSpec) or (torch.is_tensor(b) and b.dim() == 4 and b.is_cuda and b.dtype == x.dtype)):
+                        return False
                 if n_bias is not None and len(biases) != n_bias:
                     return False
                 n_bias = len(biases)
+        if any(p[2] is not None for p in parts) and sum(p[0].shape[1] for p in parts) > 384 and any(
+                torch.is_tensor(b) for p in parts if p[2] is not None for b in p[2]):
+            return False  # the per-sample bias gradient needs the merged dQ + dBias kernel (<= 384 keys)
         if len(parts) > 1 and any(p[0].dtype != parts[0][0].dtype or not p[0].is_cuda for p in parts):
             return False
         if self.encoder_layerdrop > 0.0 and self.training:
@@ -84,18 +88,22 @@ class TransformerEncoder(nn.Module):
 
     def _forward_fused(self, encoder_type, streams, parts):
         lens = [p[0].shape[1] for p in parts]
+        dense = any(torch.is_tensor(b) for p in parts if p[2] is not None for b in p[2])
         if len(parts) == 1:
             x, pad, biases = parts[0]
             no_pads = getattr(pad, "_all_false", False)
-            handles = [b.handle() for b in biases] if biases else []
+            handles = [(ops.DenseBias(b) if torch.is_tensor(b) else b.handle()) for b in biases] if biases else []
         else:
             x = torch.cat([p[0] for p in parts], dim=1)
             pad = torch.cat([p[1] for p in parts], dim=1)
             no_pads = all(getattr(p[1], "_all_false", False) for p in parts)
             n_bias = max((len(p[2]) for p in parts if p[2] is not None), default=0)
             cache = {}
-            handles = [joint_handle([p[2][i] if p[2] is not None else None for p in parts], lens, cache)
-                       for i in range(n_bias)]
+            if dense:  # per-sample blocks: assemble the block-diagonal bias densely (transformer_encoder.py:144-158)
+                handles = [ops.DenseBias(self._dense_joint_bias(parts, lens, i, x)) for i in range(n_bias)]
+            else:
+                handles = [joint_handle([p[2][i] if p[2] is not None else None for p in parts], lens, cache)
+                           for i in range(n_bias)]
         B, S, _ = x.shape
         key_pad = None
         if not no_pads:
@@ -118,6 +126,17 @@ class TransformerEncoder(nn.Module):
             x = torch.cat(segs, dim=1)
         return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": [],
                 "image_encoder_states": [], "audio_encoder_states": []}
+
+    def _dense_joint_bias(self, parts, lens, i, x):
+        B, S = x.shape[0], sum(lens)
+        full = x.new_zeros(B, self.num_attention_heads, S, S)
+        off = 0
+        for p, n in zip(parts, lens):
+            if p[2] is not None:
+                blk = p[2][i]
+                full[:, :, off:off + n, off:off + n] += blk.dense(B).to(x.dtype) if isinstance(blk, RelPosSpec) else blk
+            off += n
+        return full
 
     def _forward_torch(self, encoder_type, streams, infos, return_all_hiddens):
         parts = [infos[s] for s in streams]

@@ -134,11 +134,86 @@ def layer_fixture():
     print("layer:", out["text"]["y"].norm().item())
 
 
+PRETRAIN_ENC = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_rel_bucket_size=4,
+                    text_bucket_size=256, use_audio_moe=False)
+PRETRAIN_DEC = dict(embed_dim=64, ffn_embed_dim=128, layers=1, attention_heads=1, use_audio_moe=False, use_attn_bias=False,
+                    vision_encoder_type="none")
+
+
+def masks_for(valid, keep_fraction, gen):
+    """valid [B, S] bool (False = padding).  Position 0 (CLS) is always kept; returns preserve_ids [B, K] (-1 padded)
+    and mask_indices [B, S] bool (True = masked out), the two forms the dataset hands over
+    (data/pretrain_data/image_text_pretrain_dataset.py:85-104)."""
+    B, S = valid.shape
+    keep_rows, mask = [], torch.zeros(B, S, dtype=torch.bool)
+    for b in range(B):
+        cand = [i for i in range(1, S) if valid[b, i]]
+        n_keep = max(1, int(round(len(cand) * keep_fraction)))
+        perm = torch.randperm(len(cand), generator=gen).tolist()
+        kept = sorted(cand[i] for i in perm[:n_keep])
+        for i in cand:
+            if i not in kept:
+                mask[b, i] = True
+        keep_rows.append([0] + kept)
+    K = max(len(r) for r in keep_rows)
+    ids = torch.full((B, K), -1, dtype=torch.long)
+    for b, r in enumerate(keep_rows):
+        ids[b, :len(r)] = torch.tensor(r)
+    return ids, mask
+
+
+def pretrain_fixture():
+    """The full image-text pretraining objective (ITC + four DCL terms, image_text_pretrain_loss.py:76-160) on a micro
+    model with the small decoder: six forward passes incl. the masked ones with per-sample preserve ids."""
+    from types import SimpleNamespace
+    pm = R.ref("one_peace.models.one_peace.one_peace_pretrain")
+    crit_mod = R.ref("one_peace.criterions.image_text_pretrain_loss")
+    vocab = 1000
+    cfg = SimpleNamespace(encoder=R.make_cfg(**PRETRAIN_ENC).encoder, decoder=R.make_cfg(**PRETRAIN_DEC).encoder,
+                          copy_rel_pos_table=False, reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
+    torch.manual_seed(0)
+    m = pm.OnePeacePretrainModel(cfg, R.TinyDictionary(vocab))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.split(".")[-1] in synth.NON_SYNTH for k in missing), (missing, unexpected)
+    m.eval()
+    B = 4
+    inp = synth.synth_inputs(B, text_len=15, image_res=64, vocab=vocab)
+    g = torch.Generator().manual_seed(11)
+    text_valid = torch.cat([torch.ones(B, 1, dtype=torch.bool), inp["src_tokens"].ne(1)], dim=1)   # CLS + tokens
+    image_valid = torch.ones(B, 17, dtype=torch.bool)
+    ni = dict(inp)
+    ni["text_preserve_ids"], ni["text_mask_indices"] = masks_for(text_valid, 0.6, g)
+    ni["image_preserve_ids"], ni["image_mask_indices"] = masks_for(image_valid, 0.35, g)
+    ni["vl_text_preserve_ids"], ni["vl_text_mask_indices"] = masks_for(text_valid, 0.6, g)
+    ni["vl_image_preserve_ids"], ni["vl_image_mask_indices"] = masks_for(image_valid, 0.35, g)
+    crit = crit_mod.ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0)
+    sample = {"net_input": ni, "nsentences": B}
+    loss, _, log = crit(m, sample)
+    m.zero_grad()
+    loss.backward()
+    keep = {"logit_scale", "text_mask_token", "image_mask_token",
+            "encoder_wrapper.fusion_model.layers.0.self_attn.q_proj.weight",
+            "decoder_wrapper.fusion_model.layers.0.image_ffn.0.wi_0.weight"}
+    with torch.no_grad():
+        st = m(src_tokens=ni["src_tokens"], text_preserve_ids=ni["text_preserve_ids"], encoder_type="text")[0]
+        si = m(src_images=ni["src_images"], image_preserve_ids=ni["image_preserve_ids"], encoder_type="image")[1]
+        svt, svi, _ = m(src_tokens=ni["src_tokens"], text_preserve_ids=ni["vl_text_preserve_ids"], src_images=ni["src_images"],
+                        image_preserve_ids=ni["vl_image_preserve_ids"], encoder_type="vl")
+    fx = dict(enc=PRETRAIN_ENC, dec=PRETRAIN_DEC, vocab=vocab, shapes=shapes, net_input=ni,
+              loss=loss.detach(), log={k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in log.items()},
+              student_text=st, student_image=si, student_vl_text=svt, student_vl_image=svi, grads=grads_summary(m, keep))
+    torch.save(fx, os.path.join(HERE, "micro_pretrain.pt"))
+    print("pretrain: loss %.6f " % loss.item(), {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     micro_fixture()
     tiny_text_fixture()
     layer_fixture()
+    pretrain_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -135,3 +135,53 @@ def test_hub_interface_from_pretrained_roundtrip(golden_dir, tmp_path):
     assert torch.equal(toks.cpu(), fx["inputs"]["src_tokens"])
     out = hub.extract_text_features(toks)
     assert torch.allclose(out, fx["text_logits"], atol=ATOL, rtol=1e-4)
+
+
+def _build_pretrain(fx):
+    from types import SimpleNamespace
+    from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from tests.model_util import TinyDictionary, load_synth
+    enc = one_peace_encoder_config(drop_path_rate=0.0, **fx["enc"])
+    dec_kw = dict(fx["dec"])
+    use_attn_bias, vis = dec_kw.pop("use_attn_bias"), dec_kw.pop("vision_encoder_type")
+    dec = one_peace_encoder_config(drop_path_rate=0.0, **dec_kw)
+    dec.text_adapter.use_attn_bias = dec.image_adapter.use_attn_bias = use_attn_bias
+    dec.image_adapter.vision_encoder_type = vis
+    cfg = SimpleNamespace(encoder=enc, decoder=dec, reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
+    return load_synth(OnePeacePretrainModel(cfg, TinyDictionary(fx["vocab"])), fx["shapes"]).eval()
+
+
+def test_full_pretraining_objective_matches_reference(golden_dir):
+    """ITC + four masked-token (DCL) terms, six forward passes incl. the per-sample preserve-id gathers and the small
+    decoder (image_text_pretrain_loss.py:76-160): losses, student features and gradients of the mirror against the
+    fixture written by the unmodified reference (tests/golden/make_golden.py::pretrain_fixture)."""
+    from one_peace_amd.criterions.pretrain import ImageTextPretrainLossCriterion
+    fx = torch.load(os.path.join(golden_dir, "micro_pretrain.pt"), weights_only=False)
+    m = _build_pretrain(fx)
+    ni = fx["net_input"]
+    with torch.no_grad():
+        st = m(src_tokens=ni["src_tokens"], text_preserve_ids=ni["text_preserve_ids"], encoder_type="text")[0]
+        svt, svi, _ = m(src_tokens=ni["src_tokens"], text_preserve_ids=ni["vl_text_preserve_ids"], src_images=ni["src_images"],
+                        image_preserve_ids=ni["vl_image_preserve_ids"], encoder_type="vl")
+    assert torch.allclose(st, fx["student_text"], atol=ATOL, rtol=1e-4)
+    assert torch.allclose(svt, fx["student_vl_text"], atol=ATOL, rtol=1e-4) and torch.allclose(svi, fx["student_vl_image"], atol=ATOL, rtol=1e-4)
+    crit = ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0)
+    loss, _, log = crit(m, {"net_input": ni, "nsentences": 4})
+    for k, v in fx["log"].items():
+        if "loss" in k:
+            assert abs(float(log[k]) - float(v)) < 2e-5 * max(1.0, abs(float(v))), (k, float(log[k]), float(v))
+    assert float(log["i2t_ncorrect"]) == float(fx["log"]["i2t_ncorrect"])
+    m.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, v in fx["grads"].items():
+        if k.endswith("#norm"):
+            n = k[:-5]
+            if named[n].grad is not None:
+                assert abs(float(named[n].grad.double().norm()) - float(v)) <= 2e-4 * max(float(v), 1e-3), (n,)
+                checked += 1
+        elif not k.endswith("#rows4"):
+            assert torch.allclose(named[k].grad, v, atol=2e-5, rtol=2e-4), k
+    assert checked > 60

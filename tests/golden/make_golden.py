@@ -208,12 +208,64 @@ def pretrain_fixture():
     print("pretrain: loss %.6f " % loss.item(), {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
 
 
+PRETRAIN_AL_ENC = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, text_bucket_size=256, audio_bucket_size=512,
+                       use_image_moe=False)
+PRETRAIN_AL_DEC = dict(embed_dim=64, ffn_embed_dim=128, layers=1, attention_heads=1, use_image_moe=False, use_attn_bias=False)
+
+
+def pretrain_al_fixture():
+    """The audio-language pretraining objective (ATC + three DCL terms, audio_text_pretrain_loss.py:73-157): frozen text
+    teacher, audio / joint 'al' students with preserve ids, decoder with the spec-less fixed-position audio adapter and
+    without layer scale (pretrain_al_3B.yaml:138-176)."""
+    from types import SimpleNamespace
+    pm = R.ref("one_peace.models.one_peace.one_peace_pretrain")
+    crit_mod = R.ref("one_peace.criterions.audio_text_pretrain_loss")
+    vocab = 1000
+    dec = R.make_cfg(**PRETRAIN_AL_DEC).encoder
+    dec.audio_adapter.feature_encoder_spec = None
+    dec.audio_adapter.abs_pos_type = "fixed"
+    dec.audio_adapter.bucket_size = 256
+    dec.use_layer_scale = False
+    cfg = SimpleNamespace(encoder=R.make_cfg(**PRETRAIN_AL_ENC).encoder, decoder=dec, copy_rel_pos_table=False,
+                          reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
+    torch.manual_seed(0)
+    m = pm.OnePeacePretrainModel(cfg, R.TinyDictionary(vocab))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(shapes)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.split(".")[-1] in synth.NON_SYNTH for k in missing), (missing, unexpected)
+    m.eval()
+    B = 4
+    inp = synth.synth_inputs(B, text_len=15, audio_samples=8000, vocab=vocab)
+    frames = inp["audio_padding_masks"].shape[1]           # CLS + frames
+    inp["audio_padding_masks"][1, frames - 3:] = True      # two samples with padded audio tails
+    inp["audio_padding_masks"][3, frames - 6:] = True
+    g = torch.Generator().manual_seed(13)
+    text_valid = torch.cat([torch.ones(B, 1, dtype=torch.bool), inp["src_tokens"].ne(1)], dim=1)
+    audio_valid = ~inp["audio_padding_masks"]
+    ni = dict(inp)
+    ni["audio_preserve_ids"], ni["audio_mask_indices"] = masks_for(audio_valid, 0.45, g)
+    ni["al_text_preserve_ids"], ni["al_text_mask_indices"] = masks_for(text_valid, 0.6, g)
+    ni["al_audio_preserve_ids"], ni["al_audio_mask_indices"] = masks_for(audio_valid, 0.45, g)
+    crit = crit_mod.AudioTextPretrainLossCriterion(None, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0)
+    loss, _, log = crit(m, {"net_input": ni, "nsentences": B})
+    m.zero_grad()
+    loss.backward()
+    keep = {"logit_scale", "text_mask_token", "audio_mask_token",
+            "encoder_wrapper.fusion_model.layers.0.self_attn.q_proj.weight"}
+    fx = dict(enc=PRETRAIN_AL_ENC, dec=PRETRAIN_AL_DEC, vocab=vocab, shapes=shapes, net_input=ni, loss=loss.detach(),
+              log={k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in log.items()}, grads=grads_summary(m, keep))
+    torch.save(fx, os.path.join(HERE, "micro_pretrain_al.pt"))
+    print("pretrain al: loss %.6f " % loss.item(), {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
     micro_fixture()
     tiny_text_fixture()
     layer_fixture()
     pretrain_fixture()
+    pretrain_al_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

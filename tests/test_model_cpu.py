@@ -137,17 +137,22 @@ def test_hub_interface_from_pretrained_roundtrip(golden_dir, tmp_path):
     assert torch.allclose(out, fx["text_logits"], atol=ATOL, rtol=1e-4)
 
 
-def _build_pretrain(fx):
+def _build_pretrain(fx, audio_language=False):
     from types import SimpleNamespace
     from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel
     from one_peace_amd.unify_model_config import one_peace_encoder_config
     from tests.model_util import TinyDictionary, load_synth
     enc = one_peace_encoder_config(drop_path_rate=0.0, **fx["enc"])
     dec_kw = dict(fx["dec"])
-    use_attn_bias, vis = dec_kw.pop("use_attn_bias"), dec_kw.pop("vision_encoder_type")
+    use_attn_bias, vis = dec_kw.pop("use_attn_bias"), dec_kw.pop("vision_encoder_type", "none")
     dec = one_peace_encoder_config(drop_path_rate=0.0, **dec_kw)
-    dec.text_adapter.use_attn_bias = dec.image_adapter.use_attn_bias = use_attn_bias
+    dec.text_adapter.use_attn_bias = dec.image_adapter.use_attn_bias = dec.audio_adapter.use_attn_bias = use_attn_bias
     dec.image_adapter.vision_encoder_type = vis
+    if audio_language:  # pretrain_al_3B.yaml:138-176
+        dec.audio_adapter.feature_encoder_spec = None
+        dec.audio_adapter.abs_pos_type = "fixed"
+        dec.audio_adapter.bucket_size = 256
+        dec.use_layer_scale = False
     cfg = SimpleNamespace(encoder=enc, decoder=dec, reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
     return load_synth(OnePeacePretrainModel(cfg, TinyDictionary(fx["vocab"])), fx["shapes"]).eval()
 
@@ -185,3 +190,29 @@ def test_full_pretraining_objective_matches_reference(golden_dir):
         elif not k.endswith("#rows4"):
             assert torch.allclose(named[k].grad, v, atol=2e-5, rtol=2e-4), k
     assert checked > 60
+
+
+def test_audio_language_pretraining_objective_matches_reference(golden_dir):
+    """ATC + three DCL terms of the audio-language stage (audio_text_pretrain_loss.py:73-157; frozen text teacher, joint
+    'al' teacher, decoder with the fixed-position spec-less audio adapter and no layer scale) against the reference fixture."""
+    from one_peace_amd.criterions.pretrain import AudioTextPretrainLossCriterion
+    fx = torch.load(os.path.join(golden_dir, "micro_pretrain_al.pt"), weights_only=False)
+    m = _build_pretrain(fx, audio_language=True)
+    crit = AudioTextPretrainLossCriterion(None, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0)
+    loss, _, log = crit(m, {"net_input": fx["net_input"], "nsentences": 4})
+    for k, v in fx["log"].items():
+        if "loss" in k:
+            assert abs(float(log[k]) - float(v)) < 2e-5 * max(1.0, abs(float(v))), (k, float(log[k]), float(v))
+    m.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, v in fx["grads"].items():
+        if k.endswith("#norm"):
+            n = k[:-5]
+            if named[n].grad is not None:
+                assert abs(float(named[n].grad.double().norm()) - float(v)) <= 2e-4 * max(float(v), 1e-3), (n,)
+                checked += 1
+        elif not k.endswith("#rows4"):
+            assert torch.allclose(named[k].grad, v, atol=2e-5, rtol=2e-4), k
+    assert checked > 40

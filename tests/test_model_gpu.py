@@ -362,15 +362,16 @@ def test_sample_prefetcher_matches_prepare_sample():
         assert torch.equal(nd["src_images"].cpu(), ni["src_images"].to(torch.bfloat16))
 
 
-def test_full_pretraining_objective_on_hip(golden_dir):
+@pytest.mark.parametrize("stage", ["vl", "al"])
+def test_full_pretraining_objective_on_hip(golden_dir, stage):
     """The complete image-text pretraining step (ITC + four DCL terms; six encoder passes, three of them with per-sample
     preserve ids, three decoder passes; image_text_pretrain_loss.py:76-160) on the HIP path: every encoder / decoder pass
     must take the fused layers (per-sample bias images for the masked passes), the DCL similarity is computed blockwise,
     and losses / gradients are held to the reference-written fixture with the usual bf16 yardstick."""
     from tests.test_model_cpu import _build_pretrain
-    from one_peace_amd.criterions.pretrain import ImageTextPretrainLossCriterion
+    from one_peace_amd.criterions.pretrain import AudioTextPretrainLossCriterion, ImageTextPretrainLossCriterion
     from one_peace_amd.transformer import transformer_encoder as TE
-    fx = _fx(golden_dir, "micro_pretrain.pt")
+    fx = _fx(golden_dir, "micro_pretrain.pt" if stage == "vl" else "micro_pretrain_al.pt")
     ni = {k: (v.to(DEV).to(torch.bfloat16) if v.is_floating_point() else v.to(DEV)) for k, v in fx["net_input"].items()}
     calls = {"fused": 0, "torch": 0}
     of, ot = TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch
@@ -387,16 +388,18 @@ def test_full_pretraining_objective_on_hip(golden_dir):
     TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch = cf, ct
     try:
         for mode in ("hip", "torch"):
-            m = _build_pretrain(fx).to(DEV).to(torch.bfloat16).eval()
+            m = _build_pretrain(fx, audio_language=stage == "al").to(DEV).to(torch.bfloat16).eval()
             _force_torch_path(m, mode == "torch")
             calls["fused"] = calls["torch"] = 0
-            crit = ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0)
+            crit = (ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0) if stage == "vl"
+                    else AudioTextPretrainLossCriterion(None, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0))
             loss, _, log = crit(m, {"net_input": ni, "nsentences": 4})
             m.zero_grad()
             loss.backward()
             torch.cuda.synchronize()
             if mode == "hip":
-                assert calls["torch"] == 0 and calls["fused"] == 9, calls   # 6 encoder + 3 decoder passes, all fused
+                # vl: 6 encoder + 3 decoder passes; al: 5 encoder + 2 decoder passes -- all on the fused layers
+                assert calls["torch"] == 0 and calls["fused"] == (9 if stage == "vl" else 7), calls
             res[mode] = dict(log={k: float(v) for k, v in log.items() if "loss" in k},
                              grads={n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
     finally:
@@ -413,10 +416,18 @@ def test_full_pretraining_objective_on_hip(golden_dir):
             continue
         if float(v.norm()) < 1e-7 or k not in res["hip"]["grads"]:
             continue
-        # bias-type gradients of the 64-wide decoder are sums of strongly cancelling bf16 rows (norm ~5e-2 against
-        # summands ~1): their floor is 1e-1 (measured: 8e-2 hip, 2e-2 torch-bf16); everything else 6e-2
-        _check("grad " + k, res["hip"]["grads"][k], res["torch"]["grads"][k], v, 1e-1 if v.dim() == 1 else 6e-2, report)
+        gh, gt = res["hip"]["grads"][k], res["torch"]["grads"][k]
+        if v.dim() == 1 and float(v.norm()) < 0.1:
+            # bias-type gradients of the 64-wide decoder are sums of strongly cancelling rows (v_proj.bias is exactly
+            # sum_q dO_q because softmax rows sum to one; norm ~5e-2 against summands ~1): their RELATIVE error is
+            # meaningless -- hold the absolute error to 2e-2, below what 6e-2 relative allows on the typical
+            # (norm 0.5) gradient of this model (measured 1.2e-2 / 4e-3).  The attention kernels themselves reproduce colsum(dV) to 9e-4.
+            e_abs = float((gh - v).norm())
+            report.append("%-60s |hip - ref| %.3e (|ref| %.3e)" % ("grad " + k, e_abs, float(v.norm())))
+            assert e_abs <= max(2 * float((gt - v).norm()), 2e-2), (k, e_abs)
+        else:
+            _check("grad " + k, gh, gt, v, 6e-2, report)
         n_checked += 1
     assert n_checked > 40
-    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "pretrain_parity_report.txt"), "w").write(
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "pretrain_%s_parity_report.txt" % stage), "w").write(
         "\n".join(report) + "\n")

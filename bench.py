@@ -55,6 +55,56 @@ def build_model(layers, device, recompute=False):
     return model.to(torch.bfloat16).train()
 
 
+def build_pretrain_vl_model(layers, device, recompute=False):
+    """pretrain_vl_3B.yaml: the 4B encoder (text + image towers) plus the 2-layer 768-wide decoder of the masked branch."""
+    from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    enc = one_peace_encoder_config(embed_dim=H, ffn_embed_dim=FFN, layers=layers, attention_heads=HEADS, drop_path_rate=0.4,
+                                   layer_scale_init_value=1e-6, use_audio_moe=False, checkpoint_activations=recompute)
+    dec = one_peace_encoder_config(embed_dim=768, ffn_embed_dim=2048, layers=2, attention_heads=12, drop_path_rate=0.0,
+                                   use_audio_moe=False, checkpoint_activations=recompute)
+    dec.text_adapter.use_attn_bias = dec.image_adapter.use_attn_bias = False
+    dec.image_adapter.vision_encoder_type = "none"
+    dec.use_layer_scale = False
+    cfg = SimpleNamespace(encoder=enc, decoder=dec, copy_rel_pos_table=False, reset_logit_scale=False,
+                          logit_scale_init=1 / 0.07, stage2_pretrain=False)
+    with torch.device(device):
+        model = OnePeacePretrainModel(cfg, _Dict())
+    return model.to(torch.bfloat16).train()
+
+
+def add_pretrain_masks(batch, seed):
+    """Preserve ids / mask indices in the form of data/pretrain_data/image_text_pretrain_dataset.py:85-117 with the mask
+    ratios of pretrain_vl_3B.yaml:13-16 (position 0 = CLS is always kept)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tok = batch["src_tokens"].cpu()
+    b = tok.shape[0]
+    dev = batch["src_tokens"].device
+
+    def make(valid, ratio):
+        S = valid.shape[1]
+        rows, mask = [], torch.zeros(b, S, dtype=torch.bool)
+        for i in range(b):
+            cand = torch.nonzero(valid[i, 1:]).flatten() + 1
+            n_mask = int(len(cand) * ratio)
+            perm = cand[torch.randperm(len(cand), generator=g)]
+            mask[i, perm[:n_mask]] = True
+            rows.append(torch.cat([torch.zeros(1, dtype=torch.long), perm[n_mask:].sort().values]))
+        K = max(len(r) for r in rows)
+        ids = torch.full((b, K), -1, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = r
+        return ids.to(dev), mask.to(dev)
+    text_valid = torch.cat([torch.ones(b, 1, dtype=torch.bool), tok.ne(1)], dim=1)
+    image_valid = torch.ones(b, 257, dtype=torch.bool)
+    out = dict(batch)
+    out["text_preserve_ids"], out["text_mask_indices"] = make(text_valid, 0.15)
+    out["image_preserve_ids"], out["image_mask_indices"] = make(image_valid, 0.75)
+    out["vl_text_preserve_ids"], out["vl_text_mask_indices"] = make(text_valid, 0.4)
+    out["vl_image_preserve_ids"], out["vl_image_mask_indices"] = make(image_valid, 0.6875)
+    return out
+
+
 def synthetic_batch(b, audio_seconds, device, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
     tok = torch.randint(4, 50265, (b, 63), generator=g)
@@ -140,6 +190,9 @@ def main():
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--objective", choices=["contrastive", "pretrain-vl"], default="contrastive",
+                    help="contrastive = the headline tri-modal ITC+ATC step; pretrain-vl = the full image-text pretraining objective "
+                         "(ITC + four DCL terms, six passes incl. the masked students and the decoder) -- an extra data point")
     ap.add_argument("--host-inputs", action="store_true",
                     help="every step takes its batch from host memory through staging.SamplePrefetcher (PCIe-inclusive rate; "
                          "the headline value keeps inputs resident in HBM)")
@@ -168,14 +221,23 @@ def main():
         total_gb = torch.cuda.get_device_properties(device).total_memory / 1e9
         per_tuple_gb = (0.25 if args.recompute else 1.64) * 1.0737 * args.layers / LAYERS
         args.batch = next((b for b in (128, 64, 32, 16) if 50.0 + per_tuple_gb * b <= 0.93 * total_gb), 8)
-    model = build_model(args.layers, device, args.recompute)
+    full = args.objective == "pretrain-vl"
+    if full and args.batch > 64:
+        args.batch = 64  # five passes keep activations (two teachers, three students): 64 tuples fit
+    model = build_pretrain_vl_model(args.layers, device, args.recompute) if full else build_model(args.layers, device, args.recompute)
     nparams = sum(p.numel() for p in model.parameters())
     no_decay_names = model.no_weight_decay()
     flat = FlatParameters(model, no_decay=lambda n, p: p.dim() <= 1 or n in no_decay_names)
     reducer = BucketedGradReducer(flat)
     opt = FusedAdamW(flat, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)  # pretrain_vl_3B.yaml:24-36
-    crit = TriModalContrastiveCriterion(None, 0.0)
+    if full:
+        from one_peace_amd.criterions.pretrain import ImageTextPretrainLossCriterion
+        crit = ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, 0.0)  # pretrain_vl_3B.yaml criterion block
+    else:
+        crit = TriModalContrastiveCriterion(None, 0.0)
     batch, audio_S = synthetic_batch(args.batch, args.audio_seconds, device, 3407 + rank)
+    if full:
+        batch = add_pretrain_masks({k: v for k, v in batch.items() if "audio" not in k}, 3407 + rank)
     sample = {"net_input": batch, "nsentences": args.batch}
 
     feeder = None
@@ -234,21 +296,26 @@ def main():
         fl = 3.0 * (fwd_flops_per_sample(S_img, args.layers) + fwd_flops_per_sample(S_txt, args.layers)
                     + fwd_flops_per_sample(audio_S, args.layers) + audio_adapter_fwd_flops(args.audio_seconds))
         out = {
-            "metric": "pretrain samples/s (tri-modal global batch) ONE-PEACE-4B",
+            "metric": ("pretrain samples/s (tri-modal global batch) ONE-PEACE-4B" if not full else
+                       "EXTRA: full image-text pretraining objective (ITC + 4 DCL terms) samples/s ONE-PEACE-4B"),
             "value": global_batch * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic (random-init weights, seeded random tokens / N(0,1) pixels and waveforms)"
                                      + ("; inputs staged from pinned host memory every step" if args.host_inputs else ""),
-            "config": {"workload": "BASELINE configs[3]: ONE-PEACE-4B tri-modal (image 256^2 + text 64 + audio %.0fs) "
-                                   "contrastive pretrain step: 3 forwards, ITC+ATC, backward, grad all-reduce, grad-norm clip, AdamW"
-                                   % args.audio_seconds,
+            "config": {"workload": ("BASELINE configs[3]: ONE-PEACE-4B tri-modal (image 256^2 + text 64 + audio %.0fs) "
+                                    "contrastive pretrain step: 3 forwards, ITC+ATC, backward, grad all-reduce, grad-norm clip, AdamW"
+                                    % args.audio_seconds) if not full else
+                                   ("ONE-PEACE-4B image-text pretraining step, full objective of pretrain_vl_3B.yaml: text + image "
+                                    "teachers, joint vl teacher (no grad), masked text / image / vl students (mask ratios .15/.75/.4/"
+                                    ".6875) through the 2-layer decoder, ITC + 4 DCL terms, backward, grad-norm clip, AdamW"),
                        "embed_dim": H, "ffn": FFN, "layers": args.layers, "heads": HEADS, "params": nparams,
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "tokens_per_sample": S_img + S_txt + audio_S, "parallelism": "dp%d" % world,
+                       "tokens_per_sample": (S_img + S_txt) if full else (S_img + S_txt + audio_S), "parallelism": "dp%d" % world,
                        "activation_recompute": ("per layer (the reference's checkpoint_activations: true)" if args.recompute
                                                 else "off: layer activations are kept in HBM (288 GB/GPU)"),
-                       "algorithmic_tflop_per_sample": fl / 1e12,
-                       "step_algorithmic_tflops_per_gpu": fl * args.batch / (ms / 1e3) / 1e12, "final_loss": loss_v},
+                       "algorithmic_tflop_per_sample": None if full else fl / 1e12,
+                       "step_algorithmic_tflops_per_gpu": None if full else fl * args.batch / (ms / 1e3) / 1e12,
+                       "objective": args.objective, "final_loss": loss_v},
         }
         if prof is not None and prof[0]["count"] > 0:
             g = prof[0]

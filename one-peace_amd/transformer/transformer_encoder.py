@@ -111,9 +111,10 @@ class TransformerEncoder(nn.Module):
             key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=x.device)
             key_pad[:, :S] = pad.to(torch.uint8)
         x = x.contiguous()
+        scales = self._draw_path_scales(B, x.device)
         for idx, layer in enumerate(self.layers):
             h = None if not handles else (handles[0] if len(handles) == 1 else handles[idx])
-            x = layer.forward_fused(x, h, key_pad, encoder_type, lens)
+            x = layer.forward_fused(x, h, key_pad, encoder_type, lens, scales[idx] if scales is not None else None)
         if len(parts) == 1:
             norm = getattr(self, encoder_type + "_layer_norm")
             x = norm(x) if norm is not None else x
@@ -126,6 +127,18 @@ class TransformerEncoder(nn.Module):
             x = torch.cat(segs, dim=1)
         return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": [],
                 "image_encoder_states": [], "audio_encoder_states": []}
+
+    def _draw_path_scales(self, B, device):
+        """Per-sample stochastic-depth multipliers of the whole stack in ONE draw (transformer_layer.py:78-85 draws a fresh
+        Bernoulli mask per residual branch: 2 per layer; same distribution, 2 launches instead of 4 per layer)."""
+        if not self.training:
+            return None
+        probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers]
+        if max(probs, default=0.0) <= 0.0:
+            return None
+        keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device=device).view(-1, 1, 1)
+        draw = torch.bernoulli(keep.expand(-1, 2, B)) / keep
+        return [(None, None) if p <= 0.0 else (draw[i, 0], draw[i, 1]) for i, p in enumerate(probs)]
 
     def _dense_joint_bias(self, parts, lens, i, x):
         B, S = x.shape[0], sum(lens)

@@ -118,14 +118,18 @@ class TransformerEncoderLayer(nn.Module):
     def fused_params(self, encoder_type):
         return self.attn_params() + self.ffn_params(encoder_type)
 
-    def forward_fused(self, x_bsh, bias_handle, key_pad_u8, encoder_type, seg_lens=None):
+    def forward_fused(self, x_bsh, bias_handle, key_pad_u8, encoder_type, seg_lens=None, path_scales=None):
         """x_bsh: [B, S, H] bf16 batch-major; bias_handle: ops.RelPosBias or None; key_pad_u8: [B, Spad] or None.
         For 'vl'/'al' S = seg_lens[0] (text) + seg_lens[1] (image|audio) and the two row ranges take their own FFN
-        (transformer_layer.py:206-216) under ONE shared drop-path draw, as in the reference."""
+        (transformer_layer.py:206-216) under ONE shared drop-path draw, as in the reference.  path_scales: optional
+        (ps1, ps2) fp32 [B] multipliers (None entries = no drop-path) drawn by the caller."""
         B = x_bsh.shape[0]
         keep = not getattr(self.cfg, "checkpoint_activations", False)
-        ps1 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
-        ps2 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
+        if path_scales is not None:  # drawn for the whole stack by the encoder (one launch instead of two per layer)
+            ps1, ps2 = path_scales
+        else:
+            ps1 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
+            ps2 = sample_path_scale(B, self.drop_path_prob, self.training, x_bsh.device)
         x = ops.attn_branch(x_bsh, bias_handle, key_pad_u8, ps1, self.self_attn.num_heads, self.attn_params(), keep)
         streams = self._STREAMS[encoder_type]
         if len(streams) == 1:

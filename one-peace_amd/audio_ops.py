@@ -61,12 +61,12 @@ class StridedConv1dFn(torch.autograd.Function):
                 tgt = _as_rows(dx, R, Cin, 2 * Cin, 2 * Cin)
                 hip.gemm_nt(dyv, [hip.transpose(w2)], out=tgt, epilogue=hip.EPI_RESID, resid=tgt)
         if ctx.needs_input_grad[1]:
-            dyT = ops._t_pad(dyv)
-            dw01 = hip.gemm_nt(dyT, [ops._t_pad(_as_rows(x, R, 2 * Cin, 2 * Cin, 0))])  # [Cout, 2*Cin] as (tap, cin)
+            # dW = dy^T x straight from the strided activation views (transpose-read GEMM, no transposed copies)
+            dw01 = ops.wgrad(dyv, _as_rows(x, R, 2 * Cin, 2 * Cin, 0))  # [Cout, 2*Cin] as (tap, cin)
             dw = torch.empty(Cout, Cin, k, dtype=x.dtype, device=x.device)
             dw[:, :, :2] = dw01.view(Cout, 2, Cin).permute(0, 2, 1)
             if k == 3:
-                dw[:, :, 2] = hip.gemm_nt(dyT, [ops._t_pad(_as_rows(x, R, Cin, 2 * Cin, 2 * Cin))])
+                dw[:, :, 2] = ops.wgrad(dyv, _as_rows(x, R, Cin, 2 * Cin, 2 * Cin))
         return dx, dw
 
 
@@ -172,7 +172,7 @@ class GroupedConv1dSameFn(torch.autograd.Function):
             dwg = torch.empty(G, cg, k * cg, dtype=dy.dtype, device=dy.device)
             for g in range(G):
                 patches = _as_rows(xg[g], B * Ts, k * cg, cg, 0)
-                hip.gemm_nt(ops._t_pad(dyr[g]), [ops._t_pad(patches)], out=dwg[g])
+                ops.wgrad(dyr[g], patches, out=dwg[g])
             dw = dwg.view(G, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k)  # [g, co, j, ci] -> [C, ci, j]
         if has_bias and ctx.needs_input_grad[2]:
             db = hip.colsum(dy.view(B * T, C))

@@ -497,15 +497,17 @@ def test_attention_per_sample_bias(B, S, heads, use_pad):
     assert_close(dbias[..., :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="per-sample dbias")
 
 
-def test_audio_stem_convs_match_conv1d():
-    """audio_ops: strided-view GEMM convolutions (feature extractor + grouped positional conv) vs F.conv1d, fwd + grads."""
+@pytest.mark.parametrize("B,slots,T", [(3, 40, 37), (4, 64, 46)])
+def test_audio_stem_convs_match_conv1d(B, slots, T):
+    """audio_ops: strided-view GEMM convolutions (feature extractor + grouped positional conv) vs F.conv1d, fwd + grads.
+    The second size makes the row counts multiples of 64, so the weight gradients take the transpose-read GEMM on the
+    strided (and, for the grouped conv, overlapping-row) views; the first one takes the transposed-copy fallback."""
     from one_peace_amd import audio_ops
     import torch.nn as nn
     torch.manual_seed(0)
-    B = 3
     # --- stride-2 convs, k = 3 and k = 2, channels-last flat rows with slack ---
     for k in (3, 2):
-        Cin, Cout, slots = 64, 128, 40
+        Cin, Cout = 64, 128
         xs = rnd(B, slots, Cin, seed=3 + k)
         w = rnd(Cout, Cin, k, seed=5 + k, scale=(Cin * k) ** -0.5)
         xr, wr = xs.clone().requires_grad_(True), w.clone().requires_grad_(True)
@@ -523,7 +525,7 @@ def test_audio_stem_convs_match_conv1d():
         assert_close(xd.grad[: B * slots].view(B, slots, Cin), xr.grad, what="strided conv dx k=%d" % k)
         assert_close(wd.grad, wr.grad, what="strided conv dw k=%d" % k)
     # --- grouped same-padding conv ---
-    C, G, k, T = 128, 4, 19, 37
+    C, G, k = 128, 4, 19
     x = rnd(B, T, C, seed=11)
     w = rnd(C, C // G, k, seed=12, scale=(C // G * k) ** -0.5)
     b = rnd(C, seed=13)

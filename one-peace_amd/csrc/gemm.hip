@@ -1168,8 +1168,8 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
       return gemm_nt_impl((const bf16_t*)A + m_main * lda, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2,
                           (char*)C + m_main * ldc * esz, ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
                           h1 ? (bf16_t*)h1 + m_main * ldc : nullptr, resid ? (const bf16_t*)resid + m_main * ldr : nullptr, ldr,
-                          gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, nullptr, 0, stream, m_off + m_main,
-                          false);
+                          gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, workspace, workspace_bytes, stream,
+                          m_off + m_main, false);  // (bias-free launches may split K: 12 tiles alone are latency-bound)
     }
   }
   a.kt_per_split = plan.kt_per_split;

@@ -1043,6 +1043,55 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// Split-K fold WITH the epilogue (bias / residual + layer-scale + drop-path, optional branch output): lets the small
+// latency-bound launches that carry an epilogue (the <= 128 leftover rows of a tail-rows split) split K as well.
+struct FoldArgs {
+  const float* ws; int splits; int64_t slab;
+  bf16_t* out; int64_t ldc; int M, N;
+  const bf16_t* bias[3]; int n_seg;
+  int resid_epi;  // 0: out = acc + bias; 1: out = resid + rowscale * gamma * (acc + bias), h0 (optional) = acc + bias
+  const bf16_t* resid; int64_t ldr; const bf16_t* gamma; const float* rowscale; int rows_per_sample, m_off;
+  bf16_t* h0;
+};
+__global__ __launch_bounds__(256) void splitk_fold_epilogue_kernel(const FoldArgs p) {
+  const int n8 = p.N / 8;
+  const int64_t total = (int64_t)p.M * n8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / n8;
+    const int c = (int)(i - m * n8) * 8;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int z = 0; z < p.splits; ++z) {
+      float v[8];
+      Vec8<float>::load(p.ws + z * p.slab + m * p.N + c, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += v[j];
+    }
+    const int seg = c / p.n_seg;
+    const bf16_t* bp = p.bias[seg];
+    if (bp) {
+      float b[8];
+      Vec8<bf16_t>::load(bp + (c - seg * p.n_seg), b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += b[j];
+    }
+    if (p.resid_epi) {
+      if (p.h0) Vec8<bf16_t>::store(p.h0 + m * p.ldc + c, a);
+      float r[8], gv[8];
+      Vec8<bf16_t>::load(p.resid + m * p.ldr + c, r);
+      const float rs = p.rowscale ? p.rowscale[(m + p.m_off) / p.rows_per_sample] : 1.f;
+      if (p.gamma) {
+        Vec8<bf16_t>::load(p.gamma + c, gv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = r[j] + rs * gv[j] * a[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = r[j] + rs * a[j];
+      }
+    }
+    Vec8<bf16_t>::store(p.out + m * p.ldc + c, a);
+  }
+}
+
 // Launch plan: tile size and split-K factor from a wave-quantisation model.  One "round" fills every workgroup slot
 // once (128x128: 2 per CU = 512, 256x256: 1 per CU = 256); relative slot-round costs are calibrated on MI355X
 // micro-benchmarks (128x128 ~ 900 TF/s, 256x256 ~ 1040 TF/s sustained).
@@ -1150,7 +1199,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   const bool seg_ok = epilogue == EPI_GEGLU || a.n_seg >= (int)N || a.n_seg % 256 == 0;
   const bool off32_ok = (M * lda < ((int64_t)1 << 30)) && (N * ldb < ((int64_t)1 << 30));
   const bool allow_256 = g_tile_mode != 1 && g_default_glds && seg_ok && off32_ok;
-  const bool allow_split = epilogue == EPI_BIAS && !bias0 && workspace != nullptr && N % 8 == 0;
+  // split-K: bias-free plain launches (weight gradients, dgrads), and -- for launches of at most one M-tile, which are
+  // latency-bound on K -- also bias / residual epilogues, applied by the fold kernel
+  const bool fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && bias0)) && M <= 256 && a.n_seg % 8 == 0 && ldc % 8 == 0;
+  const bool allow_split = ((epilogue == EPI_BIAS && !bias0) || fold_epi) && workspace != nullptr && N % 8 == 0;
   GemmPlan plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, workspace_bytes);
   if (g_tile_mode == 2 && allow_256 && plan.tile != 256) plan = {256, 1, 0};
   // Tail rows.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
@@ -1177,10 +1229,18 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   int epi = epilogue;
   void* c_final = C;
   const int64_t ldc_final = ldc;
-  if (plan.splits > 1) {  // partial sums go to fp32 slabs, folded by splitk_reduce_kernel
+  FoldArgs fold;
+  if (plan.splits > 1) {  // partial sums go to fp32 slabs, folded by splitk_reduce_kernel / splitk_fold_epilogue_kernel
+    fold.ws = (const float*)workspace; fold.splits = plan.splits; fold.slab = a.slab;
+    fold.out = (bf16_t*)C; fold.ldc = ldc; fold.M = (int)M; fold.N = (int)N;
+    fold.bias[0] = a.bias[0]; fold.bias[1] = a.bias[1]; fold.bias[2] = a.bias[2]; fold.n_seg = a.n_seg;
+    fold.resid_epi = epilogue == EPI_RESID; fold.resid = a.resid; fold.ldr = a.ldr; fold.gamma = a.gamma;
+    fold.rowscale = a.rowscale; fold.rows_per_sample = a.rows_per_sample; fold.m_off = a.m_off; fold.h0 = a.H0;
     a.C = workspace;
     a.ldc = N;
     a.alpha = nullptr;
+    a.bias[0] = a.bias[1] = a.bias[2] = nullptr;  // applied once, by the fold
+    a.H0 = a.H1 = nullptr;
     epi = EPI_F32;
   }
   const int slot = op_prof_begin(0, flops, stream);
@@ -1208,8 +1268,11 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   if (rc == OP_OK && plan.splits > 1) {
     int64_t nb = ((int64_t)M * (N / 8) + 255) / 256;
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, s, (const float*)workspace, plan.splits, a.slab,
-                       (bf16_t*)c_final, ldc_final, (int)M, (int)N, 0);
+    if (fold_epi)
+      hipLaunchKernelGGL(splitk_fold_epilogue_kernel, dim3((int)nb), dim3(256), 0, s, fold);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)nb), dim3(256), 0, s, (const float*)workspace, plan.splits, a.slab,
+                         (bf16_t*)c_final, ldc_final, (int)M, (int)N, 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { op_set_error("gemm_nt: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
   }

@@ -647,3 +647,24 @@ def test_gemm_tail_rows_split(epi):
     finally:
         hip.lib().op_gemm_set_tile(51)
         hip.lib().op_gemm_set_tile(old)
+
+
+@pytest.mark.parametrize("epi", ["bias", "resid"])
+def test_gemm_small_m_split_k_with_epilogue_fold(epi):
+    """M <= 256 with a long K: the launch is latency-bound, so K is split and the epilogue (bias / residual + layer scale +
+    drop-path + saved branch output) is applied by the fold kernel."""
+    hip = hipmod()
+    M, N, K, S = 100, 512, 4096, 10
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.03), rnd(N, seed=3)
+    if epi == "bias":
+        out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)])
+        assert_close(out, a @ w.t() + b, what="bias")
+    else:
+        gamma, res = rnd(N, seed=4), rnd(M, N, seed=5)
+        ps = (torch.arange(M // S) % 3 != 1).float() / 0.66
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)], epilogue=hip.EPI_RESID, resid=dev_bf16(res),
+                          gamma=dev_bf16(gamma), rowscale=ps.to(DEV), rows_per_sample=S, h0=y)
+        branch = a @ w.t() + b
+        assert_close(y, branch, what="branch output")
+        assert_close(out, res + ps.repeat_interleave(S)[:, None] * gamma * branch, what="resid")

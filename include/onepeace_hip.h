@@ -121,6 +121,12 @@ int op_relpos_bias_bwd(const float* dbias, const int* bucket, int64_t bucket_ld,
 /* ---- HBM-bound helpers of the layer backward -----------------------------------------------------------------------
  * (the reference gets these from autograd over transformer_layer.py:54-88,149-157) */
 int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream);
+/* Many transposes in one launch (the dgrad copies of all weights after an optimiser step).  table: DEVICE array of n
+ * descriptors, op_transpose_desc_bytes() bytes each, laid out as { const void* in; void* out; int32 rows, cols;
+ * int64 ld_in, ld_out; int32 tile0, tiles_x; } with tile0 = running sum of ceil(cols/64)*ceil(rows/64) and
+ * tiles_x = ceil(cols/64); total_tiles = that sum over all descriptors. */
+int op_transpose_batched(const void* table, int64_t n, int64_t total_tiles, void* stream);
+int64_t op_transpose_desc_bytes(void);
 int64_t op_colsum_workspace_bytes(int64_t N);
 /* Per-segment column sums of x [M, n_seg*seg_cols]: the q/k/v bias gradients of the fused projection
  * (one_peace/models/transformer/multihead_attention.py:57-62; a null out_i skips that segment).  workspace: op_colsum_workspace_bytes(n_seg*seg_cols). */

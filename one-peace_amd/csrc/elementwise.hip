@@ -11,10 +11,10 @@ constexpr int CS_MAX_PARTS = 256;
 // ------------------------------------------------------------------------------------------------------------
 // bf16 2-D transpose  out[c][r] = in[r][c]   (64x64 tiles through LDS, 8-byte global accesses on both sides)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+__device__ __forceinline__ void transpose_tile(int bx, int by, const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
                                                         int rows, int cols, int64_t ld_in, int64_t ld_out) {
   __shared__ bf16_t tile[64][64 + 2];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int r0 = by * 64, c0 = bx * 64;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 elements each along the fast axis
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -46,6 +46,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
       }
     }
   }
+}
+
+
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols,
+                                                        int64_t ld_in, int64_t ld_out) {
+  transpose_tile(blockIdx.x, blockIdx.y, in, out, rows, cols, ld_in, ld_out);
+}
+
+// Many transposes in ONE launch (the dgrad copies of all weights after an optimiser step: 520 matrices at 4B).  Descriptor i
+// covers tiles [tile0[i], tile0[i+1]) of the launch; a workgroup finds its matrix by binary search.
+struct TransposeDesc { const bf16_t* in; bf16_t* out; int rows, cols; int64_t ld_in, ld_out; int tile0, tiles_x; };
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const TransposeDesc* __restrict__ table, int n) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const TransposeDesc d = table[lo];
+  const int local = b - d.tile0;
+  transpose_tile(local % d.tiles_x, local / d.tiles_x, d.in, d.out, d.rows, d.cols, d.ld_in, d.ld_out);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -445,6 +466,18 @@ int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t 
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
+
+// Batched transposes: `table` is a DEVICE array of n descriptors {in, out, rows, cols, ld_in, ld_out, tile0, tiles_x}
+// (struct TransposeDesc, 48 bytes: two pointers, two int32, two int64, two int32; tile0 = running sum of
+// ceil(cols/64)*ceil(rows/64), tiles_x = ceil(cols/64)); total_tiles = the sum over all descriptors.
+int op_transpose_batched(const void* table, int64_t n, int64_t total_tiles, void* stream) {
+  OP_CHECK_ARG(table && n > 0 && total_tiles > 0, "transpose_batched: bad args");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const TransposeDesc*)table, (int)n);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+int64_t op_transpose_desc_bytes(void) { return (int64_t)sizeof(TransposeDesc); }
 
 int64_t op_colsum_workspace_bytes(int64_t N) { return (int64_t)CS_MAX_PARTS * N * (int64_t)sizeof(float); }
 

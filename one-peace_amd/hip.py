@@ -40,6 +40,8 @@ SIGNATURES = {
                            c_int, P, I64, P]),
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
+    "op_transpose_batched": (c_int, [P, I64, I64, P]),
+    "op_transpose_desc_bytes": (I64, []),
     "op_colsum_workspace_bytes": (I64, [I64]),
     "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
     "op_resid_bwd_workspace_bytes": (I64, [I64]),
@@ -230,6 +232,25 @@ def transpose(x2d, out=None):
         out = torch.empty(cols, rows, dtype=x2d.dtype, device=x2d.device)
     _check(lib().op_transpose(ptr(x2d), ptr(out), rows, cols, x2d.stride(0), out.stride(0), stream()), "op_transpose")
     return out
+
+
+def transpose_table(jobs, device):
+    """jobs: [(src [rows, cols] (last dim contiguous), dst view [cols, rows] (last dim contiguous))] -> (device table, total tiles)
+    for transpose_batched; the table stays valid as long as the tensors keep their storage."""
+    import struct
+    assert lib().op_transpose_desc_bytes() == 48
+    raw, tile0 = b"", 0
+    for src, dst in jobs:
+        rows, cols = src.shape
+        tx, ty = (cols + 63) // 64, (rows + 63) // 64
+        raw += struct.pack("<QQiiqqii", src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), tile0, tx)
+        tile0 += tx * ty
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    return table, tile0
+
+
+def transpose_batched(table, n, total_tiles):
+    _check(lib().op_transpose_batched(ptr(table), n, total_tiles, stream()), "op_transpose_batched")
 
 
 def colsum(x, y=None, rowscale=None, rows_per_sample=0, mul=None, out=None, accumulate=False, out_dtype=torch.bfloat16):

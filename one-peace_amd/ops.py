@@ -23,10 +23,38 @@ _wt_cache = {}
 _cache_epoch = 0
 
 
+_refresh_plan = None  # (key set, device table, n, total tiles, [cache keys]) of the batched refresh
+
+
 def invalidate_weight_cache():
     """Call after parameters were updated through raw pointers (the fused AdamW kernel does not bump _version)."""
     global _cache_epoch
     _cache_epoch += 1
+
+
+def refresh_weight_cache():
+    """After an optimiser step: rebuild EVERY cached transposed weight in one batched launch (520 matrices at 4B; lazily,
+    one launch per matrix plus a concatenation per q/k/v triple, they cost 14 ms per step) and mark them current."""
+    global _cache_epoch, _refresh_plan
+    _cache_epoch += 1
+    live = [(k, v) for k, v in _wt_cache.items() if all(r() is not None for r in v[0])]
+    if not live:
+        return
+    sig = tuple((k, tuple(r().data_ptr() for r in v[0]), v[2].data_ptr()) for k, v in live)
+    if _refresh_plan is None or _refresh_plan[0] != sig:
+        jobs = []
+        for k, v in live:
+            off = 0
+            for r in v[0]:
+                w = r().detach()
+                jobs.append((w, v[2][:, off:off + w.shape[0]]))  # segment i fills columns [off, off + out_i) of [in, sum out]
+                off += w.shape[0]
+        table, tiles = hip.transpose_table(jobs, live[0][1][2].device)
+        _refresh_plan = (sig, table, len(jobs), tiles)
+    hip.transpose_batched(_refresh_plan[1], _refresh_plan[2], _refresh_plan[3])
+    for k, v in live:
+        ws = tuple(r() for r in v[0])
+        _wt_cache[k] = (v[0], (tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws), _cache_epoch), v[2])
 
 
 def _transposed(ws):

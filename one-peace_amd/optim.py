@@ -32,7 +32,7 @@ class FusedAdamW:
             if e > s:
                 hip.adamw_step(f.params[s:e], f.grads[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.lr, self.betas[0],
                                self.betas[1], self.eps, wd, self.step_count, grad_scale, sq, clip_norm)
-        ops.invalidate_weight_cache()
+        ops.refresh_weight_cache()  # the raw-pointer update does not bump _version: refresh the dgrad copies in one launch
         return sq.sqrt() * abs(grad_scale) if sq is not None else None
 
     def zero_grad(self):

@@ -431,3 +431,46 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
     assert n_checked > 40
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "pretrain_%s_parity_report.txt" % stage), "w").write(
         "\n".join(report) + "\n")
+
+
+def test_batched_weight_cache_refresh_after_optimizer_step():
+    """optim.FusedAdamW updates the flat parameters through raw pointers and then rebuilds every cached transposed weight
+    (the dgrad operands, incl. the fused q|k|v one) in ONE batched launch: after each step every cache entry must equal
+    the transpose of the just-updated weights, and training must follow the lazily-refreshed path exactly."""
+    from one_peace_amd import ops
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.optim import FusedAdamW
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_rel_bucket_size=4,
+               text_bucket_size=256, audio_bucket_size=512)
+    inp = _to_dev(synth.synth_inputs(8, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    losses = {}
+    for mode in ("batched", "lazy"):
+        m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(torch.bfloat16).eval()
+        flat = FlatParameters(m)
+        opt = FusedAdamW(flat, lr=1e-3)
+        orig = ops.refresh_weight_cache
+        if mode == "lazy":
+            ops.refresh_weight_cache = ops.invalidate_weight_cache
+        try:
+            out = []
+            for _ in range(3):
+                opt.zero_grad()
+                loss, _, _ = TriModalContrastiveCriterion(None, 0.0)(m, {"net_input": inp, "nsentences": 8})
+                loss.backward()
+                opt.step(clip_norm=3.0)
+                out.append(float(loss.detach()))
+                if mode == "batched":
+                    n = 0
+                    for key, (refs, ver, t) in ops._wt_cache.items():
+                        ws = [r() for r in refs]
+                        if any(w is None for w in ws) or not any(w is p for w in ws for p in m.parameters()):
+                            continue
+                        assert ver[2] == ops._cache_epoch
+                        assert torch.equal(t, torch.cat([w.detach() for w in ws], 0).t()), key
+                        n += 1
+                    assert n >= 2 * 6  # per layer: q|k|v, out, 3 x (wi_0, wi_1, w2) of the modality actually used ...
+        finally:
+            ops.refresh_weight_cache = orig
+        losses[mode] = out
+    assert losses["batched"] == losses["lazy"], losses

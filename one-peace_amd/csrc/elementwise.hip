@@ -550,14 +550,20 @@ int op_colsum_segments(const void* x, void* out0, void* out1, void* out2, void* 
   int parts = (int)((M + 63) / 64);
   if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
   if (parts < 1) parts = 1;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(N, 512), parts), dim3(256), 0, s, (const bf16_t*)x,
-                     (const bf16_t*)nullptr, (const float*)nullptr, 1, (float*)workspace, M, (int)N, N);
-  OP_LAUNCH_CHECK();
+  // only the segments that have a consumer are read (k_proj has no bias: a third of the q|k|v gradient stays untouched)
+  void* outs[3] = {out0, out1, out2};
   const float* ws = (const float*)workspace;
-  hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(seg_cols, 32), (int)n_seg), dim3(256), 0, s, ws,
-                     ws + seg_cols, ws + 2 * seg_cols, (const bf16_t*)nullptr, (const bf16_t*)nullptr,
-                     (const bf16_t*)nullptr, (bf16_t*)out0, (bf16_t*)out1, (bf16_t*)out2, parts, N, (int)seg_cols,
-                     accumulate);
+  for (int i = 0; i < (int)n_seg; ++i) {
+    if (outs[i] == nullptr) continue;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(seg_cols, 512), parts), dim3(256), 0, s,
+                       (const bf16_t*)x + i * seg_cols, (const bf16_t*)nullptr, (const float*)nullptr, 1,
+                       (float*)workspace + (int64_t)i * parts * seg_cols, M, (int)seg_cols, N);
+    OP_LAUNCH_CHECK();
+  }
+  const int64_t st = (int64_t)parts * seg_cols;
+  hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(seg_cols, 32), (int)n_seg), dim3(256), 0, s, ws, ws + st,
+                     ws + 2 * st, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (bf16_t*)out0,
+                     (bf16_t*)out1, (bf16_t*)out2, parts, seg_cols, (int)seg_cols, accumulate);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

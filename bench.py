@@ -193,6 +193,9 @@ def main():
     ap.add_argument("--objective", choices=["contrastive", "pretrain-vl"], default="contrastive",
                     help="contrastive = the headline tri-modal ITC+ATC step; pretrain-vl = the full image-text pretraining objective "
                          "(ITC + four DCL terms, six passes incl. the masked students and the decoder) -- an extra data point")
+    ap.add_argument("--check-replicas", action="store_true",
+                    help="after the run, compare a checksum of all parameters across ranks (every rank sees different data, so the "
+                         "replicas only stay identical if every gradient was all-reduced after its last contribution)")
     ap.add_argument("--host-inputs", action="store_true",
                     help="every step takes its batch from host memory through staging.SamplePrefetcher (PCIe-inclusive rate; "
                          "the headline value keeps inputs resident in HBM)")
@@ -228,6 +231,8 @@ def main():
     nparams = sum(p.numel() for p in model.parameters())
     no_decay_names = model.no_weight_decay()
     flat = FlatParameters(model, no_decay=lambda n, p: p.dim() <= 1 or n in no_decay_names)
+    if world > 1:  # replicas start from rank 0's weights (fairseq: distributed_utils.broadcast of the initial state)
+        dist.broadcast(flat.params, src=0)
     reducer = BucketedGradReducer(flat)
     opt = FusedAdamW(flat, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)  # pretrain_vl_3B.yaml:24-36
     if full:
@@ -283,6 +288,15 @@ def main():
     if not args.no_profile:
         hip.lib().op_prof_enable(0)
         prof = hip.profile_kernels.collect(4)
+    if args.check_replicas and world > 1:
+        chk = torch.stack([flat.params.double().sum(), flat.params.double().abs().sum(), opt.exp_avg.double().sum()])
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        same = all(torch.equal(allc[0], c) for c in allc[1:])
+        if rank == 0:
+            print("replica check: %s (param checksums %s)" % ("IDENTICAL" if same else "DIVERGED", [c.tolist() for c in allc]),
+                  file=sys.stderr, flush=True)
+        assert same, "data-parallel replicas diverged: a gradient bucket was reduced before its last contribution"
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

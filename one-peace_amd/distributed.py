@@ -61,7 +61,7 @@ class FlatParameters:
                 self.params[o:o + k].copy_(p.detach().reshape(-1))
                 p.data = self.params[o:o + k].view(p.shape)
                 p.grad = self.grads[o:o + k].view(p.shape)
-                p._op_flat = True      # ops.EncoderLayerFn may accumulate this gradient in place (see ops._direct_grad)
+                p._op_flat = True      # ops.AttnBranchFn / FfnBranchFn accumulate this gradient in place (see ops._direct_grad)
                 p._op_pending = 0
 
     def zero_grad(self):

@@ -3,7 +3,7 @@
 ``forward(x, key_padding_mask, attn_mask)`` contract (time-major x, additive dense mask, key_padding_mask unused).
 
 This module's own forward is the torch-op path (CPU / fp32 / dense-mask callers).  On MI355X the encoder layer does
-not call it: the projections, the attention core and the sub-LN are part of the fused HIP layer (ops.EncoderLayerFn)."""
+not call it: the projections, the attention core and the sub-LN are part of the fused HIP attention branch (ops.AttnBranchFn)."""
 import torch
 import torch.nn as nn
 

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
         }
       }
     }
-    float gw[CH][8];
+    float gw[CH][8], cdfs[CH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
         for (int j = 0; j < 8; ++j) {
           float cdf, pdf;
           gelu_parts(a[j], cdf, pdf);
+          cdfs[i][j] = cdf;
           // the forward rounded g to bf16 before the LayerNorm statistics were taken
           const float gval = (float)(bf16_t)(a[j] * cdf * b[j]);
           const float xh = (gval - mean) * rstd;
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
         Vec8<bf16_t>::cvt(r1[i], b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float cdf, pdf;
-          gelu_parts(a[j], cdf, pdf);
+          const float cdf = cdfs[i][j];  // kept from the first pass; only the density needs its exponential again
+          const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[j] * a[j]);
           const float ge = a[j] * cdf;
           const float xh = ((float)(bf16_t)(ge * b[j]) - mean) * rstd;
           // the unfused path rounded dg to bf16 between the two kernels; keep fp32 here

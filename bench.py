@@ -337,7 +337,7 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM, all epilogues)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": g["count"], "avg_launch_ms": g["ms"] / g["count"],
-                               "algorithmic_bytes_per_launch": hip.GEMM_ALGO_BYTES[0] / max(1, hip.GEMM_ALGO_BYTES[1]),
+                               "algorithmic_bytes_per_launch": hip.GEMM_ALGO_BYTES[0] / max(1, g["count"]),
                                "gemm_share_of_step": g["ms"] / (ms * args.steps),
                                "attention_fwd_tflops": (prof[1]["work"] / (prof[1]["ms"] * 1e-3) / 1e12) if prof[1]["count"] else None,
                                "attention_bwd_tflops": (prof[2]["work"] / (prof[2]["ms"] * 1e-3) / 1e12) if prof[2]["count"] else None}

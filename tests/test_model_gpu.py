@@ -474,3 +474,33 @@ def test_batched_weight_cache_refresh_after_optimizer_step():
             ops.refresh_weight_cache = orig
         losses[mode] = out
     assert losses["batched"] == losses["lazy"], losses
+
+
+def test_long_sequence_image_448_on_hip():
+    """BASELINE configs[4] shape class: 448^2 images -> 28 x 28 patches + CLS = 785 tokens (the streaming attention kernels
+    with 13 key tiles, separate dQ / dBias kernels, 2-D relative-position buckets at the larger grid), image tower forward +
+    backward of a small-width model, HIP against the fp32 torch path of the same mirror on the device."""
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_bucket_size=28, image_rel_bucket_size=28,
+               text_bucket_size=256, audio_bucket_size=512)
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(2, 3, 448, 448, generator=g)
+    res = {}
+    for mode in ("hip", "torch", "fp32"):
+        dt = torch.float32 if mode == "fp32" else torch.bfloat16
+        m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(dt).eval()
+        _force_torch_path(m, mode != "hip")
+        feats = m.encoder_wrapper(src_images=imgs.to(DEV).to(dt), encoder_type="image")[1]
+        assert feats.shape == (2, 785, 128)
+        w = torch.randn(feats.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
+        m.zero_grad()
+        (feats.float() * w).sum().backward()
+        res[mode] = (feats.detach().float().cpu(),
+                     {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    report = []
+    _check("448^2 image features", res["hip"][0], res["torch"][0], res["fp32"][0], 1.5e-2, report)
+    n = 0
+    for k, ref in res["fp32"][1].items():
+        if float(ref.norm()) > 1e-7:
+            _check("grad " + k, res["hip"][1][k], res["torch"][1][k], ref, 5e-2, report)
+            n += 1
+    assert n > 30 and any("rel_pos_table" in k for k in res["hip"][1])

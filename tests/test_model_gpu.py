@@ -504,3 +504,21 @@ def test_long_sequence_image_448_on_hip():
             _check("grad " + k, res["hip"][1][k], res["torch"][1][k], ref, 5e-2, report)
             n += 1
     assert n > 30 and any("rel_pos_table" in k for k in res["hip"][1])
+
+
+def test_retrieval_criteria_on_hip(golden_dir):
+    """BASELINE configs[2] objective: image_text_retrieval_criterion (ITC, eps 0) and audio_text_retrieval_criterion (ATC with
+    label smoothing 0.1, the eps/(n-1) form of image_text_retrieval_loss.py:21-24) through the HIP InfoNCE kernels, against
+    the losses and hit counts the reference produced."""
+    from one_peace_amd.criterions.contrastive import AudioTextRetrievalCriterion, ImageTextRetrievalCriterion
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    m = load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]).to(DEV).to(torch.bfloat16).eval()
+    inp = _to_dev(fx["inputs"])
+    sample = {"net_input": inp, "nsentences": 4}
+    l_it, _, log_it = ImageTextRetrievalCriterion(None, label_smoothing=0.0)(m, sample)
+    l_at, _, log_at = AudioTextRetrievalCriterion(None, label_smoothing=0.1)(m, sample)
+    assert abs(float(l_it.detach()) - float(fx["itc_loss"])) < 2e-2 and abs(float(l_at.detach()) - float(fx["atc_loss"])) < 2e-2
+    assert float(log_it["i2t_ncorrect"]) == float(fx["i2t"]) and float(log_it["t2i_ncorrect"]) == float(fx["t2i"])
+    assert float(log_at["a2t_ncorrect"]) == float(fx["a2t"]) and float(log_at["t2a_ncorrect"]) == float(fx["t2a"])
+    (l_it + l_at).backward()
+    assert m.logit_scale.grad is not None and torch.isfinite(m.logit_scale.grad)

@@ -1199,9 +1199,10 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   const bool seg_ok = epilogue == EPI_GEGLU || a.n_seg >= (int)N || a.n_seg % 256 == 0;
   const bool off32_ok = (M * lda < ((int64_t)1 << 30)) && (N * ldb < ((int64_t)1 << 30));
   const bool allow_256 = g_tile_mode != 1 && g_default_glds && seg_ok && off32_ok;
-  // split-K: bias-free plain launches (weight gradients, dgrads), and -- for launches of at most one M-tile, which are
-  // latency-bound on K -- also bias / residual epilogues, applied by the fold kernel
-  const bool fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && bias0)) && M <= 256 && a.n_seg % 8 == 0 && ldc % 8 == 0;
+  // split-K: bias-free plain launches (weight gradients, dgrads), and -- for launches of a few M-tiles (the leftover rows
+  // of a tail-rows split, batch-1 feature extraction: M = 257), which are latency-bound on K with most CUs idle -- also
+  // bias / residual epilogues, applied by the fold kernel.  plan_gemm's cost model decides whether a split pays.
+  const bool fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && bias0)) && M <= 1024 && a.n_seg % 8 == 0 && ldc % 8 == 0;
   const bool allow_split = ((epilogue == EPI_BIAS && !bias0) || fold_epi) && workspace != nullptr && N % 8 == 0;
   GemmPlan plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, workspace_bytes);
   if (g_tile_mode == 2 && allow_256 && plan.tile != 256) plan = {256, 1, 0};

@@ -1,0 +1,59 @@
+"""hipGraph capture of forward-only feature extraction (the launch-bound end of BASELINE configs[1]: batch 1-8 through 40
+layers is ~9 kernels per layer of a few microseconds each, so the host's launch path, not the GPU, sets the latency).
+
+Every kernel of the HIP path is enqueued on torch's current stream and the C-ABI never synchronises or allocates
+(include/onepeace_hip.h), so a whole ``model(...)`` call records into one graph; replay is a single hipGraphLaunch.  The
+captured call owns static input / output buffers: ``__call__`` copies the new inputs in, replays, and returns the outputs
+(clones by default -- the static buffers are overwritten by the next replay).  One graph per input-shape signature."""
+import torch
+
+
+def _signature(inputs):
+    return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(inputs.items()) if torch.is_tensor(v))
+
+
+class GraphedCall:
+    def __init__(self, fn, example_inputs, warmup=2):
+        tensors = {k: v for k, v in example_inputs.items() if torch.is_tensor(v)}
+        if not tensors or not all(v.is_cuda for v in tensors.values()):
+            raise RuntimeError("GraphedCall: inputs must be device tensors (hipGraph capture has no CPU path)")
+        self.signature = _signature(example_inputs)
+        self.static_in = {k: v.clone() for k, v in tensors.items()}
+        self.consts = {k: v for k, v in example_inputs.items() if not torch.is_tensor(v)}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():  # allocator / workspace / derived-buffer warm-up outside the capture
+            for _ in range(warmup):
+                fn(**self.static_in, **self.consts)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_out = fn(**self.static_in, **self.consts)
+
+    def __call__(self, clone=True, **inputs):
+        if _signature(inputs) != self.signature:
+            raise RuntimeError("GraphedCall: input shapes/dtypes differ from the captured ones: %s vs %s"
+                               % (_signature(inputs), self.signature))
+        for k, buf in self.static_in.items():
+            buf.copy_(inputs[k])
+        self.graph.replay()
+        out = self.static_out
+        if not clone:
+            return out
+        return out.clone() if torch.is_tensor(out) else type(out)(o.clone() if torch.is_tensor(o) else o for o in out)
+
+
+class GraphCache:
+    """fn + one GraphedCall per input signature (feature extraction sees a handful of batch shapes)."""
+
+    def __init__(self, fn, max_graphs=8):
+        self.fn, self.max_graphs, self.graphs = fn, max_graphs, {}
+
+    def __call__(self, **inputs):
+        sig = _signature(inputs)
+        g = self.graphs.get(sig)
+        if g is None:
+            if len(self.graphs) >= self.max_graphs:  # bounded: each graph pins its activations' memory pool
+                self.graphs.pop(next(iter(self.graphs)))
+            g = self.graphs[sig] = GraphedCall(self.fn, inputs)
+        return g(**inputs)

@@ -190,9 +190,9 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
     ldc_ = ldc if ldc is not None else out.stride(0)
     ws, ws_bytes = None, 0
     # fp32 scratch for split-K: bias-free plain launches with few tiles and a long K (weight gradients, dgrads), and the
-    # small latency-bound launches (at most one M-tile, e.g. the leftover rows of a tail-rows split) whose bias / residual
-    # epilogue the fold kernel applies.  The library decides; handing the scratch over costs nothing.
-    if splitk and epilogue in (EPI_BIAS, EPI_RESID) and K >= 2048:
+    # small latency-bound launches (a few M-tiles: the leftover rows of a tail-rows split, batch-1 feature extraction)
+    # whose bias / residual epilogue the fold kernel applies.  The library decides; handing the scratch over costs nothing.
+    if splitk and epilogue in (EPI_BIAS, EPI_RESID) and (K >= 2048 or M <= 1024):
         ws = workspace(SPLITK_WS_BYTES, A.device, "gemm_splitk")
         ws_bytes = ws.numel()
     outs = 1 + (2 if h1 is not None else (1 if h0 is not None else 0))

@@ -84,7 +84,6 @@ class OnePeaceHubInterface:
         self.dict = model.src_dict
         if self.dtype != torch.float32:  # hub_interface.py:107-114
             self.model.to(self.dtype)
-        self.model.logit_scale.data = self.model.logit_scale.data.float() if False else self.model.logit_scale.data
 
     def cast_data_dtype(self, t):
         return t.to(self.dtype) if t.is_floating_point() else t
@@ -121,22 +120,42 @@ class OnePeaceHubInterface:
         mask = torch.cat([mask.new_zeros(len(wav_list), 1), mask], dim=1)
         return self.cast_data_dtype(wavs.to(self.device)), mask.to(self.device)
 
+    # ---- hipGraph replay of the extract_* calls (MI355X serving path; no reference counterpart) -----------------------
+    def enable_graphs(self, on=True):
+        """Capture each extract_* call into one hipGraph per input shape (one_peace_amd/graphs.py) and replay it: at batch
+        1-8 the 40-layer forward is bound by the host's launch path.  Weights are captured by address: call again after
+        loading new weights or moving the model."""
+        self._graphs = {} if on else None
+        return self
+
+    def _run(self, tag, **kw):
+        graphs = getattr(self, "_graphs", None)
+        if graphs is None or not all(v.is_cuda for v in kw.values() if torch.is_tensor(v)):
+            return self._eager(tag, **kw)
+        if tag not in graphs:
+            from ..graphs import GraphCache
+            graphs[tag] = GraphCache(lambda _tag=tag, **k: self._eager(_tag, **k))
+        return graphs[tag](**kw)
+
+    def _eager(self, tag, **kw):
+        if tag == "vl":
+            tf, _, _ = self.model.encoder_wrapper(encoder_type="vl", **kw)
+            return tf[:, 0, :]
+        return self.model(encoder_type=tag, **kw)
+
     # ---- hub_interface.py:206-225 ---------------------------------------------------------------------------------
     @torch.no_grad()
     def extract_text_features(self, src_tokens):
-        return self.model(src_tokens=src_tokens, encoder_type="text")
+        return self._run("text", src_tokens=src_tokens)
 
     @torch.no_grad()
     def extract_image_features(self, src_images):
-        return self.model(src_images=self.cast_data_dtype(src_images), encoder_type="image")
+        return self._run("image", src_images=self.cast_data_dtype(src_images))
 
     @torch.no_grad()
     def extract_audio_features(self, src_audios, audio_padding_masks):
-        return self.model(src_audios=self.cast_data_dtype(src_audios), audio_padding_masks=audio_padding_masks,
-                          encoder_type="audio")
+        return self._run("audio", src_audios=self.cast_data_dtype(src_audios), audio_padding_masks=audio_padding_masks)
 
     @torch.no_grad()
     def extract_vl_features(self, src_images, src_tokens):
-        tf, imf, _ = self.model.encoder_wrapper(src_tokens=src_tokens, src_images=self.cast_data_dtype(src_images),
-                                                encoder_type="vl")
-        return tf[:, 0, :]
+        return self._run("vl", src_tokens=src_tokens, src_images=self.cast_data_dtype(src_images))

@@ -476,28 +476,32 @@ def test_batched_weight_cache_refresh_after_optimizer_step():
     assert losses["batched"] == losses["lazy"], losses
 
 
-def test_long_sequence_image_448_on_hip():
-    """BASELINE configs[4] shape class: 448^2 images -> 28 x 28 patches + CLS = 785 tokens (the streaming attention kernels
-    with 13 key tiles, separate dQ / dBias kernels, 2-D relative-position buckets at the larger grid), image tower forward +
-    backward of a small-width model, HIP against the fp32 torch path of the same mirror on the device."""
-    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_bucket_size=28, image_rel_bucket_size=28,
-               text_bucket_size=256, audio_bucket_size=512)
+@pytest.mark.parametrize("res_px", [448, 512])
+def test_long_sequence_image_on_hip(res_px):
+    """BASELINE configs[4] shape class: 448^2 images -> 28 x 28 patches + CLS = 785 tokens and 512^2 -> 1025 tokens (the
+    streaming attention kernels with 13 / 17 key tiles, separate dQ / dBias kernels, 2-D relative-position buckets at the
+    larger grid), image tower forward + backward of a small-width model, HIP against the fp32 torch path of the same mirror
+    on the device."""
+    grid = res_px // 16
+    S = grid * grid + 1
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_bucket_size=grid,
+               image_rel_bucket_size=grid, text_bucket_size=256, audio_bucket_size=512)
     g = torch.Generator().manual_seed(3)
-    imgs = torch.randn(2, 3, 448, 448, generator=g)
+    imgs = torch.randn(2, 3, res_px, res_px, generator=g)
     res = {}
     for mode in ("hip", "torch", "fp32"):
         dt = torch.float32 if mode == "fp32" else torch.bfloat16
         m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(dt).eval()
         _force_torch_path(m, mode != "hip")
         feats = m.encoder_wrapper(src_images=imgs.to(DEV).to(dt), encoder_type="image")[1]
-        assert feats.shape == (2, 785, 128)
+        assert feats.shape == (2, S, 128)
         w = torch.randn(feats.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
         m.zero_grad()
         (feats.float() * w).sum().backward()
         res[mode] = (feats.detach().float().cpu(),
                      {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
     report = []
-    _check("448^2 image features", res["hip"][0], res["torch"][0], res["fp32"][0], 1.5e-2, report)
+    _check("%d^2 image features" % res_px, res["hip"][0], res["torch"][0], res["fp32"][0], 1.5e-2, report)
     n = 0
     for k, ref in res["fp32"][1].items():
         if float(ref.norm()) > 1e-7:
@@ -522,3 +526,52 @@ def test_retrieval_criteria_on_hip(golden_dir):
     assert float(log_at["a2t_ncorrect"]) == float(fx["a2t"]) and float(log_at["t2a_ncorrect"]) == float(fx["t2a"])
     (l_it + l_at).backward()
     assert m.logit_scale.grad is not None and torch.isfinite(m.logit_scale.grad)
+
+
+def test_hub_interface_feature_extraction_on_hip(golden_dir):
+    """BASELINE configs[0]/[1] surface on the device: OnePeaceHubInterface(device='cuda', dtype='bf16') and its four
+    extract_*_features calls (hub_interface.py:206-225) run the HIP path and reproduce the reference's outputs."""
+    from one_peace_amd import hip
+    from one_peace_amd.one_peace.hub_interface import OnePeaceHubInterface
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    hub = OnePeaceHubInterface(load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]), device=DEV, dtype="bf16")
+    assert next(hub.model.parameters()).dtype == torch.bfloat16 and not hub.model.training
+    inp = fx["inputs"]
+    before = hip.GEMM_ALGO_BYTES[1]
+    toks = hub.process_text([row[row != 1] for row in inp["src_tokens"]])
+    assert torch.equal(toks.cpu(), inp["src_tokens"])
+    outs = {"text": hub.extract_text_features(toks),
+            "image": hub.extract_image_features(hub.process_image(inp["src_images"])),
+            "audio": hub.extract_audio_features(inp["src_audios"].to(DEV), inp["audio_padding_masks"].to(DEV)),
+            "vl": hub.extract_vl_features(inp["src_images"].to(DEV), toks)}
+    assert hip.GEMM_ALGO_BYTES[1] > before  # the HIP GEMMs ran (no torch fallback)
+    refs = {"text": fx["text_logits"], "image": fx["image_logits"], "audio": fx["audio_logits"], "vl": fx["vl_text"][:, 0]}
+    for k, ref in refs.items():
+        got = outs[k].float().cpu()
+        assert got.shape == ref.shape and not outs[k].requires_grad, k
+        assert rel_fro(got, ref) < 2e-2, (k, rel_fro(got, ref))
+
+
+def test_hub_interface_graph_replay_matches_eager(golden_dir):
+    """enable_graphs(): each extract_* call captured into one hipGraph per input shape; replay is bit-identical to the eager
+    HIP path, follows new input values, and a new batch shape gets its own graph."""
+    from one_peace_amd.one_peace.hub_interface import OnePeaceHubInterface
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    hub = OnePeaceHubInterface(load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]), device=DEV, dtype="bf16")
+    inp = _to_dev(fx["inputs"])
+    calls = {"text": lambda h, sl: h.extract_text_features(inp["src_tokens"][sl]),
+             "image": lambda h, sl: h.extract_image_features(inp["src_images"][sl]),
+             "audio": lambda h, sl: h.extract_audio_features(inp["src_audios"][sl], inp["audio_padding_masks"][sl]),
+             "vl": lambda h, sl: h.extract_vl_features(inp["src_images"][sl], inp["src_tokens"][sl])}
+    eager = {k: (f(hub, slice(0, 4)), f(hub, slice(0, 2)), f(hub, slice(2, 4))) for k, f in calls.items()}
+    hub.enable_graphs()
+    for k, f in calls.items():
+        first = f(hub, slice(0, 4))
+        assert torch.equal(first, eager[k][0]), k
+        assert torch.equal(f(hub, slice(0, 2)), eager[k][1]), k       # second shape -> second graph
+        assert torch.equal(f(hub, slice(2, 4)), eager[k][2]), k       # same graph, new values
+        assert torch.equal(f(hub, slice(0, 4)), eager[k][0]), k       # first graph again
+        assert torch.equal(first, eager[k][0])                        # returned tensors are not the static buffers
+        assert len(hub._graphs[k].graphs) == 2
+    hub.enable_graphs(False)
+    assert torch.equal(calls["text"](hub, slice(0, 4)), eager["text"][0])

@@ -649,22 +649,31 @@ def test_gemm_tail_rows_split(epi):
         hip.lib().op_gemm_set_tile(old)
 
 
+@pytest.mark.parametrize("shape", [(100, 512, 4096, 10), (257, 1536, 1536, 257), (514, 1536, 6144, 257), (1000, 4608, 1536, 8)])
 @pytest.mark.parametrize("epi", ["bias", "resid"])
-def test_gemm_small_m_split_k_with_epilogue_fold(epi):
-    """M <= 256 with a long K: the launch is latency-bound, so K is split and the epilogue (bias / residual + layer scale +
-    drop-path + saved branch output) is applied by the fold kernel."""
+def test_gemm_small_m_split_k_with_epilogue_fold(epi, shape):
+    """M <= 1024 (the leftover rows of a tail-rows split; batch-1..3 feature extraction at 257 tokens): the launch is
+    latency-bound on K with most CUs idle, so K is split and the epilogue (bias / residual + layer scale + drop-path + saved
+    branch output) is applied by the fold kernel."""
     hip = hipmod()
-    M, N, K, S = 100, 512, 4096, 10
+    M, N, K, S = shape
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.03), rnd(N, seed=3)
     if epi == "bias":
-        out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)])
-        assert_close(out, a @ w.t() + b, what="bias")
+        if N == 4608:  # three weight segments with their own biases (the q | k | v launch; k has no bias)
+            ws = [dev_bf16(w[i * 1536:(i + 1) * 1536]) for i in range(3)]
+            bs = [dev_bf16(b[:1536]), None, dev_bf16(b[3072:])]
+            out = hip.gemm_nt(dev_bf16(a), ws, bs)
+            ref = a @ w.t() + torch.cat([b[:1536], torch.zeros(1536), b[3072:]])
+        else:
+            out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)])
+            ref = a @ w.t() + b
+        assert_close(out, ref, what="bias")
     else:
         gamma, res = rnd(N, seed=4), rnd(M, N, seed=5)
-        ps = (torch.arange(M // S) % 3 != 1).float() / 0.66
+        ps = (torch.arange(-(-M // S)) % 3 != 1).float() / 0.66
         y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         out = hip.gemm_nt(dev_bf16(a), [dev_bf16(w)], [dev_bf16(b)], epilogue=hip.EPI_RESID, resid=dev_bf16(res),
                           gamma=dev_bf16(gamma), rowscale=ps.to(DEV), rows_per_sample=S, h0=y)
         branch = a @ w.t() + b
         assert_close(y, branch, what="branch output")
-        assert_close(out, res + ps.repeat_interleave(S)[:, None] * gamma * branch, what="resid")
+        assert_close(out, res + ps.repeat_interleave(S)[:M, None] * gamma * branch, what="resid")

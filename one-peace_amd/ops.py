@@ -679,7 +679,9 @@ class InfoNCEFn(torch.autograd.Function):
         loss = 0.5 * (rows[0][0].mean() + rows[1][0].mean())
         ctx.save_for_backward(a_local, b_local, a_all, b_all, scale_f, sims[0], sims[1], rows[0][2], rows[1][2])
         ctx.scale_dtype = scale.dtype
-        return loss, rows[0][1].sum(), rows[1][1].sum()
+        hits_a, hits_b = rows[0][1].sum(), rows[1][1].sum()
+        ctx.mark_non_differentiable(hits_a, hits_b)  # counters for logging, as under the reference's no-grad argmax
+        return loss, hits_a, hits_b
 
     @staticmethod
     def backward(ctx, gl, _ga, _gb):

@@ -231,7 +231,7 @@ def main():
     nparams = sum(p.numel() for p in model.parameters())
     no_decay_names = model.no_weight_decay()
     flat = FlatParameters(model, no_decay=lambda n, p: p.dim() <= 1 or n in no_decay_names)
-    if world > 1:  # replicas start from rank 0's weights (fairseq: distributed_utils.broadcast of the initial state)
+    if dist.is_initialized():  # replicas start from rank 0's weights (fairseq: distributed_utils.broadcast of the initial state)
         dist.broadcast(flat.params, src=0)
     reducer = BucketedGradReducer(flat)
     opt = FusedAdamW(flat, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)  # pretrain_vl_3B.yaml:24-36
@@ -269,7 +269,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -298,7 +298,7 @@ def main():
                   file=sys.stderr, flush=True)
         assert same, "data-parallel replicas diverged: a gradient bucket was reduced before its last contribution"
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_v = float(loss.float().item())
@@ -325,6 +325,8 @@ def main():
                        "embed_dim": H, "ffn": FFN, "layers": args.layers, "heads": HEADS, "params": nparams,
                        "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "tokens_per_sample": (S_img + S_txt) if full else (S_img + S_txt + audio_S), "parallelism": "dp%d" % world,
+                       "collectives": ("%s: broadcast, [3,b,H] all-gather, bucketed gradient all-reduce" % dist.get_backend()
+                                       if dist.is_initialized() else "none (single process)"),
                        "activation_recompute": ("per layer (the reference's checkpoint_activations: true)" if args.recompute
                                                 else "off: layer activations are kept in HBM (288 GB/GPU)"),
                        "algorithmic_tflop_per_sample": None if full else fl / 1e12,
@@ -352,7 +354,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,10 +13,16 @@ import torch
 import torch.distributed as dist
 
 
+def force_collectives():
+    """ONEPEACE_FORCE_COLLECTIVES=1: run the broadcast / all-gather / bucketed all-reduce path even at world size 1 (under
+    torchrun --nproc-per-node 1), so the RCCL code path can be exercised on a single-GPU box."""
+    return bool(os.environ.get("ONEPEACE_FORCE_COLLECTIVES")) and "RANK" in os.environ
+
+
 def init_distributed(backend=None):
     """torchrun-style env:// initialisation; returns (rank, world, local_rank).  No-op for single-process runs."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not force_collectives():
         return 0, 1, int(os.environ.get("LOCAL_RANK", "0"))
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -76,6 +82,7 @@ class BucketedGradReducer:
     def __init__(self, flat: FlatParameters, bucket_bytes=256 << 20, process_group=None):
         self.flat, self.pg = flat, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and force_collectives())
         cap = max(1, bucket_bytes // flat.grads.element_size())
         self.buckets = []  # (start, end, [param indices])
         cur_start, cur_items = 0, []
@@ -94,7 +101,7 @@ class BucketedGradReducer:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._hooks = []
-        if self.world > 1:
+        if self.active:
             for idx, (n, p, o, k) in enumerate(flat.entries):
                 hook = self._make_hook(idx)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
@@ -117,7 +124,7 @@ class BucketedGradReducer:
 
     def finish(self):
         """Waits for the launched buckets and reduces any bucket whose hooks did not all fire (unused parameters)."""
-        if self.world <= 1:
+        if not self.active:
             return
         for b, left in enumerate(self._pending):
             if left > 0:

@@ -955,6 +955,7 @@ int g_fullline = 2;  // BK = 64 full-line flavour of the 256^2 NT kernel: 0 off,
 int g_tail_rows = 1;  // 1: split off the <= 128 leftover rows when that saves a round (op_gemm_set_tile(50/51/52))
 int g_gm = 0;        // M-tiles per L2 group of the 256x256 kernels; 0 = auto (op_gemm_set_tile(40 + gm))
 int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + barriers only, 5 = MFMAs only in the steady loop
+int g_force_splits = 0;  // tools only: > 0 forces the K-split count of small problems (tools/gemm_small_m.py)
                      // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
 
 template <int EPI>
@@ -1103,6 +1104,24 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256
   const int64_t t256 = (int64_t)ceil_div(M, 256) * ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
   GemmPlan best = {128, 1, 0};
   double best_t = 1e300;
+  if (t128 <= 256 && epilogue != EPI_GEGLU) {
+    // Small problems (batch-1 feature extraction, M = 257; the leftover rows of a tail-rows split): fewer 128x128 tiles than
+    // CUs.  Measured under hipGraph replay with cold weights (tools/gemm_small_m.py, profiles/r1_gemm_small_m.txt): a launch
+    // costs 4.3 us + 0.62 us per 64-deep K-step of the slowest workgroup while every workgroup has a CU to itself, ~1.2 us
+    // per step with two per CU; the 256x256 kernel is 8 us + 0.5 us per 32-deep step and never wins here.  Splitting K
+    // spreads the K-steps over the idle CUs at the price of the fold launch (4.5 us) and the fp32 slab round trip.
+    const int nk = (int)(K / BK);
+    for (int s = 1; s <= 8; ++s) {
+      if (s > 1 && (!allow_split || (int64_t)s * M * N * 4 > ws_bytes || nk / s < 2)) break;
+      const int kps = ceil_div(nk, s), eff_s = ceil_div(nk, kps);
+      const int64_t blocks = t128 * eff_s;
+      const double per_cu = blocks <= 256 ? 1.0 : 0.94 * (double)((blocks + 255) / 256);
+      double t = 4.3 + 0.62 * per_cu * kps;
+      if (eff_s > 1) t += 4.5 + (double)eff_s * M * N * 8.0 / 4.0e6;  // slab bytes at 4 TB/s, in us
+      if (g_force_splits > 0 ? s == g_force_splits : t < best_t) { best_t = t; best = {128, eff_s, eff_s > 1 ? kps : 0}; }
+    }
+    return best;
+  }
   for (int tile = 128; tile <= 256; tile += 128) {
     if (tile == 256 && !allow_256) continue;
     const int bk = tile == 128 ? BK : BK2;
@@ -1135,6 +1154,7 @@ extern "C" {
 // 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
 int op_gemm_set_tile(int mode) {
   int old = g_tile_mode;
+  if (mode >= 60) { g_force_splits = mode - 60; return old; }  // 60: planner's choice, 60+s: s K-splits for small problems (tools)
   if (mode >= 50) { g_tail_rows = mode - 50; return old; }  // 50: off, 51: on (K >= 1024), 52: whenever it saves a round, 53: always (tests)
   if (mode >= 40) { g_gm = mode - 40; return old; }  // 40: auto, 40+g: g M-tiles per L2 group
   if (mode >= 20) { g_fullline = mode - 20; return old; }  // 20/21/22: BK = 32 / BK = 64 / auto flavour of the 256x256 NT kernel

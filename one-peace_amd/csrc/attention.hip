@@ -17,6 +17,8 @@
 // global -> registers -> LDS with the next tile's loads in flight during the current tile's MFMAs.
 //
 // Roofline: MFMA.  Algorithmic flops per launch = 4 * B * heads * S * S * 64 (QK^T + PV, 2 flops/MAC).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -55,14 +57,32 @@ __device__ __forceinline__ bf16x8 join_tr(s16x4 a, s16x4 b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// XCD-aware work mapping.  Workgroups are dispatched round-robin over the 8 XCDs by linear id, so the 2-5 workgroups that
+// share the K/V (or Q/dO) rows of one (sample, head) would land on different XCDs and each L2 would fetch those rows from
+// HBM again.  Re-deal the linear id so that consecutive work items run on ONE XCD: (bx, by, bz) replace blockIdx.
+__device__ __forceinline__ void xcd_work_item(int& bx, int& by, int& bz) {
+  const int nx = gridDim.x, ny = gridDim.y;
+  const int total = nx * ny * (int)gridDim.z;
+  int lin = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+  if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+  bx = lin % nx;
+  by = (lin / nx) % ny;
+  bz = lin / (nx * ny);
+}
+
+// HAS_BIAS / HAS_PAD are template parameters so that the bias and key-pad loads of a tile are plain straight-line loads,
+// issued together BEFORE the tile's QK^T MFMAs (as run-time `if (p.bias)` branches the compiler emitted eight serialised
+// load -> s_waitcnt pairs per tile after them: one exposed L2 round trip per fragment).
+template <bool HAS_BIAS, bool HAS_PAD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[BKV * 128 + BKV * VSTRIDE];
   char* ldsK = smem;
   char* ldsV = smem + BKV * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * BQ + wid * 32;
+  int bx, h, b;
+  xcd_work_item(bx, h, b);
+  const int q0 = bx * BQ + wid * 32;
   const bool wave_active = q0 < p.S;
   const int64_t row_base = (int64_t)b * p.S;
 
@@ -112,15 +132,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     }
   };
 
-  const int ntiles = (p.S + BKV - 1) / BKV;
-  load_tile(0);
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const int k0 = kt * BKV;
-    __syncthreads();
-    write_tile();
-    __syncthreads();
-    if (kt + 1 < ntiles) load_tile(k0 + BKV);
-    if (!wave_active) continue;  // wave-uniform; barriers above are still reached every iteration
+  // per-lane bias / key-pad row bases (clamped query row, key offset g*4 folded in); every tile of 64 keys lies inside Spad
+  const bf16_t* brow[2] = {nullptr, nullptr};
+  if constexpr (HAS_BIAS) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int qi = min(q0 + qb * 16 + t, p.S - 1);
+      brow[qb] = p.bias + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qi) * p.Spad + g * 4;
+    }
+  }
+  const uint8_t* padrow = HAS_PAD ? p.key_pad + (int64_t)b * p.Spad + g * 4 : nullptr;
+
+  // One 64-key tile.  FULL: all 64 keys are inside the sequence -> no bounds masks, no partial-block control flow.
+  auto tile = [&](const int k0, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const int nkb = FULL ? 4 : ((p.S - k0 + 15) >> 4);  // valid 16-key blocks (1..4)
+    bf16x4 bv[2][4];
+    unsigned padw[4] = {0u, 0u, 0u, 0u};
+    if constexpr (HAS_BIAS) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) bv[qb][kb] = *reinterpret_cast<const bf16x4*>(brow[qb] + k0 + kb * 16);
+    }
+    if constexpr (HAS_PAD) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) padw[kb] = *reinterpret_cast<const unsigned*>(padrow + k0 + kb * 16);
+    }
 
     // ---- S^T = K . Q^T ----
     f32x4 st[2][4];
@@ -130,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
       for (int kb = 0; kb < 4; ++kb) st[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      if (k0 + kb * 16 >= p.S) break;  // uniform: key blocks past the sequence end are masked anyway
+      if (!FULL && kb >= nkb) break;  // uniform: key blocks past the sequence end are masked anyway
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
@@ -141,31 +179,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     }
 
     // ---- scale + bias + masks; online softmax per query column ----
-    unsigned padw[4] = {0u, 0u, 0u, 0u};
-    if (p.key_pad) {
-#pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
-        padw[kb] = *reinterpret_cast<const unsigned*>(p.key_pad + (int64_t)b * p.Spad + k0 + kb * 16 + g * 4);
-    }
     bf16x8 pf[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      const int qi = min(q0 + qb * 16 + t, p.S - 1);
       float mx = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
         const int key = k0 + kb * 16 + g * 4;
-        float bb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-          const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.bias + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qi) * p.Spad + key);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
-        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float s = st[qb][kb][r] * p.scale + bb[r];
-          const bool masked = (key + r >= p.S) || ((padw[kb] >> (8 * r)) & 0xffu);
-          s = masked ? -INFINITY : s;
+          float s = st[qb][kb][r] * p.scale;
+          if constexpr (HAS_BIAS) s += (float)bv[qb][kb][r];
+          if constexpr (!FULL || HAS_PAD) {
+            bool masked = false;
+            if constexpr (!FULL) masked = key + r >= p.S;
+            if constexpr (HAS_PAD) masked = masked || ((padw[kb] >> (8 * r)) & 0xffu);
+            s = masked ? -INFINITY : s;
+          }
           st[qb][kb][r] = s;
           mx = fmaxf(mx, s);
         }
@@ -198,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-      if (k0 + m * 32 >= p.S) break;  // P is exactly zero there
+      if (!FULL && 2 * m >= nkb) break;  // P is exactly zero there
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const char* base = ldsV + (t >> 2) * VSTRIDE + (db * 16 + (t & 3) * 4) * 2;
@@ -210,6 +240,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
           ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][m], ot[qb][db], 0, 0, 0);
       }
     }
+  };
+
+  const int ntiles = (p.S + BKV - 1) / BKV;
+  load_tile(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * BKV;
+    __syncthreads();
+    write_tile();
+    __syncthreads();
+    // (measured: issuing this prefetch AFTER the tile's bias loads -- so that the bias wait does not include it -- is 10 %
+    // slower here, unlike in the backward kernels)
+    if (kt + 1 < ntiles) load_tile(k0 + BKV);
+    if (!wave_active) continue;  // wave-uniform; the barriers above are still reached every iteration
+    if (k0 + BKV <= p.S) tile(k0, std::true_type{});
+    else tile(k0, std::false_type{});
   }
 
   if (!wave_active) return;
@@ -297,14 +342,16 @@ __device__ __forceinline__ int tr_off_swz(int rowblk, int db, int g, int t) {
   return row * 128 + ((c ^ (row & 7)) << 4) + (t & 1) * 8;
 }
 
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
   char* ldsQ = smem;
   char* ldsO = smem + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int kbase = blockIdx.x * 128 + wid * 32;
+  int bx, h, b;
+  xcd_work_item(bx, h, b);
+  const int kbase = bx * 128 + wid * 32;
   const bool wave_active = kbase < p.S;
   const int64_t row_base = (int64_t)b * p.S;
 
@@ -356,14 +403,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   const int ntiles = (p.S + 63) / 64;
   const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * p.Spad;
   const float* del_b = p.delta + ((int64_t)b * p.heads + h) * p.Spad;
+  const bf16_t* brow[2] = {nullptr, nullptr};  // transposed bias image rows of this lane's two keys
+  if constexpr (HAS_BIAS) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int key = min(kbase + kb * 16 + t, p.S - 1);
+      brow[kb] = p.biasT + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + key) * p.Spad;
+    }
+  }
   load_tile(0);
   for (int qt = 0; qt < ntiles; ++qt) {
     const int q0 = qt * 64;
     __syncthreads();
     write_tile();
     __syncthreads();
-    if (qt + 1 < ntiles) load_tile(q0 + 64);
-    if (!wave_active) continue;
+    if (!wave_active) {
+      load_tile(q0 + 64);
+      continue;
+    }
+    // lse / delta / bias fragments of both 32-query halves first, THEN the next tile's Q / dO prefetch: s_waitcnt vmcnt
+    // counts in issue order, so small loads issued behind the prefetch would make their wait a wait for the prefetch.
+    f32x4 l4[2][2], d4[2][2];
+    bf16x4 bv[2][2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int qrow = q0 + (2 * m + j) * 16 + g * 4;  // + r; < Spad
+        l4[m][j] = *reinterpret_cast<const f32x4*>(lse_b + qrow);
+        d4[m][j] = *reinterpret_cast<const f32x4*>(del_b + qrow);
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) bv[m][j][kb] = *reinterpret_cast<const bf16x4*>(brow[kb] + qrow);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    load_tile(q0 + 64);  // unconditional (rows clamped to S-1): a branch here would force s_waitcnt vmcnt(0) below
+    __builtin_amdgcn_sched_barrier(0);
 
     // per 32-query half m:  S[q][key] = Q K^T, dP[q][key] = dO V^T  (lane (g,t): q = qb*16 + g*4 + r, key = t),
     // then P, dS in place, then dV^T[d][key] += dO^T[d][q] P[q][key] and dK^T[d][key] += Q^T[d][q] dS[q][key]
@@ -393,23 +469,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int qrow = q0 + (2 * m + j) * 16 + g * 4;  // + r
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_b + qrow);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_b + qrow);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          const int key = min(kbase + kb * 16 + t, p.S - 1);
-          float bb[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.biasT) {
-            const bf16x4 bv = *reinterpret_cast<const bf16x4*>(p.biasT + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + key) * p.Spad + qrow);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
-          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool dead = kmask[kb] || (qrow + r >= p.S);
-            const float pr = dead ? 0.f : __expf(s[j][kb][r] * p.scale + bb[r] - l4[r]);
+            float x = s[j][kb][r] * p.scale;
+            if constexpr (HAS_BIAS) x += (float)bv[m][j][kb][r];
+            x -= l4[m][j][r];
+            const float pr = __expf(dead ? -INFINITY : x);
             s[j][kb][r] = pr;
-            dp[j][kb][r] = pr * (dp[j][kb][r] - d4[r]);
+            // lse / delta entries at rows >= S are unspecified (possibly NaN): select, do not rely on 0 * x
+            const float dsv = pr * (dp[j][kb][r] - d4[m][j][r]);
+            dp[j][kb][r] = dead ? 0.f : dsv;
           }
         }
       }
@@ -456,11 +528,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 }
 
 // Shared by the dQ and dBias kernels: for one 64-key tile, lane (g,t) computes dS^T[key = kb*16 + g*4 + r][q = t]
-// for its two query blocks.  KF/VF: functors returning the first-operand fragment (K or V rows) for (kb, kk).
-template <int QB, typename KF, typename VF, typename BF>
+// for its QB query blocks.  KF/VF: functors returning the first-operand fragment (K or V rows) for (kb, kk).
+// HAS_BIAS is a template parameter and, with HOIST, the QB x 4 bias fragments and the key-pad words are loaded BEFORE the
+// MFMAs (a run-time `if (p.bias)` per fragment compiled to serialised load -> s_waitcnt pairs after them); masked entries
+// get -inf on the exponent's INPUT, so the exponentials are straight-line code (`dead ? 0 : exp(x)` became one exec-mask
+// branch per element).
+// `prefetch()` issues the caller's next-tile global loads; it runs AFTER the hoisted bias / pad loads (s_waitcnt vmcnt counts
+// in issue order: a bias wait behind the prefetch would wait for the prefetch too).
+template <int QB, bool HAS_BIAS, bool HOIST, typename KF, typename VF, typename BF, typename PF>
 __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int k0, int q0w, int g, int t,
                                         const bf16x8 (&qf)[QB][2], const bf16x8 (&of)[QB][2], const float (&lse)[QB],
-                                        const float (&del)[QB], KF kfrag, VF vfrag, BF biasfrag, f32x4 (&ds)[QB][4]) {
+                                        const float (&del)[QB], KF kfrag, VF vfrag, BF biasfrag, PF prefetch,
+                                        f32x4 (&ds)[QB][4]) {
+  unsigned padw[4] = {0u, 0u, 0u, 0u};
+  auto load_pad = [&]() {
+    if (p.key_pad) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+        padw[kb] = *reinterpret_cast<const unsigned*>(p.key_pad + (int64_t)b * p.Spad + k0 + kb * 16 + g * 4);
+    }
+  };
+  if constexpr (HOIST) load_pad();
+  bf16x4 bv[QB][4];
+  if constexpr (HAS_BIAS && HOIST) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int qi = min(q0w + qb * 16 + t, p.S - 1);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) bv[qb][kb] = biasfrag(qb, kb, qi, k0 + kb * 16 + g * 4);
+    }
+  }
+  if constexpr (HOIST) __builtin_amdgcn_sched_barrier(0);  // keep the small loads ahead of the prefetch
+  prefetch();
+  if constexpr (HOIST) __builtin_amdgcn_sched_barrier(0);
   f32x4 st[QB][4];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb)
@@ -480,12 +580,7 @@ __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int 
       }
     }
   }
-  unsigned padw[4] = {0u, 0u, 0u, 0u};
-  if (p.key_pad) {
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-      padw[kb] = *reinterpret_cast<const unsigned*>(p.key_pad + (int64_t)b * p.Spad + k0 + kb * 16 + g * 4);
-  }
+  if constexpr (!HOIST) load_pad();  // (the kernels at the register limit keep the short live ranges)
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int qraw = q0w + qb * 16 + t;
@@ -493,30 +588,33 @@ __device__ __forceinline__ void ds_tile(const AttnBwdArgs& p, int b, int h, int 
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int key = k0 + kb * 16 + g * 4;
-      float bb[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-        const bf16x4 bv = biasfrag(qb, kb, qi, key);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bb[r] = (float)bv[r];
-      }
+      if constexpr (HAS_BIAS && !HOIST) bv[qb][kb] = biasfrag(qb, kb, qi, key);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool dead = (key + r >= p.S) || ((padw[kb] >> (8 * r)) & 0xffu) || (qraw >= p.S);
-        const float pr = dead ? 0.f : __expf(st[qb][kb][r] * p.scale + bb[r] - lse[qb]);
-        ds[qb][kb][r] = pr * (ds[qb][kb][r] - del[qb]);
+        float x = st[qb][kb][r] * p.scale;
+        if constexpr (HAS_BIAS) x += (float)bv[qb][kb][r];
+        x -= lse[qb];
+        float pr;
+        if constexpr (HOIST) pr = __expf(dead ? -INFINITY : x);
+        else pr = dead ? 0.f : __expf(x);
+        const float dsv = pr * (ds[qb][kb][r] - del[qb]);
+        ds[qb][kb][r] = dead ? 0.f : dsv;
       }
     }
   }
 }
 
+template <bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
   char* ldsK = smem;
   char* ldsV = smem + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0w = blockIdx.x * BQ + wid * 32;
+  int bx, h, b;
+  xcd_work_item(bx, h, b);
+  const int q0w = bx * BQ + wid * 32;
   const bool wave_active = q0w < p.S;
   const int64_t row_base = (int64_t)b * p.S;
 
@@ -571,8 +669,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     __syncthreads();
     write_tile();
     __syncthreads();
-    if (kt + 1 < ntiles) load_tile(k0 + BKV);
-    if (!wave_active) continue;
+    if (!wave_active) {
+      load_tile(k0 + BKV);
+      continue;
+    }
+    auto prefetch = [&]() { load_tile(k0 + BKV); };  // unconditional: rows are clamped to S-1 past the last tile
     f32x4 ds[2][4];
     auto kfrag = [&](int kb, int kk) {
       return *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
@@ -583,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     auto biasfrag = [&](int, int, int qi, int key) {
       return *reinterpret_cast<const bf16x4*>(p.bias + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qi) * p.Spad + key);
     };
-    ds_tile<2>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
+    ds_tile<2, HAS_BIAS, true>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, prefetch, ds);
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -634,8 +735,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
   char* ldsV = smem + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
-  const int h = blockIdx.y, chunk = blockIdx.z;
-  const int q0w = blockIdx.x * 64 + wid * 16;
+  int bx, h, chunk;
+  xcd_work_item(bx, h, chunk);
+  const int q0w = bx * 64 + wid * 16;
   const bool wave_active = q0w < p.S;
   const int qi = min(q0w + t, p.S - 1);
 
@@ -709,9 +811,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
       __syncthreads();
       write_tile();
       __syncthreads();
-      if (kt + 1 < NT) load_tile(b, k0 + BKV);
-      else if (b + 1 < b_end) load_tile(b + 1, 0);
-      if (!wave_active) continue;
+      // next tile of this sample, or the first tile of the next one; unconditional (clamped) so that the compiler can count
+      // the outstanding loads instead of waiting for vmcnt(0)
+      const bool last_kt = kt + 1 >= NT;
+      const int nb = last_kt ? min(b + 1, b_end - 1) : b, nk0 = last_kt ? 0 : k0 + BKV;
+      auto prefetch = [&]() { load_tile(nb, nk0); };
+      if (!wave_active) {
+        prefetch();
+        continue;
+      }
       f32x4 ds[1][4];
       auto kfrag = [&](int kb, int kk) {
         return *reinterpret_cast<const bf16x8*>(ldsK + (kb * 16 + t) * 128 + (((kk * 4 + g) ^ (t & 7)) << 4));
@@ -722,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
       auto biasfrag = [&](int, int, int qrow, int key) {
         return *reinterpret_cast<const bf16x4*>(p.bias + bias_resample + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qrow) * p.Spad + key);
       };
-      ds_tile<1>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
+      ds_tile<1, true, (NT < 6)>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, prefetch, ds);
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
         if (kt == c) {
@@ -757,17 +865,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
     }
   }
   if (!wave_active || q0w + t >= p.S) return;
+  // slab `chunk` of dbias belongs to this batch chunk alone: plain read-modify-write (fp32 atomics from several chunks on
+  // one slab cost more than the whole rest of this kernel).  Four loads in flight per key tile, then four stores.
+  float* drow = p.dbias + (((int64_t)chunk * p.heads + h) * p.S + q0w + t) * p.Spad + g * 4;
 #pragma unroll
-  for (int kt = 0; kt < NT; ++kt)
+  for (int kt = 0; kt < NT; ++kt) {
+    f32x4 cur[4];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-      const int key = kt * BKV + kb * 16 + g * 4;
-      if (key >= p.Spad) continue;
-      // slab `chunk` of dbias belongs to this batch chunk alone: plain read-modify-write (fp32 atomics from several
-      // chunks on one slab cost more than the whole rest of this kernel)
-      f32x4* dst = reinterpret_cast<f32x4*>(p.dbias + (((int64_t)chunk * p.heads + h) * p.S + q0w + t) * p.Spad + key);
-      *dst = *dst + acc[kt][kb];
-    }
+    for (int kb = 0; kb < 4; ++kb)
+      if (kt * BKV + kb * 16 < p.Spad) cur[kb] = *reinterpret_cast<const f32x4*>(drow + kt * BKV + kb * 16);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+      if (kt * BKV + kb * 16 < p.Spad) *reinterpret_cast<f32x4*>(drow + kt * BKV + kb * 16) = cur[kb] + acc[kt][kb];
+  }
 }
 
 // grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
@@ -862,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
     };
     auto biasfrag = [&](int qb, int kb, int, int) { return breg[qb][kb]; };
     f32x4 ds[2][4];
-    ds_tile<2>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, ds);
+    ds_tile<2, true, false>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, [] {}, ds);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -884,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
   }
 }
 
-int g_merge_dbias = 1;  // 1: dQ + dBias in one kernel when the sequence fits (<= 384 keys); 0: separate kernels (tests)
+int g_merge_dbias = 1;     // 1: dQ + dBias in one kernel when the sequence fits (<= 384 keys); 0: separate kernels (tests)
 
 // number of batch chunks (= dbias slabs) of the merged dQ + dBias kernel; 1 when the separate kernels run
 inline int dbias_chunks(int64_t B, int64_t S, int64_t heads) {
@@ -934,7 +1044,11 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
   dim3 grid(ceil_div(S, BQ), (unsigned)heads, (unsigned)B);
   const int slot = op_prof_begin(1, 4.0 * (double)B * (double)heads * (double)S * (double)S * HD, stream);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+  hipStream_t s = (hipStream_t)stream;
+  if (bias && key_pad) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
+  else if (bias) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
+  else if (key_pad) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, s, a);
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
   return OP_OK;
@@ -965,6 +1079,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   OP_CHECK_ARG(head_dim == HD, "attn_bwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(Spad >= ((S + 127) / 128) * 128 && Spad % 8 == 0, "attn_bwd: Spad must be >= S rounded up to 128");
   OP_CHECK_ARG((bias == nullptr) == (biasT == nullptr), "attn_bwd: bias and biasT must be given together");
+  OP_CHECK_ARG(!dbias || bias, "attn_bwd: dbias without a bias");
   OP_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && ldg % 4 == 0, "attn_bwd: bad leading dims");
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
@@ -985,7 +1100,8 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   hipStream_t s = (hipStream_t)stream;
   const double fl = 4.0 * (double)B * (double)heads * (double)S * (double)S * HD;
   int slot = op_prof_begin(2, 2.0 * fl, stream);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
+  if (bias) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
   const int nt = ceil_div(S, BKV);
@@ -1008,7 +1124,8 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
     return OP_OK;
   }
   slot = op_prof_begin(2, 1.5 * fl, stream);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(ceil_div(S, BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
+  if (bias) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(ceil_div(S, BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(ceil_div(S, BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
   if (dbias) {

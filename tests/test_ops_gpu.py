@@ -459,6 +459,43 @@ def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias)
         assert_close(dbias[:, :, :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="dbias")
 
 
+@pytest.mark.parametrize("B,S,heads", [(20, 72, 2), (3, 257, 2), (2, 330, 1)])
+def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_dbias):
+    """lse / delta rows, bias columns and bias rows in [S, Spad) are unspecified (the wrappers allocate with torch.empty, the
+    delta kernel writes rows < S only): poison them with NaN / Inf and require the same gradients (a `0 * x` on a masked
+    entry instead of a select turns a NaN there into NaN dK / dV for the whole key block)."""
+    hip = hipmod()
+    H = heads * 64
+    qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad = _attn_inputs(B, S, heads, True, True)
+    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+    dout = dev_bf16(rnd(B * S, H, seed=3))
+    clean, clean_dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, out, lse, B, S, heads, 0.125,
+                                      bias_d, biasT_d, pad_d, Spad, want_dbias=True)
+    assert clean.isfinite().all() and clean_dbias[:, :, :S].isfinite().all()
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=DEV)
+    hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dout), hip.ptr(out), dout.stride(0), hip.ptr(delta), B, S, Spad, heads,
+                                           hip.stream()), "op_attn_bwd_delta")
+    lse_p = lse.clone()
+    lse_p[:, :, S:] = float("nan")
+    delta[:, :, S:] = float("inf")
+    bias_p, biasT_p = bias_d.clone(), biasT_d.clone()
+    bias_p[:, :, S:] = float("nan")
+    biasT_p[:, :, S:] = float("nan")
+    dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=DEV)
+    dbias = hip.attn_dbias_buffer(B, S, heads, Spad, DEV)
+    hip.attn_bwd_launch(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, bias_p, biasT_p, pad_d, lse_p, delta,
+                        dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], 3 * H, dbias, B, S, Spad, heads, 0.125)
+    assert torch.equal(dqkv, clean)
+    got = dbias.sum(0)[:, :, :S]
+    assert got.isfinite().all()
+    if merge_dbias:  # slabs with plain read-modify-write: deterministic
+        assert torch.equal(got, clean_dbias[:, :, :S])
+    else:            # the separate dBias kernel adds batch chunks with fp32 atomics: order-dependent last bits
+        assert_close(got, clean_dbias[:, :, :S].cpu(), fro=1e-5, mx=1e-4, what="dbias")
+    out_p, _ = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_p, pad_d, Spad)
+    assert torch.equal(out_p, out)
+
+
 @pytest.mark.parametrize("B,S,heads,use_pad", [(3, 70, 2, True), (5, 83, 3, False), (2, 257, 2, True)])
 def test_attention_per_sample_bias(B, S, heads, use_pad):
     """Masked pretraining gathers a different token subset per sample, so the additive bias is [B, heads, S, S]

@@ -137,6 +137,28 @@ def test_hub_interface_from_pretrained_roundtrip(golden_dir, tmp_path):
     assert torch.allclose(out, fx["text_logits"], atol=ATOL, rtol=1e-4)
 
 
+def test_hub_interface_all_modalities_and_graph_switch_on_cpu(golden_dir):
+    """extract_{text,image,audio,vl}_features of the hub mirror reproduce the reference's outputs (fp32, CPU torch path);
+    enable_graphs() is a device feature: CPU tensors keep running eagerly, and a GraphedCall over CPU tensors fails loudly."""
+    from one_peace_amd.graphs import GraphedCall
+    from one_peace_amd.one_peace.hub_interface import OnePeaceHubInterface
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    hub = OnePeaceHubInterface(load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]), device="cpu", dtype="float32")
+    inp = fx["inputs"]
+    toks = hub.process_text([row[row != 1] for row in inp["src_tokens"]])
+    refs = {"text": fx["text_logits"], "image": fx["image_logits"], "audio": fx["audio_logits"], "vl": fx["vl_text"][:, 0]}
+    for graphs in (False, True):
+        hub.enable_graphs(graphs)
+        outs = {"text": hub.extract_text_features(toks),
+                "image": hub.extract_image_features(hub.process_image(inp["src_images"])),
+                "audio": hub.extract_audio_features(inp["src_audios"], inp["audio_padding_masks"]),
+                "vl": hub.extract_vl_features(inp["src_images"], toks)}
+        for k, ref in refs.items():
+            assert torch.allclose(outs[k], ref, atol=ATOL, rtol=1e-4), k
+    with pytest.raises(RuntimeError, match="device tensors"):
+        GraphedCall(lambda x: x + 1, {"x": torch.zeros(2)})
+
+
 def _build_pretrain(fx, audio_language=False):
     from types import SimpleNamespace
     from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel

@@ -193,7 +193,9 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
     # small latency-bound launches (a few M-tiles: the leftover rows of a tail-rows split, batch-1 feature extraction)
     # whose bias / residual epilogue the fold kernel applies.  The library decides; handing the scratch over costs nothing.
     if splitk and epilogue in (EPI_BIAS, EPI_RESID) and (K >= 2048 or M <= 1024):
-        ws = workspace(SPLITK_WS_BYTES, A.device, "gemm_splitk")
+        # at most 8 fp32 slabs of the output (the planner's limit); small launches (feature extraction under hipGraph
+        # capture, where every capture stream gets its own scratch) then pin megabytes, not the training-size buffer
+        ws = workspace(min(SPLITK_WS_BYTES, 32 * M * Nn), A.device, "gemm_splitk")
         ws_bytes = ws.numel()
     outs = 1 + (2 if h1 is not None else (1 if h0 is not None else 0))
     GEMM_ALGO_BYTES[0] += 2 * (M * K + Nn * K * (2 if epilogue == EPI_GEGLU else 1) + (M * Nn if resid is not None else 0)) \

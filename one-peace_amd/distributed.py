@@ -33,7 +33,24 @@ def init_distributed(backend=None):
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        warm_up_collectives()
     return rank, world, local
+
+
+def warm_up_collectives():
+    """One tiny launch of every collective kind the step uses, right after initialisation.  RCCL sets up its rings and
+    transport buffers (device memory taken from the driver, outside torch's allocator) when a collective kind is first used;
+    doing that now keeps those allocations away from the moment the step has filled the GPU with activations."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    world = dist.get_world_size()
+    x = torch.ones(1024, dtype=torch.bfloat16, device=dev)
+    dist.broadcast(x, src=0)
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, async_op=True).wait()
+    gathered = torch.empty(world * x.numel(), dtype=x.dtype, device=dev)
+    dist.all_gather_into_tensor(gathered, x)
+    t = torch.zeros(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
 
 
 class FlatParameters:

@@ -78,9 +78,15 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
                int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* 1 = LDS-DMA (global_load_lds) operand staging [default], 0 = register-staged variant.  Returns the old value. */
 int op_gemm_set_staging(int glds);
-/* 0 = auto (256x256 four-stage kernel when it yields >= 192 workgroups, else 128x128), 1 = force 128x128,
- * 2 = force 256x256.  Returns the old value. */
+/* Tile / schedule knobs (tests and tools).  0 = auto (a cost model picks 128x128 or 256x256 tiles, K-splits and the
+ * tail-rows split), 1 = force 128x128, 2 = force 256x256; 10..16 timing ablations of the 256x256 kernel; 20/21/22 BK = 32 /
+ * BK = 64 / auto flavour; 40+g M-tiles per L2 group; 50..53 tail-rows split off / on / eager / always; 60+s forced K-split
+ * count for small problems.  Returns the old tile mode. */
 int op_gemm_set_tile(int mode);
+/* Host-only query (no GPU needed): the launch decision op_gemm_nt takes for a dense, single-segment problem.
+ * plan[0] = tile (128 | 256), plan[1] = K-splits, plan[2] = 1 if the epilogue runs in the split-K fold kernel,
+ * plan[3] = leftover rows (M % 256) split off into a second, small launch (0 = none). */
+int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int* plan);
 
 /* ---- attention ---------------------------------------------------------------------------------------------------
  * Replaces multihead_attention.py:102-115 (bmm QK^T, += attn_mask, fp32 softmax, bmm PV) and the xformers seam

@@ -1144,6 +1144,39 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256
 int g_default_glds = 1;
 int g_tile_mode = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
 
+// The whole launch decision of op_gemm_nt in one place (also served to the host by op_gemm_plan, so that it can be tested
+// without a GPU): tile, K-splits, whether the epilogue moves to the fold kernel, and whether the <= 128 leftover rows of
+// M % 256 become a second, small launch.
+struct NtDecision { GemmPlan plan; bool fold_epi; bool tail_split; int64_t m_main; };
+
+NtDecision decide_nt(int64_t M, int64_t N, int64_t K, int epilogue, bool has_bias0, bool seg_ok, bool off32_ok, bool fold_layout_ok,
+                     bool have_ws, int64_t ws_bytes, bool allow_tail_split) {
+  NtDecision d;
+  const bool allow_256 = g_tile_mode != 1 && g_default_glds && seg_ok && off32_ok;
+  // split-K: bias-free plain launches (weight gradients, dgrads), and -- for launches of a few M-tiles (the leftover rows
+  // of a tail-rows split, batch-1 feature extraction: M = 257), which are latency-bound on K with most CUs idle -- also
+  // bias / residual epilogues, applied by the fold kernel.  plan_gemm's cost model decides whether a split pays.
+  d.fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && has_bias0)) && M <= 1024 && fold_layout_ok;
+  const bool allow_split = ((epilogue == EPI_BIAS && !has_bias0) || d.fold_epi) && have_ws && N % 8 == 0;
+  d.plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, ws_bytes);
+  if (g_tile_mode == 2 && allow_256 && d.plan.tile != 256) d.plan = {256, 1, 0};
+  // Tail rows.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
+  // every CU (M = 128 x 257: 774 tiles = 3.02 rounds for N = 1536).  If dropping them saves a round, the full M-tiles run
+  // as one launch and the <= 128 leftover rows as a second, small one (128 x 128 tiles).
+  d.tail_split = false;
+  d.m_main = M;
+  if (allow_tail_split && g_tail_rows && d.plan.tile == 256 && d.plan.splits == 1 && M > 256) {
+    const int64_t m_rem = M % 256;
+    const int64_t tn = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
+    const int64_t r_full = ceil_div(ceil_div(M, 256) * tn, 256), r_main = ceil_div(((M - m_rem) / 256) * tn, 256);
+    if (m_rem > 0 && m_rem <= 128 && (g_tail_rows == 3 || (r_main < r_full && (g_tail_rows == 2 || K >= 1024)))) {
+      d.tail_split = true;
+      d.m_main = M - m_rem;
+    }
+  }
+  return d;
+}
+
 }  // namespace
 
 extern "C" int op_prof_begin(int family, double work, void* stream);
@@ -1218,32 +1251,21 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   const double flops = 2.0 * (double)M * (double)N * (double)K * (epilogue == EPI_GEGLU ? 2.0 : 1.0);
   const bool seg_ok = epilogue == EPI_GEGLU || a.n_seg >= (int)N || a.n_seg % 256 == 0;
   const bool off32_ok = (M * lda < ((int64_t)1 << 30)) && (N * ldb < ((int64_t)1 << 30));
-  const bool allow_256 = g_tile_mode != 1 && g_default_glds && seg_ok && off32_ok;
-  // split-K: bias-free plain launches (weight gradients, dgrads), and -- for launches of a few M-tiles (the leftover rows
-  // of a tail-rows split, batch-1 feature extraction: M = 257), which are latency-bound on K with most CUs idle -- also
-  // bias / residual epilogues, applied by the fold kernel.  plan_gemm's cost model decides whether a split pays.
-  const bool fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && bias0)) && M <= 1024 && a.n_seg % 8 == 0 && ldc % 8 == 0;
-  const bool allow_split = ((epilogue == EPI_BIAS && !bias0) || fold_epi) && workspace != nullptr && N % 8 == 0;
-  GemmPlan plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, workspace_bytes);
-  if (g_tile_mode == 2 && allow_256 && plan.tile != 256) plan = {256, 1, 0};
-  // Tail rows.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
-  // every CU (M = 128 x 257: 774 tiles = 3.02 rounds for N = 1536).  If dropping them saves a round, the full M-tiles run
-  // as one launch and the <= 128 leftover rows as a second, small one (128 x 128 tiles).
-  if (allow_tail_split && g_tail_rows && plan.tile == 256 && plan.splits == 1 && M > 256) {
-    const int64_t m_rem = M % 256, m_main = M - m_rem;
-    const int64_t tn = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
-    const int64_t r_full = ceil_div(ceil_div(M, 256) * tn, 256), r_main = ceil_div((m_main / 256) * tn, 256);
-    if (m_rem > 0 && m_rem <= 128 && (g_tail_rows == 3 || (r_main < r_full && (g_tail_rows == 2 || K >= 1024)))) {
-      const int64_t esz = epilogue == EPI_F32 ? 4 : 2;
-      int rc = gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
-                            rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false);
-      if (rc != OP_OK) return rc;
-      return gemm_nt_impl((const bf16_t*)A + m_main * lda, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2,
-                          (char*)C + m_main * ldc * esz, ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
-                          h1 ? (bf16_t*)h1 + m_main * ldc : nullptr, resid ? (const bf16_t*)resid + m_main * ldr : nullptr, ldr,
-                          gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, workspace, workspace_bytes, stream,
-                          m_off + m_main, false);  // (bias-free launches may split K: 12 tiles alone are latency-bound)
-    }
+  const NtDecision dec = decide_nt(M, N, K, epilogue, bias0 != nullptr, seg_ok, off32_ok, a.n_seg % 8 == 0 && ldc % 8 == 0,
+                                   workspace != nullptr, workspace_bytes, allow_tail_split);
+  const GemmPlan plan = dec.plan;
+  const bool fold_epi = dec.fold_epi;
+  if (dec.tail_split) {
+    const int64_t m_main = dec.m_main, m_rem = M - dec.m_main;
+    const int64_t esz = epilogue == EPI_F32 ? 4 : 2;
+    int rc = gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
+                          rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false);
+    if (rc != OP_OK) return rc;
+    return gemm_nt_impl((const bf16_t*)A + m_main * lda, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2,
+                        (char*)C + m_main * ldc * esz, ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
+                        h1 ? (bf16_t*)h1 + m_main * ldc : nullptr, resid ? (const bf16_t*)resid + m_main * ldr : nullptr, ldr,
+                        gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, workspace, workspace_bytes, stream,
+                        m_off + m_main, false);  // (the small launch may split K: 12 tiles alone are latency-bound)
   }
   a.kt_per_split = plan.kt_per_split;
   a.slab = (int64_t)M * N;
@@ -1299,6 +1321,25 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   }
   op_prof_end(slot, stream);
   return rc;
+}
+
+// Host-only query (no GPU needed): the launch decision op_gemm_nt takes for a dense [M,K] x [N,K]^T problem with a single
+// weight segment, contiguous operands and -- when workspace_bytes > 0 -- a split-K scratch of that size.
+// plan[0] = tile (128 | 256), plan[1] = K-splits of the (main) launch, plan[2] = 1 if the epilogue runs in the fold kernel,
+// plan[3] = rows split off into a second small launch (0 = none).
+int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int* plan) {
+  OP_CHECK_ARG(plan && M > 0 && N > 0 && K > 0 && K % BK == 0 && epilogue >= 0 && epilogue <= 3, "gemm_plan: bad arguments");
+  const bool off32_ok = (M * K < ((int64_t)1 << 30)) && (N * K < ((int64_t)1 << 30));
+  const NtDecision d = decide_nt(M, N, K, epilogue, has_bias != 0, true, off32_ok, N % 8 == 0, workspace_bytes > 0,
+                                 workspace_bytes, true);
+  NtDecision m = d;
+  if (d.tail_split)  // the plan of the main launch is taken again for its own row count, as op_gemm_nt does
+    m = decide_nt(d.m_main, N, K, epilogue, has_bias != 0, true, off32_ok, N % 8 == 0, workspace_bytes > 0, workspace_bytes, false);
+  plan[0] = m.plan.tile;
+  plan[1] = m.plan.splits;
+  plan[2] = (m.plan.splits > 1 && m.fold_epi) ? 1 : 0;
+  plan[3] = d.tail_split ? (int)(M - d.m_main) : 0;
+  return OP_OK;
 }
 
 int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const void* B2, int64_t ldb, int64_t n_seg,

@@ -36,6 +36,7 @@ SIGNATURES = {
     "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
     "op_gemm_set_staging": (c_int, [c_int]),
     "op_gemm_set_tile": (c_int, [c_int]),
+    "op_gemm_plan": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int64, P]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
                            c_int, P, I64, P]),
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, P]),
@@ -206,6 +207,13 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
                             rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, stream()), "op_gemm_nt")
     return out
+
+
+def gemm_plan(M, N, K, epilogue=EPI_BIAS, has_bias=True, workspace_bytes=SPLITK_WS_BYTES):
+    """(tile, K-splits, epilogue-in-fold-kernel, tail rows) op_gemm_nt would use; a host-only query (works without a GPU)."""
+    out = (ctypes.c_int * 4)()
+    _check(lib().op_gemm_plan(M, N, K, epilogue, int(has_bias), workspace_bytes, ctypes.cast(out, P)), "op_gemm_plan")
+    return out[0], out[1], bool(out[2]), out[3]
 
 
 def gemm_tn_supported(K, M, N, lda, ldb):

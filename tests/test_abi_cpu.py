@@ -63,3 +63,31 @@ def test_no_silent_cpu_fallback():
     lin = torch.nn.Linear(8, 8).to(torch.bfloat16)
     with pytest.raises(RuntimeError):
         FusedAdamW(FlatParameters(lin))
+
+
+def test_gemm_launch_planner_decisions(lib_path):
+    """op_gemm_plan is a host-only query of op_gemm_nt's launch decision (tile, K-splits, epilogue fold, tail-rows split):
+    the decisions the measurements in profiles/r1_gemm_experiments.md and profiles/r1_gemm_small_m.txt led to."""
+    from one_peace_amd import hip
+    H, F = 1536, 6144
+    M = 128 * 257  # the headline batch: 128 image sequences of 257 tokens
+    # training shapes: 256 x 256 tiles, no K-split, the 128 leftover rows (M % 256) as a second launch when that saves a round
+    for N, K, epi in ((3 * H, H, hip.EPI_BIAS), (H, H, hip.EPI_RESID), (H, F, hip.EPI_RESID)):
+        tile, splits, fold, tail = hip.gemm_plan(M, N, K, epi)
+        assert (tile, splits, fold, tail) == (256, 1, False, 128), (N, K, epi)
+    assert hip.gemm_plan(M, F, H, hip.EPI_GEGLU)[:2] == (256, 1)
+    assert hip.gemm_plan(64 * 256, 3 * H, H)[3] == 0                      # M a multiple of 256: nothing to split off
+    # batch-1 feature extraction (M = 257): 128 x 128 tiles; K split over the idle CUs, epilogue in the fold kernel
+    tile, splits, fold, tail = hip.gemm_plan(257, H, H)
+    assert tile == 128 and splits in (3, 4) and fold and tail == 0
+    tile, splits, fold, tail = hip.gemm_plan(257, H, F, hip.EPI_RESID)
+    assert tile == 128 and splits >= 6 and fold
+    assert hip.gemm_plan(257, 3 * H, H)[:2] == (128, 1)                  # 108 tiles: a split does not pay (measured)
+    assert hip.gemm_plan(257, F, H, hip.EPI_GEGLU)[:3] == (128, 1, False)  # two accumulators: no fold for GeGLU
+    assert hip.gemm_plan(257, H, F, hip.EPI_RESID, workspace_bytes=0)[1] == 1   # no scratch, no split
+    # bias-free launches (dgrads of the tail rows) split K without the fold epilogue; beyond 1024 rows bias epilogues never fold
+    tile, splits, fold, tail = hip.gemm_plan(128, H, F, hip.EPI_BIAS, has_bias=False)
+    assert tile == 128 and splits > 1 and not fold
+    assert hip.gemm_plan(2056, H, F, hip.EPI_RESID)[1] == 1
+    with pytest.raises(RuntimeError):
+        hip.gemm_plan(257, H, 100)  # K must be a multiple of 64

@@ -94,7 +94,19 @@ class FlatParameters:
 
 
 class BucketedGradReducer:
-    """Asynchronous SUM all-reduce of contiguous gradient buckets, each launched when its last gradient is final."""
+    """Asynchronous SUM all-reduce of contiguous gradient buckets, each launched when its last gradient is final.
+
+    Protocol per optimiser step:  ``reset()`` BEFORE the forward pass -> forward -> backward -> ``finish()``.
+    A parameter signals "final" once per backward: either autograd's post-accumulate-grad hook (gradients that flow
+    through autograd) or ``ops._direct_grad_done`` when the last fused kernel that accumulates into its flat gradient
+    view has been launched (``_op_pending`` reaches 0).  A bucket is reduced when every one of its parameters has
+    signalled.  Two situations would make a parameter signal TWICE and let a bucket go out before its last
+    contribution (silently wrong gradients), so they switch the step to *deferred* mode -- every bucket is reduced in
+    ``finish()``, correct but not overlapped:
+      * mixed use: a flat parameter is read both by a fused pass (in-place accumulation) and by a torch-op pass
+        (autograd) in the same step -- ``ops.note_torch_path_use()`` is called by the torch-op encoder path;
+      * gradient accumulation: several backward passes per step -- wrap all but the last in ``no_sync()``.
+    A second signal for a parameter whose bucket is already in flight raises instead of corrupting the sum."""
 
     def __init__(self, flat: FlatParameters, bucket_bytes=256 << 20, process_group=None):
         self.flat, self.pg = flat, process_group
@@ -115,9 +127,11 @@ class BucketedGradReducer:
         for b, (_, _, items) in enumerate(self.buckets):
             for idx in items:
                 self._bucket_of[idx] = b
-        self._pending = [0] * len(self.buckets)
-        self._handles = []
         self._hooks = []
+        self._sync = True
+        self.stats = {"steps": 0, "buckets": len(self.buckets), "launched_in_backward": 0, "launched_in_finish": 0,
+                      "deferred_steps": 0}
+        self._exposed = []  # (event before the waits, event after) per step on the compute stream (nccl only)
         if self.active:
             for idx, (n, p, o, k) in enumerate(flat.entries):
                 hook = self._make_hook(idx)
@@ -125,28 +139,84 @@ class BucketedGradReducer:
                 p._op_on_final = hook  # gradients written in place by the fused layer never pass through autograd
         self.reset()
 
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _deferred(self):
+        from . import ops
+        return ops.torch_path_uses() != self._torch_uses_at_reset
+
     def _make_hook(self, idx):
         def hook(param):
+            if not self._sync:
+                return
             b = self._bucket_of[idx]
+            if self._done[idx]:
+                if self._launched[b]:
+                    raise RuntimeError(
+                        "BucketedGradReducer: parameter %r received a gradient contribution after its bucket was all-reduced "
+                        "(mixed fused / autograd use or several backward passes per step: call reset() before the forward "
+                        "pass and wrap accumulation micro-steps in no_sync())" % self.flat.entries[idx][0])
+                return
+            self._done[idx] = True
             self._pending[b] -= 1
-            if self._pending[b] == 0:
-                s, e, _ = self.buckets[b]
-                self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if self._pending[b] == 0 and not self._deferred():
+                self._launch(b)
+                self.stats["launched_in_backward"] += 1
         return hook
 
+    def no_sync(self):
+        """Context manager for gradient-accumulation micro-steps: backward passes inside it only accumulate locally."""
+        reducer = self
+
+        class _NoSync:
+            def __enter__(self_inner):
+                reducer._sync = False
+
+            def __exit__(self_inner, *exc):
+                reducer._sync = True
+        return _NoSync()
+
     def reset(self):
-        """Call before each backward."""
+        """Call before the forward pass of each (final) micro-step."""
+        from . import ops
         self._pending = [len(items) for (_, _, items) in self.buckets]
+        self._done = [False] * len(self.flat.entries)
+        self._launched = [False] * len(self.buckets)
         self._handles = []
+        self._torch_uses_at_reset = ops.torch_path_uses()
 
     def finish(self):
-        """Waits for the launched buckets and reduces any bucket whose hooks did not all fire (unused parameters)."""
+        """Reduces every bucket that has not gone out yet (unused parameters, deferred mode) and waits for all of them."""
         if not self.active:
             return
+        self.stats["steps"] += 1
+        if self._deferred():
+            self.stats["deferred_steps"] += 1
         for b, left in enumerate(self._pending):
-            if left > 0:
-                s, e, _ = self.buckets[b]
-                self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+            if left < 0:
+                raise RuntimeError("BucketedGradReducer: bucket %d over-signalled (%d)" % (b, left))
+            if not self._launched[b]:
+                self._launch(b)
+                self.stats["launched_in_finish"] += 1
+        timed = self.flat.grads.is_cuda and dist.get_backend(self.pg) == "nccl"
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
         self._handles = []
+
+    def overlap_report(self):
+        """After a synchronize: how the buckets went out and how long the compute stream sat in finish() waiting for RCCL
+        (the part of the gradient all-reduce that backward did NOT hide), averaged per step."""
+        rep = dict(self.stats)
+        if self._exposed:
+            rep["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+        self._exposed = []
+        return rep

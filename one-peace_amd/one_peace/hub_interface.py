@@ -100,25 +100,39 @@ class OnePeaceHubInterface:
     def process_image(self, images):
         return self.cast_data_dtype(torch.as_tensor(images).to(self.device))
 
-    def process_audio(self, wav_list):
-        """list of 1-D float waveforms @16 kHz -> (src_audios [B, T], audio_padding_masks [B, frames+1])."""
-        T = max(len(w) for w in wav_list)
-        wavs = torch.zeros(len(wav_list), T)
-        pad = torch.zeros(len(wav_list), T, dtype=torch.bool)
-        for i, w in enumerate(wav_list):
+    def _feature_encoder_spec(self):
+        """The conv stack [(dim, kernel, stride), ...] of the model's audio adapter (hub_interface.py:116-118)."""
+        cfg = getattr(getattr(self.model, "cfg", None), "encoder", None)
+        spec = getattr(getattr(cfg, "audio_adapter", None), "feature_encoder_spec", None)
+        return eval(spec) if isinstance(spec, str) else (spec or [(512, 10, 5)] + [(512, 3, 2)] * 4 + [(512, 2, 2)] * 2)
+
+    def _frames(self, n):
+        """hub_interface.py:124-132 (_get_mask_indices_dims with padding 0, dilation 1)."""
+        for _, k, s in self._feature_encoder_spec():
+            n = 1 + (n - (k - 1) - 1) // s
+        return n
+
+    def process_audio(self, wav_list, sample_rate=16000):
+        """list of 1-D float waveforms @16 kHz -> (src_audios [B, T], audio_padding_masks [B, frames+1]), as
+        hub_interface.py:170-193 after librosa.load: per-waveform layer norm, crop to 15 s, tile up to 1 s, an all-False
+        frame mask of each clip's OWN length, then right-padding of waveforms with 0 and of masks with True."""
+        feats, masks = [], []
+        for w in wav_list:
             w = torch.as_tensor(w, dtype=torch.float32)
-            w = F.layer_norm(w, w.shape)  # hub_interface.py:176-178 normalises each waveform
-            wavs[i, : len(w)] = w
-            pad[i, len(w):] = True
-        frames = T
-        for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
-            frames = (frames - k) // s + 1
-        lens = (~pad).sum(1)
-        for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
-            lens = torch.div(lens - k, s, rounding_mode="floor") + 1
-        mask = torch.arange(frames).unsqueeze(0) >= lens.unsqueeze(1)
-        mask = torch.cat([mask.new_zeros(len(wav_list), 1), mask], dim=1)
-        return self.cast_data_dtype(wavs.to(self.device)), mask.to(self.device)
+            w = F.layer_norm(w, w.shape)
+            if w.numel() > sample_rate * 15:
+                w = w[: sample_rate * 15]
+            if w.numel() < sample_rate:
+                w = w.repeat(math.ceil(sample_rate / w.numel()))[:sample_rate]
+            feats.append(w)
+            masks.append(torch.zeros(self._frames(w.numel()) + 1, dtype=torch.bool))
+        T, Fm = max(w.numel() for w in feats), max(m.numel() for m in masks)
+        wavs = torch.zeros(len(feats), T)
+        pad = torch.ones(len(feats), Fm, dtype=torch.bool)
+        for i, (w, m) in enumerate(zip(feats, masks)):
+            wavs[i, : w.numel()] = w
+            pad[i, : m.numel()] = m
+        return self.cast_data_dtype(wavs.to(self.device)), pad.to(self.device)
 
     # ---- hipGraph replay of the extract_* calls (MI355X serving path; no reference counterpart) -----------------------
     def enable_graphs(self, on=True):

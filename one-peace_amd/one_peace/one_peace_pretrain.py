@@ -1,8 +1,13 @@
 """Mirror of one_peace/models/one_peace/one_peace_pretrain.py.
 
 The contrastive branch (``forward(..., encoder_type in {text,image,audio})`` -> ``(normalised CLS projection, features)``
-and ``return_logit_scale``) is the hot path and runs on the HIP kernels.  The masked-feature (DCL) branch with the small
-decoder -- ``*_preserve_ids`` -- keeps the reference semantics through the torch-op path ("next")."""
+and ``return_logit_scale``) is the hot path and runs on the HIP kernels.  The masked-feature (DCL) branch -- ``*_preserve_ids``
+gathers in the adapters, the small decoder -- runs on the same fused HIP layers (per-sample bias images, SURVEY.md 8f rank 2;
+tests/test_model_gpu.py::test_full_pretraining_objective_on_hip).
+
+Deviation from the reference's state-dict: ``cfg.decoder`` is Optional here (a contrastive-only model has no
+``decoder_wrapper.*`` / ``decoder_*`` keys); the reference always builds ``decoder_wrapper`` (one_peace_pretrain.py:57-66).
+With a decoder config the key set is identical (tests/test_model_cpu.py)."""
 import logging
 import math
 from dataclasses import dataclass, field

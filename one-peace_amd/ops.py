@@ -26,6 +26,23 @@ _cache_epoch = 0
 _refresh_plan = None  # (key set, device table, n, total tiles, [cache keys]) of the batched refresh
 
 
+_torch_path_uses = 0
+
+
+def note_torch_path_use():
+    """Called by the torch-op encoder path (TransformerEncoder._forward_torch) whenever it runs with gradients enabled on
+    a HIP device: its parameters then receive their gradients through autograd, which -- if another pass of the same step
+    accumulates into the same flat gradient views in place -- makes a parameter signal "final" twice.
+    distributed.BucketedGradReducer compares this counter with its value at reset() and defers the all-reduce of the
+    step to finish() when it moved."""
+    global _torch_path_uses
+    _torch_path_uses += 1
+
+
+def torch_path_uses():
+    return _torch_path_uses
+
+
 def invalidate_weight_cache():
     """Call after parameters were updated through raw pointers (the fused AdamW kernel does not bump _version)."""
     global _cache_epoch

@@ -60,7 +60,8 @@ class SamplePrefetcher:
             host = self._pin(slot, path, t)
             self.bytes_staged += host.numel() * host.element_size()
             d = host.to(self.device, non_blocking=True)
-            return d.to(self.dtype) if d.is_floating_point() and d.dtype != self.dtype else d
+            # trainer.py:1321-1336 (_fp_convert_sample via apply_half / apply_bfloat16): ONLY float32 tensors are converted
+            return d.to(self.dtype) if d.dtype == torch.float32 and self.dtype != torch.float32 else d
 
         # the pinned slot is reused every `depth` samples: its previous H2D copies were enqueued on copy_stream before
         # this one, and the host-side buf.copy_ above may only overwrite it once they are done

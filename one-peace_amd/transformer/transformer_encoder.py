@@ -108,8 +108,12 @@ class TransformerEncoder(nn.Module):
         key_pad = None
         if not no_pads:
             x = x * (~pad).unsqueeze(-1).to(x.dtype)  # transformer_encoder.py:141-142
-            key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=x.device)
-            key_pad[:, :S] = pad.to(torch.uint8)
+            # The reference masks padded KEYS only through the bias tensor (masked_fill_ of the assembled bias,
+            # transformer_encoder.py:144-162; MultiheadAttention.forward never looks at key_padding_mask): a model without
+            # attention bias (the pretraining decoder, use_attn_bias: false) attends to its zeroed pad rows.  Same here.
+            if handles:
+                key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=x.device)
+                key_pad[:, :S] = pad.to(torch.uint8)
         x = x.contiguous()
         scales = self._draw_path_scales(B, x.device)
         for idx, layer in enumerate(self.layers):
@@ -153,6 +157,8 @@ class TransformerEncoder(nn.Module):
 
     def _forward_torch(self, encoder_type, streams, infos, return_all_hiddens):
         parts = [infos[s] for s in streams]
+        if parts[0][0].is_cuda and torch.is_grad_enabled():
+            ops.note_torch_path_use()  # a torch-op pass next to fused passes: the gradient reducer must not overlap this step
         lens = {s: infos[s][0].size(1) for s in streams}
         x = torch.cat([p[0] for p in parts], dim=1) if len(parts) > 1 else parts[0][0]
         pad = torch.cat([p[1] for p in parts], dim=1) if len(parts) > 1 else parts[0][1]

@@ -60,6 +60,64 @@ def _worker(rank, world, initfile, outdir):
         for (n, p, o, k) in flat.entries:
             want = O.dp_mean_grads([g[n] for g in per_rank])
             assert torch.allclose(mine[o:o + k].view(p.shape), want, atol=1e-6), n
+
+        # --- a parameter that signals twice (in-place contribution from a fused pass + autograd from a torch-op pass) ---
+        from one_peace_amd import ops
+
+        def run(mixed_flag, late_after_autograd):
+            net3 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+            net3.load_state_dict(ref_state)
+            fl = FlatParameters(net3)
+            rd = BucketedGradReducer(fl, bucket_bytes=64)
+            w = net3[1].weight
+            delta = torch.full_like(w, 0.25 * (rank + 1))
+            rd.reset()
+            if mixed_flag:
+                ops.note_torch_path_use()      # what TransformerEncoder._forward_torch does
+            w._op_pending = 1                  # what ops._register_direct does in a fused forward
+            xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+            net3(xr).pow(2).sum().backward()   # autograd contribution -> post-accumulate hook (first signal)
+            if late_after_autograd:
+                w.grad.add_(delta)             # the fused pass's in-place contribution arrives afterwards ...
+                ops._direct_grad_done(w)       # ... and signals a second time
+            rd.finish()
+            return fl, rd, delta
+
+        fl, rd, delta = run(True, True)        # deferred mode: nothing may go out before finish()
+        assert rd.stats["launched_in_backward"] == 0 and rd.stats["deferred_steps"] == 1
+        for (n, p_, o, k) in fl.entries:
+            want = sum(g[n] for g in per_rank)
+            if n == "1.weight":
+                want = want + sum(torch.full_like(want, 0.25 * (r + 1)) for r in range(world))
+            assert torch.allclose(fl.grads[o:o + k].view(p_.shape), want, atol=1e-5), n
+        raised = False
+        try:
+            run(False, True)                   # not announced: must fail loudly, never reduce a half-finished bucket
+        except RuntimeError as e:
+            raised = "after its bucket was all-reduced" in str(e)
+        assert raised
+        dist.barrier()
+
+        # --- gradient accumulation: micro-step 1 under no_sync(), micro-step 2 reduces the sum of both ---
+        net4 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        net4.load_state_dict(ref_state)
+        fl4 = FlatParameters(net4)
+        rd4 = BucketedGradReducer(fl4, bucket_bytes=64)
+        xa = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+        xb = torch.randn(5, 8, generator=torch.Generator().manual_seed(50 + rank))
+        with rd4.no_sync():
+            net4(xa).pow(2).sum().backward()
+        rd4.reset()
+        net4(xb).pow(2).sum().backward()
+        rd4.finish()
+        net5 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        net5.load_state_dict(ref_state)
+        for r in range(world):
+            for seed in (10 + r, 50 + r):
+                net5(torch.randn(5, 8, generator=torch.Generator().manual_seed(seed))).pow(2).sum().backward()
+        want = {n: q.grad for n, q in net5.named_parameters()}
+        for (n, p_, o, k) in fl4.entries:
+            assert torch.allclose(fl4.grads[o:o + k].view(p_.shape), want[n], atol=1e-5), n
     finally:
         dist.barrier()
         dist.destroy_process_group()

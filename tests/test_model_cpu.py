@@ -159,6 +159,31 @@ def test_hub_interface_all_modalities_and_graph_switch_on_cpu(golden_dir):
         GraphedCall(lambda x: x + 1, {"x": torch.zeros(2)})
 
 
+def test_hub_process_audio_follows_reference_collation(golden_dir):
+    """hub_interface.py:170-193: layer-normed waveforms, 15 s crop, tiling up to 1 s, per-clip all-False frame masks of the
+    clip's own frame count (from the model's feature_encoder_spec), waveforms right-padded with 0 and masks with True."""
+    from one_peace_amd.one_peace.hub_interface import OnePeaceHubInterface
+    fx = _fx(golden_dir, "micro_retrieval.pt")
+    hub = OnePeaceHubInterface(load_synth(build_retrieval(fx["cfg"], fx["vocab"]), fx["shapes"]), device="cpu", dtype="float32")
+    spec = hub._feature_encoder_spec()
+
+    def frames(n):
+        for _, k, s in spec:
+            n = (n - k) // s + 1
+        return n
+    g = torch.Generator().manual_seed(0)
+    clips = [torch.randn(n, generator=g) * 3 + 1 for n in (5000, 80000, 16000 * 16)]
+    wavs, masks = hub.process_audio(clips)
+    assert wavs.shape == (3, 16000 * 15) and masks.shape == (3, frames(16000 * 15) + 1)
+    lens = [16000, 80000, 16000 * 15]  # tiled to 1 s, kept, cropped to 15 s
+    for i, n in enumerate(lens):
+        assert not masks[i, : frames(n) + 1].any() and masks[i, frames(n) + 1:].all()
+        assert wavs[i, n:].abs().max() == 0 if n < wavs.shape[1] else True
+    normed = torch.nn.functional.layer_norm(clips[0], clips[0].shape)
+    assert torch.allclose(wavs[0, :16000], normed.repeat(4)[:16000])
+    assert torch.allclose(wavs[2], torch.nn.functional.layer_norm(clips[2], clips[2].shape)[: 16000 * 15])
+
+
 def _build_pretrain(fx, audio_language=False):
     from types import SimpleNamespace
     from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel

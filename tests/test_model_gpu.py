@@ -190,6 +190,51 @@ def test_fused_layer_with_padding_and_drop_path(recompute):
         assert e < 3e-2, (n, e)
 
 
+def test_no_bias_encoder_attends_to_padded_keys_like_the_reference():
+    """Reference semantics (transformer_encoder.py:144-162, multihead_attention.py:102-115): padded keys are masked ONLY
+    through the bias tensor, so an encoder WITHOUT attention bias (the pretraining decoder, pretrain_vl_3B.yaml:140,150)
+    attends to its zeroed pad rows.  Fused path vs the fp32 torch path of the same mirror (which is pinned to the reference on
+    CPU), output and input gradient; the test is sensitive: masking the pads moves the output by > 10 %."""
+    from one_peace_amd.transformer.transformer_encoder import TransformerEncoder
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    cfg = one_peace_encoder_config(embed_dim=256, ffn_embed_dim=512, layers=2, attention_heads=4, drop_path_rate=0.0,
+                                   layer_scale_init_value=0.5)
+    cfg.use_text_moe, cfg.use_image_moe, cfg.use_audio_moe = True, False, False
+    torch.manual_seed(0)
+    enc32 = TransformerEncoder(cfg, None, True, False, False)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in enc32.state_dict().items()})
+    sd["version"] = enc32.state_dict()["version"]
+    enc32.load_state_dict(sd)
+    enc32.eval()
+    B, S, H = 4, 40, 256
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, S, H, generator=g).to(torch.bfloat16).float()
+    pad = torch.zeros(B, S, dtype=torch.bool)
+    pad[1, 25:] = True
+    pad[2, 9:] = True
+    dy = torch.randn(S, B, H, generator=g)
+
+    def run(enc, xin, device, mask_keys=False):
+        xin = xin.clone().to(device).requires_grad_(True)
+        out = enc(text_info=(xin, pad.to(device), None), image_info=None, audio_info=None, encoder_type="text")["encoder_out"][0]
+        valid = (~pad).t().unsqueeze(-1).to(device)  # [S, B, 1]: pad rows hold garbage by construction, compare valid rows
+        (out.float() * dy.to(device) * valid).sum().backward()
+        return (out.float() * valid).detach().cpu(), xin.grad.float().cpu()
+    ref_o, ref_g = run(enc32, x, "cpu")
+    import copy
+    encd = copy.deepcopy(enc32).to(DEV).to(torch.bfloat16).eval()
+    hip_o, hip_g = run(encd, x.to(torch.bfloat16), DEV)
+    _force_torch_path(encd, True)
+    tor_o, tor_g = run(encd, x.to(torch.bfloat16), DEV)
+    report = []
+    _check("no-bias padded encoder out", hip_o, tor_o, ref_o, 1.5e-2, report)
+    _check("no-bias padded encoder dx", hip_g, tor_g, ref_g, 5e-2, report)
+    # sensitivity: the same input with the pads masked as keys (bias of zeros + -inf) is far outside the tolerance
+    zero_bias = torch.zeros(B, 4, S, S)
+    masked = enc32(text_info=(x, pad, [zero_bias]), image_info=None, audio_info=None, encoder_type="text")["encoder_out"][0]
+    assert rel_fro(masked.float() * (~pad).t().unsqueeze(-1), ref_o) > 0.1
+
+
 def test_direct_gradient_accumulation_matches_autograd():
     """With distributed.FlatParameters the big layer weights' gradients are accumulated in place by the GEMMs (three
     modality passes share the attention weights); the result must equal the plain autograd path."""

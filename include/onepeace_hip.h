@@ -97,10 +97,19 @@ int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, in
  * Spad >= S rounded up to 128 when bias/key_pad/backward are used.
  * bias_batch_stride: 0 = one bias image shared by all samples; otherwise elements between per-sample images
  * [B][heads][S][Spad] (masked pretraining gathers a different token subset per sample, adapter/image.py:229-246); the
- * backward then returns one dbias slab per sample. */
+ * backward then returns one dbias slab per sample.
+ * bias_frag (optional): the same image(s) in the fragment-major layout of op_attn_bias_pack; with it (or without any
+ * bias) sequences of up to 320 keys run the resident-K/V kernel, which adds the bias with the matrix pipe; a biased call
+ * without bias_frag always runs the streaming kernel. */
 int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, int64_t bias_batch_stride,
-                const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad,
-                int64_t heads, int64_t head_dim, float scale, void* stream);
+                const void* bias_frag, const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B,
+                int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale, void* stream);
+/* Fragment-major repack of n_img row-major bias images [n_img][S][Spad] (n_img = heads, or B * heads for per-sample
+ * images): dst [n_img][ceil(S/16)][ceil(S/32)][64 lanes][8] bf16 = op_attn_bias_frag_elems(n_img, S) elements, zero
+ * outside the sequence.  (No reference counterpart: the reference adds a dense [B, heads, S, S] tensor,
+ * multihead_attention.py:107-108.) */
+int64_t op_attn_bias_frag_elems(int64_t n_img, int64_t S);
+int op_attn_bias_pack(const void* src, void* dst, int64_t n_img, int64_t S, int64_t Spad, void* stream);
 /* delta[b][h][q] = sum_d dout*out (fp32, row stride Spad) */
 int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,
                       int64_t heads, void* stream);
@@ -110,6 +119,8 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads);
 /* test knob: 0 = separate dQ / dBias kernels, 1 (default) = dQ + dBias in one kernel for sequences up to 384 keys */
 int op_attn_set_merge_dbias(int on);
+/* test knob: 1 (default) = resident-K/V kernels for sequences of up to 320 keys, 0 = the streaming kernels everywhere */
+int op_attn_set_resident(int on);
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
                 const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,

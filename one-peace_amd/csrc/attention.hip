@@ -57,6 +57,14 @@ __device__ __forceinline__ bf16x8 join_tr(s16x4 a, s16x4 b) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// byte offset of the 8-byte piece a transpose-read lane supplies inside a [64 rows][64 cols] bf16 tile stored with
+// 128-byte rows and 16-byte slots XOR-swizzled by (row & 7):  row = rowblk*16 + g*4 + (t>>2), cols db*16 + (t&3)*4 ..+3
+__device__ __forceinline__ int tr_off_swz(int rowblk, int db, int g, int t) {
+  const int row = rowblk * 16 + g * 4 + (t >> 2);
+  const int c = db * 2 + ((t >> 1) & 1);
+  return row * 128 + ((c ^ (row & 7)) << 4) + (t & 1) * 8;
+}
+
 // XCD-aware work mapping.  Workgroups are dispatched round-robin over the 8 XCDs by linear id, so the 2-5 workgroups that
 // share the K/V (or Q/dO) rows of one (sample, head) would land on different XCDs and each L2 would fetch those rows from
 // HBM again.  Re-deal the linear id so that consecutive work items run on ONE XCD: (bx, by, bz) replace blockIdx.
@@ -280,6 +288,253 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 
 
 // =====================================================================================================================
+// "Resident" forward for sequences of up to RES_MAX_S keys -- the model's 64 / 250 / 257-token streams (text, 5 s audio,
+// 256^2 image).  What round 2's ablations of the streaming kernel above showed at these lengths (tools/attn_abl.py,
+// profiles/r2_attention_notes.md): the MFMAs are 25 % of a wave's issue time, the softmax VALU stream (8.6 instructions
+// per score: scale, bf16 -> f32 bias conversion + add, max, subtract, exp argument scaling, exp, sum, pack) is the bound,
+// and the bias fragments -- 8-byte pieces of 16 different lines per load instruction -- cost another 40 % in the texture
+// addresser.  So this kernel
+//   * adds the bias with the MATRIX pipe: the bias image is stored "fragment-major" (op_attn_bias_pack: one contiguous
+//     1 KiB block per [16 queries x 32 keys], laid out exactly as the first-operand fragment of two 16-key blocks), one
+//     fully coalesced 16-byte load per lane fetches two blocks, and  S^T += Bias^T-fragment . Selector  (selector = 1/scale
+//     on the diagonal, exact in bf16 for head_dim 64) adds it inside the accumulator: no conversion, no add, no 8-byte
+//     loads;
+//   * works in the exp2 domain: p = exp2(acc * (scale * log2 e) - m2) is ONE fma + ONE v_exp_f32 per score (3.5 VALU
+//     instructions per score all told);
+//   * keeps the WHOLE K and V of its (sample, head) resident in LDS (S x 128 B each, <= 80 KiB together, staged once by
+//     LDS-DMA; ONE barrier), after which every wave runs its own 16-query block over all key tiles with no barriers and
+//     no lockstep -- a tail tile only costs its valid 16-key blocks -- at 5 waves per SIMD (<= 96 VGPRs);
+//   * deals the 16-query blocks of a (sample, head) evenly to ceil(nqb / 16) ... workgroups of nw = blocks-per-workgroup
+//     waves (S = 257: 17 blocks -> 2 workgroups of 9 and 8 waves instead of 3 x 128 query rows; S = 64: 4 waves).
+// LDS image: rows of 128 B, 16-byte slot index XOR (row & 7), for K (ds_read_b128 fragments) AND V (ds_read_b64_tr_b16
+// fragments, the image the backward kernels already read K^T from: bank-conflict free for both).
+// =====================================================================================================================
+constexpr int RES_MAX_S = 320;   // 2 x 320 rows x 128 B = 80 KiB -> two workgroups per CU
+constexpr int RES_MAX_NW = 10;   // waves per workgroup (20 query blocks at S = 320 -> 2 workgroups)
+constexpr float LOG2E = 1.4426950408889634f;
+
+// elements of one fragment-major bias block: [16 queries x 32 keys] = 64 lanes x 8 bf16
+constexpr int FRAG_BLOCK = 512;
+
+template <bool HAS_BIAS, bool HAS_PAD>
+__global__ __launch_bounds__(RES_MAX_NW * 64, 5) void attn_fwd_res_kernel(AttnArgs p, const bf16_t* __restrict__ bias_frag,
+                                                                            int rows_pad, int qb_per_wg, int abl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + rows_pad * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  int bx, h, b;
+  xcd_work_item(bx, h, b);
+  const int64_t row_base = (int64_t)b * p.S;
+
+  // ---- stage K and V: one wave-level LDS-DMA instruction = 8 rows x 128 B (1 KiB, lane-linear in LDS; the swizzle is
+  // applied to the per-lane SOURCE chunk).  Rows past the sequence end re-read row S-1: finite values, P is 0 there. ----
+  if (!(abl & 1)) {  // (abl: timing ablations, tools only -- 1 = no K/V staging, 2 = no compute)
+    const int ngrp = rows_pad >> 3;
+    const int r_in = lane >> 3, slot = lane & 7;
+    for (int grp = wid; grp < 2 * ngrp; grp += nw) {
+      const bool isv = grp >= ngrp;
+      const int gi = isv ? grp - ngrp : grp;
+      const int r = gi * 8 + r_in;
+      const int kr = min(r, p.S - 1);
+      const bf16_t* src = (isv ? p.v : p.k) + (row_base + kr) * p.ld + h * HD + ((slot ^ (r & 7)) << 3);
+      char* dst = (isv ? ldsV : ldsK) + gi * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  }
+
+  // ---- this wave's 16-query block ----
+  const int nqb = (p.S + 15) >> 4, nkp = (p.S + 31) >> 5;
+  const int qblk = bx * qb_per_wg + wid;
+  const bool active = wid < qb_per_wg && qblk < nqb;
+  const int q0 = min(qblk, nqb - 1) * 16;
+  const int qi = min(q0 + t, p.S - 1);
+
+  bf16x8 qf[2];
+  {
+    const bf16_t* qp = p.q + (row_base + qi) * p.ld + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) qf[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32 + g * 8);
+  }
+  // bias fragments of this query block: block (kp) at fbase + kp * FRAG_BLOCK, 16 bytes per lane
+  const bf16_t* fbase = nullptr;
+  if constexpr (HAS_BIAS) {
+    const int64_t per_head = (int64_t)nqb * nkp * FRAG_BLOCK;
+    fbase = bias_frag + ((p.bias_bs != 0 ? (int64_t)b * p.heads : 0) + h) * per_head + (int64_t)(q0 >> 4) * nkp * FRAG_BLOCK + lane * 8;
+  }
+  const uint8_t* padrow = HAS_PAD ? p.key_pad + (int64_t)b * p.Spad + g * 4 : nullptr;
+  // selectors: second operand that copies first-operand column j = t (key block 0 of a pair) / j = 16 + t (block 1) of
+  // the bias fragment into output column t, times 1/scale
+  bf16x8 sel_lo, sel_hi;
+  {
+    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
+      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
+    }
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // the only barrier: K and V are resident
+  if (!active || (abl & 2)) return;
+
+  f32x4 ot[4];
+  float m2_run = -INFINITY, l_run = 0.f;  // running max in the exp2 domain (scores * scale * log2 e), running sum
+#pragma unroll
+  for (int db = 0; db < 4; ++db) ot[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int trsw[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+  const int kswz[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+  const float c1 = p.scale * LOG2E;
+
+  auto tile = [&](const int k0, auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const int nkb = FULL ? 4 : ((p.S - k0 + 15) >> 4);  // valid 16-key blocks (1..4)
+    bf16x8 bf[2];
+    unsigned padw[4] = {0u, 0u, 0u, 0u};
+    if constexpr (HAS_BIAS) {  // (a one-tile-ahead register prefetch spills at 96 VGPRs and measured 5-15 % slower)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (FULL || 2 * m < nkb) bf[m] = *reinterpret_cast<const bf16x8*>(fbase + ((k0 >> 5) + m) * FRAG_BLOCK);
+    }
+    if constexpr (HAS_PAD) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) padw[kb] = *reinterpret_cast<const unsigned*>(padrow + k0 + kb * 16);
+    }
+    const char* kt = ldsK + k0 * 128;
+    const char* vt = ldsV + k0 * 128;
+
+    // ---- S^T = K . Q^T  (+ Bias^T / scale through the selector) ----
+    f32x4 st[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      if (!FULL && kb >= nkb) break;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt + (kb * 16 + t) * 128 + kswz[kk]);
+        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+      }
+      if constexpr (HAS_BIAS)
+        st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kb >> 1], (kb & 1) ? sel_hi : sel_lo, st[kb], 0, 0, 0);
+    }
+
+    // ---- masks; online softmax per query column in the exp2 domain (only over the valid key blocks of a tail tile) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      if (!FULL && kb >= nkb) break;
+      const int key = k0 + kb * 16 + g * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (!FULL || HAS_PAD) {
+          bool masked = false;
+          if constexpr (!FULL) masked = key + r >= p.S;
+          if constexpr (HAS_PAD) masked = masked || ((padw[kb] >> (8 * r)) & 0xffu);
+          st[kb][r] = masked ? -INFINITY : st[kb][r];
+        }
+        mx = fmaxf(mx, st[kb][r]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m2_new = fmaxf(m2_run, mx * c1);
+    const float m2_use = (m2_new == -INFINITY) ? 0.f : m2_new;
+    const float alpha = __builtin_amdgcn_exp2f(m2_run - m2_use);  // m2_run = -inf -> 0
+    m2_run = m2_new;
+    float psum = 0.f;
+    float pv[4][4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      if (FULL || kb < nkb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c1, -m2_use));
+          pv[kb][r] = e;
+          psum += e;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[kb][r] = 0.f;
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ot[db][r] *= alpha;
+    bf16x8 pf[2];
+    pf[0] = pack8(pv[0], pv[1]);  // key slots e: kb = 2m + (e >> 2), r = e & 3
+    pf[1] = pack8(pv[2], pv[3]);
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      if (!FULL && 2 * m >= nkb) break;  // P is exactly zero there
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 vf = join_tr(tr_read(vt + trsw[db] + (2 * m) * 2048), tr_read(vt + trsw[db] + (2 * m + 1) * 2048));
+        ot[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[m], ot[db], 0, 0, 0);
+      }
+    }
+  };
+
+  const int ntiles = (p.S + BKV - 1) / BKV;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int k0 = kt * BKV;
+    if (k0 + BKV <= p.S) tile(k0, std::true_type{});
+    else tile(k0, std::false_type{});
+  }
+
+  float l = l_run;
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (q0 + t >= p.S) return;
+  const float inv = 1.f / l;
+  bf16_t* op = p.out + (row_base + q0 + t) * p.ldo + h * HD;
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(ot[db][r] * inv);
+    *reinterpret_cast<bf16x4*>(op + db * 16 + g * 4) = o;
+  }
+  if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.lse_ld + q0 + t] = m2_run * (1.0f / LOG2E) + logf(l);
+}
+
+// Fragment-major bias image (what attn_fwd_res_kernel's bias MFMA reads): for every 16-query block qb and 32-key pair-block
+// kp one contiguous block of 64 lanes x 8 bf16; lane (g,t) holds bias[q = qb*16 + (g&1)*8 + i][key = kp*32 + (g>>1)*16 + t],
+// i = 0..7, zero outside the sequence.  src: row-major image [n_img][S][Spad] (n_img = heads, or B * heads per-sample).
+__global__ __launch_bounds__(256) void bias_pack_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int S, int Spad,
+                                                        int nqb, int nkp, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (image, qb, kp, lane)
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  int64_t blk = idx >> 6;
+  const int kp = (int)(blk % nkp);
+  blk /= nkp;
+  const int qb = (int)(blk % nqb);
+  const int64_t img = blk / nqb;
+  const int g = lane >> 4, t = lane & 15;
+  const int key = kp * 32 + (g >> 1) * 16 + t;
+  const int qbase = qb * 16 + (g & 1) * 8;
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = qbase + i;
+    v[i] = (q < S && key < S) ? src[(img * S + q) * Spad + key] : (bf16_t)0.f;
+  }
+  *reinterpret_cast<bf16x8*>(dst + idx * 8) = v;
+}
+
+// =====================================================================================================================
 // Backward.  With P = softmax(scale*QK^T + bias), D[q] = sum_d dO[q][d]*O[q][d]:
 //   dP = dO V^T,  dS = P o (dP - D),  dV = P^T dO,  dK = scale * dS^T Q,  dQ = scale * dS K,  dBias = sum_b dS.
 // Three kernels, each recomputing P from the saved log-sum-exp (no S x S tensor is ever stored):
@@ -332,14 +587,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     const int qi = (int)(row - bb * S);
     delta[(bb * heads + h) * Spad + qi] = s;
   }
-}
-
-// byte offset of the 8-byte piece a transpose-read lane supplies inside a [64 rows][64 cols] bf16 tile stored with
-// 128-byte rows and 16-byte slots XOR-swizzled by (row & 7):  row = rowblk*16 + g*4 + (t>>2), cols db*16 + (t&3)*4 ..+3
-__device__ __forceinline__ int tr_off_swz(int rowblk, int db, int g, int t) {
-  const int row = rowblk * 16 + g * 4 + (t >> 2);
-  const int c = db * 2 + ((t >> 1) & 1);
-  return row * 128 + ((c ^ (row & 7)) << 4) + (t & 1) * 8;
 }
 
 template <bool HAS_BIAS>
@@ -995,6 +1242,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 }
 
 int g_merge_dbias = 1;     // 1: dQ + dBias in one kernel when the sequence fits (<= 384 keys); 0: separate kernels (tests)
+int g_resident = 1;        // 1: resident-K/V kernels for S <= RES_MAX_S; 0: always the streaming kernels (tests / A-B timing)
+
+template <bool HAS_BIAS, bool HAS_PAD>
+int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, size_t sh, int rows_pad, int qb_per_wg, int abl,
+                   hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_res_kernel<HAS_BIAS, HAS_PAD>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RES_MAX_S * 128);
+    if (e != hipSuccess) { op_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_res_kernel<HAS_BIAS, HAS_PAD>), grid, dim3(nw * 64), sh, s, a, frag, rows_pad, qb_per_wg, abl);
+  return OP_OK;
+}
 
 // number of batch chunks (= dbias slabs) of the merged dQ + dBias kernel; 1 when the separate kernels run
 inline int dbias_chunks(int64_t B, int64_t S, int64_t heads) {
@@ -1019,6 +1281,13 @@ extern "C" {
 // dQ + dBias kernel add into their own slab without atomics; sum the slabs afterwards).
 int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads) { return dbias_chunks(B, S, heads); }
 
+// Debug/test knob: 1 (default) = resident-K/V kernels for sequences of up to 320 keys, 0 = streaming kernels everywhere.
+int op_attn_set_resident(int on) {
+  const int old = g_resident;
+  g_resident = on;  // bit 0: on / off; tools only: bits 1-2 timing ablations (no staging / no compute), bit 3: one query block per wave
+  return old;
+}
+
 int op_attn_set_merge_dbias(int on) {
   const int old = g_merge_dbias;
   g_merge_dbias = on ? 1 : 0;
@@ -1030,8 +1299,8 @@ int op_attn_set_merge_dbias(int on) {
 // bias: bf16 [heads][S][Spad] or null.  key_pad: uint8 [B][Spad], non-zero = masked key, or null.
 // out: bf16 [B*S][ldo] (head h at columns h*64..).  lse: fp32 [B][heads][lse_ld] (natural log) or null.
 int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, int64_t bias_batch_stride,
-                const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B, int64_t S, int64_t Spad,
-                int64_t heads, int64_t head_dim, float scale, void* stream) {
+                const void* bias_frag, const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B,
+                int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale, void* stream) {
   OP_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
   OP_CHECK_ARG(head_dim == HD, "attn_fwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(B > 0 && S > 0 && heads > 0 && ld % 8 == 0 && ldo % 4 == 0, "attn_fwd: bad sizes");
@@ -1045,6 +1314,27 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   dim3 grid(ceil_div(S, BQ), (unsigned)heads, (unsigned)B);
   const int slot = op_prof_begin(1, 4.0 * (double)B * (double)heads * (double)S * (double)S * HD, stream);
   hipStream_t s = (hipStream_t)stream;
+  // resident-K/V kernel: needs the fragment-major bias image when a bias is used, and 1/scale exact in bf16 (head_dim 64)
+  const bool inv_exact = (float)(bf16_t)(1.0f / scale) * scale == 1.0f;
+  if ((g_resident & 1) && S <= RES_MAX_S && (!bias || (bias_frag && inv_exact))) {
+    const int nqb = ceil_div(S, 16);
+    const int nwg = ceil_div(nqb, RES_MAX_NW);
+    const int qb_per_wg = ceil_div(nqb, nwg);              // = waves per workgroup
+    const int rows_pad = ceil_div(S, 32) * 32;
+    const size_t sh = (size_t)2 * rows_pad * 128;
+    const dim3 rgrid(nwg, (unsigned)heads, (unsigned)B);
+    const int abl = (g_resident >> 1) & 3;
+    const bf16_t* fr = (const bf16_t*)bias_frag;
+    int rc;
+    if (bias && key_pad) rc = launch_fwd_res<true, true>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
+    else if (bias) rc = launch_fwd_res<true, false>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
+    else if (key_pad) rc = launch_fwd_res<false, true>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
+    else rc = launch_fwd_res<false, false>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
+    op_prof_end(slot, stream);
+    if (rc != OP_OK) return rc;
+    OP_LAUNCH_CHECK();
+    return OP_OK;
+  }
   if (bias && key_pad) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid, dim3(256), 0, s, a);
   else if (bias) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid, dim3(256), 0, s, a);
   else if (key_pad) hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, s, a);
@@ -1054,6 +1344,24 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   return OP_OK;
 }
 
+
+// Elements of the fragment-major image of n_img bias images of an S-token sequence (see op_attn_bias_pack).
+int64_t op_attn_bias_frag_elems(int64_t n_img, int64_t S) {
+  return n_img * (int64_t)ceil_div(S, 16) * ceil_div(S, 32) * FRAG_BLOCK;
+}
+
+// Repack row-major bias images  src [n_img][S][Spad] (bf16; n_img = heads for a shared image, B * heads for per-sample
+// images)  into the fragment-major layout the resident forward kernel adds with the matrix pipe:
+// dst [n_img][ceil(S/16)][ceil(S/32)][64][8] bf16, zero outside the sequence (op_attn_bias_frag_elems elements).
+int op_attn_bias_pack(const void* src, void* dst, int64_t n_img, int64_t S, int64_t Spad, void* stream) {
+  OP_CHECK_ARG(src && dst && n_img > 0 && S > 0 && Spad >= S, "attn_bias_pack: bad args");
+  const int nqb = ceil_div(S, 16), nkp = ceil_div(S, 32);
+  const int64_t total = n_img * nqb * nkp * 64;
+  hipLaunchKernelGGL(bias_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     (bf16_t*)dst, (int)S, (int)Spad, nqb, nkp, total);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
 
 // delta[b][h][q] = sum_d dout * out  (fp32, row stride Spad); dout/out: [B*S][ldo]
 int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,

@@ -96,17 +96,19 @@ class FlatParameters:
 class BucketedGradReducer:
     """Asynchronous SUM all-reduce of contiguous gradient buckets, each launched when its last gradient is final.
 
-    Protocol per optimiser step:  ``reset()`` BEFORE the forward pass -> forward -> backward -> ``finish()``.
-    A parameter signals "final" once per backward: either autograd's post-accumulate-grad hook (gradients that flow
-    through autograd) or ``ops._direct_grad_done`` when the last fused kernel that accumulates into its flat gradient
-    view has been launched (``_op_pending`` reaches 0).  A bucket is reduced when every one of its parameters has
-    signalled.  Two situations would make a parameter signal TWICE and let a bucket go out before its last
-    contribution (silently wrong gradients), so they switch the step to *deferred* mode -- every bucket is reduced in
-    ``finish()``, correct but not overlapped:
-      * mixed use: a flat parameter is read both by a fused pass (in-place accumulation) and by a torch-op pass
-        (autograd) in the same step -- ``ops.note_torch_path_use()`` is called by the torch-op encoder path;
-      * gradient accumulation: several backward passes per step -- wrap all but the last in ``no_sync()``.
-    A second signal for a parameter whose bucket is already in flight raises instead of corrupting the sum."""
+    Protocol per optimiser step:  ``reset()`` -> forward -> backward -> ``finish()``.
+    A parameter's gradient is final when BOTH hold:
+      * autograd's post-accumulate-grad hook of the parameter has fired -- the engine runs a leaf's AccumulateGrad node only
+        after EVERY backward function that consumes the parameter has returned, whether those functions hand their
+        gradient to autograd (torch-op passes) or return None and accumulate into the flat gradient view in place (the
+        fused HIP layers; PyTorch >= 2.1 runs the hook for such undefined gradients too), and
+      * no in-place contribution is outstanding (``_op_pending == 0``; ``ops._direct_grad_done`` reports here when the
+        last fused kernel writing the view has been enqueued -- on PyTorch versions that skip the hook for undefined
+        gradients the parameter then simply stays open and its bucket goes out in ``finish()``).
+    So a parameter completes exactly once per backward pass also when fused and torch-op passes share it.  A bucket is
+    all-reduced as soon as all of its parameters are complete (overlapping the rest of backward); ``finish()`` reduces what
+    is left (unused parameters).  Gradient accumulation: wrap all micro-steps but the last in ``no_sync()``; a second
+    completion of a parameter whose bucket is already in flight raises instead of corrupting the sum."""
 
     def __init__(self, flat: FlatParameters, bucket_bytes=256 << 20, process_group=None):
         self.flat, self.pg = flat, process_group
@@ -129,14 +131,12 @@ class BucketedGradReducer:
                 self._bucket_of[idx] = b
         self._hooks = []
         self._sync = True
-        self.stats = {"steps": 0, "buckets": len(self.buckets), "launched_in_backward": 0, "launched_in_finish": 0,
-                      "deferred_steps": 0}
+        self.stats = {"steps": 0, "buckets": len(self.buckets), "launched_in_backward": 0, "launched_in_finish": 0}
         self._exposed = []  # (event before the waits, event after) per step on the compute stream (nccl only)
         if self.active:
             for idx, (n, p, o, k) in enumerate(flat.entries):
-                hook = self._make_hook(idx)
-                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
-                p._op_on_final = hook  # gradients written in place by the fused layer never pass through autograd
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx, from_autograd=True)))
+                p._op_on_final = self._make_hook(idx, from_autograd=False)
         self.reset()
 
     def _launch(self, b):
@@ -144,25 +144,23 @@ class BucketedGradReducer:
         self._launched[b] = True
         self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
-    def _deferred(self):
-        from . import ops
-        return ops.torch_path_uses() != self._torch_uses_at_reset
-
-    def _make_hook(self, idx):
+    def _make_hook(self, idx, from_autograd):
         def hook(param):
             if not self._sync:
                 return
             b = self._bucket_of[idx]
-            if self._done[idx]:
-                if self._launched[b]:
+            if from_autograd:
+                if self._hooked[idx] and self._launched[b]:
                     raise RuntimeError(
-                        "BucketedGradReducer: parameter %r received a gradient contribution after its bucket was all-reduced "
-                        "(mixed fused / autograd use or several backward passes per step: call reset() before the forward "
-                        "pass and wrap accumulation micro-steps in no_sync())" % self.flat.entries[idx][0])
+                        "BucketedGradReducer: parameter %r finished a second backward pass after its bucket was all-reduced "
+                        "(several backward passes per step: wrap the accumulation micro-steps in no_sync() and call reset() "
+                        "before the last one)" % self.flat.entries[idx][0])
+                self._hooked[idx] = True
+            if self._done[idx] or not self._hooked[idx] or getattr(param, "_op_pending", 0) > 0:
                 return
             self._done[idx] = True
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._deferred():
+            if self._pending[b] == 0:
                 self._launch(b)
                 self.stats["launched_in_backward"] += 1
         return hook
@@ -180,24 +178,19 @@ class BucketedGradReducer:
         return _NoSync()
 
     def reset(self):
-        """Call before the forward pass of each (final) micro-step."""
-        from . import ops
+        """Call before each (final) backward pass."""
         self._pending = [len(items) for (_, _, items) in self.buckets]
         self._done = [False] * len(self.flat.entries)
+        self._hooked = [False] * len(self.flat.entries)
         self._launched = [False] * len(self.buckets)
         self._handles = []
-        self._torch_uses_at_reset = ops.torch_path_uses()
 
     def finish(self):
-        """Reduces every bucket that has not gone out yet (unused parameters, deferred mode) and waits for all of them."""
+        """Reduces every bucket that has not gone out yet (unused parameters) and waits for all of them."""
         if not self.active:
             return
         self.stats["steps"] += 1
-        if self._deferred():
-            self.stats["deferred_steps"] += 1
-        for b, left in enumerate(self._pending):
-            if left < 0:
-                raise RuntimeError("BucketedGradReducer: bucket %d over-signalled (%d)" % (b, left))
+        for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)
                 self.stats["launched_in_finish"] += 1

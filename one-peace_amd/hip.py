@@ -18,6 +18,7 @@ _lib = None
 DT_BF16, DT_F32 = 0, 1
 EPI_BIAS, EPI_F32, EPI_GEGLU, EPI_RESID = 0, 1, 2, 3
 PROF_GEMM, PROF_ATTN = 0, 1
+ATTN_RESIDENT_MAX_S = 320  # sequences up to this length run the resident-K/V attention kernels (csrc/attention.hip: RES_MAX_S)
 
 P = c_void_p
 I64 = c_int64
@@ -32,6 +33,7 @@ SIGNATURES = {
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
     "op_layernorm_set_grid": (c_int, [c_int, c_int]),
     "op_attn_set_merge_dbias": (c_int, [c_int]),
+    "op_attn_set_resident": (c_int, [c_int]),
     "op_attn_bwd_dbias_slabs": (I64, [I64, I64, I64]),
     "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
     "op_gemm_set_staging": (c_int, [c_int]),
@@ -58,7 +60,9 @@ SIGNATURES = {
     "op_sqnorm": (c_int, [P, I64, P, P, P]),
     "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
-    "op_attn_fwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_fwd": (c_int, [P, P, P, I64, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_bias_frag_elems": (I64, [I64, I64]),
+    "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
     "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
@@ -398,16 +402,26 @@ def _bias_bstride(bias):
     return bias.stride(0) if bias is not None and bias.dim() == 4 else 0
 
 
-def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, out=None, want_lse=True):
+def attn_bias_pack(image, S):
+    """Row-major bias image(s) [heads, S, Spad] or [B, heads, S, Spad] -> the fragment-major layout the resident forward
+    kernel adds with the matrix pipe (flat bf16 tensor; see op_attn_bias_pack)."""
+    n_img = image.numel() // (image.shape[-2] * image.shape[-1])
+    out = torch.empty(lib().op_attn_bias_frag_elems(n_img, S), dtype=torch.bfloat16, device=image.device)
+    _check(lib().op_attn_bias_pack(ptr(image), ptr(out), n_img, S, image.shape[-1], stream()), "op_attn_bias_pack")
+    return out
+
+
+def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, out=None, want_lse=True, bias_frag=None):
     """q, k, v: bf16 views into [B*S, ld] rows (head h at columns h*64..); returns out [B*S, heads*64] and
-    lse [B, heads, Spad] (fp32, natural log; entries >= S are unspecified)."""
+    lse [B, heads, Spad] (fp32, natural log; entries >= S are unspecified).  bias_frag: attn_bias_pack(bias, S) -- with it
+    sequences of up to 320 keys take the resident-K/V kernel (without it a biased call runs the streaming kernel)."""
     dev = q.device
     H = heads * 64
     Spad = Spad or attn_spad(S)
     if out is None:
         out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev) if want_lse else None
-    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), _bias_bstride(bias), ptr(key_pad), ptr(out), out.stride(0),
+    _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), _bias_bstride(bias), ptr(bias_frag), ptr(key_pad), ptr(out), out.stride(0),
                              ptr(lse), Spad, B, S, Spad, heads, 64, scale, stream()), "op_attn_fwd")
     return out, lse
 

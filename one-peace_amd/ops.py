@@ -26,23 +26,6 @@ _cache_epoch = 0
 _refresh_plan = None  # (key set, device table, n, total tiles, [cache keys]) of the batched refresh
 
 
-_torch_path_uses = 0
-
-
-def note_torch_path_use():
-    """Called by the torch-op encoder path (TransformerEncoder._forward_torch) whenever it runs with gradients enabled on
-    a HIP device: its parameters then receive their gradients through autograd, which -- if another pass of the same step
-    accumulates into the same flat gradient views in place -- makes a parameter signal "final" twice.
-    distributed.BucketedGradReducer compares this counter with its value at reset() and defers the all-reduce of the
-    step to finish() when it moved."""
-    global _torch_path_uses
-    _torch_path_uses += 1
-
-
-def torch_path_uses():
-    return _torch_path_uses
-
-
 def invalidate_weight_cache():
     """Call after parameters were updated through raw pointers (the fused AdamW kernel does not bump _version)."""
     global _cache_epoch
@@ -259,7 +242,15 @@ class RelPosBias:
         self.table = table
         self.acc = None
         self._imageT = None
+        self._frag = None
         self.image = _RelPosImageFn.apply(table, self)
+
+    @property
+    def frag(self):
+        """Fragment-major copy of the image for the resident forward kernel (built on first use, shared by all layers)."""
+        if self._frag is None:
+            self._frag = hip.attn_bias_pack(self.image.detach(), self.S)
+        return self._frag
 
     @property
     def imageT(self):
@@ -286,7 +277,14 @@ class DenseBias:
         self.B, self.Spad = B, hip.attn_spad(self.S)
         self.acc = None
         self._imageT = None
+        self._frag = None
         self.image = _DenseBiasFn.apply(dense, self)
+
+    @property
+    def frag(self):
+        if self._frag is None:
+            self._frag = hip.attn_bias_pack(self.image.detach(), self.S)
+        return self._frag
 
     @property
     def imageT(self):
@@ -351,7 +349,7 @@ FFN_PARAMS = ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
 LAYER_PARAMS = ATTN_PARAMS + FFN_PARAMS
 
 
-def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep):
+def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_frag=None):
     """x_mid = x + ps1 * g1 * out_proj(subLN(attention(LN1(x))))  on x2 [B*S, H]."""
     H = x2.shape[1]
     xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
@@ -363,7 +361,7 @@ def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep):
             hip.gemm_nt(xln1, [w], [b] if b is not None else None, out=qkv[:, i * H:(i + 1) * H], ldc=3 * H)
     Spad = hip.attn_spad(S)
     attn, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, B, S, heads, scale, bias_img, key_pad,
-                             Spad, want_lse=keep)
+                             Spad, want_lse=keep, bias_frag=bias_frag)
     if P["aln_w"] is not None:
         aln, mean_a, rstd_a = hip.layernorm_fwd(attn, P["aln_w"], P["aln_b"], want_stats=keep)
     else:
@@ -493,7 +491,8 @@ class AttnBranchFn(torch.autograd.Function):
         bias_img = bias.image.detach() if bias is not None else None
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
-        x_mid, acts = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, keep)
+        x_mid, acts = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, keep,
+                                    bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None)
         ctx.bias, ctx.dims, ctx.n_params = bias, (B, S, H, heads, scale), len(params)
         ctx.direct = ()
         if need_grad:
@@ -514,7 +513,8 @@ class AttnBranchFn(torch.autograd.Function):
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_a", "rstd_a"))
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, True)
+            _, A = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, True,
+                                 bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None)
         dx_mid = dx_mid.reshape(B * S, H)
         if not dx_mid.is_contiguous():
             dx_mid = dx_mid.contiguous()

@@ -157,8 +157,6 @@ class TransformerEncoder(nn.Module):
 
     def _forward_torch(self, encoder_type, streams, infos, return_all_hiddens):
         parts = [infos[s] for s in streams]
-        if parts[0][0].is_cuda and torch.is_grad_enabled():
-            ops.note_torch_path_use()  # a torch-op pass next to fused passes: the gradient reducer must not overlap this step
         lens = {s: infos[s][0].size(1) for s in streams}
         x = torch.cat([p[0] for p in parts], dim=1) if len(parts) > 1 else parts[0][0]
         pad = torch.cat([p[1] for p in parts], dim=1) if len(parts) > 1 else parts[0][1]

@@ -61,10 +61,10 @@ def _worker(rank, world, initfile, outdir):
             want = O.dp_mean_grads([g[n] for g in per_rank])
             assert torch.allclose(mine[o:o + k].view(p.shape), want, atol=1e-6), n
 
-        # --- a parameter that signals twice (in-place contribution from a fused pass + autograd from a torch-op pass) ---
+        # --- a parameter shared by an autograd pass and a fused pass that accumulates in place (mixed use) ---
         from one_peace_amd import ops
 
-        def run(mixed_flag, late_after_autograd):
+        def run(late_after_autograd):
             net3 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
             net3.load_state_dict(ref_state)
             fl = FlatParameters(net3)
@@ -72,30 +72,41 @@ def _worker(rank, world, initfile, outdir):
             w = net3[1].weight
             delta = torch.full_like(w, 0.25 * (rank + 1))
             rd.reset()
-            if mixed_flag:
-                ops.note_torch_path_use()      # what TransformerEncoder._forward_torch does
             w._op_pending = 1                  # what ops._register_direct does in a fused forward
             xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
-            net3(xr).pow(2).sum().backward()   # autograd contribution -> post-accumulate hook (first signal)
+            net3(xr).pow(2).sum().backward()   # autograd contribution -> post-accumulate hook; w stays open (pending 1)
+            b_of_w = rd._bucket_of[[n for n, *_ in fl.entries].index("1.weight")]
+            assert not rd._launched[b_of_w], "bucket went out with an in-place contribution outstanding"
             if late_after_autograd:
                 w.grad.add_(delta)             # the fused pass's in-place contribution arrives afterwards ...
-                ops._direct_grad_done(w)       # ... and signals a second time
+                ops._direct_grad_done(w)       # ... and completes the parameter
+                assert rd._launched[b_of_w]
             rd.finish()
-            return fl, rd, delta
+            return fl, rd
 
-        fl, rd, delta = run(True, True)        # deferred mode: nothing may go out before finish()
-        assert rd.stats["launched_in_backward"] == 0 and rd.stats["deferred_steps"] == 1
+        fl, rd = run(True)
         for (n, p_, o, k) in fl.entries:
             want = sum(g[n] for g in per_rank)
             if n == "1.weight":
                 want = want + sum(torch.full_like(want, 0.25 * (r + 1)) for r in range(world))
             assert torch.allclose(fl.grads[o:o + k].view(p_.shape), want, atol=1e-5), n
+        assert rd.stats["launched_in_backward"] == len(rd.buckets)
+        dist.barrier()
+
+        # --- a second backward pass without no_sync() must fail loudly, never re-reduce an already reduced bucket ---
+        net6 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Linear(8, 4))
+        fl6 = FlatParameters(net6)
+        rd6 = BucketedGradReducer(fl6, bucket_bytes=64)
+        rd6.reset()
+        x6 = torch.randn(5, 8)
+        net6(x6).pow(2).sum().backward()
         raised = False
         try:
-            run(False, True)                   # not announced: must fail loudly, never reduce a half-finished bucket
+            net6(x6).pow(2).sum().backward()
         except RuntimeError as e:
-            raised = "after its bucket was all-reduced" in str(e)
+            raised = "second backward pass" in str(e)
         assert raised
+        rd6.finish()
         dist.barrier()
 
         # --- gradient accumulation: micro-step 1 under no_sync(), micro-step 2 reduces the sum of both ---

@@ -25,6 +25,9 @@ def test_two_rank_step_keeps_replicas_identical():
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--batch", "8", "--layers", "3", "--check-replicas", "--no-profile"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    if r.returncode != 0:  # the ranks' own tracebacks come before torchrun's summary: keep the whole log
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        open(os.path.join(ROOT, "gpurun_out", "dist_test_stderr.txt"), "w").write(r.stderr)
+    assert r.returncode == 0, r.stderr[-6000:]
     assert "replica check: IDENTICAL" in r.stderr, r.stderr[-2000:]
     assert '"n_gpus": 2' in r.stdout

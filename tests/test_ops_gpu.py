@@ -434,10 +434,22 @@ def merge_dbias(request):
     hip.lib().op_attn_set_merge_dbias(old)
 
 
+@pytest.fixture(params=[1, 0], ids=["resident", "streaming"])
+def resident(request):
+    """S <= 320 runs the resident-K/V kernels by default; the streaming kernels (all longer sequences) stay tested at the
+    same shapes through the knob."""
+    hip = hipmod()
+    old = hip.lib().op_attn_set_resident(request.param)
+    yield request.param
+    hip.lib().op_attn_set_resident(old)
+
+
 @pytest.mark.parametrize("B,S,heads,use_bias,use_pad", ATTN_CASES + [(5, 327, 2, True, True), (3, 384, 1, True, False),
                                                                      (3, 250, 2, True, True), (2, 272, 1, False, True),
-                                                                     (4, 100, 2, True, False), (2, 16, 1, True, True)])
-def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias):
+                                                                     (4, 100, 2, True, False), (2, 16, 1, True, True),
+                                                                     (3, 257, 2, True, False), (2, 320, 2, True, True),
+                                                                     (2, 289, 1, False, False), (7, 64, 3, True, True)])
+def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias, resident):
     hip = hipmod()
     H = heads * 64
     qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad = _attn_inputs(B, S, heads, use_bias, use_pad)
@@ -447,7 +459,8 @@ def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias)
     ref, lse_ref = _attn_ref(q, k, v, heads, 0.125, bias_r, key_pad)
     dout = rnd(B * S, H, seed=3)
     ref.backward(dout.view(B, S, H))
-    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+    frag = hip.attn_bias_pack(bias_d, S) if (use_bias and resident) else None  # with it S <= 320 takes the resident kernel
+    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad, bias_frag=frag)
     assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
     assert_close(lse[:, :, :S], lse_ref, fro=1e-3, mx=2e-3, what="lse")
     dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
@@ -467,7 +480,8 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
     hip = hipmod()
     H = heads * 64
     qkv, bias, key_pad, d, bias_d, biasT_d, pad_d, Spad = _attn_inputs(B, S, heads, True, True)
-    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad,
+                            bias_frag=hip.attn_bias_pack(bias_d, S))
     dout = dev_bf16(rnd(B * S, H, seed=3))
     clean, clean_dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, out, lse, B, S, heads, 0.125,
                                       bias_d, biasT_d, pad_d, Spad, want_dbias=True)
@@ -492,8 +506,16 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
         assert torch.equal(got, clean_dbias[:, :, :S])
     else:            # the separate dBias kernel adds batch chunks with fp32 atomics: order-dependent last bits
         assert_close(got, clean_dbias[:, :, :S].cpu(), fro=1e-5, mx=1e-4, what="dbias")
-    out_p, _ = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_p, pad_d, Spad)
+    out_p, _ = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_p, pad_d, Spad,
+                            bias_frag=hip.attn_bias_pack(bias_p, S))
     assert torch.equal(out_p, out)
+    hip.lib().op_attn_set_resident(0)  # the streaming kernel reads the row-major image: same requirement
+    try:
+        out_s, _ = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+        out_sp, _ = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_p, pad_d, Spad)
+    finally:
+        hip.lib().op_attn_set_resident(1)
+    assert torch.equal(out_sp, out_s)
 
 
 @pytest.mark.parametrize("B,S,heads,use_pad", [(3, 70, 2, True), (5, 83, 3, False), (2, 257, 2, True)])
@@ -524,7 +546,10 @@ def test_attention_per_sample_bias(B, S, heads, use_pad):
     if use_pad:
         pad_d = torch.ones(B, Spad, dtype=torch.uint8, device=DEV)
         pad_d[:, :S] = key_pad.to(torch.uint8).to(DEV)
-    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)
+    out_s, _ = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad)  # streaming
+    assert_close(out_s.view(B, S, H), ref, fro=6e-3, what="attn out (streaming kernel)")
+    out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad,
+                            bias_frag=hip.attn_bias_pack(bias_d, S))  # resident kernel, per-sample fragment-major images
     assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
     dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
                                bias_d, biasT_d, pad_d, Spad, want_dbias=True)

@@ -958,6 +958,8 @@ int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + bar
 int g_force_splits = 0;  // tools only: > 0 forces the K-split count of small problems (tools/gemm_small_m.py)
                      // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
 
+int g_tile_mode = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
+
 template <int EPI>
 int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
@@ -1142,7 +1144,6 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256
 }
 
 int g_default_glds = 1;
-int g_tile_mode = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
 
 // The whole launch decision of op_gemm_nt in one place (also served to the host by op_gemm_plan, so that it can be tested
 // without a GPU): tile, K-splits, whether the epilogue moves to the fold kernel, and whether the <= 128 leftover rows of

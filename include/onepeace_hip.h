@@ -88,6 +88,18 @@ int op_gemm_set_tile(int mode);
  * plan[3] = leftover rows (M % 256) split off into a second, small launch (0 = none). */
 int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int* plan);
 
+/* ---- fp8 (OCP e4m3) variant of the FFN GEMMs: BASELINE configs[4], explicit opt-in (csrc/fp8.hip) -------------------------
+ * No reference counterpart (the reference trains in bf16/fp16, trainer.py:86-88); replaces, when the caller opts in, the
+ * forward GEMMs of transformer_layer.py:54-67,149-157.  Per-row quantisation (x ~= q * scale[row], q = e4m3 of x * 448 / amax_row),
+ * fp32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4, dequantisation by scale_a[m] * scale_b[n] in the epilogue. */
+int op_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t cols, void* stream);
+/* epilogue 0: + bias; 2: GeGLU (B0 = wi_0, B1 = wi_1, scales sb0 / sb1, optional h0 / h1); 3: residual epilogue of op_gemm_nt.
+ * A8 [M,K], B8 [N,K] fp8 bytes (row strides lda / ldb in bytes, multiples of 16); K % 128 == 0; C / h0 / h1 / resid bf16. */
+int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0, const void* B1, int64_t ldb, const float* sb0,
+                   const float* sb1, const void* bias, void* C, int64_t ldc, void* h0, void* h1, const void* resid, int64_t ldr,
+                   const void* gamma, const float* rowscale, int64_t rows_per_sample, int64_t M, int64_t N, int64_t K, int epilogue,
+                   void* stream);
+
 /* ---- attention ---------------------------------------------------------------------------------------------------
  * Replaces multihead_attention.py:102-115 (bmm QK^T, += attn_mask, fp32 softmax, bmm PV) and the xformers seam
  * :79-101, plus the dense-bias assembly of transformer_encoder.py:144-162: bias is the per-table image
@@ -198,6 +210,8 @@ int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream)
 int op_probe_mfma32(const void* a, const void* b, float* d, int n, void* stream);
 int op_probe_tr16(const void* img, const int* addr, void* out, int n, void* stream);
 int op_probe_glds(const void* src, const int* src_off, int lds_base, void* dump, void* stream);
+/* raw v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 e4m3 x fp8 e4m3): a, b = [n][64 lanes][8 dwords], sa, sb = [n][64] E8M0 scale dwords */
+int op_probe_mfma_f8(const void* a, const void* b, const void* sa, const void* sb, float* d, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,9 +59,34 @@ __global__ void probe_glds_kernel(const char* src, const int* src_off, int lds_b
   for (int i = l; i < 8192; i += 64) dump[i] = lds[i];
 }
 
+// v_mfma_scale_f32_16x16x128_f8f6f4 with both operands fp8 (e4m3): lane l supplies 8 dwords (32 fp8) of A and of B plus one
+// dword of E8M0 scales each (byte 0 is used); raw accumulator dump.
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+__global__ void probe_mfma_f8_kernel(const int* a, const int* b, const int* sa, const int* sb, float* d, int n) {
+  const int l = threadIdx.x;
+  for (int r = 0; r < n; ++r) {
+    i32x8_t av, bv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      av[i] = a[((int64_t)r * 64 + l) * 8 + i];
+      bv[i] = b[((int64_t)r * 64 + l) * 8 + i];
+    }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, sa[r * 64 + l], 0, sb[r * 64 + l]);
+    *reinterpret_cast<f32x4*>(d + ((int64_t)r * 64 + l) * 4) = c;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int op_probe_mfma_f8(const void* a, const void* b, const void* sa, const void* sb, float* d, int n, void* stream) {
+  hipLaunchKernelGGL(probe_mfma_f8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)a, (const int*)b, (const int*)sa,
+                     (const int*)sb, d, n);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
 
 int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream) {
   hipLaunchKernelGGL(probe_mfma16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, d, n);

@@ -65,10 +65,13 @@ SIGNATURES = {
     "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
     "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
+    "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
+    "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
     "op_probe_mfma32": (c_int, [P, P, P, c_int, P]),
     "op_probe_tr16": (c_int, [P, P, P, c_int, P]),
     "op_probe_glds": (c_int, [P, P, c_int, P, P]),
+    "op_probe_mfma_f8": (c_int, [P, P, P, P, P, c_int, P]),
 }
 
 
@@ -210,6 +213,31 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
                             ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), ptr(out), ldc_, ptr(h0), ptr(h1),
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
                             rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, stream()), "op_gemm_nt")
+    return out
+
+
+def quant_fp8_rows(x2d):
+    """bf16 [rows, cols] -> (fp8 e4m3 bytes [rows, cols] as uint8, fp32 row scales [rows]) with x ~= q * scale[row]."""
+    rows, cols = x2d.shape
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=x2d.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _check(lib().op_quant_fp8_rows(ptr(x2d), x2d.stride(0), ptr(q), q.stride(0), ptr(scale), rows, cols, stream()), "op_quant_fp8_rows")
+    return q, scale
+
+
+def gemm_nt_fp8(A8, sa, B8s, sbs, bias=None, out=None, epilogue=EPI_BIAS, h0=None, h1=None, resid=None, gamma=None, rowscale=None,
+                rows_per_sample=0):
+    """C[M,N] bf16 = epilogue((A8 @ B8^T) * sa[:, None] * sb[None, :]) on the fp8 MFMA path; A8 [M,K] / B8 [N,K] uint8 (e4m3),
+    per-row fp32 scales.  B8s / sbs: [W] or, for the GeGLU epilogue, [W0, W1]."""
+    M, K = A8.shape
+    N = B8s[0].shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=A8.device)
+    B1, sb1 = (B8s[1], sbs[1]) if len(B8s) > 1 else (None, None)
+    _check(lib().op_gemm_nt_fp8(ptr(A8), A8.stride(0), ptr(sa), ptr(B8s[0]), ptr(B1), B8s[0].stride(0), ptr(sbs[0]), ptr(sb1),
+                                ptr(bias), ptr(out), out.stride(0), ptr(h0), ptr(h1), ptr(resid),
+                                resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale), rows_per_sample, M, N, K,
+                                epilogue, stream()), "op_gemm_nt_fp8")
     return out
 
 

@@ -81,6 +81,37 @@ def _transposed(ws):
     return t
 
 
+# --------------------------------------------------------------------------------------------------------------
+# fp8 (e4m3) variant of the forward FFN GEMMs -- BASELINE configs[4], explicit opt-in (bench.py --config 4 --fp8)
+# --------------------------------------------------------------------------------------------------------------
+FP8_FFN = False
+_fp8_cache = {}
+
+
+def set_fp8_ffn(on):
+    """Opt in / out of running the FORWARD FFN GEMMs (GeGLU up-projection, down-projection) on fp8 e4m3 operands with per-row
+    scales (csrc/fp8.hip).  Backward stays on the bf16 kernels and the bf16 activations saved by the forward pass."""
+    global FP8_FFN
+    old, FP8_FFN = FP8_FFN, bool(on)
+    return old
+
+
+def _fp8_weight(w):
+    """(fp8 bytes, row scales) of a weight [out, in]; a derived buffer like the transposed dgrad copies, re-quantised when
+    the weight changes (parameter version / optimiser epoch)."""
+    key = id(w)
+    ver = (w._version, w.data_ptr(), _cache_epoch)
+    hit = _fp8_cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == ver:
+        return hit[2]
+    if len(_fp8_cache) > 4096:
+        for k in [k for k, v in _fp8_cache.items() if v[0]() is None]:
+            del _fp8_cache[k]
+    qs = hip.quant_fp8_rows(w.detach())
+    _fp8_cache[key] = (weakref.ref(w), ver, qs)
+    return qs
+
+
 def _round_up(n, m):
     return ((n + m - 1) // m) * m
 
@@ -383,14 +414,26 @@ def _ffn_forward(x_mid, P, S, ps2, keep):
     if keep:
         h0 = torch.empty(x_mid.shape[0], Fd, dtype=x_mid.dtype, device=x_mid.device)
         h1 = torch.empty_like(h0)
-    g = hip.gemm_nt(xln2, [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+    fp8 = FP8_FFN and x_mid.shape[1] % 128 == 0 and Fd % 128 == 0
+    if fp8:  # opt-in: e4m3 operands with per-row scales, fp32 accumulation (csrc/fp8.hip)
+        xq, xs = hip.quant_fp8_rows(xln2)
+        (w0q, w0s), (w1q, w1s) = _fp8_weight(P["w0"]), _fp8_weight(P["w1"])
+        g = hip.gemm_nt_fp8(xq, xs, [w0q, w1q], [w0s, w1s], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+    else:
+        g = hip.gemm_nt(xln2, [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
     if P["fln_w"] is not None:
         gln, mean_f, rstd_f = hip.layernorm_fwd(g, P["fln_w"], P["fln_b"], want_stats=keep)
     else:
         gln, mean_f, rstd_f = g, None, None
     y2 = torch.empty_like(x_mid) if keep else None
-    out = hip.gemm_nt(gln, [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x_mid, gamma=P["g2"], rowscale=ps2,
-                      rows_per_sample=S, h0=y2)
+    if fp8:
+        gq, gs = hip.quant_fp8_rows(gln)
+        w2q, w2s = _fp8_weight(P["w2"])
+        out = hip.gemm_nt_fp8(gq, gs, [w2q], [w2s], bias=P["b2"], epilogue=hip.EPI_RESID, resid=x_mid, gamma=P["g2"], rowscale=ps2,
+                              rows_per_sample=S, h0=y2)
+    else:
+        out = hip.gemm_nt(gln, [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x_mid, gamma=P["g2"], rowscale=ps2,
+                          rows_per_sample=S, h0=y2)
     if not keep:
         return out, None
     # g (the GeGLU output) is not kept: the fused LN(F)+GeGLU backward recomputes it from h0, h1

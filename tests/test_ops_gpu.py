@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import onepeace_oracle as O
-from tests.util import assert_close, bf16_round
+from tests.util import assert_close, bf16_round, rel_fro
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -739,3 +739,105 @@ def test_gemm_small_m_split_k_with_epilogue_fold(epi, shape):
         branch = a @ w.t() + b
         assert_close(y, branch, what="branch output")
         assert_close(out, res + ps.repeat_interleave(S)[:M, None] * gamma * branch, what="resid")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp8 (e4m3) variant of the FFN GEMMs (BASELINE configs[4], opt-in).  Stated tolerance of the variant: rel-Frobenius <= 5e-2
+# of the bf16 kernel's result (per-row scaled e4m3 has 3 mantissa bits: ~3 % RMS per operand element, averaged over K);
+# the KERNEL itself must be exact: against the fp32 product of the dequantised operands it meets the bf16 output tolerance.
+# ---------------------------------------------------------------------------------------------------------------------
+FP8_TOL = 5e-2
+
+
+def _deq(q, s):
+    return q.view(torch.float8_e4m3fn).float() * s[:, None]
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 128), (130, 1536), (33, 6144), (64, 8192), (7, 264)])
+def test_fp8_row_quantisation(rows, cols):
+    hip = hipmod()
+    x = rnd(rows, cols, seed=1, scale=3.0)
+    x[0] = 0.0  # an all-zero row must not divide by zero
+    q, s = hip.quant_fp8_rows(dev_bf16(x))
+    amax = x.abs().amax(dim=1)
+    want_s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(s.cpu(), want_s, rtol=1e-6)
+    want_q = (x / want_s[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    got = q.cpu().view(torch.float8_e4m3fn).float()
+    # identical e4m3 codes except where x * (1 / s) and x / s straddle a rounding boundary (bf16 inputs sit on a coarse grid, so
+    # exact ties are not rare): those few land on the neighbouring code
+    diff = got != want_q.float()
+    assert diff.float().mean() < 1e-2
+    assert ((got - want_q.float()).abs() <= 0.126 * want_q.float().abs() + 2 ** -9)[diff].all()
+    assert rel_fro(_deq(q.cpu(), s.cpu()), x) < 4e-2 or rows == 1
+    assert got[0].abs().max() == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 128), (515, 1536, 6144), (130, 1536, 1536), (257, 520, 256)])
+def test_fp8_gemm_bias_and_residual(M, N, K):
+    hip = hipmod()
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, gamma = rnd(N, seed=3), rnd(N, seed=4)
+    resid = rnd(M, N, seed=5)
+    rps = 5
+    ps = (torch.arange((M + rps - 1) // rps) % 3 != 0).float() / 0.7
+    xq, xs = hip.quant_fp8_rows(dev_bf16(x))
+    wq, ws = hip.quant_fp8_rows(dev_bf16(w))
+    exact = _deq(xq.cpu(), xs.cpu()) @ _deq(wq.cpu(), ws.cpu()).t() + bias
+    out = hip.gemm_nt_fp8(xq, xs, [wq], [ws], bias=dev_bf16(bias))
+    assert_close(out, exact, what="fp8 kernel vs dequantised operands")
+    ref16 = hip.gemm_nt(dev_bf16(x), [dev_bf16(w)], [dev_bf16(bias)])
+    assert rel_fro(out.float(), ref16.float()) <= FP8_TOL
+    # residual epilogue: resid + rowscale * gamma * (acc + bias), branch output y
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    out_r = hip.gemm_nt_fp8(xq, xs, [wq], [ws], bias=dev_bf16(bias), epilogue=hip.EPI_RESID, resid=dev_bf16(resid),
+                            gamma=dev_bf16(gamma), rowscale=ps.to(DEV), rows_per_sample=rps, h0=y)
+    rs = ps.repeat_interleave(rps)[:M, None]
+    assert_close(y, exact, what="fp8 branch output")
+    assert_close(out_r, resid + rs * gamma * exact, what="fp8 residual epilogue")
+
+
+@pytest.mark.parametrize("M,F_,K", [(200, 256, 128), (515, 1024, 256), (130, 6144, 1536)])
+def test_fp8_gemm_geglu(M, F_, K):
+    hip = hipmod()
+    x = rnd(M, K, seed=1)
+    w0, w1 = rnd(F_, K, seed=2, scale=K ** -0.5), rnd(F_, K, seed=3, scale=K ** -0.5)
+    xq, xs = hip.quant_fp8_rows(dev_bf16(x))
+    (w0q, w0s), (w1q, w1s) = hip.quant_fp8_rows(dev_bf16(w0)), hip.quant_fp8_rows(dev_bf16(w1))
+    xd = _deq(xq.cpu(), xs.cpu())
+    e0, e1 = xd @ _deq(w0q.cpu(), w0s.cpu()).t(), xd @ _deq(w1q.cpu(), w1s.cpu()).t()
+    h0 = torch.empty(M, F_, dtype=torch.bfloat16, device=DEV)
+    h1 = torch.empty_like(h0)
+    g = hip.gemm_nt_fp8(xq, xs, [w0q, w1q], [w0s, w1s], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+    assert_close(h0, e0, what="fp8 geglu h0")
+    assert_close(h1, e1, what="fp8 geglu h1")
+    assert_close(g, F.gelu(e0) * e1, fro=6e-3, mx=2e-2, what="fp8 geglu out")
+    g16 = hip.gemm_nt(dev_bf16(x), [dev_bf16(w0), dev_bf16(w1)], epilogue=hip.EPI_GEGLU)
+    assert rel_fro(g.float(), g16.float()) <= 1.5 * FP8_TOL  # product of two quantised projections
+
+
+def test_fp8_ffn_branch_forward_close_to_bf16_and_backward_unchanged():
+    """ops.set_fp8_ffn: the fused FFN branch with its two forward GEMMs on the fp8 path stays within the variant's tolerance of
+    the bf16 branch, and the backward pass (bf16 kernels on the saved bf16 activations) still produces every gradient."""
+    from one_peace_amd import ops
+    H, Fd, B, S = 256, 512, 3, 40
+    torch.manual_seed(0)
+    params = [dev_bf16(1 + 0.1 * rnd(H, seed=1)), dev_bf16(0.1 * rnd(H, seed=2)), dev_bf16(rnd(Fd, H, seed=3, scale=H ** -0.5)),
+              dev_bf16(rnd(Fd, H, seed=4, scale=H ** -0.5)), dev_bf16(1 + 0.1 * rnd(Fd, seed=5)), dev_bf16(0.1 * rnd(Fd, seed=6)),
+              dev_bf16(rnd(H, Fd, seed=7, scale=Fd ** -0.5)), dev_bf16(0.1 * rnd(H, seed=8)), dev_bf16(0.5 + 0.1 * rnd(H, seed=9))]
+    x = dev_bf16(rnd(B, S, H, seed=10))
+    outs, grads = [], []
+    for on in (False, True):
+        old = ops.set_fp8_ffn(on)
+        try:
+            ps = [p.clone().requires_grad_(True) for p in params]
+            xi = x.clone().requires_grad_(True)
+            y = ops.ffn_branch(xi, None, ps, save_acts=True)
+            y.float().pow(2).sum().backward()
+            outs.append(y.detach().float())
+            grads.append([xi.grad.float()] + [p.grad.float() for p in ps])
+        finally:
+            ops.set_fp8_ffn(old)
+    assert rel_fro(outs[1] - x.float(), outs[0] - x.float()) <= 1.5 * FP8_TOL   # the branch itself, without the residual
+    for g8, g16 in zip(grads[1], grads[0]):
+        assert g8.isfinite().all() and rel_fro(g8, g16) <= 0.15  # same bf16 backward kernels on slightly different activations

@@ -201,6 +201,14 @@ int op_infonce_rows(float* sim, int64_t rows, int64_t n, int64_t ld, int64_t tar
 int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, float grad_scale, const float* grad_sqnorm, float clip_norm,
                   void* stream);
+/* The same update over a flat buffer partitioned into n_groups <= 256 contiguous parameter groups, ONE launch: the param groups
+ * of trainer.py:265-278 / utils/layer_decay.py:34-77 ("layer_<id>_<decay|no_decay>" with lr_scale and weight_decay; lr_g = lr *
+ * lr_scale_g as optim/base_optimizer.py:8-14 sets it).  group_end8[g] (device, ascending, int64) = end of group g in 8-element
+ * vectors; group_lr_scale / group_weight_decay: device fp32 tables. */
+int op_adamw_step_groups(void* p, const void* g, float* m, float* v, int64_t numel, const int64_t* group_end8,
+                         const float* group_lr_scale, const float* group_weight_decay, int64_t n_groups, float lr, float beta1,
+                         float beta2, float eps, int64_t step, float grad_scale, const float* grad_sqnorm, float clip_norm,
+                         void* stream);
 /* out[0] = sum of squares of a bf16 vector in fp32 (the global gradient norm of fairseq/fairseq/utils.py:349-391 over the
  * flat gradient buffer; feeds op_adamw_step's device-side clip coefficient, trainer.py:929).  workspace: 1024 floats. */
 int op_sqnorm(const void* x, int64_t numel, float* workspace, float* out, void* stream);

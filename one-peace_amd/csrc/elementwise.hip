@@ -387,6 +387,63 @@ __global__ __launch_bounds__(256) void adamw_kernel(bf16_t* __restrict__ p, cons
   }
 }
 
+// The same update over a flat buffer that is partitioned into parameter groups (trainer.py:265-278, utils/layer_decay.py:34-77:
+// "layer_<id>_<decay|no_decay>" groups with their own lr_scale and weight decay; optim/base_optimizer.py:8-14 sets
+// lr_g = lr * lr_scale_g): group g owns the 8-element vectors [end8[g-1], end8[g]).  ONE launch for all groups: the group of a
+// vector is found by binary search in a table staged in LDS (<= 256 groups), and re-used while consecutive vectors stay in it.
+constexpr int ADAM_MAX_GROUPS = 256;
+__global__ __launch_bounds__(256) void adamw_groups_kernel(bf16_t* __restrict__ p, const bf16_t* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, int64_t n8,
+                                                           const int64_t* __restrict__ end8, const float* __restrict__ lr_scale,
+                                                           const float* __restrict__ wd, int n_groups, float lr, float beta1,
+                                                           float beta2, float eps, float bias_corr, float grad_scale,
+                                                           const float* __restrict__ sqnorm, float clip_norm) {
+  __shared__ int64_t s_end[ADAM_MAX_GROUPS];
+  __shared__ float s_step[ADAM_MAX_GROUPS], s_decay[ADAM_MAX_GROUPS];
+  for (int i = threadIdx.x; i < n_groups; i += 256) {
+    const float lr_g = lr * lr_scale[i];
+    s_end[i] = end8[i];
+    s_step[i] = lr_g * bias_corr;          // lr_g * sqrt(1 - beta2^t) / (1 - beta1^t)
+    s_decay[i] = 1.f - wd[i] * lr_g;       // p <- p - wd * lr_g * p, before the Adam update (adam.py:243-246)
+  }
+  __syncthreads();
+  if (sqnorm != nullptr && clip_norm > 0.f) {
+    const float norm = fabsf(grad_scale) * sqrtf(*sqnorm);
+    grad_scale *= fminf(1.0f, clip_norm / (norm + 1e-6f));
+  }
+  int grp = 0;
+  int64_t lo = 0, hi = s_end[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    if (i < lo || i >= hi) {  // first group whose end is > i
+      int a = 0, b = n_groups - 1;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (s_end[mid] > i) b = mid; else a = mid + 1;
+      }
+      grp = a;
+      lo = grp ? s_end[grp - 1] : 0;
+      hi = s_end[grp];
+    }
+    const float step_size = s_step[grp], decay_mul = s_decay[grp];
+    float pv[8], gv[8], mv[8], vv[8];
+    Vec8<bf16_t>::load(p + i * 8, pv);
+    Vec8<bf16_t>::load(g + i * 8, gv);
+    Vec8<float>::load(m + i * 8, mv);
+    Vec8<float>::load(v + i * 8, vv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gr = gv[j] * grad_scale;
+      mv[j] = mv[j] * beta1 + (1.f - beta1) * gr;
+      vv[j] = vv[j] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[j]) + eps;
+      pv[j] = pv[j] * decay_mul - step_size * (mv[j] / denom);
+    }
+    Vec8<bf16_t>::store(p + i * 8, pv);
+    Vec8<float>::store(m + i * 8, mv);
+    Vec8<float>::store(v + i * 8, vv);
+  }
+}
+
 // sum of squares, stage 1: one partial per workgroup (grid-stride over 8-element vectors); stage 2 folds the partials
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const bf16_t* __restrict__ x, int64_t n8, float* __restrict__ part) {
   __shared__ float red[4];
@@ -659,6 +716,27 @@ int op_adamw_step(void* p, const void* g, float* m, float* v, int64_t numel, flo
   const float decay_mul = 1.f - weight_decay * lr;
   hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (const bf16_t*)g,
                      m, v, numel / 8, beta1, beta2, eps, step_size, decay_mul, grad_scale, grad_sqnorm, clip_norm);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// AdamW over a flat buffer partitioned into n_groups (<= 256) contiguous parameter groups in ONE launch: group g covers
+// elements [8 * group_end8[g-1], 8 * group_end8[g]) (device table, ascending, last entry = numel / 8) and uses
+// lr * group_lr_scale[g] and group_weight_decay[g] (device tables; they are static, the scheduled lr is the scalar argument).
+// Same update rule, clip handling and byte traffic as op_adamw_step.
+int op_adamw_step_groups(void* p, const void* g, float* m, float* v, int64_t numel, const int64_t* group_end8,
+                         const float* group_lr_scale, const float* group_weight_decay, int64_t n_groups, float lr, float beta1,
+                         float beta2, float eps, int64_t step, float grad_scale, const float* grad_sqnorm, float clip_norm,
+                         void* stream) {
+  OP_CHECK_ARG(p && g && m && v && group_end8 && group_lr_scale && group_weight_decay, "adamw_groups: null pointer");
+  OP_CHECK_ARG(numel % 8 == 0 && step >= 1 && n_groups >= 1 && n_groups <= ADAM_MAX_GROUPS,
+               "adamw_groups: numel %% 8 == 0, step >= 1, 1 <= n_groups <= %d required", ADAM_MAX_GROUPS);
+  if (numel == 0) return OP_OK;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_groups_kernel, dim3(ew_grid(numel / 8)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p,
+                     (const bf16_t*)g, m, v, numel / 8, group_end8, group_lr_scale, group_weight_decay, (int)n_groups, lr, beta1,
+                     beta2, eps, (float)(sqrt(bc2) / bc1), grad_scale, grad_sqnorm, clip_norm);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

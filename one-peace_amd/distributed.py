@@ -56,25 +56,42 @@ def warm_up_collectives():
 class FlatParameters:
     """Re-homes a module's parameters (and their .grad) into two flat buffers of the parameter dtype.
 
-    Parameters are laid out in REVERSE registration order (roughly the order backward finishes them), each start
-    aligned to 8 elements (16 bytes for bf16) so the vector kernels can run over any sub-range; ``no_decay`` names go
-    to the tail so weight decay is a contiguous range."""
+    Parameters are laid out group by group -- a group = (lr_scale, weight decay on/off), the optimiser's param groups of
+    trainer.py:265-278 / utils/layer_decay.py:34-77 -- so that every group is ONE contiguous range the fused AdamW kernel
+    addresses through a small table.  Groups appear in the order their first parameter appears in REVERSE registration order
+    (roughly the order backward finishes them: with layer decay the groups are the layers, last layer first), and inside a
+    group the reverse registration order is kept; each parameter start is aligned to 8 elements (16 bytes for bf16) so the
+    vector kernels can run over any sub-range.
+
+    no_decay(name, p) -> bool: parameters without weight decay.  lr_scale(name, p) -> float (optional): layer-wise lr decay.
+    ``groups``: [(start, end, lr_scale, decays)]; ``decay_range`` / ``no_decay_range`` are kept for the two-group layout."""
 
     ALIGN = 8
 
-    def __init__(self, module, no_decay=lambda name, p: p.dim() <= 1):
+    def __init__(self, module, no_decay=lambda name, p: p.dim() <= 1, lr_scale=None):
         named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         named.reverse()
-        decay = [(n, p) for n, p in named if not no_decay(n, p)]
-        nodecay = [(n, p) for n, p in named if no_decay(n, p)]
-        self.entries = []
+        if lr_scale is None:  # two groups, all decayed parameters first (the layout the bucketed reducer was tuned on)
+            keyed = [((1.0, not no_decay(n, p)), n, p) for n, p in named]
+            order = [(1.0, True), (1.0, False)]
+        else:
+            keyed = [((float(lr_scale(n, p)), not no_decay(n, p)), n, p) for n, p in named]
+            order = []
+            for k, _, _ in keyed:
+                if k not in order:
+                    order.append(k)
+        self.entries, self.groups = [], []
         off = 0
-        for group, items in (("decay", decay), ("no_decay", nodecay)):
+        for key in order:
             start = off
-            for n, p in items:
-                self.entries.append((n, p, off, p.numel()))
-                off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-            setattr(self, group + "_range", (start, off))
+            for k, n, p in keyed:
+                if k == key:
+                    self.entries.append((n, p, off, p.numel()))
+                    off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if off > start or lr_scale is None:
+                self.groups.append((start, off, key[0], key[1]))
+        if lr_scale is None:
+            self.decay_range, self.no_decay_range = self.groups[0][:2], self.groups[1][:2]
         self.numel = off
         p0 = named[0][1]
         self.params = torch.zeros(off, dtype=p0.dtype, device=p0.device)

@@ -57,6 +57,7 @@ SIGNATURES = {
     "op_l2norm_bwd": (c_int, [P, P, P, P, I64, I64, c_int, P]),
     "op_infonce_rows": (c_int, [P, I64, I64, I64, I64, c_float, c_float, P, P, P, c_int, P]),
     "op_adamw_step": (c_int, [P, P, P, P, I64, c_float, c_float, c_float, c_float, c_float, I64, c_float, P, c_float, P]),
+    "op_adamw_step_groups": (c_int, [P, P, P, P, I64, P, P, P, I64, c_float, c_float, c_float, c_float, I64, c_float, P, c_float, P]),
     "op_sqnorm": (c_int, [P, I64, P, P, P]),
     "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
@@ -392,6 +393,14 @@ def infonce_rows(sim, target0, label_smoothing=0.0, gscale=1.0, write_grad=True)
 def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_sqnorm=None, clip_norm=0.0):
     _check(lib().op_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                grad_scale, ptr(grad_sqnorm), clip_norm, stream()), "op_adamw_step")
+
+
+def adamw_step_groups(p, g, m, v, group_end8, group_lr_scale, group_wd, lr, beta1, beta2, eps, step, grad_scale=1.0,
+                      grad_sqnorm=None, clip_norm=0.0):
+    """One launch over the whole flat buffer; group tables are device tensors (int64 ends in 8-element vectors, fp32 scales)."""
+    _check(lib().op_adamw_step_groups(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(group_end8), ptr(group_lr_scale),
+                                      ptr(group_wd), group_end8.numel(), lr, beta1, beta2, eps, step, grad_scale, ptr(grad_sqnorm),
+                                      clip_norm, stream()), "op_adamw_step_groups")
 
 
 def sqnorm(x, out=None):

@@ -2,12 +2,50 @@
 
 Update rule = the reference's in-repo ``Adam`` (one_peace/optim/adam.py:186-253; what runs when apex is absent):
 fp32 moments, fp32 math on bf16 parameters (the ``MemoryEfficientFP16Optimizer`` arrangement: no fp32 master copy),
-decoupled weight decay applied before the Adam update, eps added to sqrt(v).  One HIP launch per decay group over the
-flat buffers of ``distributed.FlatParameters``: 22 bytes/parameter of HBM traffic per step."""
+decoupled weight decay applied before the Adam update, eps added to sqrt(v).  Param groups = the reference's
+(trainer.py:265-278 -> utils/layer_decay.py:34-77): no weight decay for ``ndim <= 1`` / ``.bias`` / ``no_weight_decay()`` names,
+and -- with ``layer_decay < 1`` -- the lr of layer id i scaled by ``layer_decay ** (L + 1 - i)`` (optim/base_optimizer.py:8-14).
+ONE HIP launch over the flat buffers of ``distributed.FlatParameters`` per step, whatever the number of groups (a device table
+maps ranges to their lr scale / weight decay): 22 bytes/parameter of HBM traffic.
+
+Deviation from the reference, stated: global-norm clipping multiplies the gradient by the clip coefficient in fp32 inside the
+update kernel; the reference scales its bf16 gradients in place first (fairseq/utils.py:393-397: one extra bf16 rounding)."""
+import re
+
 import torch
 
 from . import hip, ops
 from .distributed import FlatParameters
+
+
+def layer_id_of(var_name, num_max_layer):
+    """one_peace/utils/layer_decay.py:8-21 (get_num_layer): adapters' embeddings -> 0, adapter rel_pos_table k and encoder
+    layer k -> k + 1, everything else (projections, logit scale, final norms) -> the last id."""
+    for ad in ("text_adapter", "image_adapter", "audio_adapter"):
+        if var_name.startswith(ad):
+            rest = var_name[len(ad) + 1:]
+            return int(rest.split(".")[1]) + 1 if rest.startswith("rel_pos_table") else 0
+    if var_name.startswith("fusion_model.layers"):
+        return int(var_name.split(".")[2]) + 1
+    return num_max_layer - 1
+
+
+def reference_param_groups(model, num_layers=None, layer_decay=1.0):
+    """(no_decay(name, p), lr_scale(name, p)) callables for ``FlatParameters`` that reproduce trainer.py:265-278."""
+    skip = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
+
+    def no_decay(name, p):
+        name = re.sub("^module.module.", "", name)
+        return p.ndim <= 1 or name.endswith(".bias") or name in skip
+
+    if num_layers is None or layer_decay >= 1.0:
+        return no_decay, None
+    values = [layer_decay ** (num_layers + 1 - i) for i in range(num_layers + 2)]
+
+    def lr_scale(name, p):
+        name = re.sub("^module.module.", "", name)
+        return values[layer_id_of(re.sub("^encoder_wrapper.", "", name), len(values))]
+    return no_decay, lr_scale
 
 
 class FusedAdamW:
@@ -19,6 +57,16 @@ class FusedAdamW:
         self.exp_avg = torch.zeros(flat.numel, dtype=torch.float32, device=flat.params.device)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.step_count = 0
+        groups = [g for g in flat.groups if g[1] > g[0]]
+        dev = flat.params.device
+        self._end8 = torch.tensor([g[1] // 8 for g in groups], dtype=torch.int64, device=dev)
+        self._scale = torch.tensor([g[2] for g in groups], dtype=torch.float32, device=dev)
+        self._wd = torch.tensor([weight_decay if g[3] else 0.0 for g in groups], dtype=torch.float32, device=dev)
+        assert groups and groups[0][0] == 0 and groups[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(groups, groups[1:]))
+
+    def set_lr(self, lr):
+        """optim/base_optimizer.py:8-14: the scheduled lr; group g runs at lr * lr_scale_g."""
+        self.lr = lr
 
     def step(self, grad_scale=1.0, clip_norm=0.0):
         """grad_scale multiplies the gradient inside the kernel (1/world_size after a SUM all-reduce, trainer.py:917-923).
@@ -28,10 +76,8 @@ class FusedAdamW:
         self.step_count += 1
         f = self.flat
         sq = hip.sqnorm(f.grads) if clip_norm > 0 else None
-        for (s, e), wd in ((f.decay_range, self.weight_decay), (f.no_decay_range, 0.0)):
-            if e > s:
-                hip.adamw_step(f.params[s:e], f.grads[s:e], self.exp_avg[s:e], self.exp_avg_sq[s:e], self.lr, self.betas[0],
-                               self.betas[1], self.eps, wd, self.step_count, grad_scale, sq, clip_norm)
+        hip.adamw_step_groups(f.params, f.grads, self.exp_avg, self.exp_avg_sq, self._end8, self._scale, self._wd, self.lr,
+                              self.betas[0], self.betas[1], self.eps, self.step_count, grad_scale, sq, clip_norm)
         ops.refresh_weight_cache()  # the raw-pointer update does not bump _version: refresh the dgrad copies in one launch
         return sq.sqrt() * abs(grad_scale) if sq is not None else None
 

@@ -421,6 +421,54 @@ def clip_coef(grads, max_norm):
     return total, coef
 
 
+def layer_id_of(name, num_max_layer):
+    """one_peace/utils/layer_decay.py:8-21 (get_num_layer) on a parameter name without the 'encoder_wrapper.' prefix."""
+    for ad in ("text_adapter", "image_adapter", "audio_adapter"):
+        if name.startswith(ad):
+            rest = name[len(ad) + 1:]
+            return int(rest.split(".")[1]) + 1 if rest.startswith("rel_pos_table") else 0
+    if name.startswith("fusion_model.layers"):
+        return int(name.split(".")[2]) + 1
+    return num_max_layer - 1
+
+
+def param_groups(named_params, weight_decay, skip_list, num_layers=None, layer_decay=1.0):
+    """trainer.py:265-278 + utils/layer_decay.py:34-77: {name: (lr_scale, weight_decay)}.  No decay for ndim <= 1, '.bias' and
+    the model's no_weight_decay() names; with layer_decay < 1 the lr of layer id i is scaled by layer_decay ** (L + 1 - i)."""
+    out = {}
+    for name, p in named_params:
+        wd = 0.0 if (p.ndim <= 1 or name.endswith(".bias") or name in skip_list) else weight_decay
+        scale = 1.0
+        if num_layers is not None and layer_decay < 1.0:
+            values = [layer_decay ** (num_layers + 1 - i) for i in range(num_layers + 2)]
+            var = name[len("encoder_wrapper."):] if name.startswith("encoder_wrapper.") else name
+            scale = values[layer_id_of(var, len(values))]
+        out[name] = (scale, wd)
+    return out
+
+
+def clip_grad_norm_(grads, max_norm):
+    """fairseq/fairseq/utils.py:349-398: returns the total norm and scales the gradients IN PLACE (in their own dtype: bf16
+    gradients are rounded after the multiplication)."""
+    total, coef = clip_coef(grads, max_norm)
+    if max_norm > 0:
+        for g in grads:
+            g.mul_(coef)
+    return total
+
+
+def optimizer_step(params, grads, state, groups, step, lr, betas, eps, max_norm=0.0):
+    """One trainer step of the optimiser leg: clip (in place), then Adam per parameter with its group's lr * lr_scale and
+    weight decay (optim/base_optimizer.py:8-14, optim/adam.py:186-253).  params / grads / state: dicts by name; state[name] =
+    (exp_avg, exp_avg_sq) fp32."""
+    total = clip_grad_norm_([grads[n] for n in params], max_norm)
+    for n, p in params.items():
+        scale, wd = groups[n]
+        m, v = state[n]
+        adamw_step(p, grads[n], m, v, step, lr * scale, betas[0], betas[1], eps, wd)
+    return total
+
+
 def dp_mean_grads(per_rank_grads):
     """fairseq legacy_distributed_data_parallel.py:76-165: each rank divides by world size, then SUM."""
     w = len(per_rank_grads)

@@ -176,6 +176,35 @@ def install():
     _INSTALLED = True
 
 
+def ref_optim():
+    """The reference's optimiser leg, loaded verbatim: one_peace/optim/adam.py (class Adam, :124-253),
+    one_peace/utils/layer_decay.py (LayerDecayValueAssigner, get_parameter_groups, :8-77) and
+    fairseq/fairseq/utils.py (clip_grad_norm_, :349-398).  adam.py's module level needs fairseq.optim / omegaconf names for
+    its *config* classes only; they are stubbed (the Adam class itself is plain torch)."""
+    install()
+    if "one_peace.optim.adam" not in sys.modules:
+        fo = _shell("fairseq.optim")
+
+        class FairseqOptimizer:
+            def __init__(self, cfg):
+                self.cfg = cfg
+
+        fo.FairseqOptimizer = FairseqOptimizer
+        fo.register_optimizer = lambda name, dataclass=None: (lambda cls: cls)
+        if "omegaconf" not in sys.modules:
+            oc = _shell("omegaconf")
+            oc.II = lambda key: None
+            oc.OmegaConf = type("OmegaConf", (), {"to_container": staticmethod(lambda x: x)})
+        _shell("one_peace.optim", os.path.join(REFERENCE_ROOT, "one_peace", "optim"))
+        _shell("one_peace.utils", os.path.join(REFERENCE_ROOT, "one_peace", "utils"))
+    adam = importlib.import_module("one_peace.optim.adam")
+    ld = importlib.import_module("one_peace.utils.layer_decay")
+    fu = sys.modules.get("_ref_fairseq_utils_full") or _load_file(
+        "_ref_fairseq_utils_full", os.path.join(REFERENCE_ROOT, "fairseq", "fairseq", "utils.py"))
+    return SimpleNamespace(Adam=adam.Adam, LayerDecayValueAssigner=ld.LayerDecayValueAssigner,
+                           get_parameter_groups=ld.get_parameter_groups, clip_grad_norm_=fu.clip_grad_norm_)
+
+
 def ref(modname):
     """Import a reference module, e.g. ref('one_peace.models.transformer.transformer_layer')."""
     install()

@@ -84,3 +84,10 @@ def audio_frames(n_samples):
     for k, s in [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2:
         n = (n - k) // s + 1
     return n
+
+
+def optim_grad(name, shape, step):
+    """Deterministic synthetic gradient of parameter `name` at optimiser step `step` (bf16), shared by the golden generator
+    (tests/golden/make_golden.py::optim_fixture) and the optimiser parity tests."""
+    g = synth_tensor("grad%d/%s" % (step, name), shape, seed=99)
+    return (g * 0.05).to(torch.bfloat16).reshape(tuple(shape))

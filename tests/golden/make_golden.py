@@ -259,13 +259,62 @@ def pretrain_al_fixture():
     print("pretrain al: loss %.6f " % loss.item(), {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
 
 
+OPTIM = dict(lr=[1e-3, 2e-3, 1.5e-3], betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, layer_decay=0.8, clip_norm=0.7)
+
+
+optim_grad = synth.optim_grad
+
+
+def optim_fixture():
+    """The reference's optimiser leg on the micro model in bf16, three steps with layer-wise lr decay (trainer.py:265-278 ->
+    utils/layer_decay.py:34-77 param groups with lr_scale; optim/base_optimizer.py:8-14 set_lr), global-norm clipping
+    (fairseq/utils.py:349-398, applied IN PLACE to the bf16 gradients) and the in-repo Adam (optim/adam.py:124-253: fp32 moments,
+    fp32 math on bf16 parameters).  Stored: the group of every parameter, the gradient norms, and all parameters after each step."""
+    ro = R.ref_optim()
+    m, shapes = build_ref_model(MICRO, 1000)
+    m = m.to(torch.bfloat16)
+    L = MICRO["layers"]
+    assigner = ro.LayerDecayValueAssigner([OPTIM["layer_decay"] ** (L + 1 - i) for i in range(L + 2)])
+    groups = ro.get_parameter_groups(m, OPTIM["weight_decay"], m.no_weight_decay(), assigner.get_layer_id, assigner.get_scale)
+    opt = ro.Adam(groups, lr=OPTIM["lr"][0], betas=OPTIM["betas"], eps=OPTIM["eps"], weight_decay=OPTIM["weight_decay"])
+    names = {id(p): n for n, p in m.named_parameters()}
+    assign = {}
+    for gr in opt.param_groups:
+        for p in gr["params"]:
+            assign[names[id(p)]] = (float(gr["lr_scale"]), float(gr["weight_decay"]))
+    params_after, norms = [], []
+    for step, lr in enumerate(OPTIM["lr"], start=1):
+        for gr in opt.param_groups:  # optim/base_optimizer.py:8-14
+            gr["lr"] = lr * gr["lr_scale"]
+        for n, p in m.named_parameters():
+            p.grad = optim_grad(n, p.shape, step)
+        norms.append(ro.clip_grad_norm_(list(m.parameters()), OPTIM["clip_norm"]).float().clone())
+        opt.step()
+        snap = {}
+        for n, p in m.named_parameters():  # every parameter's norm; small ones in full, the first rows of the big ones
+            d = p.detach()
+            snap[n + "#norm"] = d.double().norm().float()
+            if d.numel() <= 4096:
+                snap[n] = d.clone()
+            else:
+                snap[n + "#head"] = d.reshape(-1)[:2048].clone()
+        params_after.append(snap)
+    fx = dict(cfg=MICRO, vocab=1000, shapes=shapes, optim=OPTIM, assign=assign, grad_norms=norms, params_after=params_after)
+    torch.save(fx, os.path.join(HERE, "optim.pt"))
+    print("optim: %d groups, grad norms %s" % (len(opt.param_groups), [round(float(x), 4) for x in norms]))
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
+    if len(sys.argv) > 1 and sys.argv[1] == "optim":
+        optim_fixture()
+        sys.exit(0)
     micro_fixture()
     tiny_text_fixture()
     layer_fixture()
     pretrain_fixture()
     pretrain_al_fixture()
+    optim_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -263,3 +263,34 @@ def test_audio_language_pretraining_objective_matches_reference(golden_dir):
         elif not k.endswith("#rows4"):
             assert torch.allclose(named[k].grad, v, atol=2e-5, rtol=2e-4), k
     assert checked > 40
+
+
+def test_flat_parameter_groups_follow_reference_param_groups(golden_dir):
+    """distributed.FlatParameters + optim.reference_param_groups lay the micro model out as the reference's optimiser groups it
+    (trainer.py:265-278, utils/layer_decay.py:34-77; tests/golden/optim.pt holds the reference's own assignment): every group
+    is one contiguous, 8-aligned range, and parameter views keep their values."""
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.optim import reference_param_groups
+    fx = _fx(golden_dir, "optim.pt")
+    cfg, oc = fx["cfg"], fx["optim"]
+    m = load_synth(build_retrieval(dict(cfg), fx["vocab"]), fx["shapes"])
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    no_decay, lr_scale = reference_param_groups(m, cfg["layers"], oc["layer_decay"])
+    flat = FlatParameters(m, no_decay=no_decay, lr_scale=lr_scale)
+    assert flat.groups[0][0] == 0 and flat.groups[-1][1] == flat.numel
+    assert all(a[1] == b[0] and a[1] % 8 == 0 for a, b in zip(flat.groups, flat.groups[1:]))
+    seen = {}
+    for n, p, o, k in flat.entries:
+        grp = [g for g in flat.groups if g[0] <= o < g[1]]
+        assert len(grp) == 1 and o + k <= grp[0][1]
+        seen[n] = (grp[0][2], oc["weight_decay"] if grp[0][3] else 0.0)
+        assert torch.equal(p.detach(), before[n]) and p.data_ptr() == flat.params[o:].data_ptr()
+    assert seen.keys() == fx["assign"].keys()
+    for n, (scale, wd) in fx["assign"].items():
+        assert abs(seen[n][0] - scale) < 1e-12 and seen[n][1] == wd, n
+    assert len(flat.groups) == len(set(fx["assign"].values())) == 8
+    # without layer decay: the two-range layout (all decayed parameters, then the rest)
+    m2 = load_synth(build_retrieval(dict(cfg), fx["vocab"]), fx["shapes"])
+    nd, sc = reference_param_groups(m2)
+    flat2 = FlatParameters(m2, no_decay=nd, lr_scale=sc)
+    assert sc is None and len(flat2.groups) == 2 and flat2.decay_range == flat2.groups[0][:2]

@@ -481,6 +481,48 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
         "\n".join(report) + "\n")
 
 
+def test_fused_adamw_with_layer_decay_groups_matches_reference_optimizer(golden_dir):
+    """tests/golden/optim.pt = the reference's Adam + clip_grad_norm_ + layer-decay param groups run for three steps on the bf16
+    micro model (generated through ref_shim).  FusedAdamW over FlatParameters with the same groups (one launch per step, per-range
+    lr table) must land on the same parameters: every norm within 2e-4 relative, every stored element within one bf16 ulp (+ 1.5e-5 absolute)
+    (the reference rounds the clipped gradient to bf16 before Adam; the fused kernel applies the clip coefficient in fp32)."""
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.optim import FusedAdamW, reference_param_groups
+    fx = _fx(golden_dir, "optim.pt")
+    cfg, oc = fx["cfg"], fx["optim"]
+    m = load_synth(build_retrieval(dict(cfg), fx["vocab"]), fx["shapes"]).to(DEV).to(torch.bfloat16)
+    no_decay, lr_scale = reference_param_groups(m, cfg["layers"], oc["layer_decay"])
+    flat = FlatParameters(m, no_decay=no_decay, lr_scale=lr_scale)
+    by_name = {n: (o, k) for n, _, o, k in flat.entries}
+    for start, end, scale, decays in flat.groups:  # the reference's group of every parameter (lr_scale, weight decay)
+        for n, (o, k) in by_name.items():
+            if start <= o < end:
+                want_scale, want_wd = fx["assign"][n]
+                assert abs(scale - want_scale) < 1e-12 and (oc["weight_decay"] if decays else 0.0) == want_wd, n
+    assert len([g for g in flat.groups if g[1] > g[0]]) == len(set(fx["assign"].values()))
+    opt = FusedAdamW(flat, lr=oc["lr"][0], betas=oc["betas"], eps=oc["eps"], weight_decay=oc["weight_decay"])
+    for step, lr in enumerate(oc["lr"], start=1):
+        opt.zero_grad()
+        for n, p in m.named_parameters():
+            p.grad.copy_(synth.optim_grad(n, p.shape, step).to(DEV))
+        opt.set_lr(lr)
+        norm = opt.step(clip_norm=oc["clip_norm"])
+        torch.cuda.synchronize()
+        assert abs(float(norm) - float(fx["grad_norms"][step - 1])) <= 1e-3 * float(fx["grad_norms"][step - 1])
+        snap = fx["params_after"][step - 1]
+        for n, p in m.named_parameters():
+            got = p.detach().float().cpu()
+            want_norm = float(snap[n + "#norm"])
+            assert abs(float(got.double().norm()) - want_norm) <= 2e-4 * want_norm + 1e-6, (step, n)
+            ref = (snap[n] if n in snap else snap[n + "#head"]).float().reshape(-1)
+            g = got.reshape(-1)[: ref.numel()]
+            # one bf16 ulp of the parameter, plus 0.5 % of the largest possible update (lr * sqrt(1-b2)/(1-b1) ~ 3e-3): where the
+            # update nearly cancels the parameter, the 2^-9 relative difference of the clipped gradient is all that is left
+            # (one ulp PER STEP: a parameter that rounded the other way keeps that offset in the following steps)
+            tol = step * torch.maximum(ref.abs(), g.abs()) * 2.0 ** -7 + 1.5e-5
+            assert ((g - ref).abs() <= tol).all(), (step, n, float(((g - ref).abs() / tol).max()))
+
+
 def test_batched_weight_cache_refresh_after_optimizer_step():
     """optim.FusedAdamW updates the flat parameters through raw pointers and then rebuilds every cached transposed weight
     (the dgrad operands, incl. the fused q|k|v one) in ONE batched launch: after each step every cache entry must equal

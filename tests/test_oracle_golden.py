@@ -128,3 +128,31 @@ def test_adamw_matches_reference_formula():
     step_size = 0.1 * (1 - 0.999) ** 0.5 / (1 - 0.9)
     want = torch.tensor([1.0, -2.0]) * (1 - 0.01 * 0.1) - step_size * m1 / (v1.sqrt() + 1e-8)
     assert torch.allclose(p, want, atol=1e-6)
+
+
+def test_optimizer_leg_matches_reference_adam_clip_and_layer_decay(golden_dir):
+    """tests/golden/optim.pt: the reference's Adam (optim/adam.py:124-253) + clip_grad_norm_ (fairseq/utils.py:349-398) +
+    layer-decay param groups (utils/layer_decay.py, trainer.py:265-278) executed through ref_shim on the bf16 micro model for
+    three steps.  The oracle restatement must reproduce group assignment, gradient norms and every parameter bit for bit."""
+    from tests.model_util import build_retrieval
+    fx = _load(golden_dir, "optim.pt")
+    cfg, oc = fx["cfg"], fx["optim"]
+    model = build_retrieval(dict(cfg), fx["vocab"])  # the mirror: same parameter names / no_weight_decay() as the reference
+    sd = synth.synth_state_dict(fx["shapes"])
+    params = {n: sd[n].to(torch.bfloat16) for n, _ in model.named_parameters()}
+    groups = O.param_groups(list(params.items()), oc["weight_decay"], model.no_weight_decay(), cfg["layers"], oc["layer_decay"])
+    assert set(groups) == set(fx["assign"])
+    for n, (scale, wd) in fx["assign"].items():
+        assert abs(groups[n][0] - scale) < 1e-12 and groups[n][1] == wd, n
+    state = {n: (torch.zeros(p.shape), torch.zeros(p.shape)) for n, p in params.items()}
+    for step, lr in enumerate(oc["lr"], start=1):
+        grads = {n: synth.optim_grad(n, p.shape, step) for n, p in params.items()}
+        total = O.optimizer_step(params, grads, state, groups, step, lr, oc["betas"], oc["eps"], oc["clip_norm"])
+        assert torch.allclose(total.float(), fx["grad_norms"][step - 1], rtol=1e-6)
+        snap = fx["params_after"][step - 1]
+        for n, p in params.items():
+            assert torch.allclose(p.double().norm().float(), snap[n + "#norm"], rtol=1e-6), (step, n)
+            if n in snap:
+                assert torch.equal(p.reshape(snap[n].shape), snap[n]), (step, n)
+            else:
+                assert torch.equal(p.reshape(-1)[:2048], snap[n + "#head"]), (step, n)

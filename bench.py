@@ -503,8 +503,15 @@ def main():
         }
         if sweep:
             out["config"]["sweep"] = sweep
-        if reducer is not None and world > 1:
-            out["config"]["grad_allreduce_overlap"] = reducer.overlap_report()
+        if reducer is not None and (world > 1 or reducer.active):
+            rep = reducer.overlap_report()
+            out["config"]["grad_allreduce_overlap"] = rep
+            # every parameter of this model takes part in every step: a bucket that only goes out in finish() means a
+            # completion signal was lost (the three passes share the attention weights) -- fail loudly, never silently serialise
+            if rep["launched_in_finish"] > rep["buckets"]:  # (the first step learns which parameters are unused: its buckets may wait)
+                msg = "gradient buckets were not all all-reduced during backward (no overlap for them): %s" % rep
+                assert not args.check_replicas, msg
+                print("bench: WARNING " + msg, file=sys.stderr, flush=True)
         if prof is not None and prof[0]["count"] > 0:
             g = prof[0]
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12

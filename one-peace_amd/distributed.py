@@ -124,7 +124,8 @@ class BucketedGradReducer:
         gradients the parameter then simply stays open and its bucket goes out in ``finish()``).
     So a parameter completes exactly once per backward pass also when fused and torch-op passes share it.  A bucket is
     all-reduced as soon as all of its parameters are complete (overlapping the rest of backward); ``finish()`` reduces what
-    is left (unused parameters).  Gradient accumulation: wrap all micro-steps but the last in ``no_sync()``; a second
+    is left; parameters that took no part in the first step (unused ones, e.g. mask embeddings in a contrastive-only step) are
+    remembered and no longer hold their bucket back in later steps (static graph; ``forget_unused()`` re-learns).  Gradient accumulation: wrap all micro-steps but the last in ``no_sync()``; a second
     completion of a parameter whose bucket is already in flight raises instead of corrupting the sum."""
 
     def __init__(self, flat: FlatParameters, bucket_bytes=256 << 20, process_group=None):
@@ -148,6 +149,7 @@ class BucketedGradReducer:
                 self._bucket_of[idx] = b
         self._hooks = []
         self._sync = True
+        self._unused = None  # indices of parameters that took no part in the first step (learned in its finish())
         self.stats = {"steps": 0, "buckets": len(self.buckets), "launched_in_backward": 0, "launched_in_finish": 0}
         self._exposed = []  # (event before the waits, event after) per step on the compute stream (nccl only)
         if self.active:
@@ -167,6 +169,11 @@ class BucketedGradReducer:
                 return
             b = self._bucket_of[idx]
             if from_autograd:
+                if self._unused and idx in self._unused and self._launched[b]:
+                    raise RuntimeError(
+                        "BucketedGradReducer: parameter %r took no part in the first step (its bucket no longer waits for it) but "
+                        "received a gradient now; call forget_unused() when the set of used parameters changes"
+                        % self.flat.entries[idx][0])
                 if self._hooked[idx] and self._launched[b]:
                     raise RuntimeError(
                         "BucketedGradReducer: parameter %r finished a second backward pass after its bucket was all-reduced "
@@ -201,12 +208,21 @@ class BucketedGradReducer:
         self._hooked = [False] * len(self.flat.entries)
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        for idx in (self._unused or ()):  # static graph: parameters without a gradient in step 1 (e.g. the mask embeddings in a
+            self._done[idx] = True        # contrastive-only step) do not hold their bucket back until finish()
+            self._pending[self._bucket_of[idx]] -= 1
+
+    def forget_unused(self):
+        """Re-learn which parameters take part in a step (after switching objective / modalities)."""
+        self._unused = None
 
     def finish(self):
         """Reduces every bucket that has not gone out yet (unused parameters) and waits for all of them."""
         if not self.active:
             return
         self.stats["steps"] += 1
+        if self._unused is None and self._sync:
+            self._unused = {i for i, d in enumerate(self._done) if not d}
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)

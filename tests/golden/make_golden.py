@@ -259,6 +259,35 @@ def pretrain_al_fixture():
     print("pretrain al: loss %.6f " % loss.item(), {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
 
 
+DEEP = dict(embed_dim=1536, ffn_embed_dim=6144, layers=8, attention_heads=24, image_rel_bucket_size=16,
+            text_bucket_size=256, audio_bucket_size=512)
+
+
+def deep_vision_fixture():
+    """Vision branch at the 4B layer dimensions (H=1536, F=6144, 24 heads), EIGHT layers deep, 256^2 images (257 tokens), b=2:
+    the reference's image-only retrieval model (head_type 'image').  Stored: the normalised CLS embeddings, the first feature
+    rows, and -- for loss = sum(logits * w) -- every parameter gradient's norm (+ small gradients in full).  Weights are the
+    deterministic synthetic ones of oracle/synth.py (302 M parameters, never stored)."""
+    m, shapes = build_ref_model(DEEP, 1000, head_type="image")
+    B = 2
+    imgs = synth.synth_inputs(B, image_res=256, vocab=1000)["src_images"]
+    logits = m(src_images=imgs, encoder_type="image")
+    feats = m.encoder_wrapper(src_images=imgs, encoder_type="image")[1]
+    w = synth.synth_tensor("deep/w", logits.shape, seed=5)
+    m.zero_grad()
+    (logits * w).sum().backward()
+    grads = {}
+    for n, q in m.named_parameters():  # the inputs / weights are regenerated from oracle/synth.py: store results only
+        if q.grad is not None:
+            grads[n + "#norm"] = q.grad.double().norm().float()
+            if q.grad.numel() <= 1536:
+                grads[n] = q.grad.clone()
+    fx = dict(cfg=DEEP, vocab=1000, shapes=shapes, batch=B, image_res=256, logits=logits.detach(),
+              feats_head=feats[:, :4].detach().clone(), grads=grads)
+    torch.save(fx, os.path.join(HERE, "deep_vision.pt"))
+    print("deep vision: logits norm %.4f, %d grads" % (float(logits.norm()), len(fx["grads"])))
+
+
 OPTIM = dict(lr=[1e-3, 2e-3, 1.5e-3], betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, layer_decay=0.8, clip_norm=0.7)
 
 
@@ -306,8 +335,8 @@ def optim_fixture():
 
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
-    if len(sys.argv) > 1 and sys.argv[1] == "optim":
-        optim_fixture()
+    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep"):
+        {"optim": optim_fixture, "deep": deep_vision_fixture}[sys.argv[1]]()
         sys.exit(0)
     micro_fixture()
     tiny_text_fixture()
@@ -315,6 +344,7 @@ if __name__ == "__main__":
     pretrain_fixture()
     pretrain_al_fixture()
     optim_fixture()
+    deep_vision_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -24,10 +24,14 @@ def _fx(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
 
-def _check(name, hip_val, torch_val, ref, floor, report):
+def _check(name, hip_val, torch_val, ref, floor, report, abs_err=0.0):
+    """abs_err: absolute Frobenius slack for ill-conditioned tensors (small-norm gradients whose bf16 error does not scale
+    with their norm): the gate is  |hip - ref|_F <= max(2 x torch-bf16 error, floor) * |ref|_F + abs_err."""
     e_hip, e_t = rel_fro(hip_val.float(), ref), rel_fro(torch_val.float(), ref)
     report.append("%-60s hip %.3e  torch-bf16 %.3e" % (name, e_hip, e_t))
-    assert e_hip <= max(2 * e_t, floor), "%s: hip %.3e vs torch-bf16 %.3e (floor %.1e)" % (name, e_hip, e_t, floor)
+    nref = float(ref.double().norm())
+    assert e_hip * nref <= max(2 * e_t, floor) * nref + abs_err, "%s: hip %.3e vs torch-bf16 %.3e (floor %.1e, abs %.1e, |ref| %.3e)" % (
+        name, e_hip, e_t, floor, abs_err, nref)
 
 
 def _force_torch_path(model, flag):
@@ -92,10 +96,11 @@ def test_micro_model_forward_backward(golden_dir):
         ref = sd[n].grad
         if ref is None or float(ref.norm()) < 1e-7:
             continue
-        # ill-conditioned gradients (|g| < 1e-2: the audio relative-position table, 8.6e-3, 5x below the text table's) move
-        # between 0.06 and 0.15 relative error on the bf16 TORCH path under +-1 ulp of input noise
-        # (tools/grad_conditioning.py), so the bf16 torch error of one draw is no yardstick for them: wider floor
-        _check("grad " + n, g, tt["grads"][n], ref, 5e-2 if float(ref.norm()) >= 1e-2 else 0.3, report)
+        # ill-conditioned gradients (the audio relative-position table: |g|_F = 8.6e-3, 5x below the text table's) carry a bf16
+        # error that does NOT scale with their norm: 0.5 - 1.3e-3 absolute on the bf16 TORCH path under +-1 ulp of input noise
+        # (tools/grad_conditioning.py).  They get the same 5e-2 relative floor as every gradient plus that absolute slack
+        # (1.5e-3 Frobenius) -- negligible for every well-conditioned tensor (norms 0.1 - 50).
+        _check("grad " + n, g, tt["grads"][n], ref, 5e-2, report, abs_err=1.5e-3)
         worst = max(worst, rel_fro(g, ref))
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "model_parity_report.txt"), "w").write(
         "\n".join(report) + "\nworst grad rel-fro %.3e\n" % worst)
@@ -328,8 +333,7 @@ def test_joint_vl_al_streams_on_hip(golden_dir, train):
 
 def test_full_size_layer_4b_dimensions():
     """One encoder layer at the BASELINE dimensions (H=1536, F=6144, 24 heads, image S=257) on the HIP path against the
-    fp32 torch path of the same mirror on the same device (the mirror's torch path is pinned to the reference at 1e-5 on
-    CPU): outputs and every parameter gradient, plus two size-independent properties -- batch-permutation equivariance
+    fp32 CPU oracle: outputs and every parameter gradient, plus two size-independent properties -- batch-permutation equivariance
     (bit-exact: rows never mix across samples) and invariance to appended, masked keys."""
     from one_peace_amd.relpos import RelPosSpec, make_image_bucket_position
     from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
@@ -364,16 +368,24 @@ def test_full_size_layer_4b_dimensions():
         grads = {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None}
         return y.detach().float(), xd.grad.detach().float(), tab.grad.detach().float(), grads
 
-    y32, dx32, dt32, g32 = run(torch.float32, False, x)
+    # fp32 reference: the CPU oracle (oracle/onepeace_oracle.py, pinned to the reference by tests/test_oracle_golden.py)
+    sdo = {"L." + k: v.detach().clone().float().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xo, tabo = x.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    bias_o = O.rel_pos_bias(tabo, bucket).unsqueeze(0).expand(B, -1, -1, -1)
+    yo = O.encoder_layer(xo.transpose(0, 1), sdo, "L", heads, "image", bias_o).transpose(0, 1)
+    (yo * dy).sum().backward()
+    y32, dx32, dt32 = yo.detach(), xo.grad, tabo.grad
+    g32 = {k[2:]: v.grad for k, v in sdo.items() if v.grad is not None}
     yb, dxb, dtb, gb = run(torch.bfloat16, False, x)     # yardstick: the reference algorithm op by op in bf16
     yh, dxh, dth, gh = run(torch.bfloat16, True, x)
     report = []
-    _check("4B-dim layer out", yh, yb, y32, 1.5e-2, report)
-    _check("4B-dim layer dx", dxh, dxb, dx32, 5e-2, report)
-    _check("4B-dim layer dtable", dth, dtb, dt32, 5e-2, report)
+    _check("4B-dim layer out", yh.cpu(), yb.cpu(), y32, 1.5e-2, report)
+    _check("4B-dim layer dx", dxh.cpu(), dxb.cpu(), dx32, 5e-2, report)
+    _check("4B-dim layer dtable", dth.cpu(), dtb.cpu(), dt32, 5e-2, report)
     for n, ref in g32.items():
-        if float(ref.norm()) > 1e-7:
-            _check("4B-dim grad " + n, gh[n], gb[n], ref, 5e-2, report)
+        if n in gh and float(ref.norm()) > 1e-7:
+            _check("4B-dim grad " + n, gh[n].cpu(), gb[n].cpu(), ref, 5e-2, report)
+    assert len([n for n in g32 if n in gh]) >= 20  # attention + image-FFN parameters (the text / audio FFNs take no part)
     # property 1: permuting the samples permutes the outputs, bit for bit
     perm = torch.tensor([3, 0, 5, 1, 4, 2])
     yp = run(torch.bfloat16, True, x[perm])[0]
@@ -570,8 +582,7 @@ def test_batched_weight_cache_refresh_after_optimizer_step():
 def test_long_sequence_image_on_hip(res_px):
     """BASELINE configs[4] shape class: 448^2 images -> 28 x 28 patches + CLS = 785 tokens and 512^2 -> 1025 tokens (the
     streaming attention kernels with 13 / 17 key tiles, separate dQ / dBias kernels, 2-D relative-position buckets at the
-    larger grid), image tower forward + backward of a small-width model, HIP against the fp32 torch path of the same mirror
-    on the device."""
+    larger grid), image tower forward + backward of a small-width model, HIP against the fp32 CPU oracle."""
     grid = res_px // 16
     S = grid * grid + 1
     cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_bucket_size=grid,
@@ -579,25 +590,78 @@ def test_long_sequence_image_on_hip(res_px):
     g = torch.Generator().manual_seed(3)
     imgs = torch.randn(2, 3, res_px, res_px, generator=g)
     res = {}
-    for mode in ("hip", "torch", "fp32"):
-        dt = torch.float32 if mode == "fp32" else torch.bfloat16
-        m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(dt).eval()
+    w = torch.randn(2, S, 128, generator=torch.Generator().manual_seed(4))
+    for mode in ("hip", "torch"):
+        m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(torch.bfloat16).eval()
         _force_torch_path(m, mode != "hip")
-        feats = m.encoder_wrapper(src_images=imgs.to(DEV).to(dt), encoder_type="image")[1]
+        feats = m.encoder_wrapper(src_images=imgs.to(DEV).to(torch.bfloat16), encoder_type="image")[1]
         assert feats.shape == (2, S, 128)
-        w = torch.randn(feats.shape, generator=torch.Generator().manual_seed(4)).to(DEV)
         m.zero_grad()
-        (feats.float() * w).sum().backward()
+        (feats.float() * w.to(DEV)).sum().backward()
         res[mode] = (feats.detach().float().cpu(),
                      {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    # fp32 reference: the CPU oracle on the same synthetic weights (buffers -- bucket tables, position ids -- from the mirror)
+    m32 = load_synth(build_retrieval(cfg, 1000))
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in m32.state_dict().items()}
+    fo = O.model_wrapper_forward(sd, "encoder_wrapper", cfg["attention_heads"], cfg["layers"], "image", src_images=imgs)[0]["image"]
+    (fo * w).sum().backward()
+    res["fp32"] = (fo.detach(), {k: v.grad for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad and v.grad is not None})
     report = []
     _check("%d^2 image features" % res_px, res["hip"][0], res["torch"][0], res["fp32"][0], 1.5e-2, report)
     n = 0
     for k, ref in res["fp32"][1].items():
-        if float(ref.norm()) > 1e-7:
-            _check("grad " + k, res["hip"][1][k], res["torch"][1][k], ref, 5e-2, report)
+        if k in res["hip"][1] and float(ref.norm()) > 1e-7:
+            _check("grad " + k, res["hip"][1][k], res["torch"][1][k], ref, 5e-2, report, abs_err=1.5e-3)
             n += 1
     assert n > 30 and any("rel_pos_table" in k for k in res["hip"][1])
+
+
+def test_deep_vision_branch_8_layers_4b_dimensions(golden_dir):
+    """tests/golden/deep_vision.pt: the reference's image-only retrieval model at the 4B layer dimensions (H=1536, F=6144, 24
+    heads), EIGHT layers deep, two 256^2 images, run on CPU in fp32 through ref_shim.  The HIP path in bf16 must reproduce the
+    normalised CLS embeddings, the first feature rows and every parameter-gradient norm of loss = sum(logits * w).
+    Stated, ABSOLUTE tolerances (bf16 storage, 8 layers; one 4B-dimension layer measures 3e-3, test_full_size_layer_4b_dimensions):
+    embeddings rel-Frobenius <= 2e-2 and cosine >= 0.9998 per sample; features <= 2e-2; gradient norms within 2 %, small
+    gradients (<= 1536 elements) rel-Frobenius <= 5e-2 + 1.5e-3 absolute.  Measured on MI355X: 1.31e-2 / 0.99991 / 1.30e-2 / 0.4 % /
+    1.6e-2 (profiles/r2_deep_vision_parity_report.txt).  The bf16 torch path of the mirror is reported next to it (not a gate)."""
+    fx = _fx(golden_dir, "deep_vision.pt")
+    imgs = synth.synth_inputs(fx["batch"], image_res=fx["image_res"], vocab=fx["vocab"])["src_images"]
+    w = synth.synth_tensor("deep/w", fx["logits"].shape, seed=5)
+    out = {}
+    for mode in ("hip", "torch"):
+        m = load_synth(build_retrieval(dict(fx["cfg"]), fx["vocab"], head_type="image"), fx["shapes"]).to(DEV).to(torch.bfloat16).eval()
+        _force_torch_path(m, mode == "torch")
+        x = imgs.to(DEV).to(torch.bfloat16)
+        logits = m(src_images=x, encoder_type="image")
+        feats = m.encoder_wrapper(src_images=x, encoder_type="image")[1]
+        m.zero_grad()
+        (logits.float() * w.to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+        out[mode] = (logits.detach().float().cpu(), feats[:, :4].detach().float().cpu(),
+                     {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+        del m
+        torch.cuda.empty_cache()
+    report = []
+    for mode in ("hip", "torch"):
+        lg, ft, gr = out[mode]
+        e_l, e_f = rel_fro(lg, fx["logits"]), rel_fro(ft, fx["feats_head"])
+        cos = torch.nn.functional.cosine_similarity(lg, fx["logits"], dim=1).min()
+        worst_n, worst_s = 0.0, 0.0
+        for k, ref in fx["grads"].items():
+            if k.endswith("#norm"):
+                n = k[:-5]
+                if float(ref) > 1e-6:
+                    worst_n = max(worst_n, abs(float(gr[n].double().norm()) - float(ref)) / float(ref))
+            elif float(ref.norm()) > 1e-6:
+                worst_s = max(worst_s, (float((gr[k] - ref).double().norm()) - 1.5e-3) / float(ref.double().norm()))
+        report.append("%-6s logits rel-fro %.3e cos %.6f | feats %.3e | worst grad-norm dev %.3e | worst small-grad rel-fro (after abs slack) %.3e"
+                      % (mode, e_l, float(cos), e_f, worst_n, worst_s))
+        if mode == "hip":
+            assert e_l <= 2e-2 and float(cos) >= 0.9998, report[-1]
+            assert e_f <= 2e-2, report[-1]
+            assert worst_n <= 2e-2 and worst_s <= 5e-2, report[-1]
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "deep_vision_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")
 
 
 def test_retrieval_criteria_on_hip(golden_dir):

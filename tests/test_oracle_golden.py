@@ -156,3 +156,20 @@ def test_optimizer_leg_matches_reference_adam_clip_and_layer_decay(golden_dir):
                 assert torch.equal(p.reshape(snap[n].shape), snap[n]), (step, n)
             else:
                 assert torch.equal(p.reshape(-1)[:2048], snap[n + "#head"]), (step, n)
+
+
+def test_deep_vision_branch_against_reference(golden_dir):
+    """tests/golden/deep_vision.pt (reference, H=1536 / F=6144 / 24 heads, 8 layers, 2 images): the oracle reproduces the
+    embeddings and feature rows; forward only (the backward of 302 M parameters is covered at 2-4 layers by the other fixtures
+    and would double this test's two minutes)."""
+    fx = _load(golden_dir, "deep_vision.pt")
+    sd = synth.synth_state_dict(fx["shapes"])
+    rb = fx["cfg"]["image_rel_bucket_size"]
+    sd["encoder_wrapper.image_adapter.rp_bucket"] = O.image_bucket_position(rb, (2 * rb - 1) ** 2 + 3)
+    imgs = synth.synth_inputs(fx["batch"], image_res=fx["image_res"], vocab=fx["vocab"])["src_images"]
+    with torch.no_grad():
+        feats = O.model_wrapper_forward(sd, "encoder_wrapper", fx["cfg"]["attention_heads"], fx["cfg"]["layers"], "image",
+                                        src_images=imgs)[0]["image"]
+        logits = O.l2_normalize(O.linear(feats[:, 0], sd["image_proj.weight"], sd["image_proj.bias"]))
+    assert torch.allclose(feats[:, :4], fx["feats_head"], atol=2e-4, rtol=1e-4)
+    assert torch.allclose(logits, fx["logits"], atol=ATOL, rtol=1e-4)

@@ -10,7 +10,10 @@
  *   - the caller owns every buffer (inputs, outputs, workspaces); the library never allocates, frees or keeps a
  *     pointer past the call.
  *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no internal synchronisation.
- *     Stateless and re-entrant: safe from the Python main thread, autograd's backward thread and recompute.
+ *     Stateless and re-entrant: no tuning knobs or caches live in the library (kernel flavours are selected by the per-call
+ *     `tune` word of the GEMM / attention entry points, 0 = production defaults); safe from the Python main thread,
+ *     autograd's backward thread and recompute.  The only process-wide state is the opt-in launch profiler (op_prof_*:
+ *     mutex-protected event log, off by default) and hipFuncSetAttribute bookkeeping (idempotent).
  *   - return 0 on success, a negative errno-style code (-22 EINVAL, -95 ENOTSUP) or a positive hipError_t otherwise;
  *     never throws, never aborts.  op_last_error() gives the thread-local message.
  *   - dtype codes: 0 = bf16, 1 = f32.  Matrices are row-major; `ld*` are row strides in ELEMENTS.
@@ -25,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void);
+int op_abi_version(void); /* 2 since the per-call `tune` words replaced the process-wide knob setters */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -42,8 +45,6 @@ int op_prof_collect(double* ms, int64_t* count, double* work, int n_families);
 int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
                      int64_t cols, float eps, int act_gelu, int dtype, void* stream);
 int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
-/* tuning knob: caps of the persistent LayerNorm grids (<= 0 keeps the current value) */
-int op_layernorm_set_grid(int fwd_blocks, int bwd_blocks);
 /* dx = LN backward (+ `add`: gradient arriving through the residual path, may be NULL, may alias dx);
  * dw, db [cols] optional (need `workspace`); accumulate != 0 adds into dw/db. */
 int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
@@ -69,24 +70,24 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
                const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
-               void* stream);
+               int64_t tune, void* stream);
 /* C[M,N] (bf16) = A^T B with A [K,M] (lda), B [K,N] (ldb) row-major bf16: the weight-gradient GEMM dW = dy^T x of
  * nn.Linear (autograd of components.py:29-34 users) straight from the activation matrices (transpose-read fragments,
  * no transposed copies).  K % 64 == 0, M/N/lda/ldb % 8 == 0, else returns -95 (use op_transpose + op_gemm_nt).
  * accumulate != 0: C += A^T B.  workspace: optional fp32 scratch enabling split-K. */
 int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-               int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
-/* 1 = LDS-DMA (global_load_lds) operand staging [default], 0 = register-staged variant.  Returns the old value. */
-int op_gemm_set_staging(int glds);
-/* Tile / schedule knobs (tests and tools).  0 = auto (a cost model picks 128x128 or 256x256 tiles, K-splits and the
- * tail-rows split), 1 = force 128x128, 2 = force 256x256; 10..16 timing ablations of the 256x256 kernel; 20/21/22 BK = 32 /
- * BK = 64 / auto flavour; 40+g M-tiles per L2 group; 50..53 tail-rows split off / on / eager / always; 60+s forced K-split
- * count for small problems.  Returns the old tile mode. */
-int op_gemm_set_tile(int mode);
+               int accumulate, void* workspace, int64_t workspace_bytes, int64_t tune, void* stream);
+/* `tune` (op_gemm_nt, op_gemm_tn, op_gemm_plan): per-call tuning word, 0 = what production uses.  The library keeps NO tuning
+ * state, so every entry point is a pure function of its arguments; tests and tools select a kernel flavour with the call:
+ * bits 0-1 tile (0 auto: a cost model picks 128x128 or 256x256 tiles, K-splits and the tail-rows split; 1 force 128x128;
+ * 2 force 256x256); bits 2-3 BK = 64 full-line flavour (0 auto, 1 never, 2 always); bits 4-6 tail-rows split (0 default, 1 off,
+ * 3 whenever it saves a round, 4 always); bits 7-11 M-tiles per L2 group (0 auto); bits 12-14 timing ablations of the 256x256
+ * kernel (tools; wrong results); bits 15-18 forced K-split count of small problems (tools); bit 19 register-staged operands
+ * instead of LDS-DMA (global_load_lds). */
 /* Host-only query (no GPU needed): the launch decision op_gemm_nt takes for a dense, single-segment problem.
  * plan[0] = tile (128 | 256), plan[1] = K-splits, plan[2] = 1 if the epilogue runs in the split-K fold kernel,
  * plan[3] = leftover rows (M % 256) split off into a second, small launch (0 = none). */
-int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int* plan);
+int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int64_t tune, int* plan);
 
 /* ---- fp8 (OCP e4m3) variant of the FFN GEMMs: BASELINE configs[4], explicit opt-in (csrc/fp8.hip) -------------------------
  * No reference counterpart (the reference trains in bf16/fp16, trainer.py:86-88); replaces, when the caller opts in, the
@@ -115,7 +116,7 @@ int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0,
  * without bias_frag always runs the streaming kernel. */
 int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, int64_t bias_batch_stride,
                 const void* bias_frag, const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B,
-                int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale, void* stream);
+                int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale, int64_t tune, void* stream);
 /* Fragment-major repack of n_img row-major bias images [n_img][S][Spad] (n_img = heads, or B * heads for per-sample
  * images): dst [n_img][ceil(S/16)][ceil(S/32)][64 lanes][8] bf16 = op_attn_bias_frag_elems(n_img, S) elements, zero
  * outside the sequence.  (No reference counterpart: the reference adds a dense [B, heads, S, S] tensor,
@@ -128,15 +129,11 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 /* autograd of the above (reference: torch autograd through the bmm/softmax ops).  biasT = bias with rows = key.
  * dq/dk/dv rows have stride ldg; dbias fp32 [slabs][heads][S][Spad] (optional, accumulated into: pre-zero it; the
  * gradient is the sum over slabs, slabs = op_attn_bwd_dbias_slabs(B, S, heads)). */
-int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads);
-/* test knob: 0 = separate dQ / dBias kernels, 1 (default) = dQ + dBias in one kernel for sequences up to 384 keys */
-int op_attn_set_merge_dbias(int on);
-/* test knob: 1 (default) = resident-K/V kernels for sequences of up to 320 keys, 0 = the streaming kernels everywhere */
-int op_attn_set_resident(int on);
+int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune);
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
                 const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
-                int64_t head_dim, float scale, void* stream);
+                int64_t head_dim, float scale, int64_t tune, void* stream);
 
 /* ---- relative-position bias tables -------------------------------------------------------------------------------
  * Replaces get_rel_pos_bias of adapter/image.py:164-171, adapter/text.py:76-83, adapter/audio.py:117-124:

@@ -1241,8 +1241,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
   }
 }
 
-int g_merge_dbias = 1;     // 1: dQ + dBias in one kernel when the sequence fits (<= 384 keys); 0: separate kernels (tests)
-int g_resident = 1;        // 1: resident-K/V kernels for S <= RES_MAX_S; 0: always the streaming kernels (tests / A-B timing)
+// Per-call tuning words (last argument before the stream; 0 = what production uses; the library keeps no tuning state):
+//   op_attn_fwd:  bit 0 = always the streaming kernel (tests / A-B timing); bits 1-2 = timing ablations of the resident kernel
+//                 (tools only: 1 no K/V staging, 2 no compute)
+//   op_attn_bwd / op_attn_bwd_dbias_slabs:  bit 0 = separate dQ and dBias kernels instead of the merged one (tests)
 
 template <bool HAS_BIAS, bool HAS_PAD>
 int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, size_t sh, int rows_pad, int qb_per_wg, int abl,
@@ -1259,8 +1261,8 @@ int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, siz
 }
 
 // number of batch chunks (= dbias slabs) of the merged dQ + dBias kernel; 1 when the separate kernels run
-inline int dbias_chunks(int64_t B, int64_t S, int64_t heads) {
-  if (!g_merge_dbias || ceil_div(S, BKV) > 6) return 1;
+inline int dbias_chunks(int64_t B, int64_t S, int64_t heads, bool merge) {
+  if (!merge || ceil_div(S, BKV) > 6) return 1;
   const int64_t base = (int64_t)ceil_div(S, 64) * heads;
   int chunks = (int)((768 + base - 1) / base);
   if (chunks < 1) chunks = 1;
@@ -1276,23 +1278,9 @@ extern "C" void op_prof_end(int slot, void* stream);
 
 extern "C" {
 
-// Debug/test knob: 0 = separate dQ and dBias kernels, 1 (default) = merged kernel for sequences up to 384 keys.  Returns the old value.
 // dbias of op_attn_bwd is fp32 [slabs][heads][S][Spad], pre-zeroed, slabs = this value (the batch chunks of the merged
-// dQ + dBias kernel add into their own slab without atomics; sum the slabs afterwards).
-int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads) { return dbias_chunks(B, S, heads); }
-
-// Debug/test knob: 1 (default) = resident-K/V kernels for sequences of up to 320 keys, 0 = streaming kernels everywhere.
-int op_attn_set_resident(int on) {
-  const int old = g_resident;
-  g_resident = on;  // bit 0: on / off; tools only: bits 1-2 timing ablations (no staging / no compute), bit 3: one query block per wave
-  return old;
-}
-
-int op_attn_set_merge_dbias(int on) {
-  const int old = g_merge_dbias;
-  g_merge_dbias = on ? 1 : 0;
-  return old;
-}
+// dQ + dBias kernel add into their own slab without atomics; sum the slabs afterwards).  `tune` as for op_attn_bwd.
+int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune) { return dbias_chunks(B, S, heads, !(tune & 1)); }
 
 // q, k, v: bf16 rows of `ld` elements (row = b*S + s), head h occupies columns [h*64, h*64+64) of each pointer
 // (so one packed [B*S, 3H] projection output serves all three with pointer offsets 0, H, 2H).
@@ -1300,7 +1288,7 @@ int op_attn_set_merge_dbias(int on) {
 // out: bf16 [B*S][ldo] (head h at columns h*64..).  lse: fp32 [B][heads][lse_ld] (natural log) or null.
 int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const void* bias, int64_t bias_batch_stride,
                 const void* bias_frag, const void* key_pad, void* out, int64_t ldo, float* lse, int64_t lse_ld, int64_t B,
-                int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale, void* stream) {
+                int64_t S, int64_t Spad, int64_t heads, int64_t head_dim, float scale, int64_t tune, void* stream) {
   OP_CHECK_ARG(q && k && v && out, "attn_fwd: null pointer");
   OP_CHECK_ARG(head_dim == HD, "attn_fwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(B > 0 && S > 0 && heads > 0 && ld % 8 == 0 && ldo % 4 == 0, "attn_fwd: bad sizes");
@@ -1316,14 +1304,14 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   hipStream_t s = (hipStream_t)stream;
   // resident-K/V kernel: needs the fragment-major bias image when a bias is used, and 1/scale exact in bf16 (head_dim 64)
   const bool inv_exact = (float)(bf16_t)(1.0f / scale) * scale == 1.0f;
-  if ((g_resident & 1) && S <= RES_MAX_S && (!bias || (bias_frag && inv_exact))) {
+  if (!(tune & 1) && S <= RES_MAX_S && (!bias || (bias_frag && inv_exact))) {
     const int nqb = ceil_div(S, 16);
     const int nwg = ceil_div(nqb, RES_MAX_NW);
     const int qb_per_wg = ceil_div(nqb, nwg);              // = waves per workgroup
     const int rows_pad = ceil_div(S, 32) * 32;
     const size_t sh = (size_t)2 * rows_pad * 128;
     const dim3 rgrid(nwg, (unsigned)heads, (unsigned)B);
-    const int abl = (g_resident >> 1) & 3;
+    const int abl = (int)((tune >> 1) & 3);
     const bf16_t* fr = (const bf16_t*)bias_frag;
     int rc;
     if (bias && key_pad) rc = launch_fwd_res<true, true>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
@@ -1382,7 +1370,8 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
                 const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
-                int64_t head_dim, float scale, void* stream) {
+                int64_t head_dim, float scale, int64_t tune, void* stream) {
+  const bool merge_dbias = !(tune & 1);
   OP_CHECK_ARG(q && k && v && dout && lse && delta && dq && dk && dv, "attn_bwd: null pointer");
   OP_CHECK_ARG(head_dim == HD, "attn_bwd: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(Spad >= ((S + 127) / 128) * 128 && Spad % 8 == 0, "attn_bwd: Spad must be >= S rounded up to 128");
@@ -1393,7 +1382,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
   a.dout = (const bf16_t*)dout; a.ldo = ldo; a.bias = (const bf16_t*)bias; a.biasT = (const bf16_t*)biasT;
   a.bias_bs = bias ? bias_batch_stride : 0;
-  OP_CHECK_ARG(!(dbias && a.bias_bs != 0) || (g_merge_dbias && ceil_div(S, BKV) <= 6),
+  OP_CHECK_ARG(!(dbias && a.bias_bs != 0) || (merge_dbias && ceil_div(S, BKV) <= 6),
                "attn_bwd: the gradient of a per-sample bias needs the merged dQ + dBias kernel (S <= 384)");
   a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
@@ -1413,9 +1402,9 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
   const int nt = ceil_div(S, BKV);
-  if (dbias && nt <= 6 && g_merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
+  if (dbias && nt <= 6 && merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
     // per-sample bias: every sample is its own chunk, slab b of dbias is the gradient of sample b's bias image
-    const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads);
+    const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads, true);
     a.bchunk = ceil_div(B, chunks);
     const dim3 grid(ceil_div(S, 64), (unsigned)heads, (unsigned)chunks);
     slot = op_prof_begin(2, 1.5 * fl, stream);

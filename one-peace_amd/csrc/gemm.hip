@@ -951,17 +951,32 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
   return OP_OK;
 }
 
-int g_fullline = 2;  // BK = 64 full-line flavour of the 256^2 NT kernel: 0 off, 1 always, 2 auto (op_gemm_set_tile(20/21/22))
-int g_tail_rows = 1;  // 1: split off the <= 128 leftover rows when that saves a round (op_gemm_set_tile(50/51/52))
-int g_gm = 0;        // M-tiles per L2 group of the 256x256 kernels; 0 = auto (op_gemm_set_tile(40 + gm))
-int g_ablation = 0;  // debug: 1 = no MFMA, 2 = no global loads, 4 = MFMAs + barriers only, 5 = MFMAs only in the steady loop
-int g_force_splits = 0;  // tools only: > 0 forces the K-split count of small problems (tools/gemm_small_m.py)
-                     // (timing ablations of the 256x256 kernel, wrong results; tools/gemm_ablate.py)
-
-int g_tile_mode = 0;  // 0 = auto, 1 = force 128x128, 2 = force 256x256
+// Per-call tuning word of the GEMM entry points (last argument before the stream; 0 = the defaults production uses).  The
+// library keeps NO tuning state: tests and tools that want a specific kernel flavour pass it with the call.
+//   bits 0-1   tile: 0 auto, 1 force 128x128, 2 force 256x256
+//   bits 2-3   BK = 64 full-line flavour of the 256x256 NT kernel: 0 auto (when the launch fills every CU), 1 never, 2 always
+//   bits 4-6   tail-rows split: 0 default (when it saves a round and K >= 1024), 1 off, 3 whenever it saves a round, 4 always
+//   bits 7-11  M-tiles per L2 group of the 256x256 kernels (0 = auto)
+//   bits 12-14 timing ablation of the 256x256 BK = 32 kernel (tools only; wrong results)
+//   bits 15-18 forced K-split count of small problems (tools only)
+//   bit  19    register-staged operand path instead of LDS-DMA (128x128 kernel; tests)
+struct GemmTune { int tile_mode, fullline, tail_rows, gm, ablation, force_splits, glds; };
+static GemmTune decode_tune(int64_t t) {
+  GemmTune T;
+  T.tile_mode = (int)(t & 3);
+  const int fl = (int)((t >> 2) & 3);
+  T.fullline = fl == 0 ? 2 : fl - 1;          // internal: 0 never, 1 always, 2 auto
+  const int tr = (int)((t >> 4) & 7);
+  T.tail_rows = tr == 0 ? 1 : tr - 1;         // internal: 0 off, 1 default, 2 whenever it saves a round, 3 always
+  T.gm = (int)((t >> 7) & 31);
+  T.ablation = (int)((t >> 12) & 7);
+  T.force_splits = (int)((t >> 15) & 15);
+  T.glds = ((t >> 19) & 1) ? 0 : 1;
+  return T;
+}
 
 template <int EPI>
-int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
+int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 1) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = STAGES2 * STAGE2_BYTES;
   static bool attr_set = false;
@@ -970,8 +985,8 @@ int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
     if (e != hipSuccess) { op_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  // g_fullline: 0 never, 1 always, 2 (default) when the launch fills every CU at least once
-  if ((g_fullline == 1 || (g_fullline == 2 && (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1)) &&
+  // T.fullline: 0 never, 1 always, 2 (default) when the launch fills every CU at least once
+  if ((T.fullline == 1 || (T.fullline == 2 && (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1)) &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
     static bool attr5 = false;
@@ -981,19 +996,19 @@ int launch256(const GemmArgs& a, hipStream_t s, int splits = 1) {
       attr5 = true;
     }
     hipLaunchKernelGGL((gemm256b_kernel<EPI>), grid, dim3(512), sh5, s, a);
-  } else if (EPI == EPI_BIAS && g_ablation == 1) {
+  } else if (EPI == EPI_BIAS && T.ablation == 1) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 1>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && g_ablation == 2) {
+  } else if (EPI == EPI_BIAS && T.ablation == 2) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 2>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && g_ablation == 4) {
+  } else if (EPI == EPI_BIAS && T.ablation == 4) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 4>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && g_ablation == 5) {
+  } else if (EPI == EPI_BIAS && T.ablation == 5) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 5>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && g_ablation == 6) {
+  } else if (EPI == EPI_BIAS && T.ablation == 6) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 6>), grid, dim3(512), sh, s, a);
   } else {
@@ -1100,7 +1115,7 @@ __global__ __launch_bounds__(256) void splitk_fold_epilogue_kernel(const FoldArg
 // micro-benchmarks (128x128 ~ 900 TF/s, 256x256 ~ 1040 TF/s sustained).
 struct GemmPlan { int tile; int splits; int kt_per_split; };
 
-GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256, bool allow_split, int64_t ws_bytes) {
+GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256, bool allow_split, int64_t ws_bytes, const GemmTune& T) {
   const double c128 = 2.0 * 128 * 128 / 920.0, c256 = 256.0 * 256 / 1080.0;  // time of one slot-round per unit K
   const int64_t t128 = (int64_t)ceil_div(M, 128) * ceil_div(N, epilogue == EPI_GEGLU ? 64 : 128);
   const int64_t t256 = (int64_t)ceil_div(M, 256) * ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
@@ -1120,7 +1135,7 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256
       const double per_cu = blocks <= 256 ? 1.0 : 0.94 * (double)((blocks + 255) / 256);
       double t = 4.3 + 0.62 * per_cu * kps;
       if (eff_s > 1) t += 4.5 + (double)eff_s * M * N * 8.0 / 4.0e6;  // slab bytes at 4 TB/s, in us
-      if (g_force_splits > 0 ? s == g_force_splits : t < best_t) { best_t = t; best = {128, eff_s, eff_s > 1 ? kps : 0}; }
+      if (T.force_splits > 0 ? s == T.force_splits : t < best_t) { best_t = t; best = {128, eff_s, eff_s > 1 ? kps : 0}; }
     }
     return best;
   }
@@ -1143,7 +1158,6 @@ GemmPlan plan_gemm(int64_t M, int64_t N, int64_t K, int epilogue, bool allow_256
   return best;
 }
 
-int g_default_glds = 1;
 
 // The whole launch decision of op_gemm_nt in one place (also served to the host by op_gemm_plan, so that it can be tested
 // without a GPU): tile, K-splits, whether the epilogue moves to the fold kernel, and whether the <= 128 leftover rows of
@@ -1151,26 +1165,26 @@ int g_default_glds = 1;
 struct NtDecision { GemmPlan plan; bool fold_epi; bool tail_split; int64_t m_main; };
 
 NtDecision decide_nt(int64_t M, int64_t N, int64_t K, int epilogue, bool has_bias0, bool seg_ok, bool off32_ok, bool fold_layout_ok,
-                     bool have_ws, int64_t ws_bytes, bool allow_tail_split) {
+                     bool have_ws, int64_t ws_bytes, bool allow_tail_split, const GemmTune& T) {
   NtDecision d;
-  const bool allow_256 = g_tile_mode != 1 && g_default_glds && seg_ok && off32_ok;
+  const bool allow_256 = T.tile_mode != 1 && T.glds && seg_ok && off32_ok;
   // split-K: bias-free plain launches (weight gradients, dgrads), and -- for launches of a few M-tiles (the leftover rows
   // of a tail-rows split, batch-1 feature extraction: M = 257), which are latency-bound on K with most CUs idle -- also
   // bias / residual epilogues, applied by the fold kernel.  plan_gemm's cost model decides whether a split pays.
   d.fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && has_bias0)) && M <= 1024 && fold_layout_ok;
   const bool allow_split = ((epilogue == EPI_BIAS && !has_bias0) || d.fold_epi) && have_ws && N % 8 == 0;
-  d.plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, ws_bytes);
-  if (g_tile_mode == 2 && allow_256 && d.plan.tile != 256) d.plan = {256, 1, 0};
+  d.plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, ws_bytes, T);
+  if (T.tile_mode == 2 && allow_256 && d.plan.tile != 256) d.plan = {256, 1, 0};
   // Tail rows.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
   // every CU (M = 128 x 257: 774 tiles = 3.02 rounds for N = 1536).  If dropping them saves a round, the full M-tiles run
   // as one launch and the <= 128 leftover rows as a second, small one (128 x 128 tiles).
   d.tail_split = false;
   d.m_main = M;
-  if (allow_tail_split && g_tail_rows && d.plan.tile == 256 && d.plan.splits == 1 && M > 256) {
+  if (allow_tail_split && T.tail_rows && d.plan.tile == 256 && d.plan.splits == 1 && M > 256) {
     const int64_t m_rem = M % 256;
     const int64_t tn = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
     const int64_t r_full = ceil_div(ceil_div(M, 256) * tn, 256), r_main = ceil_div(((M - m_rem) / 256) * tn, 256);
-    if (m_rem > 0 && m_rem <= 128 && (g_tail_rows == 3 || (r_main < r_full && (g_tail_rows == 2 || K >= 1024)))) {
+    if (m_rem > 0 && m_rem <= 128 && (T.tail_rows == 3 || (r_main < r_full && (T.tail_rows == 2 || K >= 1024)))) {
       d.tail_split = true;
       d.m_main = M - m_rem;
     }
@@ -1185,25 +1199,6 @@ extern "C" void op_prof_end(int slot, void* stream);
 
 extern "C" {
 
-// 0 = auto (256x256 four-stage kernel for large problems), 1 = always 128x128, 2 = always 256x256.  Returns the old value.
-int op_gemm_set_tile(int mode) {
-  int old = g_tile_mode;
-  if (mode >= 60) { g_force_splits = mode - 60; return old; }  // 60: planner's choice, 60+s: s K-splits for small problems (tools)
-  if (mode >= 50) { g_tail_rows = mode - 50; return old; }  // 50: off, 51: on (K >= 1024), 52: whenever it saves a round, 53: always (tests)
-  if (mode >= 40) { g_gm = mode - 40; return old; }  // 40: auto, 40+g: g M-tiles per L2 group
-  if (mode >= 20) { g_fullline = mode - 20; return old; }  // 20/21/22: BK = 32 / BK = 64 / auto flavour of the 256x256 NT kernel
-  if (mode >= 10) { g_ablation = mode - 10; return old; }  // 10..15: timing ablations of the 256x256 kernel (tools only)
-  g_tile_mode = mode;
-  return old;
-}
-
-// 1 = LDS-DMA staging (default), 0 = register-staged fallback.  Returns the previous value.
-int op_gemm_set_staging(int glds) {
-  int old = g_default_glds;
-  g_default_glds = glds ? 1 : 0;
-  return old;
-}
-
 // Generic entry.  epilogue: 0 bias->bf16, 1 alpha*acc+bias -> f32, 2 GeGLU, 3 residual.
 //   A [M,K] bf16 (lda), B0/B1/B2: weight segments [n_seg, K] each (ldb); for GeGLU B0 = wi_0, B1 = wi_1 [N, K].
 //   bias0..2 nullable [n_seg] bf16.  C [M,N] (ldc) bf16 (f32 for epilogue 1).
@@ -1216,7 +1211,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
                         const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                         const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                         const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace,
-                        int64_t workspace_bytes, void* stream, int64_t m_off, bool allow_tail_split) {
+                        int64_t workspace_bytes, void* stream, int64_t m_off, bool allow_tail_split, const GemmTune& T) {
   OP_CHECK_ARG(A && B0 && C, "gemm_nt: null A/B/C");
   OP_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   OP_CHECK_ARG(K % BK == 0, "gemm_nt: K=%lld must be a multiple of %d (pad on the host)", (long long)K, BK);  // => even number of 32-deep stages
@@ -1253,20 +1248,20 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   const bool seg_ok = epilogue == EPI_GEGLU || a.n_seg >= (int)N || a.n_seg % 256 == 0;
   const bool off32_ok = (M * lda < ((int64_t)1 << 30)) && (N * ldb < ((int64_t)1 << 30));
   const NtDecision dec = decide_nt(M, N, K, epilogue, bias0 != nullptr, seg_ok, off32_ok, a.n_seg % 8 == 0 && ldc % 8 == 0,
-                                   workspace != nullptr, workspace_bytes, allow_tail_split);
+                                   workspace != nullptr, workspace_bytes, allow_tail_split, T);
   const GemmPlan plan = dec.plan;
   const bool fold_epi = dec.fold_epi;
   if (dec.tail_split) {
     const int64_t m_main = dec.m_main, m_rem = M - dec.m_main;
     const int64_t esz = epilogue == EPI_F32 ? 4 : 2;
     int rc = gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
-                          rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false);
+                          rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false, T);
     if (rc != OP_OK) return rc;
     return gemm_nt_impl((const bf16_t*)A + m_main * lda, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2,
                         (char*)C + m_main * ldc * esz, ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
                         h1 ? (bf16_t*)h1 + m_main * ldc : nullptr, resid ? (const bf16_t*)resid + m_main * ldr : nullptr, ldr,
                         gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, workspace, workspace_bytes, stream,
-                        m_off + m_main, false);  // (the small launch may split K: 12 tiles alone are latency-bound)
+                        m_off + m_main, false, T);  // (the small launch may split K: 12 tiles alone are latency-bound)
   }
   a.kt_per_split = plan.kt_per_split;
   a.slab = (int64_t)M * N;
@@ -1294,19 +1289,19 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
     a.tiles_n = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
     // L2 tile-group depth (tools/gemm_gm.py): few column tiles (N = 1536) -> walk all N-tiles of ONE M-tile together
     // (+3-5 %); wide outputs -> 8 M-tiles per group (+1-2 % over 4)
-    a.gm = g_gm > 0 ? g_gm : (a.tiles_n <= 8 ? 1 : 8);
+    a.gm = T.gm > 0 ? T.gm : (a.tiles_n <= 8 ? 1 : 8);
     switch (epi) {
-      case EPI_BIAS: rc = launch256<EPI_BIAS>(a, s, plan.splits); break;
-      case EPI_F32: rc = launch256<EPI_F32>(a, s, plan.splits); break;
-      case EPI_GEGLU: rc = launch256<EPI_GEGLU>(a, s, plan.splits); break;
-      default: rc = launch256<EPI_RESID>(a, s, plan.splits); break;
+      case EPI_BIAS: rc = launch256<EPI_BIAS>(a, s, T, plan.splits); break;
+      case EPI_F32: rc = launch256<EPI_F32>(a, s, T, plan.splits); break;
+      case EPI_GEGLU: rc = launch256<EPI_GEGLU>(a, s, T, plan.splits); break;
+      default: rc = launch256<EPI_RESID>(a, s, T, plan.splits); break;
     }
   } else {
     switch (epi) {
-      case EPI_BIAS: rc = launch<EPI_BIAS>(a, g_default_glds, s, plan.splits); break;
-      case EPI_F32: rc = launch<EPI_F32>(a, g_default_glds, s, plan.splits); break;
-      case EPI_GEGLU: rc = launch<EPI_GEGLU>(a, g_default_glds, s, plan.splits); break;
-      default: rc = launch<EPI_RESID>(a, g_default_glds, s, plan.splits); break;
+      case EPI_BIAS: rc = launch<EPI_BIAS>(a, T.glds, s, plan.splits); break;
+      case EPI_F32: rc = launch<EPI_F32>(a, T.glds, s, plan.splits); break;
+      case EPI_GEGLU: rc = launch<EPI_GEGLU>(a, T.glds, s, plan.splits); break;
+      default: rc = launch<EPI_RESID>(a, T.glds, s, plan.splits); break;
     }
   }
   if (rc == OP_OK && plan.splits > 1) {
@@ -1328,14 +1323,15 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
 // weight segment, contiguous operands and -- when workspace_bytes > 0 -- a split-K scratch of that size.
 // plan[0] = tile (128 | 256), plan[1] = K-splits of the (main) launch, plan[2] = 1 if the epilogue runs in the fold kernel,
 // plan[3] = rows split off into a second small launch (0 = none).
-int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int* plan) {
+int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, int64_t workspace_bytes, int64_t tune, int* plan) {
+  const GemmTune T = decode_tune(tune);
   OP_CHECK_ARG(plan && M > 0 && N > 0 && K > 0 && K % BK == 0 && epilogue >= 0 && epilogue <= 3, "gemm_plan: bad arguments");
   const bool off32_ok = (M * K < ((int64_t)1 << 30)) && (N * K < ((int64_t)1 << 30));
   const NtDecision d = decide_nt(M, N, K, epilogue, has_bias != 0, true, off32_ok, N % 8 == 0, workspace_bytes > 0,
-                                 workspace_bytes, true);
+                                 workspace_bytes, true, T);
   NtDecision m = d;
   if (d.tail_split)  // the plan of the main launch is taken again for its own row count, as op_gemm_nt does
-    m = decide_nt(d.m_main, N, K, epilogue, has_bias != 0, true, off32_ok, N % 8 == 0, workspace_bytes > 0, workspace_bytes, false);
+    m = decide_nt(d.m_main, N, K, epilogue, has_bias != 0, true, off32_ok, N % 8 == 0, workspace_bytes > 0, workspace_bytes, false, T);
   plan[0] = m.plan.tile;
   plan[1] = m.plan.splits;
   plan[2] = (m.plan.splits > 1 && m.fold_epi) ? 1 : 0;
@@ -1347,9 +1343,9 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
                const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
-               void* stream) {
+               int64_t tune, void* stream) {
   return gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
-                      rows_per_sample, alpha, M, N, K, epilogue, workspace, workspace_bytes, stream, 0, true);
+                      rows_per_sample, alpha, M, N, K, epilogue, workspace, workspace_bytes, stream, 0, true, decode_tune(tune));
 }
 
 
@@ -1359,7 +1355,8 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
 // qualify (the caller then uses op_transpose + op_gemm_nt).  accumulate != 0: C += A^T B (gradient accumulation into a
 // pre-existing buffer).  workspace: optional fp32 scratch enabling split-K.
 int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-               int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+               int accumulate, void* workspace, int64_t workspace_bytes, int64_t tune, void* stream) {
+  const GemmTune T = decode_tune(tune);
   OP_CHECK_ARG(A && B && C, "gemm_tn: null pointer");
   if (K % 64 != 0 || M % 8 != 0 || N % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 || M < 8 || N < 8 ||
       31 * lda + M >= ((int64_t)1 << 30) || 31 * ldb + N >= ((int64_t)1 << 30)) {
@@ -1377,7 +1374,7 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.m_off = 0;
   a.tiles_m = ceil_div(M, 256);
   a.tiles_n = ceil_div(N, 256);
-  a.gm = g_gm > 0 ? g_gm : (a.tiles_n <= 8 ? 1 : 8);
+  a.gm = T.gm > 0 ? T.gm : (a.tiles_n <= 8 ? 1 : 8);
   // split-K: fill the chip (256 slots per round) while keeping chunks long and even
   const int nk = (int)(K / BK2);
   const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;

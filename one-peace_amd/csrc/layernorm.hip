@@ -13,7 +13,7 @@
 namespace {
 
 constexpr int LN_MAX_BLOCKS = 4096;       // workspace bound for the dw/db partials
-int g_ln_blocks_fwd = 512, g_ln_blocks_bwd = 512;  // persistent-grid caps (tuning knobs, op_layernorm_set_grid)
+constexpr int g_ln_blocks_fwd = 512, g_ln_blocks_bwd = 512;  // persistent-grid caps (round-1 sweep: tools/ln_sweep.py, profiles/)
 
 template <int NW>
 __device__ __forceinline__ float group_sum(float v, float* red) {
@@ -454,12 +454,6 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
 
 extern "C" {
 
-// Tuning knob: caps of the persistent grids (values <= 0 keep the current one).
-int op_layernorm_set_grid(int fwd_blocks, int bwd_blocks) {
-  if (fwd_blocks > 0) g_ln_blocks_fwd = fwd_blocks;
-  if (bwd_blocks > 0) g_ln_blocks_bwd = bwd_blocks > LN_MAX_BLOCKS ? LN_MAX_BLOCKS : bwd_blocks;
-  return OP_OK;
-}
 
 // Bytes of fp32 workspace op_layernorm_bwd needs for dw/db partials.
 int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {

@@ -31,17 +31,12 @@ SIGNATURES = {
     "op_prof_collect": (c_int, [P, P, P, c_int]),
     "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
-    "op_layernorm_set_grid": (c_int, [c_int, c_int]),
-    "op_attn_set_merge_dbias": (c_int, [c_int]),
-    "op_attn_set_resident": (c_int, [c_int]),
-    "op_attn_bwd_dbias_slabs": (I64, [I64, I64, I64]),
+    "op_attn_bwd_dbias_slabs": (I64, [I64, I64, I64, I64]),
     "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
-    "op_gemm_set_staging": (c_int, [c_int]),
-    "op_gemm_set_tile": (c_int, [c_int]),
-    "op_gemm_plan": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int64, P]),
+    "op_gemm_plan": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int64, I64, P]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
-                           c_int, P, I64, P]),
-    "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, P]),
+                           c_int, P, I64, I64, P]),
+    "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
     "op_transpose_desc_bytes": (I64, []),
@@ -61,11 +56,11 @@ SIGNATURES = {
     "op_sqnorm": (c_int, [P, I64, P, P, P]),
     "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
-    "op_attn_fwd": (c_int, [P, P, P, I64, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_fwd": (c_int, [P, P, P, I64, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_attn_bias_frag_elems": (I64, [I64, I64]),
     "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
-    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, P]),
+    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
     "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
@@ -74,6 +69,84 @@ SIGNATURES = {
     "op_probe_glds": (c_int, [P, P, c_int, P, P]),
     "op_probe_mfma_f8": (c_int, [P, P, P, P, P, c_int, P]),
 }
+
+
+class Tuning:
+    """Kernel-flavour selection for tests and tools.  The C library keeps no tuning state: every GEMM / attention entry point
+    takes a per-call `tune` word (include/onepeace_hip.h), and this host-side object is where the Python binding keeps the
+    values it passes.  Production code never touches it (all zeros = the defaults)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.tile_mode = 0       # 0 auto, 1 force 128x128, 2 force 256x256
+        self.fullline = 2        # BK = 64 flavour of the 256x256 NT kernel: 0 never, 1 always, 2 auto
+        self.tail_rows = 1       # 0 off, 1 default, 2 whenever it saves a round, 3 always
+        self.gm = 0              # M-tiles per L2 group (0 auto)
+        self.ablation = 0        # timing ablations of the 256x256 kernel (tools)
+        self.force_splits = 0    # forced K-split count of small problems (tools)
+        self.glds = 1            # 1 LDS-DMA staging, 0 register-staged operands
+        self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
+        self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
+
+    def gemm(self):
+        fl = {2: 0, 0: 1, 1: 2}[self.fullline]
+        tr = 0 if self.tail_rows == 1 else self.tail_rows + 1
+        return (self.tile_mode | fl << 2 | tr << 4 | (self.gm & 31) << 7 | (self.ablation & 7) << 12 | (self.force_splits & 15) << 15
+                | (0 if self.glds else 1) << 19)
+
+    def attn_fwd(self):
+        return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1
+
+    def attn_bwd(self):
+        return 0 if self.merge_dbias else 1
+
+
+TUNE = Tuning()
+
+
+class _LibProxy:
+    """The ctypes library plus the historical op_*_set_* knob functions, now pure Python on `TUNE` (tools/ and tests/ written
+    against the round-1 ABI keep working; the shared library no longer exports or stores any knob)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        return getattr(self._cdll, name)
+
+    @staticmethod
+    def op_gemm_set_tile(mode):
+        old = TUNE.tile_mode
+        if mode >= 60:
+            TUNE.force_splits = mode - 60
+        elif mode >= 50:
+            TUNE.tail_rows = mode - 50
+        elif mode >= 40:
+            TUNE.gm = mode - 40
+        elif mode >= 20:
+            TUNE.fullline = mode - 20
+        elif mode >= 10:
+            TUNE.ablation = mode - 10
+        else:
+            TUNE.tile_mode = mode
+        return old
+
+    @staticmethod
+    def op_gemm_set_staging(glds):
+        old, TUNE.glds = TUNE.glds, 1 if glds else 0
+        return old
+
+    @staticmethod
+    def op_attn_set_merge_dbias(on):
+        old, TUNE.merge_dbias = TUNE.merge_dbias, 1 if on else 0
+        return old
+
+    @staticmethod
+    def op_attn_set_resident(mode):
+        old, TUNE.resident = TUNE.resident, int(mode)
+        return old
 
 
 def lib():
@@ -89,7 +162,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
+        _lib = _LibProxy(L)
     return _lib
 
 
@@ -213,7 +286,7 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
     _check(lib().op_gemm_nt(ptr(A), A.stride(0), ptr(Bs[0]), ptr(Bs[1]), ptr(Bs[2]), Bs[0].stride(0), n_seg,
                             ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), ptr(out), ldc_, ptr(h0), ptr(h1),
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
-                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, stream()), "op_gemm_nt")
+                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, TUNE.gemm(), stream()), "op_gemm_nt")
     return out
 
 
@@ -245,7 +318,7 @@ def gemm_nt_fp8(A8, sa, B8s, sbs, bias=None, out=None, epilogue=EPI_BIAS, h0=Non
 def gemm_plan(M, N, K, epilogue=EPI_BIAS, has_bias=True, workspace_bytes=SPLITK_WS_BYTES):
     """(tile, K-splits, epilogue-in-fold-kernel, tail rows) op_gemm_nt would use; a host-only query (works without a GPU)."""
     out = (ctypes.c_int * 4)()
-    _check(lib().op_gemm_plan(M, N, K, epilogue, int(has_bias), workspace_bytes, ctypes.cast(out, P)), "op_gemm_plan")
+    _check(lib().op_gemm_plan(M, N, K, epilogue, int(has_bias), workspace_bytes, TUNE.gemm(), ctypes.cast(out, P)), "op_gemm_plan")
     return out[0], out[1], bool(out[2]), out[3]
 
 
@@ -265,7 +338,7 @@ def gemm_tn(A_km, B_kn, out=None, accumulate=False):
     GEMM_ALGO_BYTES[0] += 2 * (K * M + K * N + M * N * (2 if accumulate else 1))
     GEMM_ALGO_BYTES[1] += 1
     _check(lib().op_gemm_tn(ptr(A_km), A_km.stride(0), ptr(B_kn), B_kn.stride(0), ptr(out), out.stride(0), M, N, K,
-                            int(accumulate), ptr(ws), ws.numel(), stream()), "op_gemm_tn")
+                            int(accumulate), ptr(ws), ws.numel(), TUNE.gemm(), stream()), "op_gemm_tn")
     return out
 
 
@@ -459,7 +532,7 @@ def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, o
         out = torch.empty(B * S, H, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev) if want_lse else None
     _check(lib().op_attn_fwd(ptr(q), ptr(k), ptr(v), ld, ptr(bias), _bias_bstride(bias), ptr(bias_frag), ptr(key_pad), ptr(out), out.stride(0),
-                             ptr(lse), Spad, B, S, Spad, heads, 64, scale, stream()), "op_attn_fwd")
+                             ptr(lse), Spad, B, S, Spad, heads, 64, scale, TUNE.attn_fwd(), stream()), "op_attn_fwd")
     return out, lse
 
 
@@ -487,13 +560,13 @@ def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=N
 def attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, ldg, dbias, B, S, Spad, heads, scale):
     _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), _bias_bstride(bias),
                              ptr(key_pad), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldg, ptr(dbias), B, S, Spad, heads,
-                             64, scale, stream()), "op_attn_bwd")
+                             64, scale, TUNE.attn_bwd(), stream()), "op_attn_bwd")
 
 
 def attn_dbias_buffer(B, S, heads, Spad, device, per_sample=False):
     """Zeroed fp32 [slabs, heads, S, Spad] accumulator for op_attn_bwd's dbias: a shared bias image gets one slab per
     batch chunk (the gradient is the sum over dim 0), per-sample images one slab per sample (slab b = gradient of image b)."""
-    slabs = B if per_sample else lib().op_attn_bwd_dbias_slabs(B, S, heads)
+    slabs = B if per_sample else lib().op_attn_bwd_dbias_slabs(B, S, heads, TUNE.attn_bwd())
     return torch.zeros(slabs, heads, S, Spad, dtype=torch.float32, device=device)
 
 

@@ -19,7 +19,7 @@ def main():
                 name = "%s grid=%sx%s wg=%s" % (name[:70], r.get("Grid_Size_X"), r.get("Grid_Size_Y"), r.get("Workgroup_Size_X"))
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
+    adam = [i for i, r in enumerate(rows) if "adamw" in r[2]]
     if len(adam) < 2 * per_step:
         lo, hi = 0, len(rows)
     else:

@@ -126,12 +126,16 @@ int op_attn_bias_pack(const void* src, void* dst, int64_t n_img, int64_t S, int6
 /* delta[b][h][q] = sum_d dout*out (fp32, row stride Spad) */
 int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* delta, int64_t B, int64_t S, int64_t Spad,
                       int64_t heads, void* stream);
-/* autograd of the above (reference: torch autograd through the bmm/softmax ops).  biasT = bias with rows = key.
- * dq/dk/dv rows have stride ldg; dbias fp32 [slabs][heads][S][Spad] (optional, accumulated into: pre-zero it; the
- * gradient is the sum over slabs, slabs = op_attn_bwd_dbias_slabs(B, S, heads)). */
+/* autograd of the above (reference: torch autograd through the bmm/softmax ops).  biasT = bias with rows = key; its pad
+ * columns [S, Spad) must hold FINITE values (op_relpos_bias_build writes zeros): the dK/dV kernel adds the bias with the matrix
+ * pipe, where 0 * NaN would leak into live rows.  lse / delta entries and the q-major image's columns at [S, Spad) stay
+ * unspecified.  bias_frag (optional): op_attn_bias_pack of `bias`; with it the merged dQ + dBias kernel adds the bias with
+ * the matrix pipe too.  dq/dk/dv rows have stride ldg; dbias fp32 [slabs][heads][S][Spad] (optional, accumulated into:
+ * pre-zero it; the gradient is the sum over slabs, slabs = op_attn_bwd_dbias_slabs(B, S, heads, tune)). */
 int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune);
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
-                const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
+                const void* biasT, const void* bias_frag, int64_t bias_batch_stride, const void* key_pad, const float* lse,
+                const float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
                 int64_t head_dim, float scale, int64_t tune, void* stream);
 

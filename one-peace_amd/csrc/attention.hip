@@ -551,7 +551,8 @@ struct AttnBwdArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v; int64_t ld;
   const bf16_t* dout; int64_t ldo;   // [B*S][ldo]
   const bf16_t* bias;                // [heads][S][Spad]  (rows = query)
-  const bf16_t* biasT;               // [heads][S][Spad]  (rows = key), same values transposed
+  const bf16_t* biasT;               // [heads][S][Spad]  (rows = key), same values transposed; columns >= S must be FINITE
+  const bf16_t* bias_frag;           // fragment-major image (op_attn_bias_pack) or null
   int64_t bias_bs;                   // elements between the images of consecutive samples (0: shared by all samples)
   const uint8_t* key_pad;            // [B][Spad]
   const float* lse;                  // [B][heads][Spad]
@@ -589,6 +590,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
+// Softmax part rewritten in round 2 like the resident forward kernel (profiles/r2_experiments.md: these kernels are bound by
+// their VALU stream and by 8-byte bias loads, not by the matrix pipe): the bias is added by the matrix pipe -- the transposed
+// image's rows are already the second-operand fragment [32 queries x 16 keys] of  S += Selector_j(1/scale) . BiasT-fragment  --
+// P = exp2(s * scale*log2e - lse*log2e) is one fma + one v_exp_f32, dS = P * (dP - delta) two more: 5 VALU instructions per
+// score instead of 11.  Keys that do not exist or are padded need NO masking here: a key is a COLUMN of every product of this
+// kernel, so whatever its P / dS columns hold only reaches its own dK / dV rows, which are written as zeros (padded keys) or
+// not at all (keys >= S).  Query rows >= S of the last tile get lse = +inf (P = 0) and delta = 0.
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 
   // K, V fragments (second operand): lane (g,t) <- X[kbase + kb*16 + t][kk*32 + g*8 ..]
   bf16x8 kf[2][2], vf[2][2];
-  bool kmask[2];
+  bool kdead[2];
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int key = kbase + kb * 16 + t;
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
       kf[kb][kk] = *reinterpret_cast<const bf16x8*>(p.k + off + kk * 32 + g * 8);
       vf[kb][kk] = *reinterpret_cast<const bf16x8*>(p.v + off + kk * 32 + g * 8);
     }
-    kmask[kb] = (key >= p.S) || (p.key_pad && p.key_pad[(int64_t)b * p.Spad + kc]);
+    kdead[kb] = p.key_pad && key < p.S && p.key_pad[(int64_t)b * p.Spad + key];  // padded key: its dK / dV rows are zero
   }
   f32x4 dvT[2][4], dkT[2][4];
 #pragma unroll
@@ -650,14 +658,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   const int ntiles = (p.S + 63) / 64;
   const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * p.Spad;
   const float* del_b = p.delta + ((int64_t)b * p.heads + h) * p.Spad;
-  const bf16_t* brow[2] = {nullptr, nullptr};  // transposed bias image rows of this lane's two keys
+  // transposed bias image rows of this lane's two keys: 8 consecutive queries at g*8 = one second-operand fragment
+  const bf16_t* brow[2] = {nullptr, nullptr};
+  bf16x8 sel_lo, sel_hi;  // first operand that copies second-operand row j = t (j = 16 + t) into output row t, times 1/scale
   if constexpr (HAS_BIAS) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int key = min(kbase + kb * 16 + t, p.S - 1);
-      brow[kb] = p.biasT + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + key) * p.Spad;
+      brow[kb] = p.biasT + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + key) * p.Spad + g * 8;
+    }
+    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
+      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
     }
   }
+  const float c1 = p.scale * LOG2E;
   load_tile(0);
   for (int qt = 0; qt < ntiles; ++qt) {
     const int q0 = qt * 64;
@@ -671,24 +688,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     // lse / delta / bias fragments of both 32-query halves first, THEN the next tile's Q / dO prefetch: s_waitcnt vmcnt
     // counts in issue order, so small loads issued behind the prefetch would make their wait a wait for the prefetch.
     f32x4 l4[2][2], d4[2][2];
-    bf16x4 bv[2][2][2];
+    bf16x8 bfr[2][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int qrow = q0 + (2 * m + j) * 16 + g * 4;  // + r; < Spad
         l4[m][j] = *reinterpret_cast<const f32x4*>(lse_b + qrow);
         d4[m][j] = *reinterpret_cast<const f32x4*>(del_b + qrow);
-        if constexpr (HAS_BIAS) {
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) bv[m][j][kb] = *reinterpret_cast<const bf16x4*>(brow[kb] + qrow);
-        }
       }
+      if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) bfr[m][kb] = *reinterpret_cast<const bf16x8*>(brow[kb] + q0 + m * 32);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     load_tile(q0 + 64);  // unconditional (rows clamped to S-1): a branch here would force s_waitcnt vmcnt(0) below
     __builtin_amdgcn_sched_barrier(0);
 
-    // per 32-query half m:  S[q][key] = Q K^T, dP[q][key] = dO V^T  (lane (g,t): q = qb*16 + g*4 + r, key = t),
+    // per 32-query half m:  S[q][key] = Q K^T (+ bias / scale), dP[q][key] = dO V^T  (lane (g,t): q = qb*16 + g*4 + r, key = t),
     // then P, dS in place, then dV^T[d][key] += dO^T[d][q] P[q][key] and dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -712,23 +730,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
             dp[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kb][kk], dp[j][kb], 0, 0, 0);
           }
         }
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+            s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j ? sel_hi : sel_lo, bfr[m][kb], s[j][kb], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int qrow = q0 + (2 * m + j) * 16 + g * 4;  // + r
+        float l2[4], dl[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // rows >= S: lse / delta are unspecified (possibly NaN / inf) -> P = 0, delta = 0
+          const bool live = qrow + r < p.S;
+          l2[r] = live ? l4[m][j][r] * LOG2E : INFINITY;
+          dl[r] = live ? d4[m][j][r] : 0.f;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool dead = kmask[kb] || (qrow + r >= p.S);
-            float x = s[j][kb][r] * p.scale;
-            if constexpr (HAS_BIAS) x += (float)bv[m][j][kb][r];
-            x -= l4[m][j][r];
-            const float pr = __expf(dead ? -INFINITY : x);
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][r], c1, -l2[r]));
             s[j][kb][r] = pr;
-            // lse / delta entries at rows >= S are unspecified (possibly NaN): select, do not rely on 0 * x
-            const float dsv = pr * (dp[j][kb][r] - d4[m][j][r]);
-            dp[j][kb][r] = dead ? 0.f : dsv;
+            dp[j][kb][r] = pr * (dp[j][kb][r] - dl[r]);
           }
         }
       }
@@ -767,7 +791,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     for (int db = 0; db < 4; ++db) {
       bf16x4 a, c;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { a[r] = (bf16_t)(dkT[kb][db][r] * p.scale); c[r] = (bf16_t)dvT[kb][db][r]; }
+      for (int r = 0; r < 4; ++r) {
+        a[r] = kdead[kb] ? (bf16_t)0.f : (bf16_t)(dkT[kb][db][r] * p.scale);
+        c[r] = kdead[kb] ? (bf16_t)0.f : (bf16_t)dvT[kb][db][r];
+      }
       *reinterpret_cast<bf16x4*>(kp + db * 16 + g * 4) = a;
       *reinterpret_cast<bf16x4*>(vp + db * 16 + g * 4) = c;
     }
@@ -975,8 +1002,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 // (NT x 4 accumulators per lane) and added to dbias once at the end -- the separate dBias kernel recomputed S and dP
 // (two of the five backward matmuls) just for that sum.  One 16-query block per wave keeps the NT x 64 dS accumulators
 // within the register budget; 64-row query tiles also waste less on S = 257 (5 tiles = 320 rows instead of 3 x 128).
-template <int NT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p) {
+template <int NT, bool FRAG, int LASTB>  // LASTB: 16-key blocks of the last key tile that can hold keys (1 or 4): S = 257 is 4 tiles + ONE
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p) {  // block, whose 3 absent neighbours cost no accumulator
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
   char* ldsK = smem;
   char* ldsV = smem + 64 * 128;
@@ -1031,6 +1058,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
 #pragma unroll
   for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
 
+  // fragment-major bias image of this wave's query block, selectors of the bias MFMA (see attn_fwd_res_kernel)
+  const int nqb = (p.S + 15) >> 4, nkp = (p.S + 31) >> 5;
+  const int64_t per_head = (int64_t)nqb * nkp * FRAG_BLOCK;
+  const bf16_t* fbase = nullptr;
+  bf16x8 sel_lo, sel_hi;
+  const float c1 = p.scale * LOG2E;
+  if constexpr (FRAG) {
+    fbase = p.bias_frag + (int64_t)h * per_head + (int64_t)(min(q0w, p.S - 1) >> 4) * nkp * FRAG_BLOCK + lane * 8;
+    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
+      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
+    }
+  }
   const int b_begin = chunk * p.bchunk, b_end = min(p.B, (chunk + 1) * p.bchunk);
   if (b_begin >= b_end) return;
   load_tile(b_begin, 0);
@@ -1077,12 +1119,67 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
       auto biasfrag = [&](int, int, int qrow, int key) {
         return *reinterpret_cast<const bf16x4*>(p.bias + bias_resample + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + qrow) * p.Spad + key);
       };
-      ds_tile<1, true, (NT < 6)>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, prefetch, ds);
+      if constexpr (FRAG) {
+        // Round-2 softmax part (see attn_fwd_res_kernel): bias through the matrix pipe from the fragment-major image (ONE
+        // coalesced 16-byte load per lane per 32 keys), P = exp2(s * scale*log2e - lse*log2e) as one fma + one v_exp_f32,
+        // dS = P * (dP - delta); only keys are masked (they are the contraction index of dQ), and only in tiles that can
+        // hold a dead key (the last tile, or any tile of a padded sample).  A dead QUERY is a column of everything here:
+        // it needs no masking, its dQ row / dBias row is simply not written.
+        bf16x8 bfr[2];
+        unsigned padw[4] = {0u, 0u, 0u, 0u};
+        const bf16_t* fb = fbase + (p.bias_bs != 0 ? (int64_t)b * p.heads * per_head : 0) + bias_resample;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) bfr[m] = *reinterpret_cast<const bf16x8*>(fb + (int64_t)min((k0 >> 5) + m, nkp - 1) * FRAG_BLOCK);
+        if (p.key_pad) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+            padw[kb] = *reinterpret_cast<const unsigned*>(p.key_pad + (int64_t)b * p.Spad + k0 + kb * 16 + g * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the small loads ahead of the prefetch (vmcnt counts in issue order)
+        prefetch();
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 st[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) { st[kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; ds[0][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          if (k0 + kb * 16 >= p.S) break;  // uniform; those dS entries stay exactly zero
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfrag(kb, kk), qf[0][kk], st[kb], 0, 0, 0);
+            ds[0][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfrag(kb, kk), of[0][kk], ds[0][kb], 0, 0, 0);
+          }
+          st[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[kb >> 1], (kb & 1) ? sel_hi : sel_lo, st[kb], 0, 0, 0);
+        }
+        const float nl2 = -lse[0] * LOG2E, dl = del[0];
+        const bool may_mask = (k0 + BKV > p.S) || (p.key_pad != nullptr);  // uniform
+        if (may_mask) {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            const int key = k0 + kb * 16 + g * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const bool dead = (key + r >= p.S) || ((padw[kb] >> (8 * r)) & 0xffu);
+              const float pr = __builtin_amdgcn_exp2f(dead ? -INFINITY : __builtin_fmaf(st[kb][r], c1, nl2));
+              ds[0][kb][r] = pr * (ds[0][kb][r] - dl);  // dP and delta of a live query are finite: 0 * x = 0
+            }
+          }
+        } else {
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              ds[0][kb][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c1, nl2)) * (ds[0][kb][r] - dl);
+        }
+      } else {
+        ds_tile<1, true, (NT < 6)>(p, b, h, k0, q0w, g, t, qf, of, lse, del, kfrag, vfrag, biasfrag, prefetch, ds);
+      }
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
         if (kt == c) {
 #pragma unroll
-          for (int kb = 0; kb < 4; ++kb) acc[c][kb] += ds[0][kb];
+          for (int kb = 0; kb < 4; ++kb)
+            if (c < NT - 1 || kb < LASTB) acc[c][kb] += ds[0][kb];
         }
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -1120,10 +1217,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
     f32x4 cur[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
-      if (kt * BKV + kb * 16 < p.Spad) cur[kb] = *reinterpret_cast<const f32x4*>(drow + kt * BKV + kb * 16);
+      if ((kt < NT - 1 || kb < LASTB) && kt * BKV + kb * 16 < p.Spad) cur[kb] = *reinterpret_cast<const f32x4*>(drow + kt * BKV + kb * 16);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
-      if (kt * BKV + kb * 16 < p.Spad) *reinterpret_cast<f32x4*>(drow + kt * BKV + kb * 16) = cur[kb] + acc[kt][kb];
+      if ((kt < NT - 1 || kb < LASTB) && kt * BKV + kb * 16 < p.Spad)
+        *reinterpret_cast<f32x4*>(drow + kt * BKV + kb * 16) = cur[kb] + acc[kt][kb];
   }
 }
 
@@ -1368,7 +1466,8 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 // bias_batch_stride != 0: bias / biasT hold one image per sample (that many elements apart; the masked-pretraining
 // branch gathers a different token subset per sample, adapter/image.py:229-246); dbias then has B slabs, one per sample.
 int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
-                const void* biasT, int64_t bias_batch_stride, const void* key_pad, const float* lse, const float* delta, void* dq,
+                const void* biasT, const void* bias_frag, int64_t bias_batch_stride, const void* key_pad, const float* lse,
+                const float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
                 int64_t head_dim, float scale, int64_t tune, void* stream) {
   const bool merge_dbias = !(tune & 1);
@@ -1381,6 +1480,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   AttnBwdArgs a;
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
   a.dout = (const bf16_t*)dout; a.ldo = ldo; a.bias = (const bf16_t*)bias; a.biasT = (const bf16_t*)biasT;
+  a.bias_frag = bias ? (const bf16_t*)bias_frag : nullptr;
   a.bias_bs = bias ? bias_batch_stride : 0;
   OP_CHECK_ARG(!(dbias && a.bias_bs != 0) || (merge_dbias && ceil_div(S, BKV) <= 6),
                "attn_bwd: the gradient of a per-sample bias needs the merged dQ + dBias kernel (S <= 384)");
@@ -1407,15 +1507,26 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
     const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads, true);
     a.bchunk = ceil_div(B, chunks);
     const dim3 grid(ceil_div(S, 64), (unsigned)heads, (unsigned)chunks);
+    const bool one_block = ceil_div(S - (nt - 1) * BKV, 16) == 1;  // last key tile = a single 16-key block (S = 257: 256 + CLS)
+    // (the fragment path of 5 full tiles / 6 tiles would spill its dS accumulators: those lengths keep the round-1 softmax code)
+    const bool frag = a.bias_frag != nullptr && (float)(bf16_t)(1.0f / scale) * scale == 1.0f && (nt <= 4 || (nt == 5 && one_block));
+#define DQDB(N)                                                                                                           \
+  do {                                                                                                                    \
+    if (frag && one_block) hipLaunchKernelGGL((attn_bwd_dq_dbias_kernel<N, true, 1>), grid, dim3(256), 0, s, a);           \
+    else if (frag) hipLaunchKernelGGL((attn_bwd_dq_dbias_kernel<N, true, 4>), grid, dim3(256), 0, s, a);                   \
+    else if (one_block) hipLaunchKernelGGL((attn_bwd_dq_dbias_kernel<N, false, 1>), grid, dim3(256), 0, s, a);             \
+    else hipLaunchKernelGGL((attn_bwd_dq_dbias_kernel<N, false, 4>), grid, dim3(256), 0, s, a);                            \
+  } while (0)
     slot = op_prof_begin(2, 1.5 * fl, stream);
     switch (nt) {
-      case 1: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<1>, grid, dim3(256), 0, s, a); break;
-      case 2: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<2>, grid, dim3(256), 0, s, a); break;
-      case 3: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<3>, grid, dim3(256), 0, s, a); break;
-      case 4: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<4>, grid, dim3(256), 0, s, a); break;
-      case 5: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<5>, grid, dim3(256), 0, s, a); break;
-      default: hipLaunchKernelGGL(attn_bwd_dq_dbias_kernel<6>, grid, dim3(256), 0, s, a); break;
+      case 1: DQDB(1); break;
+      case 2: DQDB(2); break;
+      case 3: DQDB(3); break;
+      case 4: DQDB(4); break;
+      case 5: DQDB(5); break;
+      default: DQDB(6); break;
     }
+#undef DQDB
     op_prof_end(slot, stream);
     OP_LAUNCH_CHECK();
     return OP_OK;

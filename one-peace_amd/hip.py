@@ -60,7 +60,7 @@ SIGNATURES = {
     "op_attn_bias_frag_elems": (I64, [I64, I64]),
     "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
-    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
+    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
     "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
@@ -537,7 +537,7 @@ def attn_fwd(q, k, v, ld, B, S, heads, scale, bias=None, key_pad=None, Spad=0, o
 
 
 def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=None, key_pad=None, Spad=0, dqkv=None,
-             want_dbias=False):
+             want_dbias=False, bias_frag=None):
     """Returns dqkv [B*S, 3H] (dq | dk | dv packed like a fused projection output) and dbias fp32: [heads,S,Spad] for a
     shared bias image, [B,heads,S,Spad] when bias / biasT hold one image per sample."""
     dev = q.device
@@ -551,14 +551,17 @@ def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=N
     per_sample = bias is not None and bias.dim() == 4
     dbias = attn_dbias_buffer(B, S, heads, Spad, dev, per_sample) if want_dbias else None
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
-    attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, dqkv.stride(0), dbias, B, S, Spad, heads, scale)
+    attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, dqkv.stride(0), dbias, B, S, Spad, heads, scale,
+                    bias_frag)
     if dbias is None:
         return dqkv, None
     return dqkv, (dbias if per_sample else dbias.sum(0))
 
 
-def attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, ldg, dbias, B, S, Spad, heads, scale):
-    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), _bias_bstride(bias),
+def attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, ldg, dbias, B, S, Spad, heads, scale,
+                    bias_frag=None):
+    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), ptr(bias_frag),
+                             _bias_bstride(bias),
                              ptr(key_pad), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldg, ptr(dbias), B, S, Spad, heads,
                              64, scale, TUNE.attn_bwd(), stream()), "op_attn_bwd")
 

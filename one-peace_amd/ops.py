@@ -574,7 +574,8 @@ class AttnBranchFn(torch.autograd.Function):
         else:
             dattn = daln
         dqkv, _ = _attn_backward(A["qkv"], dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
-                                 bias.grad_accumulator(B) if want_dbias else None)
+                                 bias.grad_accumulator(B) if want_dbias else None,
+                                 bias.frag if bias is not None and S <= 384 else None)
         (tq, tv), acc = _targets(direct, "bq", "bv")
         if H % 8 == 0:
             sums = hip.colsum_segments(dqkv, H, [tq, None, tv] if acc else None, accumulate=acc)
@@ -668,7 +669,7 @@ class FfnBranchFn(torch.autograd.Function):
         return (dx.view(B, S, H), None, None, *grads)
 
 
-def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc):
+def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag=None):
     H = heads * 64
     dev = qkv.device
     Spad = hip.attn_spad(S)
@@ -679,7 +680,7 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
     dqkv = torch.empty_like(qkv)
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     hip.attn_bwd_launch(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, bias_img, biasT, key_pad, lse, delta, dq, dk,
-                        dv, 3 * H, dbias_acc, B, S, Spad, heads, scale)
+                        dv, 3 * H, dbias_acc, B, S, Spad, heads, scale, bias_frag)
     return dqkv, dbias_acc
 
 

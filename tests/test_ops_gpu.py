@@ -464,7 +464,7 @@ def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias,
     assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
     assert_close(lse[:, :, :S], lse_ref, fro=1e-3, mx=2e-3, what="lse")
     dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
-                               bias_d, biasT_d, pad_d, Spad, want_dbias=use_bias)
+                               bias_d, biasT_d, pad_d, Spad, want_dbias=use_bias, bias_frag=frag)
     # gradients pass through bf16 P / dS operands: tolerance 1.2e-2 rel-Frobenius, 3e-2 max
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
@@ -484,7 +484,7 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
                             bias_frag=hip.attn_bias_pack(bias_d, S))
     dout = dev_bf16(rnd(B * S, H, seed=3))
     clean, clean_dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, out, lse, B, S, heads, 0.125,
-                                      bias_d, biasT_d, pad_d, Spad, want_dbias=True)
+                                      bias_d, biasT_d, pad_d, Spad, want_dbias=True, bias_frag=hip.attn_bias_pack(bias_d, S))
     assert clean.isfinite().all() and clean_dbias[:, :, :S].isfinite().all()
     delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=DEV)
     hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dout), hip.ptr(out), dout.stride(0), hip.ptr(delta), B, S, Spad, heads,
@@ -494,11 +494,12 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
     delta[:, :, S:] = float("inf")
     bias_p, biasT_p = bias_d.clone(), biasT_d.clone()
     bias_p[:, :, S:] = float("nan")
-    biasT_p[:, :, S:] = float("nan")
+    biasT_p[:, :, S:] = 3.0e4  # the transposed image's pad columns must be finite (the dK/dV kernel adds the bias with an MFMA)
     dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=DEV)
     dbias = hip.attn_dbias_buffer(B, S, heads, Spad, DEV)
     hip.attn_bwd_launch(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, bias_p, biasT_p, pad_d, lse_p, delta,
-                        dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], 3 * H, dbias, B, S, Spad, heads, 0.125)
+                        dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], 3 * H, dbias, B, S, Spad, heads, 0.125,
+                        hip.attn_bias_pack(bias_p, S))
     assert torch.equal(dqkv, clean)
     got = dbias.sum(0)[:, :, :S]
     assert got.isfinite().all()
@@ -551,10 +552,12 @@ def test_attention_per_sample_bias(B, S, heads, use_pad):
     out, lse = hip.attn_fwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad,
                             bias_frag=hip.attn_bias_pack(bias_d, S))  # resident kernel, per-sample fragment-major images
     assert_close(out.view(B, S, H), ref, fro=6e-3, what="attn out")
-    dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
-                               bias_d, biasT_d, pad_d, Spad, want_dbias=True)
-    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
+    for fr in (hip.attn_bias_pack(bias_d, S), None):  # merged dQ + dBias kernel with the fragment image / with the q-major image
+        dqkv, dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dev_bf16(dout), out, lse, B, S, heads, 0.125,
+                                   bias_d, biasT_d, pad_d, Spad, want_dbias=True, bias_frag=fr)
+        for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+            assert_close(dqkv[:, sl], qkv_r.grad[:, sl], fro=1.2e-2, mx=3e-2, what=name)
+        assert_close(dbias[..., :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="per-sample dbias")
     assert dbias.shape == (B, heads, S, Spad)
     assert_close(dbias[..., :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="per-sample dbias")
 

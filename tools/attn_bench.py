@@ -28,9 +28,10 @@ for S in (257, 250, 64, 320, 327):
         out, lse = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True, bias_frag=frag)
         dout = torch.randn_like(out)
         tf = timeit(lambda: hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True, bias_frag=frag), iters=20)
-        tb0 = timeit(lambda: hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias, biasT, None, Spad), iters=20)
+        fr = frag if res else None  # "streaming" arm = the round-1 softmax code of the backward kernels as well
+        tb0 = timeit(lambda: hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias, biasT, None, Spad, bias_frag=fr), iters=20)
         tb1 = timeit(lambda: hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias, biasT, None, Spad,
-                                          want_dbias=True), iters=20)
+                                          want_dbias=True, bias_frag=fr), iters=20)
         print("B=%d S=%d %-9s: fwd %.4f ms (%.0f TF, %.2f TB/s algorithmic)  bwd %.4f ms (%.0f TF)  bwd+dbias %.4f ms" % (
             B, S, "resident" if res else "streaming", tf, fl / tf / 1e9, algo_bytes / tf / 1e9, tb0, 2.5 * fl / tb0 / 1e9, tb1),
             flush=True)

@@ -147,6 +147,16 @@ int op_relpos_bias_build(const void* table, const int* bucket, int64_t bucket_ld
 /* dtable[bucket[i][j]][h] += dbias[h][i][j]  (fp32; dtable pre-zeroed by the caller) */
 int op_relpos_bias_bwd(const float* dbias, const int* bucket, int64_t bucket_ld, float* dtable, int64_t heads, int64_t S,
                        int64_t Spad, void* stream);
+/* Per-sample images for the masked-pretraining passes (adapter/image.py:188-204,229-246, adapter/text.py, adapter/audio.py:
+ * gather_features selects rows and columns preserve_ids[b] of the dense bias): out[b][h][i][j] = table[bucket[ids[b][i]][ids[b][j]]][h]
+ * straight from the table -- out [B][heads][K][Kpad] bf16, pad columns zero; transposed != 0: rows = keys.  ids [B][K] int32
+ * position ids (padding already mapped to a valid id, adapter/image.py:241-243; it is masked through key_pad).  The backward
+ * folds the per-sample gradient slabs dbias [B][heads][K][Kpad] of op_attn_bwd into dense_ws (fp32 [heads][Sfull][Sfull], zeroed
+ * by the caller; Sfull = extent of the bucket table) and scatters that onto dtable [num_rel][heads] (pre-zeroed). */
+int op_relpos_bias_build_ids(const void* table, const int* bucket, int64_t bucket_ld, const int* ids, void* out, int64_t B,
+                             int64_t heads, int64_t K, int64_t Kpad, int transposed, void* stream);
+int op_relpos_bias_bwd_ids(const float* dbias, const int* bucket, int64_t bucket_ld, const int* ids, float* dense_ws, int64_t Sfull,
+                           float* dtable, int64_t B, int64_t heads, int64_t K, int64_t Kpad, void* stream);
 
 /* ---- HBM-bound helpers of the layer backward -----------------------------------------------------------------------
  * (the reference gets these from autograd over transformer_layer.py:54-88,149-157) */

@@ -15,11 +15,15 @@ def take_rows(t, ids):
 
 
 def take_bias(bias_list, ids, bsz):
-    """Select rows and columns ids[b] of each (dense or lazy) bias -> dense [B, heads, K, K] tensors."""
+    """Select rows and columns ids[b] of each bias (adapter/image.py:188-204).  A lazy RelPosSpec stays lazy (the HIP path builds
+    the per-sample images straight from the table, relpos.RelPosSpec.with_ids); dense tensors are gathered densely."""
     if bias_list is None:
         return None
     out = []
     for bias in bias_list:
+        if isinstance(bias, RelPosSpec) and bias.ids is None:
+            out.append(bias.with_ids(ids))
+            continue
         d = bias.dense(bsz) if isinstance(bias, RelPosSpec) else bias
         heads, full = d.size(1), d.size(-1)
         k = ids.size(1)

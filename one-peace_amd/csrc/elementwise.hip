@@ -503,6 +503,47 @@ __global__ __launch_bounds__(256) void relpos_bwd_kernel(const float* __restrict
   }
 }
 
+// Per-sample bias images of the masked-pretraining passes (adapter/image.py:188-204,229-246: the adapters gather a different
+// token subset per sample, and with it rows AND columns of the dense [B, heads, S, S] bias): here straight from the table,
+//   out[b][h][i][j] = table[bucket[ids[b][i]][ids[b][j]]][h]   (ids = position ids of the K kept tokens of sample b)
+// so neither the dense bias nor its gathers are ever materialised.  transposed: out[b][h][j][i] holds that value.
+__global__ __launch_bounds__(256) void relpos_build_ids_kernel(const bf16_t* __restrict__ table, const int* __restrict__ bucket,
+                                                               int64_t bucket_ld, const int* __restrict__ ids, bf16_t* __restrict__ out,
+                                                               int B, int heads, int K, int Kpad, int transposed) {
+  const int64_t total = (int64_t)B * K * Kpad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j = (int)(idx % Kpad);
+    const int64_t bi = idx / Kpad;
+    const int i = (int)(bi % K), b = (int)(bi / K);
+    bf16_t* o = out + (((int64_t)b * heads) * K + i) * Kpad + j;
+    if (j < K) {
+      const int pi = ids[(int64_t)b * K + i], pj = ids[(int64_t)b * K + j];
+      const int bk = transposed ? bucket[(int64_t)pj * bucket_ld + pi] : bucket[(int64_t)pi * bucket_ld + pj];
+      for (int h = 0; h < heads; ++h) o[(int64_t)h * K * Kpad] = table[(int64_t)bk * heads + h];
+    } else {
+      for (int h = 0; h < heads; ++h) o[(int64_t)h * K * Kpad] = (bf16_t)0.f;
+    }
+  }
+}
+
+// Stage 1 of the table gradient of per-sample images: dense[h][ids[b][i]][ids[b][j]] += dbias[b][h][i][j] -- the per-sample
+// slabs are folded into ONE full-sequence image (heads x Sfull x Sfull addresses: little contention), which the ordinary
+// relpos_bwd_kernel then scatters onto the table.  (Adding the slabs straight onto the table was 29 ms per call: ten million
+// fp32 atomics on a few thousand addresses.)
+__global__ __launch_bounds__(256) void relpos_fold_ids_kernel(const float* __restrict__ dbias, const int* __restrict__ ids,
+                                                              float* __restrict__ dense, int B, int heads, int K, int Kpad, int Sfull) {
+  const int64_t total = (int64_t)B * heads * K * K;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j = (int)(idx % K);
+    int64_t r = idx / K;
+    const int i = (int)(r % K);
+    r /= K;
+    const int h = (int)(r % heads), b = (int)(r / heads);
+    const float v = dbias[((((int64_t)b * heads) + h) * K + i) * Kpad + j];
+    atomicAdd(&dense[((int64_t)h * Sfull + ids[(int64_t)b * K + i]) * Sfull + ids[(int64_t)b * K + j]], v);
+  }
+}
+
 inline int ew_grid(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   if (b > 2048) b = 2048;
@@ -747,6 +788,32 @@ int op_relpos_bias_build(const void* table, const int* bucket, int64_t bucket_ld
   OP_CHECK_ARG(table && bucket && out && Spad >= S && Spad % 8 == 0, "relpos_bias_build: bad args");
   hipLaunchKernelGGL(relpos_build_kernel, dim3(ew_grid(S * Spad)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table,
                      bucket, bucket_ld, (bf16_t*)out, (int)heads, (int)S, (int)Spad, transposed);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// Per-sample images from position ids: out [B][heads][K][Kpad] bf16 (pad columns zero), ids [B][K] int32 (valid positions;
+// the caller maps padding to a valid id and masks it through key_pad, as the reference does: adapter/image.py:241-246).
+int op_relpos_bias_build_ids(const void* table, const int* bucket, int64_t bucket_ld, const int* ids, void* out, int64_t B,
+                             int64_t heads, int64_t K, int64_t Kpad, int transposed, void* stream) {
+  OP_CHECK_ARG(table && bucket && ids && out && B > 0 && K > 0 && Kpad >= K && Kpad % 8 == 0, "relpos_bias_build_ids: bad args");
+  hipLaunchKernelGGL(relpos_build_ids_kernel, dim3(ew_grid(B * K * Kpad)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table,
+                     bucket, bucket_ld, ids, (bf16_t*)out, (int)B, (int)heads, (int)K, (int)Kpad, transposed);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// Table gradient from the per-sample bias gradients dbias [B][heads][K][Kpad] fp32 (one slab per sample from op_attn_bwd);
+// dtable [num_rel][heads] fp32 is accumulated into (pre-zero it).  dense_ws: fp32 [heads][Sfull][Sfull] scratch, ZEROED by the
+// caller, Sfull = extent of the bucket table the ids index (the slabs are first folded into it, then scattered onto the table).
+int op_relpos_bias_bwd_ids(const float* dbias, const int* bucket, int64_t bucket_ld, const int* ids, float* dense_ws, int64_t Sfull,
+                           float* dtable, int64_t B, int64_t heads, int64_t K, int64_t Kpad, void* stream) {
+  OP_CHECK_ARG(dbias && bucket && ids && dense_ws && dtable && B > 0 && K > 0 && Sfull > 0, "relpos_bias_bwd_ids: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(relpos_fold_ids_kernel, dim3(ew_grid(B * heads * K * K)), dim3(256), 0, s, dbias, ids, dense_ws, (int)B,
+                     (int)heads, (int)K, (int)Kpad, (int)Sfull);
+  hipLaunchKernelGGL(relpos_bwd_kernel, dim3(ew_grid(Sfull * Sfull)), dim3(256), 0, s, (const float*)dense_ws, bucket, bucket_ld,
+                     dtable, (int)heads, (int)Sfull, (int)Sfull);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

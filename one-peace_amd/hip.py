@@ -56,6 +56,8 @@ SIGNATURES = {
     "op_sqnorm": (c_int, [P, I64, P, P, P]),
     "op_relpos_bias_build": (c_int, [P, P, I64, P, I64, I64, I64, c_int, P]),
     "op_relpos_bias_bwd": (c_int, [P, P, I64, P, I64, I64, I64, P]),
+    "op_relpos_bias_build_ids": (c_int, [P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
+    "op_relpos_bias_bwd_ids": (c_int, [P, P, I64, P, P, I64, P, I64, I64, I64, I64, P]),
     "op_attn_fwd": (c_int, [P, P, P, I64, P, I64, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_attn_bias_frag_elems": (I64, [I64, I64]),
     "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
@@ -499,6 +501,26 @@ def relpos_bias_bwd(dbias_f32, bucket_i32, num_rel, S, Spad):
     dtable = torch.zeros(num_rel, heads, dtype=torch.float32, device=dbias_f32.device)
     _check(lib().op_relpos_bias_bwd(ptr(dbias_f32), ptr(bucket_i32), bucket_i32.stride(0), ptr(dtable), heads, S, Spad,
                                     stream()), "op_relpos_bias_bwd")
+    return dtable
+
+
+def relpos_bias_build_ids(table, bucket_i32, ids_i32, Kpad, transposed=False):
+    """Per-sample images [B, heads, K, Kpad] of table[bucket[ids[b, i], ids[b, j]]] (see op_relpos_bias_build_ids)."""
+    B, K = ids_i32.shape
+    heads = table.shape[1]
+    out = torch.empty(B, heads, K, Kpad, dtype=torch.bfloat16, device=table.device)
+    _check(lib().op_relpos_bias_build_ids(ptr(table), ptr(bucket_i32), bucket_i32.stride(0), ptr(ids_i32), ptr(out), B, heads, K, Kpad,
+                                          int(transposed), stream()), "op_relpos_bias_build_ids")
+    return out
+
+
+def relpos_bias_bwd_ids(dbias_f32, bucket_i32, ids_i32, num_rel):
+    B, heads, K, Kpad = dbias_f32.shape
+    dtable = torch.zeros(num_rel, heads, dtype=torch.float32, device=dbias_f32.device)
+    Sfull = bucket_i32.shape[0]
+    dense = torch.zeros(heads, Sfull, Sfull, dtype=torch.float32, device=dbias_f32.device)
+    _check(lib().op_relpos_bias_bwd_ids(ptr(dbias_f32), ptr(bucket_i32), bucket_i32.stride(0), ptr(ids_i32), ptr(dense), Sfull,
+                                        ptr(dtable), B, heads, K, Kpad, stream()), "op_relpos_bias_bwd_ids")
     return dtable
 
 

@@ -266,7 +266,11 @@ def linear(x, w, b=None):
 class RelPosBias:
     """Per-forward handle: bf16 images of table[bucket] plus the fp32 accumulator the attention backward adds into."""
 
-    def __init__(self, table, bucket_i32, S):
+    def __init__(self, table, bucket_i32, S, ids=None):
+        """ids: optional int32 [B, K] position ids (masked pretraining: a different kept-token subset per sample) -- the images
+        are then per sample, [B, heads, K, Kpad], built straight from the table (no dense [B, heads, S, S] tensor, no gathers),
+        and S is K."""
+        self.ids = ids
         self.S, self.Spad = S, hip.attn_spad(S)
         self.num_rel, self.heads = table.shape
         self.bucket = bucket_i32
@@ -287,13 +291,17 @@ class RelPosBias:
     def imageT(self):
         """out[h][key][query]: what the dK/dV kernel reads (built on first use in a backward pass)."""
         if self._imageT is None:
-            self._imageT = hip.relpos_bias_build(self.table.detach(), self.bucket, self.S, self.Spad, transposed=True)
+            if self.ids is not None:
+                self._imageT = hip.relpos_bias_build_ids(self.table.detach(), self.bucket, self.ids, self.Spad, transposed=True)
+            else:
+                self._imageT = hip.relpos_bias_build(self.table.detach(), self.bucket, self.S, self.Spad, transposed=True)
         return self._imageT
 
     def grad_accumulator(self, B):
-        """fp32 [slabs, heads, S, Spad]: the attention backward of every layer that uses this table adds its dS sums here."""
+        """fp32 [slabs, heads, S, Spad]: the attention backward of every layer that uses this table adds its dS sums here
+        (per-sample images: one slab per sample)."""
         if self.acc is None:
-            self.acc = hip.attn_dbias_buffer(B, self.S, self.heads, self.Spad, self.image.device)
+            self.acc = hip.attn_dbias_buffer(B, self.S, self.heads, self.Spad, self.image.device, per_sample=self.ids is not None)
         return self.acc
 
 
@@ -357,6 +365,8 @@ class _RelPosImageFn(torch.autograd.Function):
     def forward(ctx, table, handle):
         ctx.handle_ref = weakref.ref(handle)  # the layers' ctx keep the handle alive until their backward ran
         ctx.shape = tuple(table.shape)
+        if handle.ids is not None:
+            return hip.relpos_bias_build_ids(table, handle.bucket, handle.ids, handle.Spad)
         return hip.relpos_bias_build(table, handle.bucket, handle.S, handle.Spad)
 
     @staticmethod
@@ -366,7 +376,10 @@ class _RelPosImageFn(torch.autograd.Function):
         h = ctx.handle_ref()
         if h is None or h.acc is None:
             return torch.zeros(ctx.shape, dtype=torch.bfloat16, device=_unused.device), None
-        dtable = hip.relpos_bias_bwd(h.acc.sum(0), h.bucket, h.num_rel, h.S, h.Spad)
+        if h.ids is not None:
+            dtable = hip.relpos_bias_bwd_ids(h.acc, h.bucket, h.ids, h.num_rel)
+        else:
+            dtable = hip.relpos_bias_bwd(h.acc.sum(0), h.bucket, h.num_rel, h.S, h.Spad)
         h.acc = None
         return dtable.to(torch.bfloat16), None
 

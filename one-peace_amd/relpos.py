@@ -46,36 +46,53 @@ def add_cls_buckets(rp_bucket, num_rel_dis):
 
 
 class RelPosSpec:
-    """table: nn.Embedding weight [num_rel, heads]; bucket: long [S, S] (already sliced to the sequence)."""
+    """table: nn.Embedding weight [num_rel, heads]; bucket: long [S, S] (already sliced to the sequence).
+    ids (optional): long [B, K] position ids of the K tokens each sample keeps (masked pretraining,
+    adapter/image.py:188-204,229-246): the bias of sample b is then rows AND columns ids[b] of table[bucket]."""
 
-    def __init__(self, table, bucket, bucket_i32=None):
-        self.table, self.bucket, self.bucket_i32 = table, bucket, bucket_i32
+    def __init__(self, table, bucket, bucket_i32=None, ids=None):
+        self.table, self.bucket, self.bucket_i32, self.ids = table, bucket, bucket_i32, ids
+
+    def with_ids(self, ids):
+        return RelPosSpec(self.table, self.bucket, self.bucket_i32, ids)
 
     def dense(self, bsz):
         v = self.table[self.bucket]  # [S, S, heads]
-        return v.permute(2, 0, 1).unsqueeze(0).expand(bsz, -1, -1, -1)
+        d = v.permute(2, 0, 1).unsqueeze(0).expand(bsz, -1, -1, -1)
+        if self.ids is None:
+            return d
+        heads, full, k = d.size(1), d.size(-1), self.ids.size(1)  # the reference's two gathers (adapter/image.py:196-200)
+        rows = torch.gather(d, 2, self.ids[:, None, :, None].expand(-1, heads, -1, full))
+        return torch.gather(rows, 3, self.ids[:, None, None, :].expand(-1, heads, k, -1))
+
+    def _b32(self):
+        return self.bucket_i32 if self.bucket_i32 is not None else self.bucket.to(torch.int32).contiguous()
 
     def handle(self):
-        S = self.bucket.shape[0]
-        b32 = self.bucket_i32 if self.bucket_i32 is not None else self.bucket.to(torch.int32).contiguous()
-        return ops.RelPosBias(self.table, b32, S)
+        if self.ids is not None:
+            return ops.RelPosBias(self.table, self._b32(), self.ids.size(1), ids=self.ids.to(torch.int32).contiguous())
+        return ops.RelPosBias(self.table, self._b32(), self.bucket.shape[0])
 
 
 def joint_handle(specs, lens, bucket_cache=None):
     """Block-diagonal bias of a joint stream (transformer_encoder.py:144-158: zeros, then each modality's block added on
     its own diagonal square) as ONE table + bucket: rows of the per-modality tables stacked, plus a constant zero row
     that every cross-modal (off-diagonal) position points at.  ``torch.cat`` routes the table gradient back to each
-    modality's own embedding.  specs: RelPosSpec or None per segment; lens: segment lengths."""
+    modality's own embedding.  specs: RelPosSpec or None per segment; lens: segment lengths.
+    Segments with per-sample position ids (masked students): the joint bucket is built over the FULL positions of every
+    segment and the ids are concatenated with the segments' offsets -- the joint stream is then one ids-indexed bias."""
     live = [sp for sp in specs if sp is not None]
     ref = live[0].table
-    S = sum(lens)
-    key = tuple(id(sp.bucket) if sp is not None else None for sp in specs) + tuple(lens)
+    with_ids = any(sp is not None and sp.ids is not None for sp in specs)
+    full = [(sp.bucket.shape[0] if sp is not None else n) for sp, n in zip(specs, lens)] if with_ids else list(lens)
+    S = sum(full)
+    key = tuple(id(sp.bucket) if sp is not None else None for sp in specs) + tuple(full)
     bucket = bucket_cache.get(key) if bucket_cache is not None else None
     n_rows = sum(sp.table.shape[0] for sp in live)
     if bucket is None:
         bucket = torch.full((S, S), n_rows, dtype=torch.int32, device=ref.device)
         off = base = 0
-        for sp, n in zip(specs, lens):
+        for sp, n in zip(specs, full):
             if sp is not None:
                 bucket[off:off + n, off:off + n] = sp.bucket.to(torch.int32) + base
                 base += sp.table.shape[0]
@@ -83,4 +100,15 @@ def joint_handle(specs, lens, bucket_cache=None):
         if bucket_cache is not None:
             bucket_cache[key] = bucket
     table = torch.cat([sp.table for sp in live] + [ref.new_zeros(1, ref.shape[1])], dim=0)
-    return ops.RelPosBias(table, bucket, S)
+    if not with_ids:
+        return ops.RelPosBias(table, bucket, S)
+    B = next(sp.ids.shape[0] for sp in live if sp.ids is not None)
+    parts, off = [], 0
+    for sp, n_full, n in zip(specs, full, lens):
+        if sp is not None and sp.ids is not None:
+            parts.append(sp.ids.to(torch.int32) + off)
+        else:  # a segment that keeps all its positions (or has no bias): its own positions in order
+            parts.append(torch.arange(off, off + n, dtype=torch.int32, device=ref.device).unsqueeze(0).expand(B, -1))
+        off += n_full
+    ids = torch.cat(parts, dim=1).contiguous()
+    return ops.RelPosBias(table, bucket, ids.shape[1], ids=ids)

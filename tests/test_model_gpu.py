@@ -434,6 +434,14 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
     fx = _fx(golden_dir, "micro_pretrain.pt" if stage == "vl" else "micro_pretrain_al.pt")
     ni = {k: (v.to(DEV).to(torch.bfloat16) if v.is_floating_point() else v.to(DEV)) for k, v in fx["net_input"].items()}
     calls = {"fused": 0, "torch": 0}
+    from one_peace_amd import ops as _ops
+    dense_inits = []
+    orig_dense_init = _ops.DenseBias.__init__
+
+    def _no_dense(self, dense):  # the masked passes must build their per-sample images from position ids, never from a dense
+        dense_inits.append(tuple(dense.shape))  # [B, heads, K, K] tensor (adapter/image.py:188-204 is replaced, not ported)
+        orig_dense_init(self, dense)
+    _ops.DenseBias.__init__ = _no_dense
     of, ot = TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch
 
     def cf(self, *a, **k):
@@ -464,6 +472,8 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
                              grads={n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
     finally:
         TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch = of, ot
+        _ops.DenseBias.__init__ = orig_dense_init
+    assert not dense_inits, "dense per-sample bias tensors were built: %s" % dense_inits
     report = []
     for k, ref in fx["log"].items():
         if "loss" in k:

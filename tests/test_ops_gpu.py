@@ -383,6 +383,39 @@ def test_relpos_bias_build_and_bwd():
     assert_close(dt, tr.grad, fro=1e-5, mx=1e-4, what="dtable")
 
 
+def test_relpos_bias_build_from_position_ids():
+    """Per-sample images of the masked-pretraining passes straight from the table: out[b][h][i][j] =
+    table[bucket[ids[b,i]][ids[b,j]]][h] (what the reference obtains by gathering rows and columns of the dense bias,
+    adapter/image.py:188-204), its transposed image, zero pad columns, and the scatter of per-sample gradient slabs back
+    into the table."""
+    hip = hipmod()
+    heads, n, B, K = 3, 4, 5, 9
+    num_rel = (2 * n - 1) ** 2 + 3
+    bucket = O.image_bucket_position(n, num_rel)
+    S, Kpad = n * n + 1, 128
+    table = rnd(num_rel, heads, seed=1)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.stack([torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(S - 1, generator=g)[: K - 1].sort().values])
+                       for _ in range(B)])
+    ids[2, -2:] = K - 1  # padded slots are mapped to a valid position id by the adapters (adapter/image.py:241-243)
+    dense = O.rel_pos_bias(table, bucket).unsqueeze(0).expand(B, -1, -1, -1)
+    ref = torch.gather(torch.gather(dense, 2, ids[:, None, :, None].expand(-1, heads, -1, S)), 3,
+                       ids[:, None, None, :].expand(-1, heads, K, -1))
+    b32, i32 = bucket.to(torch.int32).to(DEV), ids.to(torch.int32).to(DEV)
+    out = hip.relpos_bias_build_ids(dev_bf16(table), b32, i32, Kpad)
+    outT = hip.relpos_bias_build_ids(dev_bf16(table), b32, i32, Kpad, transposed=True)
+    assert torch.equal(out[..., :K].float().cpu(), ref) and torch.equal(outT[..., :K].float().cpu(), ref.transpose(2, 3))
+    assert float(out[..., K:].abs().max()) == 0.0 and float(outT[..., K:].abs().max()) == 0.0
+    dbias = torch.randn(B, heads, K, Kpad, generator=torch.Generator().manual_seed(2))
+    tr = table.clone().requires_grad_(True)
+    dense_r = O.rel_pos_bias(tr, bucket).unsqueeze(0).expand(B, -1, -1, -1)
+    got = torch.gather(torch.gather(dense_r, 2, ids[:, None, :, None].expand(-1, heads, -1, S)), 3,
+                       ids[:, None, None, :].expand(-1, heads, K, -1))
+    got.backward(dbias[..., :K])
+    dt = hip.relpos_bias_bwd_ids(dbias.to(DEV), b32, i32, num_rel)
+    assert_close(dt, tr.grad, fro=1e-5, mx=1e-4, what="dtable from per-sample slabs")
+
+
 def _attn_ref(q, k, v, heads, scale, bias, key_pad):
     """q,k,v: [B,S,H] fp32; bias [heads,S,S]; key_pad [B,S] bool.  multihead_attention.py:102-115."""
     B, S, H = q.shape

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // pipe; sched_group_barrier spreads the 16 memory instructions between the 32 MFMAs (1 per 2) instead.
   auto step_steady = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
     WAIT_LGKM0();
-    if (ABL != 2 && (ABL < 4 || ABL == 6)) WAIT_VM(8); else WAIT_VM(0);
+    if (ABL == 3) WAIT_VM(4); else if (ABL != 2 && (ABL < 4 || ABL == 6)) WAIT_VM(8); else WAIT_VM(0);
     if (ABL != 5) __builtin_amdgcn_s_barrier();
     const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;  // fragments of the next stage
     char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;              // slot being refilled with stage kt+4
@@ -523,7 +523,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
         else if (j < 12) nxt_x[j - 4] = cur_x[j - 4];
       } else if (j < 4) {
         const int o = (EPI == EPI_GEGLU) ? ((j >> 1) * 128 + (j & 1) * 16) * 64 : j * 16 * 64;
-        nxt_w[j] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
+        if (ABL == 3) nxt_w[j] = cur_w[j];  // 3: the weight operand neither staged nor read (activations through LDS only)
+        else nxt_w[j] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
       } else if (j < 12) {
         nxt_x[j - 4] = *reinterpret_cast<const bf16x8*>(st + baseX + (j - 4) * 1024);
       } else {
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
           if ((j & 1) == 0)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
                                              (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
-          else
+          else if (ABL != 3)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
                                              (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
         }
@@ -1002,6 +1003,9 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
   } else if (EPI == EPI_BIAS && T.ablation == 2) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 2>), grid, dim3(512), sh, s, a);
+  } else if (EPI == EPI_BIAS && T.ablation == 3) {
+    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 3>), grid, dim3(512), sh, s, a);
   } else if (EPI == EPI_BIAS && T.ablation == 4) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 4>), grid, dim3(512), sh, s, a);

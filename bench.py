@@ -247,6 +247,10 @@ def main():
                     help="every step takes its batch from host memory through staging.SamplePrefetcher (PCIe-inclusive rate; "
                          "the headline value keeps inputs resident in HBM)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--graphs", action="store_true",
+                    help="single process, training configs: zero-grad + forwards + loss + backward of a step replayed as ONE "
+                         "hipGraph (graphs.TrainStepGraph; the optimiser step stays eager).  For launch-bound small batches; the "
+                         "per-launch HIP-event roofline needs eager launches and is omitted")
     args = ap.parse_args()
 
     from one_peace_amd import hip
@@ -374,6 +378,14 @@ def main():
     def infer_step(inp=None):
         return model(src_images=(inp if inp is not None else batch["src_images"]), encoder_type="image")
 
+    graph = None
+
+    def graphed_train_step():
+        loss = graph.replay()
+        reducer.finish()
+        opt.step(grad_scale=1.0 / world, clip_norm=3.0)
+        return loss
+
     step = train_step if train else infer_step
 
     def sync():
@@ -444,8 +456,27 @@ def main():
             torch.cuda.synchronize()
             sweep["batch_%d_images_per_s" % b] = round(b * 5 / (time.perf_counter() - t0), 1)
 
-    loss = warm(max(args.warmup, 0))
+    # --graphs: no eager step before the capture -- autograd creates the parameters' AccumulateGrad nodes on the stream of the
+    # first backward, and nodes that live on the default stream cannot take part in a capture on another one
+    loss = warm(max(args.warmup, 0)) if not args.graphs else None
     sync()
+    if args.graphs:
+        if not train or world > 1 or feeder is not None:
+            raise SystemExit("--graphs: single-process training configs with resident inputs")
+        from one_peace_amd.graphs import TrainStepGraph
+        args.no_profile = True
+
+        def fwd_bwd():
+            opt.zero_grad()
+            reducer.reset()
+            loss, _, _ = crit(model, sample)
+            loss.backward()
+            return loss
+        graph = TrainStepGraph(fwd_bwd, warmup=1)
+        step = graphed_train_step
+        for _ in range(max(args.warmup, 1)):
+            loss = step()
+        sync()
     hip.GEMM_ALGO_BYTES[0] = hip.GEMM_ALGO_BYTES[1] = 0
     profiled_steps = 0
     t0 = time.perf_counter()
@@ -499,7 +530,9 @@ def main():
                                                 else "off: layer activations are kept in HBM (288 GB/GPU)"),
                        "algorithmic_tflop_per_sample": None if full else fl / 1e12,
                        "step_algorithmic_tflops_per_gpu": None if full else fl * args.batch / (ms / 1e3) / 1e12,
-                       "objective": "forward" if not train else args.objective, "final_loss": loss_v if train else None},
+                       "objective": "forward" if not train else args.objective, "final_loss": loss_v if train else None,
+                       "launch_path": ("hipGraph replay of zero-grad + forwards + loss + backward, eager optimiser step" if args.graphs
+                                       else "eager (one ctypes call per kernel)")},
         }
         if sweep:
             out["config"]["sweep"] = sweep

@@ -4,7 +4,12 @@ layers is ~9 kernels per layer of a few microseconds each, so the host's launch 
 Every kernel of the HIP path is enqueued on torch's current stream and the C-ABI never synchronises or allocates
 (include/onepeace_hip.h), so a whole ``model(...)`` call records into one graph; replay is a single hipGraphLaunch.  The
 captured call owns static input / output buffers: ``__call__`` copies the new inputs in, replays, and returns the outputs
-(clones by default -- the static buffers are overwritten by the next replay).  One graph per input-shape signature."""
+(clones by default -- the static buffers are overwritten by the next replay).  One graph per input-shape signature.
+
+``TrainStepGraph`` does the same for the launch-bound end of TRAINING (small per-GPU batches: 7 000 launches per step cost
+the host ~30 us each, more than the kernels take below ~32 tuples): gradient zeroing, the forwards, the loss and the whole
+backward -- autograd included -- record into one graph; the optimiser step stays outside (its bias-correction step count is a
+host-side kernel argument) and so do the gradient collectives of a multi-rank run."""
 import torch
 
 
@@ -57,3 +62,33 @@ class GraphCache:
                 self.graphs.pop(next(iter(self.graphs)))
             g = self.graphs[sig] = GraphedCall(self.fn, inputs)
         return g(**inputs)
+
+
+class TrainStepGraph:
+    """One hipGraph of ``fwd_bwd()`` = zero the gradients, forward(s), loss, backward, on a STATIC batch.
+
+    ``fwd_bwd`` must not synchronise, must keep every gradient buffer at a fixed address (``FlatParameters`` does: ``.grad`` of
+    every parameter is a view of one flat buffer that the kernels and autograd accumulate into in place) and returns the tensors
+    to read after a replay (the loss).  Random draws of torch ops inside it (drop-path masks) are replay-safe: torch registers
+    its Philox state with the graph and advances it per replay.  New data: ``copy_`` into the tensors the captured call read.
+    Build it BEFORE any eager backward of the model: autograd creates a parameter's AccumulateGrad node on the stream of the first
+    backward that reaches it, and nodes living on the default stream cannot take part in a capture (the warm-up here runs on a
+    side stream for that reason)."""
+
+    def __init__(self, fwd_bwd, warmup=2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("TrainStepGraph: hipGraph capture has no CPU path")
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # autograd's stream bookkeeping, workspaces and derived buffers settle on a side stream
+            for _ in range(warmup):
+                fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fwd_bwd()
+
+    def replay(self):
+        self.graph.replay()
+        return self.out

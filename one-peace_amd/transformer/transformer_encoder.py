@@ -140,7 +140,11 @@ class TransformerEncoder(nn.Module):
         probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers]
         if max(probs, default=0.0) <= 0.0:
             return None
-        keep = 1.0 - torch.tensor(probs, dtype=torch.float32, device=device).view(-1, 1, 1)
+        cached = getattr(self, "_keep_probs", None)  # device-resident: no host-to-device copy per forward (hipGraph capture)
+        if cached is None or cached[0] != (tuple(probs), device):
+            cached = ((tuple(probs), device), 1.0 - torch.tensor(probs, dtype=torch.float32, device=device).view(-1, 1, 1))
+            self._keep_probs = cached
+        keep = cached[1]
         draw = torch.bernoulli(keep.expand(-1, 2, B)) / keep
         return [(None, None) if p <= 0.0 else (draw[i, 0], draw[i, 1]) for i, p in enumerate(probs)]
 

@@ -674,6 +674,53 @@ def test_deep_vision_branch_8_layers_4b_dimensions(golden_dir):
         "\n".join(report) + "\n")
 
 
+def test_train_step_graph_replay_matches_eager_training():
+    """graphs.TrainStepGraph: zero-grad + three forwards + ITC/ATC + the whole backward (custom autograd functions, in-place
+    accumulation into the flat gradient buffer, autograd's own accumulation for the adapters) recorded into ONE hipGraph and
+    replayed, optimiser step eager in between: losses and parameters must follow eager training bit for bit, also when the
+    static batch is overwritten with new data between replays."""
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.distributed import BucketedGradReducer, FlatParameters
+    from one_peace_amd.graphs import TrainStepGraph
+    from one_peace_amd.optim import FusedAdamW
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_rel_bucket_size=4,
+               text_bucket_size=256, audio_bucket_size=512)
+    batches = [_to_dev(synth.synth_inputs(8, text_len=15, image_res=64, audio_samples=8000, vocab=1000, seed=s)) for s in (1, 2)]
+    runs = {}
+    for mode in ("eager", "graph"):
+        m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(torch.bfloat16).eval()
+        flat = FlatParameters(m)
+        reducer = BucketedGradReducer(flat)
+        opt = FusedAdamW(flat, lr=1e-3)
+        crit = TriModalContrastiveCriterion(None, 0.0)
+        static = {k: v.clone() for k, v in batches[0].items()}
+
+        def fwd_bwd():
+            opt.zero_grad()
+            reducer.reset()
+            loss, _, _ = crit(m, {"net_input": static, "nsentences": 8})
+            loss.backward()
+            return loss
+        start = flat.params.clone()
+        g = None
+        if mode == "graph":
+            g = TrainStepGraph(fwd_bwd, warmup=1)  # the warm-up / capture passes only touch gradients, never parameters
+            assert torch.equal(flat.params, start)
+        losses = []
+        for i in range(4):
+            for k, v in batches[i % 2].items():
+                static[k].copy_(v)
+            loss = g.replay() if g is not None else fwd_bwd()
+            reducer.finish()
+            opt.step(clip_norm=3.0)
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        runs[mode] = (losses, flat.params.clone())
+    assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
+    assert torch.equal(runs["eager"][1], runs["graph"][1])
+    assert len(set(runs["eager"][0])) == 4  # the steps really differ (new data, updated weights)
+
+
 def test_retrieval_criteria_on_hip(golden_dir):
     """BASELINE configs[2] objective: image_text_retrieval_criterion (ITC, eps 0) and audio_text_retrieval_criterion (ATC with
     label smoothing 0.1, the eps/(n-1) form of image_text_retrieval_loss.py:21-24) through the HIP InfoNCE kernels, against

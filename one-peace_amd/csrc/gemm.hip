@@ -23,7 +23,6 @@
 //
 // Roofline: MFMA (dense bf16, 2.5 PFLOP/s).  Algorithmic work = 2*M*N*K flops per launch.
 #include "common.h"
-#include <type_traits>
 
 namespace {
 
@@ -390,7 +389,6 @@ __device__ __forceinline__ int w_row_to_col256(int p) {
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]); the builtin form keeps
 // the compiler's own scoreboard in sync, so it does not add conservative waits of its own around ours.
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
-#define WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
 #define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 0xF) | ((((n) >> 4) & 3) << 14))
 
 template <int EPI, int ABL = 0>
@@ -762,201 +760,6 @@ __global__ __launch_bounds__(512, 2) void gemm256b_kernel(const GemmArgs p) {
 }
 
 // =====================================================================================================================
-// "Weights from L2" flavour of the 256 x 256 NT kernel.  Only the ACTIVATION operand goes through LDS (five 32 KiB slots =
-// five K-tiles of [256 rows][64 k], LDS-DMA, same image / swizzle / fragment reads as gemm256b_kernel); every wave loads
-// its 64 weight rows -- the MFMA's first operand, already in fragment order: lane (g, t) owns 16 bytes of row t -- with
-// plain global loads straight into registers, one and a half K-tiles ahead (a register ring of 2 tiles x 2 halves x 4
-// fragments = 64 VGPRs).  The weight panel is hot in L2 (every M-tile of a group reads it) and shared by only two of the
-// eight waves, so it gains the least from LDS and costs a third of the fragment reads and half of the LDS-DMA writes --
-// the two streams whose interference bounds the main loop (profiles/r2_experiments.md section 5: with the weight path
-// removed the BK = 32 kernel runs 13 % faster).  To pay for the ring the activation fragments are no longer double
-// buffered per half-step but rolled through four registers (read three MFMA groups ahead).
-//   per K-tile j:   half (j,0): 32 MFMAs on W(j,h0);  loads W(j+1,h1)
-//                   s_waitcnt vmcnt(12) [own share of A(j+1), A(j+2) landed; W(j,h1) here], ONE s_barrier
-//                   half (j,1): 32 MFMAs on W(j,h1);  loads W(j+2,h0);  LDS-DMA A(j+4) -> slot of A(j-1)
-//   RAW: the first fragment reads of A(j+1) are issued at the end of (j,1), after that barrier; WAR: a wave that passed it
-//   has consumed every fragment of A(j-1).  vmcnt counts global loads and LDS-DMA ops alike, in issue order.
-// Requires N % (128 | 256) == 0, K % 128 == 0, K >= 768, no split-K.
-// =====================================================================================================================
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256c_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
-  const int g = lane >> 4, t = lane & 15;
-  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
-
-  const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  const int GM = p.gm;
-  const int per_group = GM * p.tiles_n;
-  const int first_m = (pid / per_group) * GM;
-  const int gsz = min(p.tiles_m - first_m, GM);
-  const int in_group = pid % per_group;
-  const int pid_m = first_m + in_group % gsz;
-  const int pid_n = in_group / gsz;
-  const int m0 = pid_m * BM2, n0 = pid_n * BN_OUT;
-  const int nk = p.K / 64;  // even, >= 6
-
-  // ---- activations: op i of a K-tile covers LDS rows i*64 + (tid >> 3), 16-byte slot tid & 7 (as gemm256b_kernel) ----
-  const int srow = tid >> 3;
-  const int sc = (tid & 7) ^ (srow & 7);
-  const char* baseA = (const char*)p.A;
-  unsigned offA[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int gm = min(m0 + i * 64 + srow, p.M - 1);
-    offA[i] = (unsigned)(((int64_t)gm * p.lda + sc * 8) * 2);
-  }
-  // ---- weights: fragment ni of this wave = 16 weight rows, lane (g, t) reads 16 bytes of row t at k-chunk h*4 + g ----
-  const char* wb[4];  // wave-uniform, advanced by one K-tile (128 bytes) per tile
-  unsigned offW;
-  {
-    const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;
-    const int rl = (EPI == EPI_GEGLU) ? ((t >> 2) * 8 + (t & 3)) : ((t >> 2) * 16 + (t & 3));  // = w_row_to_col256 of the row
-    offW = (unsigned)(((int64_t)rl * p.ldb + g * 8) * 2);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const bf16_t* w;
-      int col0;
-      if (EPI == EPI_GEGLU) {
-        w = p.B[ni >> 1];
-        col0 = n0 + wn * 32 + (ni & 1) * 4;
-      } else {
-        w = p.B[seg];
-        col0 = n0 - seg * p.n_seg + wn * 64 + ni * 4;
-      }
-      wb[ni] = (const char*)(w + (int64_t)col0 * p.ldb);
-    }
-  }
-
-  f32x4 acc[4][8];  // [ni][mi]
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
-  const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
-
-  int slot_issue = 0;  // LDS slot of the next activation tile to be issued
-  auto dma_op = [&](int i) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
-                                     (__attribute__((address_space(3))) void*)(smem + slot_issue * SLOT3_BYTES + wid * 1024 + i * 8192),
-                                     16, 0, 0);
-  };
-  auto dma_done = [&]() {
-    baseA += 128;
-    slot_issue = slot_issue == SLOTS3 - 1 ? 0 : slot_issue + 1;
-  };
-  auto wload = [&](int ni, int byte_off) {  // byte_off relative to the current tile: (tile delta) * 128 + half * 64
-    return *reinterpret_cast<const bf16x8*>(wb[ni] + offW + byte_off);
-  };
-  auto xread = [&](const char* sa, int h, int mi) { return *reinterpret_cast<const bf16x8*>(sa + rowX + mi * 2048 + fsw[h]); };
-
-  bf16x8 W0[2][4], W1[2][4];  // weight ring: [tile parity][half][ni]
-  bf16x8 X[4];                // activation fragments, fragment f = half * 8 + mi of a tile lives in X[f & 3]
-
-  // One K-tile.  Q < 0: steady state; Q = 0..3: the tile nk-4+Q (nothing left to issue step by step).
-  // EVERY wait is explicit and counted.  The compiler's own wait insertion cannot be used next to LDS-DMA: it books a
-  // global_load_lds as a FLAT access to both memories, and while one is pending every wait it inserts itself becomes
-  // vmcnt(0) / lgkmcnt(0) -- which would drain the activation prefetch once per tile.  An explicit s_waitcnt advances its
-  // scoreboard instead, so that it finds nothing left to insert (checked in the ISA: no compiler-made waits in the loop) --
-  // provided the NEXT instruction does not itself need the registers (the pass folds a wait it wants for that instruction
-  // into ours, taking the minimum): hence the s_nop after every wait.
-  //   start of (j,0): W(j,h0) was issued in (j-2,1); younger ops: 4 LDS-DMA + 4 + 8 = 16 (fewer in the last tiles)
-  //   start of (j,1): W(j,h1), issued in (j-1,0), and the own share of A(j+1), A(j+2); younger ops: 8 + 4 = 12
-  //   every MFMA group: its activation fragment has two younger ds_reads in flight
-  auto tile_step = [&](auto qtag, bf16x8 (&Wc)[2][4], bf16x8 (&Wo)[2][4], const char* sa, const char* sn) {
-    constexpr int Q = decltype(qtag)::value;
-    constexpr bool DMA = Q < 0, WL2 = Q < 2, WL1 = Q < 3, NEXT = Q < 3;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 0) {
-        if (Q <= 0) WAIT_VM(16); else if (Q == 1) WAIT_VM(12); else if (Q == 2) WAIT_VM(8); else WAIT_VM(4);
-        asm volatile("s_nop 0");
-      } else {
-        if (Q <= 0) WAIT_VM(12); else if (Q < 3) WAIT_VM(8); else WAIT_VM(0);
-        __builtin_amdgcn_s_barrier();
-      }
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        const int f = h * 8 + mi;
-        if (NEXT || f < 14) WAIT_LGKM(2); else if (f == 14) WAIT_LGKM(1); else WAIT_LGKM(0);
-        asm volatile("s_nop 0");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wc[h][ni], X[f & 3], acc[ni][mi], 0, 0, 0);
-        // fragment f + 3 replaces fragment f - 1 (its MFMAs are issued)
-        const int f3 = f + 3;
-        if (f3 < 16) X[f3 & 3] = xread(sa, f3 >> 3, f3 & 7);
-        else if (NEXT) X[f3 & 3] = xread(sn, 0, f3 - 16);
-        if (mi < 4) {
-          if (h == 0) { if (WL1) Wo[1][mi] = wload(mi, 128 + 64); }   // W(j+1, h1): registers free since (j-1,1)
-          else        { if (WL2) Wc[0][mi] = wload(mi, 256); }        // W(j+2, h0): registers free since (j,0)
-        } else if (h == 1 && DMA) {
-          dma_op(mi - 4);                                             // A(j+4) -> slot of A(j-1)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (DMA) dma_done();
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) wb[ni] += 128;
-  };
-
-  // ---- prologue (issue order fixes the vmcnt arithmetic): A0 A1 W(0,h0) A2 W(0,h1) W(1,h0) A3 ----
-  auto dma_tile = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) dma_op(i);
-    dma_done();
-  };
-  // (sched_barriers: the compiler must not sink the register loads below the LDS-DMA ops -- the counted waits of the loop
-  // are merged with this block's state at the loop header, and a weight load that is the YOUNGEST op here makes them vmcnt(0))
-  dma_tile();
-  dma_tile();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) W0[0][ni] = wload(ni, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  dma_tile();
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) W0[1][ni] = wload(ni, 64);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ni = 0; ni < 4; ++ni) W1[0][ni] = wload(ni, 128);
-  __builtin_amdgcn_sched_barrier(0);
-  dma_tile();
-  __builtin_amdgcn_sched_barrier(0);
-  WAIT_VM(24);  // own share of A0 landed
-  __builtin_amdgcn_s_barrier();
-  X[0] = xread(smem, 0, 0);
-  X[1] = xread(smem, 0, 1);
-  X[2] = xread(smem, 0, 2);
-  __builtin_amdgcn_sched_barrier(0);
-
-  int sl = 0;  // slot of the current tile
-  auto next_slot = [&](int s_) { return s_ == SLOTS3 - 1 ? 0 : s_ + 1; };
-  int j = 0;
-  for (; j + 4 < nk; j += 2) {
-    int s1 = next_slot(sl);
-    tile_step(std::integral_constant<int, -1>{}, W0, W1, smem + sl * SLOT3_BYTES, smem + s1 * SLOT3_BYTES);
-    sl = next_slot(s1);
-    tile_step(std::integral_constant<int, -1>{}, W1, W0, smem + s1 * SLOT3_BYTES, smem + sl * SLOT3_BYTES);
-  }
-  {
-    int s1 = next_slot(sl), s2 = next_slot(s1), s3 = next_slot(s2);
-    tile_step(std::integral_constant<int, 0>{}, W0, W1, smem + sl * SLOT3_BYTES, smem + s1 * SLOT3_BYTES);
-    tile_step(std::integral_constant<int, 1>{}, W1, W0, smem + s1 * SLOT3_BYTES, smem + s2 * SLOT3_BYTES);
-    tile_step(std::integral_constant<int, 2>{}, W0, W1, smem + s2 * SLOT3_BYTES, smem + s3 * SLOT3_BYTES);
-    tile_step(std::integral_constant<int, 3>{}, W1, W0, smem + s3 * SLOT3_BYTES, smem + s3 * SLOT3_BYTES);
-  }
-  gemm_epilogue<EPI, 8>(p, p.C, acc, m0 + wm * 128, n0 + wn * 64, n0 + wn * 32, g, t);
-}
-
-// =====================================================================================================================
 // TN variant of the 256x256 kernel:  C[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands stored K-major ([K, M] and
 // [K, N] row-major) -- the weight-gradient GEMM dW = dy^T x straight from the activation matrices, no transposed copies.
 // Same four-stage LDS-DMA pipeline and epilogue; operand tiles are [32 k][256] (512-byte rows) and the MFMA fragments
@@ -1152,8 +955,7 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
 // Per-call tuning word of the GEMM entry points (last argument before the stream; 0 = the defaults production uses).  The
 // library keeps NO tuning state: tests and tools that want a specific kernel flavour pass it with the call.
 //   bits 0-1   tile: 0 auto, 1 force 128x128, 2 force 256x256
-//   bits 2-3   flavour of the 256x256 NT kernel: 0 auto, 1 BK = 32 (four-stage), 2 BK = 64 full-line, 3 weights-from-L2
-//              (gemm256c_kernel; falls back to the full-line flavour where its shape conditions do not hold)
+//   bits 2-3   BK = 64 full-line flavour of the 256x256 NT kernel: 0 auto (when the launch fills every CU), 1 never, 2 always
 //   bits 4-6   tail-rows split: 0 default (when it saves a round and K >= 1024), 1 off, 3 whenever it saves a round, 4 always
 //   bits 7-11  M-tiles per L2 group of the 256x256 kernels (0 = auto)
 //   bits 12-14 timing ablation of the 256x256 BK = 32 kernel (tools only; wrong results)
@@ -1164,7 +966,7 @@ static GemmTune decode_tune(int64_t t) {
   GemmTune T;
   T.tile_mode = (int)(t & 3);
   const int fl = (int)((t >> 2) & 3);
-  T.fullline = fl == 0 ? 2 : fl == 3 ? 3 : fl - 1;  // internal: 0 BK = 32, 1 full-line, 2 auto, 3 weights-from-L2
+  T.fullline = fl == 0 ? 2 : fl == 3 ? 2 : fl - 1;  // internal: 0 never, 1 always, 2 auto
   const int tr = (int)((t >> 4) & 7);
   T.tail_rows = tr == 0 ? 1 : tr - 1;         // internal: 0 off, 1 default, 2 whenever it saves a round, 3 always
   T.gm = (int)((t >> 7) & 31);
@@ -1185,20 +987,8 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
     attr_set = true;
   }
   const bool fills = (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1;
-  if (T.fullline == 3 && splits == 1 && a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 128 == 0 && a.K >= 768) {
-    const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
-    static bool attr6 = false;
-    if (!attr6) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm256c_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
-      if (e != hipSuccess) { op_set_error("gemm256c: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-      attr6 = true;
-    }
-    hipLaunchKernelGGL((gemm256c_kernel<EPI>), grid, dim3(512), sh5, s, a);
-    OP_LAUNCH_CHECK();
-    return OP_OK;
-  }
   // T.fullline: 0 BK = 32, 1 full-line always, 2 (default) full-line when the launch fills every CU at least once
-  if ((T.fullline == 1 || T.fullline == 3 || (T.fullline == 2 && fills)) &&
+  if ((T.fullline == 1 || (T.fullline == 2 && fills)) &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
     static bool attr5 = false;

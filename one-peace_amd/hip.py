@@ -93,7 +93,7 @@ class Tuning:
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
 
     def gemm(self):
-        fl = {2: 0, 0: 1, 1: 2, 3: 3}[self.fullline]
+        fl = {2: 0, 0: 1, 1: 2}[self.fullline]
         tr = 0 if self.tail_rows == 1 else self.tail_rows + 1
         return (self.tile_mode | fl << 2 | tr << 4 | (self.gm & 31) << 7 | (self.ablation & 7) << 12 | (self.force_splits & 15) << 15
                 | (0 if self.glds else 1) << 19)

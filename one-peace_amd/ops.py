@@ -135,13 +135,41 @@ def _wgrad(dyT, xT):
 USE_TN_WGRAD = True
 
 
+_tail_pads = {}
+
+
+def _tail_pad(t, rows0):
+    """The last len(t) - rows0 (< 64) rows of `t` as a 64-row matrix whose other rows are zero.  The buffer is cached per
+    (device, stream, row count, width): it is zeroed once and only its first rows are ever overwritten."""
+    r, cols = t.shape[0] - rows0, t.shape[1]
+    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream, r, cols)
+    buf = _tail_pads.get(key)
+    if buf is None:
+        if len(_tail_pads) > 64:
+            _tail_pads.clear()
+        buf = _tail_pads[key] = torch.zeros(64, cols, dtype=t.dtype, device=t.device)
+    buf[:r].copy_(t[rows0:])
+    return buf
+
+
+def wgrad_tn_rows(K):
+    """Rows of a weight-gradient GEMM the transpose-read kernel takes in its main launch (it consumes 64 rows per step)."""
+    return K - K % 64
+
+
 def wgrad(dy, x, out=None, accumulate=False):
-    """dW[out, in] (+)= dy[rows, out]^T x[rows, in].  Transpose-read GEMM straight from the row-major activations when the
-    shape qualifies (rows % 64 == 0 ...), otherwise two transposed K-padded copies + the NT kernel."""
+    """dW[out, in] (+)= dy[rows, out]^T x[rows, in].  Transpose-read GEMM straight from the row-major activations; a row count
+    that is not a multiple of 64 (16 x 257 image tokens) is split into the multiple-of-64 part and a second, one-step launch
+    over a zero-padded copy of the < 64 leftover rows, accumulated into the same output.  Shapes the kernel does not take
+    at all (fewer than 64 rows, widths that are not multiples of 8): two transposed K-padded copies + the NT kernel."""
     K, M = dy.shape
     N = x.shape[1]
-    if USE_TN_WGRAD and hip.gemm_tn_supported(K, M, N, dy.stride(0), x.stride(0)):
-        return hip.gemm_tn(dy, x, out, accumulate)
+    K0 = wgrad_tn_rows(K)
+    if USE_TN_WGRAD and K0 >= 64 and hip.gemm_tn_supported(K0, M, N, dy.stride(0), x.stride(0)):
+        out = hip.gemm_tn(dy[:K0], x[:K0], out, accumulate)
+        if K0 != K:
+            hip.gemm_tn(_tail_pad(dy, K0), _tail_pad(x, K0), out, True)
+        return out
     if out is not None and accumulate:
         return out.add_(hip.gemm_nt(_t_pad(dy), [_t_pad(x)]))
     return hip.gemm_nt(_t_pad(dy), [_t_pad(x)], out=out)
@@ -660,7 +688,7 @@ class FfnBranchFn(torch.autograd.Function):
             _finish(direct, G, ("fln_w", "fln_b"), (dw_, db_), acc)
         else:
             dh0, dh1 = hip.geglu_bwd(dgln, A["h0"], A["h1"])
-        if ("w0" in direct and "w1" in direct) or (USE_TN_WGRAD and hip.gemm_tn_supported(N, Fd, H, Fd, H)):
+        if ("w0" in direct and "w1" in direct) or (USE_TN_WGRAD and N >= 64 and hip.gemm_tn_supported(wgrad_tn_rows(N), Fd, H, Fd, H)):
             weight_grad("w0", dh0, A["xln2"])
             weight_grad("w1", dh1, A["xln2"])
         else:

@@ -118,6 +118,37 @@ def test_gemm_tn_transpose_read(K, M, N):
     assert_close(out2, ref, what="gemm_tn strided")
 
 
+@pytest.mark.parametrize("rows", [16 * 257, 4000, 96 * 5 + 7, 40])
+def test_weight_gradient_with_row_count_not_a_multiple_of_64(rows):
+    """ops.wgrad: 16 x 257 image tokens (4112 = 64 x 64 + 16) stay on the transpose-read kernel -- the multiple-of-64 part plus
+    a one-step launch over a zero-padded copy of the leftover rows -- fresh output and accumulation into an existing gradient,
+    also from strided views of the packed qkv gradient; fewer than 64 rows take the transposed-copies path."""
+    from one_peace_amd import ops
+    hip = hipmod()
+    M, N = 384, 256
+    dy, x = rnd(rows, M, seed=1, scale=0.5), rnd(rows, N, seed=2, scale=0.5)
+    ref = dy.t() @ x
+    calls = []
+    orig = hip.gemm_tn
+    hip.gemm_tn = lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1]
+    try:
+        out = ops.wgrad(dev_bf16(dy), dev_bf16(x))
+        assert_close(out, ref, what="wgrad")
+        base = rnd(M, N, seed=3)
+        acc = dev_bf16(base).clone()
+        ops.wgrad(dev_bf16(dy), dev_bf16(x), out=acc, accumulate=True)
+        assert_close(acc, base.bfloat16().float() + ref, what="wgrad accumulate")
+        wide = dev_bf16(torch.cat([dy, dy, dy], dim=1))
+        assert_close(ops.wgrad(wide[:, M:2 * M], dev_bf16(x)), ref, what="wgrad strided")
+    finally:
+        hip.gemm_tn = orig
+    if rows >= 64:
+        expect = [rows - rows % 64] + ([64] if rows % 64 else [])
+        assert calls == expect * 3, calls
+    else:
+        assert calls == []
+
+
 @pytest.mark.parametrize("glds", [1, 0])
 def test_gemm_three_segments_qkv(glds, tile_mode):
     hip = hipmod()

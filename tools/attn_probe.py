@@ -19,10 +19,11 @@ Spad = hip.attn_spad(S)
 qkv = torch.randn(B * S, 3 * H, **bf)
 bias = torch.randn(heads, S, Spad, **bf)
 biasT = torch.randn(heads, S, Spad, **bf)
+frag = hip.attn_bias_pack(bias, S)  # round 2: fragment-major copy -> resident forward kernel, matrix-pipe bias add
 q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
-out, lse = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True)
+out, lse = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True, bias_frag=frag)
 dout = torch.randn_like(out)
 for _ in range(iters):
-    hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True)
-    hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias, biasT, None, Spad, want_dbias=True)
+    hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True, bias_frag=frag)
+    hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias, biasT, None, Spad, want_dbias=True, bias_frag=frag)
 torch.cuda.synchronize()

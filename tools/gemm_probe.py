@@ -8,7 +8,7 @@ from one_peace_amd import hip
 which = sys.argv[1] if len(sys.argv) > 1 else "qkv"
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-M, H, F = 64 * 257, 1536, 6144
+M, H, F = (int(sys.argv[4]) if len(sys.argv) > 4 else 64) * 257, 1536, 6144
 bf = dict(dtype=torch.bfloat16, device="cuda")
 hip.lib().op_gemm_set_tile(tile)
 x, xf = torch.randn(M, H, **bf), torch.randn(M, F, **bf)

@@ -9,7 +9,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA"; do
   n=$(echo $set | cut -c1-14 | tr " " "_")
   rm -rf /tmp/pmca_$n
-  timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmca_$n -o p -- python $GRAFT_REPO_ROOT/tools/attn_probe.py $S $B 3 > /tmp/pmca_$n.log 2>&1
+  timeout 120 rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "attn_" --output-format csv -d /tmp/pmca_$n -o p -- python $GRAFT_REPO_ROOT/tools/attn_probe.py $S $B 3 > /tmp/pmca_$n.log 2>&1
   f=$(find /tmp/pmca_$n -name "*counter_collection.csv" | head -1)
   if [ -z "$f" ]; then echo "# pass '$set' produced no counters: $(tail -2 /tmp/pmca_$n.log | tr '\n' ' ')" >> $out; continue; fi
   python - "$f" >> $out <<PY

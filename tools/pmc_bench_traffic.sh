@@ -1,14 +1,15 @@
 #!/bin/bash
 # HBM traffic of the GEMM family over a bench.py run, per launch (run on the GPU box):
 #   tools/pmc_bench_traffic.sh <out.json>
+# (round 2: counters collected for the GEMM kernels only -- --kernel-include-regex -- which cuts a pass from minutes to seconds)
 # Two separate --pmc passes (FETCH_SIZE, WRITE_SIZE do not fit one pass), kernel-trace only, plus the two calibration runs.
 out=$1; R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$c /tmp/pmcc0_$c /tmp/pmcc1_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcb_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcc0_$c -o p -- python $R/tools/pmc_calib.py 0 > /dev/null 2>&1
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcc1_$c -o p -- python $R/tools/pmc_calib.py 1 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcb_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcc0_$c -o p -- python $R/tools/pmc_calib.py 0 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcc1_$c -o p -- python $R/tools/pmc_calib.py 1 > /dev/null 2>&1
 done
 python - "$out" <<'PY'
 import csv, glob, json, sys

@@ -6,7 +6,7 @@ cd /tmp; export TMPDIR=/tmp
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_UNALIGNED_STALL"; do
   n=$(echo $set | cut -c1-12 | tr " " "_")
   rm -rf /tmp/pmc_$n
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc_$n -o p -- python $GRAFT_REPO_ROOT/tools/gemm_probe.py $which 0 3 > /dev/null 2>&1
+  rocprofv3 --pmc $set --kernel-trace --kernel-include-regex "gemm" --output-format csv -d /tmp/pmc_$n -o p -- python $GRAFT_REPO_ROOT/tools/gemm_probe.py $which 0 3 ${PROBE_B:-64} > /dev/null 2>&1
   f=$(find /tmp/pmc_$n -name "*counter_collection.csv" | head -1)
   python - "$f" "$kern" >> $out <<PY
 import csv,sys

@@ -10,7 +10,10 @@ IT = int(os.environ.get("ITERS", "200"))
 VARIANTS = ((0, "full (BK=32 flavour)"), (5, "MFMAs only (no loads, no LDS, no barriers)"), (4, "MFMAs + barriers"),
             (2, "MFMAs + fragment ds_reads (no global loads)"), (3, "activations through LDS only (weights neither staged nor read)"),
             (1, "LDS-DMA + fragment reads, no MFMA"), (6, "LDS-DMA + barriers only"), (0, "full again"))
-for M, N, K in ((64 * 257, 4608, 1536), (128 * 256, 4608, 1536), (128 * 257, 4608, 1536), (128 * 256, 1536, 1536)):
+SHAPES = ((64 * 257, 4608, 1536), (128 * 256, 4608, 1536), (128 * 257, 4608, 1536), (128 * 256, 1536, 1536))
+if os.environ.get("SHAPES") == "k":  # fixed cost per tile vs K: same 3.00-round launch at K = 512 ... 6144
+    SHAPES = tuple((128 * 256, 1536, k) for k in (512, 1024, 1536, 3072, 6144))
+for M, N, K in SHAPES:
     x = torch.randn(M, K, **bf)
     w = torch.randn(N, K, **bf) * 0.02
     out = torch.empty(M, N, **bf)

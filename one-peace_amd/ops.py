@@ -138,11 +138,11 @@ USE_TN_WGRAD = True
 _tail_pads = {}
 
 
-def _tail_pad(t, rows0):
+def _tail_pad(t, rows0, operand):
     """The last len(t) - rows0 (< 64) rows of `t` as a 64-row matrix whose other rows are zero.  The buffer is cached per
-    (device, stream, row count, width): it is zeroed once and only its first rows are ever overwritten."""
+    (device, stream, operand, row count, width): it is zeroed once and only its first rows are ever overwritten."""
     r, cols = t.shape[0] - rows0, t.shape[1]
-    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream, r, cols)
+    key = (t.device, torch.cuda.current_stream(t.device).cuda_stream, operand, r, cols)
     buf = _tail_pads.get(key)
     if buf is None:
         if len(_tail_pads) > 64:
@@ -168,7 +168,7 @@ def wgrad(dy, x, out=None, accumulate=False):
     if USE_TN_WGRAD and K0 >= 64 and hip.gemm_tn_supported(K0, M, N, dy.stride(0), x.stride(0)):
         out = hip.gemm_tn(dy[:K0], x[:K0], out, accumulate)
         if K0 != K:
-            hip.gemm_tn(_tail_pad(dy, K0), _tail_pad(x, K0), out, True)
+            hip.gemm_tn(_tail_pad(dy, K0, 0), _tail_pad(x, K0, 1), out, True)
         return out
     if out is not None and accumulate:
         return out.add_(hip.gemm_nt(_t_pad(dy), [_t_pad(x)]))

@@ -118,14 +118,15 @@ def test_gemm_tn_transpose_read(K, M, N):
     assert_close(out2, ref, what="gemm_tn strided")
 
 
+@pytest.mark.parametrize("N", [256, 384])
 @pytest.mark.parametrize("rows", [16 * 257, 4000, 96 * 5 + 7, 40])
-def test_weight_gradient_with_row_count_not_a_multiple_of_64(rows):
+def test_weight_gradient_with_row_count_not_a_multiple_of_64(rows, N):
     """ops.wgrad: 16 x 257 image tokens (4112 = 64 x 64 + 16) stay on the transpose-read kernel -- the multiple-of-64 part plus
     a one-step launch over a zero-padded copy of the leftover rows -- fresh output and accumulation into an existing gradient,
     also from strided views of the packed qkv gradient; fewer than 64 rows take the transposed-copies path."""
     from one_peace_amd import ops
     hip = hipmod()
-    M, N = 384, 256
+    M = 384  # N == M: both operands' leftover rows have the same shape (their pad buffers must still be distinct)
     dy, x = rnd(rows, M, seed=1, scale=0.5), rnd(rows, N, seed=2, scale=0.5)
     ref = dy.t() @ x
     calls = []

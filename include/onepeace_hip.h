@@ -80,7 +80,7 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 /* `tune` (op_gemm_nt, op_gemm_tn, op_gemm_plan): per-call tuning word, 0 = what production uses.  The library keeps NO tuning
  * state, so every entry point is a pure function of its arguments; tests and tools select a kernel flavour with the call:
  * bits 0-1 tile (0 auto: a cost model picks 128x128 or 256x256 tiles, K-splits and the tail-rows split; 1 force 128x128;
- * 2 force 256x256); bits 2-3 BK = 64 full-line flavour (0 auto, 1 never, 2 always); bits 4-6 tail-rows split (0 default, 1 off,
+ * 2 force 256x256); bits 2-3 flavour of the 256x256 NT kernel (0 auto, 1 BK = 32, 2 eight-wave full-line, 3 four-wave full-line); bits 4-6 tail-rows split (0 default, 1 off,
  * 3 whenever it saves a round, 4 always); bits 7-11 M-tiles per L2 group (0 auto); bits 12-14 timing ablations of the 256x256
  * kernel (tools; wrong results); bits 15-18 forced K-split count of small problems (tools); bit 19 register-staged operands
  * instead of LDS-DMA (global_load_lds). */

@@ -23,6 +23,7 @@
 //
 // Roofline: MFMA (dense bf16, 2.5 PFLOP/s).  Algorithmic work = 2*M*N*K flops per launch.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -760,6 +761,207 @@ __global__ __launch_bounds__(512, 2) void gemm256b_kernel(const GemmArgs p) {
 }
 
 // =====================================================================================================================
+// Four-wave flavour of the BK = 64 kernel: ONE wave per SIMD, 128 x 128 per wave (2 x 2 waves, 8 x 8 accumulator tiles = 256
+// registers).  Same LDS image, LDS-DMA staging, slot rotation and barrier protocol as gemm256b_kernel; per 32-deep half-step a
+// wave issues 64 MFMAs, the 16 fragment reads of the NEXT half-step (into the other register set) and 8 LDS-DMA ops.  The point:
+// 64 KiB instead of 96 KiB of fragment reads per half-step and CU -- the LDS pipe (DMA writes + fragment reads) is what bounds
+// the eight-wave main loop (profiles/r2_experiments.md section 5).  With a single wave per SIMD nothing hides a stall of that
+// wave, so: every wait is explicit (the compiler's own wait insertion degrades to vmcnt(0)/lgkmcnt(0) next to LDS-DMA, see
+// the note there), the fragment reads are issued in the first six of the eight MFMA groups of a half-step (>= 16 MFMAs before
+// they are waited for), the DMA ops in the last six.
+// =====================================================================================================================
+#define WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256w_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int GM = p.gm;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM2, n0 = pid_n * BN_OUT;
+  const int nk = p.K / 64;
+
+  // ---- staging: op j (0..7) of an operand tile covers LDS rows j*32 + (tid >> 3), 16-byte slot tid & 7 ----
+  const int srow = tid >> 3;                       // 0..31
+  const int sc = (tid & 7) ^ (srow & 7);
+  const char* baseA = (const char*)p.A;
+  unsigned offA[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gm = min(m0 + j * 32 + srow, p.M - 1);
+    offA[j] = (unsigned)(((int64_t)gm * p.lda + sc * 8) * 2);
+  }
+  const char* baseB[8];
+  unsigned offB;
+  {
+    const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;
+    // LDS row j*32 + q  <-  output column w_row_to_col256(j*32 + q) = (uniform in j) + (per lane in q)
+    const int lanecol = (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
+                                           : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
+    offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bf16_t* wb;
+      int col0;
+      if (EPI == EPI_GEGLU) {
+        wb = p.B[j >> 2];
+        col0 = n0 + (j & 3) * 32;
+      } else {
+        wb = p.B[seg];
+        col0 = n0 - seg * p.n_seg + (j >> 1) * 64 + (j & 1) * 8;
+      }
+      baseB[j] = (const char*)(wb + (int64_t)col0 * p.ldb);
+    }
+  }
+
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+  const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
+  auto w_off = [&](int f) {  // byte offset of weight fragment f = blk * 4 + ni inside the operand tile
+    const int blk = f >> 2, ni = f & 3;
+    if (EPI == EPI_GEGLU) return ((ni >> 1) * 128 + (wn * 2 + blk) * 32 + (ni & 1) * 16 + t) * 128;
+    return (wn * 128 + blk * 64 + ni * 16 + t) * 128;
+  };
+
+  int qslot_issue = 0;
+  auto issue_tile = [&](bool is_b) {
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const char* src = is_b ? baseB[j] + offB : baseA + offA[j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+    }
+    if (is_b) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) baseB[j] += 128;
+    } else {
+      baseA += 128;
+    }
+    qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
+  };
+
+  // One half-step.  cur: fragments of this half (complete); nxt: receives the next half-step's; WHAT: 0 issue an A tile, 1 a B
+  // tile, 2 nothing; READ: whether a next half-step exists.  Group k (8 MFMAs on activation fragment k) carries two fragment reads
+  // and one LDS-DMA op (reads early / DMA late and the reverse measured within 1 % of this uniform order).
+  auto half_step = [&](auto what_tag, auto read_tag, const bf16x8 (&cur_w)[8], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[8],
+                       bf16x8 (&nxt_x)[8], const char* sa, const char* sb, int h) {
+    constexpr int WHAT = decltype(what_tag)::value;
+    constexpr bool READ = decltype(read_tag)::value;
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+    auto rd = [&](int r) {  // r = 0..15: weight fragments first (the MFMA groups need all eight of them at once)
+      if (r < 8) nxt_w[r] = *reinterpret_cast<const bf16x8*>(sb + w_off(r) + fsw[h]);
+      else nxt_x[r - 8] = *reinterpret_cast<const bf16x8*>(sa + rowX + (r - 8) * 2048 + fsw[h]);
+    };
+    auto dma = [&](int j) {
+      if (WHAT == 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[j]),
+                                         (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+      else if (WHAT == 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[j] + offB),
+                                         (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
+      if (READ) { rd(2 * k); rd(2 * k + 1); }
+      if (WHAT != 2) dma(k);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (WHAT == 0) {
+      baseA += 128;
+    } else if (WHAT == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) baseB[j] += 128;
+    }
+    if (WHAT != 2) qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+
+  // ---- prologue: A0 B0 A1 B1 (nk >= 2); fragments of (0,0) ----
+  issue_tile(false);
+  issue_tile(true);
+  issue_tile(false);
+  issue_tile(true);
+  WAIT_VM(16);
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfA[8], xfA[8], wfB[8], xfB[8];
+  int sa = 0, sb = 1;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) wfA[r] = *reinterpret_cast<const bf16x8*>(smem + sb * SLOT3_BYTES + w_off(r) + fsw[0]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) xfA[r] = *reinterpret_cast<const bf16x8*>(smem + sa * SLOT3_BYTES + rowX + r * 2048 + fsw[0]);
+  auto step_slots = [&](int& sa1, int& sb1) {
+    sa1 = sa + 2 >= SLOTS3 ? sa + 2 - SLOTS3 : sa + 2;
+    sb1 = sb + 2 >= SLOTS3 ? sb + 2 - SLOTS3 : sb + 2;
+  };
+  auto lgkm0 = [&]() {
+    WAIT_LGKM(0);
+    asm volatile("s_nop 0");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int i = 0;
+  for (; i + 2 < nk; ++i) {  // steady state: tiles i+2 still to be issued
+    int sa1, sb1;
+    step_slots(sa1, sb1);
+    lgkm0();
+    half_step(I0{}, Yes{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);   // (i,0): A(i+2)
+    WAIT_LGKM(0);
+    WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    half_step(I1{}, Yes{}, wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0);  // (i,1): B(i+2)
+    sa = sa1;
+    sb = sb1;
+  }
+  {  // tile nk-2: nothing left to issue, tile nk-1 is in flight
+    int sa1, sb1;
+    step_slots(sa1, sb1);
+    lgkm0();
+    half_step(I2{}, Yes{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);
+    WAIT_LGKM(0);
+    WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    half_step(I2{}, Yes{}, wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0);
+    sa = sa1;
+    sb = sb1;
+  }
+  {  // tile nk-1
+    lgkm0();
+    half_step(I2{}, Yes{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);
+    lgkm0();
+    half_step(I2{}, No{}, wfB, xfB, wfA, xfA, smem, smem, 0);
+  }
+  // the accumulators were written by inline-asm MFMAs the hazard recogniser does not see: let the last ones retire
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+  gemm_epilogue<EPI, 8>(p, p.C, acc[0], m0 + wm * 128, n0 + wn * 128, n0 + (wn * 2) * 32, g, t);
+  gemm_epilogue<EPI, 8>(p, p.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, n0 + (wn * 2 + 1) * 32, g, t);
+}
+
+// =====================================================================================================================
 // TN variant of the 256x256 kernel:  C[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands stored K-major ([K, M] and
 // [K, N] row-major) -- the weight-gradient GEMM dW = dy^T x straight from the activation matrices, no transposed copies.
 // Same four-stage LDS-DMA pipeline and epilogue; operand tiles are [32 k][256] (512-byte rows) and the MFMA fragments
@@ -955,7 +1157,8 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
 // Per-call tuning word of the GEMM entry points (last argument before the stream; 0 = the defaults production uses).  The
 // library keeps NO tuning state: tests and tools that want a specific kernel flavour pass it with the call.
 //   bits 0-1   tile: 0 auto, 1 force 128x128, 2 force 256x256
-//   bits 2-3   BK = 64 full-line flavour of the 256x256 NT kernel: 0 auto (when the launch fills every CU), 1 never, 2 always
+//   bits 2-3   flavour of the 256x256 NT kernel: 0 auto (launches that fill every CU: BK = 64 full-line staging, four waves of
+//              128 x 128 when K >= 3072, eight waves of 128 x 64 otherwise), 1 BK = 32 four-stage, 2 eight-wave full-line, 3 four-wave
 //   bits 4-6   tail-rows split: 0 default (when it saves a round and K >= 1024), 1 off, 3 whenever it saves a round, 4 always
 //   bits 7-11  M-tiles per L2 group of the 256x256 kernels (0 = auto)
 //   bits 12-14 timing ablation of the 256x256 BK = 32 kernel (tools only; wrong results)
@@ -966,7 +1169,7 @@ static GemmTune decode_tune(int64_t t) {
   GemmTune T;
   T.tile_mode = (int)(t & 3);
   const int fl = (int)((t >> 2) & 3);
-  T.fullline = fl == 0 ? 2 : fl == 3 ? 2 : fl - 1;  // internal: 0 never, 1 always, 2 auto
+  T.fullline = fl == 0 ? 2 : fl == 3 ? 3 : fl - 1;  // internal: 0 BK = 32, 1 eight-wave full-line, 2 auto, 3 four-wave
   const int tr = (int)((t >> 4) & 7);
   T.tail_rows = tr == 0 ? 1 : tr - 1;         // internal: 0 off, 1 default, 2 whenever it saves a round, 3 always
   T.gm = (int)((t >> 7) & 31);
@@ -987,6 +1190,21 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
     attr_set = true;
   }
   const bool fills = (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1;
+  // four-wave flavour (one wave per SIMD, 128 x 128 per wave): faster where the main loop dominates the launch (K >= 3072:
+  // +6 ... +14 %), slower on the K = 1536 launches with heavy epilogues; bit-identical results either way
+  if ((T.fullline == 3 || (T.fullline == 2 && fills && a.K >= 3072)) && splits == 1 &&
+      a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0 && a.K >= 128) {
+    const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
+    static bool attr6 = false;
+    if (!attr6) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm256w_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
+      if (e != hipSuccess) { op_set_error("gemm256w: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+      attr6 = true;
+    }
+    hipLaunchKernelGGL((gemm256w_kernel<EPI>), grid, dim3(256), sh5, s, a);
+    OP_LAUNCH_CHECK();
+    return OP_OK;
+  }
   // T.fullline: 0 BK = 32, 1 full-line always, 2 (default) full-line when the launch fills every CU at least once
   if ((T.fullline == 1 || (T.fullline == 2 && fills)) &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0) {

@@ -83,7 +83,7 @@ class Tuning:
 
     def reset(self):
         self.tile_mode = 0       # 0 auto, 1 force 128x128, 2 force 256x256
-        self.fullline = 2        # BK = 64 flavour of the 256x256 NT kernel: 0 never, 1 always, 2 auto
+        self.fullline = 2        # flavour of the 256x256 NT kernel: 0 BK = 32, 1 eight-wave full-line, 2 auto, 3 four-wave full-line
         self.tail_rows = 1       # 0 off, 1 default, 2 whenever it saves a round, 3 always
         self.gm = 0              # M-tiles per L2 group (0 auto)
         self.ablation = 0        # timing ablations of the 256x256 kernel (tools)
@@ -93,7 +93,7 @@ class Tuning:
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
 
     def gemm(self):
-        fl = {2: 0, 0: 1, 1: 2}[self.fullline]
+        fl = {2: 0, 0: 1, 1: 2, 3: 3}[self.fullline]
         tr = 0 if self.tail_rows == 1 else self.tail_rows + 1
         return (self.tile_mode | fl << 2 | tr << 4 | (self.gm & 31) << 7 | (self.ablation & 7) << 12 | (self.force_splits & 15) << 15
                 | (0 if self.glds else 1) << 19)

@@ -62,13 +62,14 @@ def test_layernorm_fp32_no_affine():
 GEMM_SHAPES = [(128, 128, 64), (300, 384, 192), (1000, 1536, 256), (257, 136, 128), (64, 4608, 1536), (4099, 256, 1024)]
 
 
-@pytest.fixture(params=[1, 2, 3], ids=["tile128", "tile256_bk32", "tile256_bk64"])
+@pytest.fixture(params=[1, 2, 3, 4], ids=["tile128", "tile256_bk32", "tile256_bk64", "tile256_bk64_four_waves"])
 def tile_mode(request):
     """Run every GEMM test on all tile configurations (auto-selection would pick 128x128 at these small sizes): the
-    128x128 kernel, the 256x256 kernel with 64-byte (BK = 32) rows and its full-line (BK = 64) flavour."""
+    128x128 kernel, the 256x256 kernel with 64-byte (BK = 32) rows, its full-line (BK = 64) flavour with eight waves of
+    128 x 64 and the one with four waves of 128 x 128 (one wave per SIMD)."""
     hip = hipmod()
     old = hip.lib().op_gemm_set_tile(1 if request.param == 1 else 2)
-    hip.lib().op_gemm_set_tile(21 if request.param == 3 else 20)
+    hip.lib().op_gemm_set_tile({3: 21, 4: 23}.get(request.param, 20))
     yield request.param
     hip.lib().op_gemm_set_tile(22)
     hip.lib().op_gemm_set_tile(old)
@@ -89,6 +90,41 @@ def test_gemm_bias(M, N, K, glds, tile_mode):
         assert_close(out32, 0.5 * (A @ W.t()), fro=1e-5, mx=1e-4, what="gemm f32")
     finally:
         hip.lib().op_gemm_set_staging(1)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 1536, 1536), (4099, 256, 3072), (8192, 1536, 6144)])
+def test_gemm_four_wave_flavour_is_bit_identical_to_eight_waves(M, N, K):
+    """The two BK = 64 flavours of the 256x256 kernel accumulate every output element in the same order (k ascending, one MFMA
+    per 32 k): bias, residual (+ branch output), GeGLU (+ pre-activations) and fp32 outputs must agree bit for bit, so the
+    planner may pick either one per launch (four waves when K >= 3072) without changing results."""
+    hip = hipmod()
+    L = hip.lib()
+    a = dev_bf16(rnd(M, K, seed=1))
+    w, w1 = dev_bf16(rnd(N, K, seed=2, scale=K ** -0.5)), dev_bf16(rnd(N, K, seed=3, scale=K ** -0.5))
+    b, gamma, res = dev_bf16(rnd(N, seed=4)), dev_bf16(rnd(N, seed=5)), dev_bf16(rnd(M, N, seed=6))
+    ps = torch.rand((M + 6) // 7, device=DEV)
+    outs = {}
+    old = L.op_gemm_set_tile(2)
+    try:
+        for flavour in (21, 23):
+            L.op_gemm_set_tile(flavour)
+            h0, h1, y = (torch.empty(M, N, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+            outs[flavour] = [
+                hip.gemm_nt(a, [w], [b]),
+                hip.gemm_nt(a, [w], None, epilogue=hip.EPI_F32, alpha=torch.tensor([0.25], device=DEV)),
+                hip.gemm_nt(a, [w, w1], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1), h0, h1,
+                hip.gemm_nt(a, [w], [b], epilogue=hip.EPI_RESID, resid=res, gamma=gamma, rowscale=ps, rows_per_sample=7, h0=y), y,
+            ]
+            if N % 768 == 0:  # three weight segments, middle one without bias (the fused q|k|v projection)
+                seg = N // 3
+                outs[flavour].append(hip.gemm_nt(a, [w[:seg], w[seg:2 * seg], w[2 * seg:]], [b[:seg], None, b[:seg]], n_seg=seg, N=N))
+        torch.cuda.synchronize()
+    finally:
+        L.op_gemm_set_tile(22)
+        L.op_gemm_set_tile(old)
+    for i, (x, y) in enumerate(zip(outs[21], outs[23])):
+        assert torch.equal(x, y), (i, float((x.float() - y.float()).abs().max()))
+    assert_close(outs[23][0], rnd(M, K, seed=1) @ rnd(N, K, seed=2, scale=K ** -0.5).t() + rnd(N, seed=4), what="four-wave bias")
 
 
 @pytest.mark.parametrize("M,N,K", [(1536, 1536, 8192), (384, 256, 16448 - 16448 % 64), (4608, 1536, 4096)])

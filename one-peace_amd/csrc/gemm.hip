@@ -368,8 +368,18 @@ constexpr int STAGE2_BYTES = 2 * OPER2_BYTES;   // 32 KiB
 
 __device__ __forceinline__ int swz64(int row) { return (row & 1) | (((row >> 2) & 1) << 1); }
 
-__device__ __forceinline__ s16x4 tr_read16(const char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+// ds_read_b64_tr_b16 through inline asm, NOT the builtin: the compiler cannot tell what a transpose read touches, so next to
+// LDS-DMA it puts an s_waitcnt vmcnt(0) in front of the first one after every barrier -- which drained the whole four-stage
+// LDS-DMA pipeline once per K-step (round 1's TN kernel ran that way).  As asm the read is invisible to its wait insertion; the
+// kernels wait for the results themselves (lgkmcnt(0) before the barrier of the step that consumes them).  `hi`: + 2048 bytes.
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+  return (unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p);
+}
+__device__ __forceinline__ s16x4 tr_read16(unsigned addr, bool hi) {
+  s16x4 r;
+  if (hi) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(r) : "v"(addr));
+  else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
 }
 __device__ __forceinline__ bf16x8 join16(s16x4 a, s16x4 b) {
   typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -1062,13 +1072,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
     const char* st = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
-      f.w[ni][0] = tr_read16(st + rdW[ni]);
-      f.w[ni][1] = tr_read16(st + rdW[ni] + 2048);
+      f.w[ni][0] = tr_read16(lds_addr(st) + rdW[ni], false);
+      f.w[ni][1] = tr_read16(lds_addr(st) + rdW[ni], true);
     }
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
-      f.x[mi][0] = tr_read16(st + rdX[mi]);
-      f.x[mi][1] = tr_read16(st + rdX[mi] + 2048);
+      f.x[mi][0] = tr_read16(lds_addr(st) + rdX[mi], false);
+      f.x[mi][1] = tr_read16(lds_addr(st) + rdX[mi], true);
     }
   };
   auto mma = [&](const Frags& f) {
@@ -1083,6 +1093,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
     WAIT_LGKM0();
     WAIT_VM(8);
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);  // the MFMAs below consume asm-read fragments: nothing may move above the waits
     const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;
     char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
     char* lb = la + OPER2_BYTES;
@@ -1092,10 +1103,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
       acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join16(cur.w[ni][0], cur.w[ni][1]), join16(cur.x[mi][0], cur.x[mi][1]),
                                                             acc[ni][mi], 0, 0, 0);
       if (j < 8) {
-        nxt.w[j >> 1][j & 1] = tr_read16(st + rdW[j >> 1] + (j & 1) * 2048);
+        nxt.w[j >> 1][j & 1] = tr_read16(lds_addr(st) + rdW[j >> 1], (j & 1) != 0);
       } else if (j < 24) {
         const int e = j - 8;
-        nxt.x[e >> 1][e & 1] = tr_read16(st + rdX[e >> 1] + (e & 1) * 2048);
+        nxt.x[e >> 1][e & 1] = tr_read16(lds_addr(st) + rdX[e >> 1], (e & 1) != 0);
       } else if (j < 28) {
         const int i = (j - 24) >> 1;
         const int wbase = (i * 512 + wid * 64) * 16;
@@ -1116,8 +1127,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
     WAIT_LGKM0();
     if (has_next) wait_landed(min(nk - 2 - kt, STAGES2 - 2));
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     if (has_next) read_frags(kt + 1, nxt);
     mma(cur);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
 #pragma unroll
@@ -1139,8 +1152,161 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
   gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, 0, g, t);
 }
 
+// Four-wave flavour of the TN kernel (one wave per SIMD, 128 x 128 per wave; see gemm256w_kernel): the same four-stage
+// [32 k][256] LDS image and transpose-read fragments, 32 ds_read_b64_tr_b16 per 64 MFMAs and wave instead of 24 per 32, i.e. a
+// third fewer LDS bytes per MFMA; accumulators pinned in AGPRs (inline-asm MFMA), steady state unrolled over both fragment sets.
 template <int EPI>
-int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
+__global__ __launch_bounds__(256) void gemm256w_tn_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int GM = p.gm;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM2, n0 = pid_n * 256;
+
+  int nk = p.K / BK2;
+  int kt0 = 0;
+  void* Cout = p.C;
+  if (p.kt_per_split > 0) {
+    kt0 = blockIdx.y * p.kt_per_split;
+    nk = min(nk - kt0, p.kt_per_split);
+    Cout = (float*)p.C + (int64_t)blockIdx.y * p.slab;
+  }
+
+  // staging: slot q = i*256 + tid (i = 0..3) -> k-row q>>5, 16-byte slot q&31
+  const char* baseA = (const char*)(p.A + (int64_t)kt0 * BK2 * p.lda);
+  const char* baseB = (const char*)(p.B[0] + (int64_t)kt0 * BK2 * p.ldb);
+  unsigned offA[4], offB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = i * 256 + tid;
+    const int kr = q >> 5, pc = q & 31;
+    const int ca = min(m0 + (pc ^ swzA_tn(kr)) * 8, p.M - 8);
+    const int cb = min(n0 + (pc ^ swzB_tn(kr)) * 8, p.N - 8);
+    offA[i] = (unsigned)(((int64_t)kr * p.lda + ca) * 2);
+    offB[i] = (unsigned)(((int64_t)kr * p.ldb + cb) * 2);
+  }
+  const int64_t stepA = (int64_t)BK2 * p.lda * 2, stepB = (int64_t)BK2 * p.ldb * 2;
+
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int krow = g * 8 + (t >> 2);
+  const int rowoff = krow * 512;
+  int rdX[8], rdW[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int chunk = wm * 16 + mi * 2 + ((t & 3) >> 1);
+    rdX[mi] = rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {  // f = blk * 4 + ni
+    const int chunk = (wn * 2 + (f >> 2)) * 8 + (t & 3) * 2 + ((f & 3) >> 1);
+    rdW[f] = OPER2_BYTES + rowoff + ((chunk ^ swzB_tn(krow)) << 4) + (f & 1) * 8;
+  }
+
+  auto dma = [&](char* la, int j) {  // op j = 0..7 of a stage: A ops 0..3, B ops 4..7
+    const int i = j & 3;
+    const int wbase = (i * 256 + wid * 64) * 16;
+    if (j < 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                       (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB + offB[i]),
+                                       (__attribute__((address_space(3))) void*)(la + OPER2_BYTES + wbase), 16, 0, 0);
+  };
+  auto issue = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma(smem + slot * STAGE2_BYTES, j);
+    baseA += stepA;
+    baseB += stepB;
+  };
+  auto wait_landed = [&](int younger) {  // 8 LDS-DMA ops per stage and wave
+    if (younger >= 3) WAIT_VM(24);
+    else if (younger == 2) WAIT_VM(16);
+    else if (younger == 1) WAIT_VM(8);
+    else WAIT_VM(0);
+  };
+  struct Frags { s16x4 w[8][2]; s16x4 x[8][2]; };
+  auto rd = [&](const char* st, Frags& f, int r) {  // r = 0..31: the 16 weight-side halves first, then the activation side
+    if (r < 16) f.w[r >> 1][r & 1] = tr_read16(lds_addr(st) + rdW[r >> 1], (r & 1) != 0);
+    else f.x[(r - 16) >> 1][r & 1] = tr_read16(lds_addr(st) + rdX[(r - 16) >> 1], (r & 1) != 0);
+  };
+  auto mfma1 = [&](const Frags& f, int j) {  // j = 0..63: activation fragment j>>3, weight fragment j&7
+    const int mi = j >> 3, ff = j & 7;
+    const bf16x8 wv = join16(f.w[ff][0], f.w[ff][1]), xv = join16(f.x[mi][0], f.x[mi][1]);
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ff >> 2][ff & 3][mi]) : "v"(wv), "v"(xv));
+  };
+  // steady step: 64 MFMAs on `cur`, the 32 transpose reads of stage kt+1 into `nxt`, the refill of this stage's slot with stage
+  // kt+4 -- one memory instruction per MFMA in the first 40 of the 64 groups (reads first, they are waited for next)
+  auto step_steady = [&](int kt, const Frags& cur, Frags& nxt) {
+    WAIT_LGKM(0);
+    WAIT_VM(16);
+    __builtin_amdgcn_s_barrier();
+    const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;
+    char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+      mfma1(cur, j);
+      if (j < 32) rd(st, nxt, j);
+      else if (j < 40) dma(la, j - 32);
+      if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    baseA += stepA;
+    baseB += stepB;
+  };
+  auto step_tail = [&](int kt, const Frags& cur, Frags& nxt) {
+    const bool has_next = kt + 1 < nk;
+    WAIT_LGKM(0);
+    if (has_next) wait_landed(min(nk - 2 - kt, STAGES2 - 2));
+    __builtin_amdgcn_s_barrier();
+    if (has_next) {
+      const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) rd(st, nxt, r);
+    }
+#pragma unroll
+    for (int j = 0; j < 64; ++j) mfma1(cur, j);
+  };
+
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES2; ++s0)
+    if (s0 < nk) issue(s0);
+  Frags fA, fB;
+  wait_landed(min(nk - 1, STAGES2 - 1));
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int r = 0; r < 32; ++r) rd(smem, fA, r);
+  int kt = 0;
+  for (; kt + STAGES2 + 1 < nk; kt += 2) {
+    step_steady(kt, fA, fB);
+    step_steady(kt + 1, fB, fA);
+  }
+  for (; kt < nk; kt += 2) {
+    step_tail(kt, fA, fB);
+    step_tail(kt + 1, fB, fA);
+  }
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the inline-asm MFMAs are invisible to the hazard recogniser
+  gemm_epilogue<EPI, 8>(p, Cout, acc[0], m0 + wm * 128, n0 + wn * 128, 0, g, t);
+  gemm_epilogue<EPI, 8>(p, Cout, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, 0, g, t);
+}
+
+template <int EPI>
+int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = STAGES2 * STAGE2_BYTES;
   static bool attr_set = false;
@@ -1149,7 +1315,17 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits) {
     if (e != hipSuccess) { op_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), grid, dim3(512), sh, s, a);
+  if (four_waves) {
+    static bool attr_w = false;
+    if (!attr_w) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      if (e != hipSuccess) { op_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+      attr_w = true;
+    }
+    hipLaunchKernelGGL((gemm256w_tn_kernel<EPI>), grid, dim3(256), sh, s, a);
+  } else {
+    hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), grid, dim3(512), sh, s, a);
+  }
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
@@ -1191,8 +1367,9 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
   }
   const bool fills = (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1;
   // four-wave flavour (one wave per SIMD, 128 x 128 per wave): faster where the main loop dominates the launch (K >= 3072:
-  // +6 ... +14 %), slower on the K = 1536 launches with heavy epilogues; bit-identical results either way
-  if ((T.fullline == 3 || (T.fullline == 2 && fills && a.K >= 3072)) && splits == 1 &&
+  // +6 ... +14 %; plain-bias launches at K = 1536: +0 ... +2 %), slower on the K = 1536 launches with heavy epilogues (residual
+  // -7 %, GeGLU -1 %: four waves keep fewer loads and stores in flight); bit-identical results either way
+  if ((T.fullline == 3 || (T.fullline == 2 && fills && (a.K >= 3072 || EPI == EPI_BIAS || EPI == EPI_F32))) && splits == 1 &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0 && a.K >= 128) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
     static bool attr6 = false;
@@ -1615,12 +1792,15 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   }
   a.slab = (int64_t)M * N;
   hipStream_t s = (hipStream_t)stream;
+  // kernel flavour (tune bits 2-3): 0 auto, 2 eight waves of 128 x 64, 3 four waves of 128 x 128 (bit-identical results)
+  // measured at K = 32 896 tokens: four waves +14 % on 36 output tiles (1536 x 1536), +6 % on 108, -1 % on 144; -2 % at K = 8 192
+  const bool four_waves = T.fullline == 3 || (T.fullline == 2 && tiles <= 108 && K >= 16384);
   const int slot = op_prof_begin(0, 2.0 * (double)M * (double)N * (double)K, stream);
   int rc;
   if (best_s > 1) {
     a.C = workspace;
     a.ldc = N;
-    rc = launch256_tn<EPI_F32>(a, s, best_s);
+    rc = launch256_tn<EPI_F32>(a, s, best_s, four_waves);
     if (rc == OP_OK) {
       int64_t nb = ((int64_t)M * (N / 8) + 255) / 256;
       if (nb > 2048) nb = 2048;
@@ -1633,10 +1813,10 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
     a.kt_per_split = 0;
     a.resid = (const bf16_t*)C;
     a.ldr = ldc;
-    rc = launch256_tn<EPI_RESID>(a, s, 1);
+    rc = launch256_tn<EPI_RESID>(a, s, 1, four_waves);
   } else {
     a.kt_per_split = 0;
-    rc = launch256_tn<EPI_BIAS>(a, s, 1);
+    rc = launch256_tn<EPI_BIAS>(a, s, 1, four_waves);
   }
   op_prof_end(slot, stream);
   return rc;

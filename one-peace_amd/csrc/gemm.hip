@@ -142,6 +142,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
       for (int j = 0; j < 16; ++j) gv[j] = 1.f;
     }
   }
+  // residual epilogue: ALL residual rows (and row scales) of the MI fragments are requested first -- one load -> wait -> store
+  // chain per fragment left eight HBM latencies in a row per wave, which the four waves of gemm256w_kernel cannot hide
+  typename Vec8<bf16_t>::raw_t rraw[(EPI == EPI_RESID) ? MI : 1][2];
+  float rsv[(EPI == EPI_RESID) ? MI : 1];
+  if (EPI == EPI_RESID) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int mc = min(mrow0 + mi * 16 + t, p.M - 1);
+      const bf16_t* rp = p.resid + (int64_t)mc * p.ldr + nc0;
+      rraw[mi][0] = Vec8<bf16_t>::ldraw(rp);
+      rraw[mi][1] = Vec8<bf16_t>::ldraw(second ? rp + 8 : rp);
+      rsv[mi] = p.rowscale ? p.rowscale[(mc + p.m_off) / p.rows_per_sample] : 1.f;
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int m = mrow0 + mi * 16 + t;
@@ -158,18 +172,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
 #pragma unroll
       for (int j = 0; j < 16; ++j) o[j] = alpha * o[j] + bv[j];
     } else if (EPI == EPI_RESID) {
-      float rs = 1.f;
-      if (p.rowscale) rs = p.rowscale[(m + p.m_off) / p.rows_per_sample];
+      const float rs = rsv[mi];
       float rv[16];
       float tmp[8];
-      Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0, tmp);
+      Vec8<bf16_t>::cvt(rraw[mi][0], tmp);
 #pragma unroll
       for (int j = 0; j < 8; ++j) rv[j] = tmp[j];
-      if (second) {
-        Vec8<bf16_t>::load(p.resid + (int64_t)m * p.ldr + nc0 + 8, tmp);
+      Vec8<bf16_t>::cvt(rraw[mi][1], tmp);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rv[8 + j] = tmp[j];
-      }
+      for (int j = 0; j < 8; ++j) rv[8 + j] = tmp[j];
 #pragma unroll
       for (int j = 0; j < 16; ++j) o[j] += bv[j];
       if (p.H0) {  // branch output y (pre layer-scale), needed by the backward pass for d gamma
@@ -1366,10 +1377,10 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
     attr_set = true;
   }
   const bool fills = (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1;
-  // four-wave flavour (one wave per SIMD, 128 x 128 per wave): faster where the main loop dominates the launch (K >= 3072:
-  // +6 ... +14 %; plain-bias launches at K = 1536: +0 ... +2 %), slower on the K = 1536 launches with heavy epilogues (residual
-  // -7 %, GeGLU -1 %: four waves keep fewer loads and stores in flight); bit-identical results either way
-  if ((T.fullline == 3 || (T.fullline == 2 && fills && (a.K >= 3072 || EPI == EPI_BIAS || EPI == EPI_F32))) && splits == 1 &&
+  // four-wave flavour (one wave per SIMD, 128 x 128 per wave): +9 ... +14 % at K = 6144, +1 ... +5 % at K = 1536 (bias and
+  // residual epilogues); the GeGLU launch (VALU-heavy epilogue on half as many waves) is 2 % slower and stays on eight waves;
+  // bit-identical results either way
+  if ((T.fullline == 3 || (T.fullline == 2 && fills && EPI != EPI_GEGLU)) && splits == 1 &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0 && a.K >= 128) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
     static bool attr6 = false;

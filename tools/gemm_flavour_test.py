@@ -33,8 +33,13 @@ def case(name, M, N, K, fn, flops, time_it=True):
         t3 = timeit(fn, iters=IT, warmup=20)
         L.op_gemm_set_tile(21)
         t1b = timeit(fn, iters=IT, warmup=5)
+        L.op_gemm_set_tile(0)
+        L.op_gemm_set_tile(22)
+        ta = timeit(fn, iters=IT, warmup=5)
+        L.op_gemm_set_tile(2)
         line += "  full-line %.3f / %.3f ms (%.0f TF/s)  flavour 3 %.3f ms (%.0f TF/s)  %+.1f%%" % (
             t1, t1b, flops / min(t1, t1b) / 1e9, t3, flops / t3 / 1e9, 100.0 * (min(t1, t1b) / t3 - 1.0))
+        line += "  auto dispatch %.3f" % ta
         if name.startswith(("qkv", "dgrad")):  # plain-bias launches: the other schedule variants of the experimental kernel
             L.op_gemm_set_tile(23)
             for v in (1, 2, 3):
@@ -60,7 +65,7 @@ def _with_h2(fn, M, N):
 
 
 H, F = 1536, 6144
-for M in (300, 2048, 128 * 257, 128 * 256):
+for M in ([int(v) for v in os.environ["MS"].split(",")] if os.environ.get("MS") else (300, 2048, 128 * 257, 128 * 256)):
     big = M > 4096
     x = torch.randn(M, H, **bf)
     xf = torch.randn(M, F, **bf)

@@ -549,7 +549,7 @@ def main():
             g = prof[0]
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "GEMM family (gemm256b / gemm256 / gemm_nt / gemm256_tn kernels incl. their split-K folds)",
+                               "kernel": "GEMM family (gemm256w / gemm256b / gemm256 / gemm_nt / gemm256_tn / gemm256w_tn kernels incl. their split-K folds)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": g["count"], "avg_launch_ms": g["ms"] / g["count"],
                                "profiled_steps": profiled_steps,

@@ -20,7 +20,7 @@ def load(d):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         fam = "gemm" if "gemm" in k else "other"
-        key = (fam, "tn" if "gemm256_tn" in k else ("b" if "gemm256b" in k else ("a" if "gemm256_kernel" in k else ("s" if "gemm_nt" in k else "-"))))
+        key = (fam, "wtn" if "gemm256w_tn" in k else ("tn" if "gemm256_tn" in k else ("w" if "gemm256w" in k else ("b" if "gemm256b" in k else ("a" if "gemm256_kernel" in k else ("s" if "gemm_nt" in k else "-"))))))
         agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
     return agg
 res = {}

@@ -1,4 +1,4 @@
-"""An experimental flavour of the 256x256 NT kernel (tune bits 2-3 = 3) against the full-line flavour: bit-equality and time, all four epilogues."""
+"""The four-wave flavour of the 256x256 NT kernel (tune bits 2-3 = 3) against the eight-wave full-line flavour and the planner's own choice: bit-equality and time, all four epilogues.  MS=8192,16000 selects other row counts."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from one_peace_amd import hip
@@ -37,17 +37,9 @@ def case(name, M, N, K, fn, flops, time_it=True):
         L.op_gemm_set_tile(22)
         ta = timeit(fn, iters=IT, warmup=5)
         L.op_gemm_set_tile(2)
-        line += "  full-line %.3f / %.3f ms (%.0f TF/s)  flavour 3 %.3f ms (%.0f TF/s)  %+.1f%%" % (
+        line += "  eight waves %.3f / %.3f ms (%.0f TF/s)  four waves %.3f ms (%.0f TF/s)  %+.1f%%" % (
             t1, t1b, flops / min(t1, t1b) / 1e9, t3, flops / t3 / 1e9, 100.0 * (min(t1, t1b) / t3 - 1.0))
         line += "  auto dispatch %.3f" % ta
-        if name.startswith(("qkv", "dgrad")):  # plain-bias launches: the other schedule variants of the experimental kernel
-            L.op_gemm_set_tile(23)
-            for v in (1, 2, 3):
-                L.op_gemm_set_tile(10 + v)
-                tv = timeit(fn, iters=IT, warmup=10)
-                line += "  V%d %.3f" % (v, tv)
-            L.op_gemm_set_tile(10)
-            L.op_gemm_set_tile(21)
     print(line, flush=True)
     if not same:
         d = (a[0].float() - b[0].float()).abs()

@@ -788,8 +788,10 @@ __global__ __launch_bounds__(512, 2) void gemm256b_kernel(const GemmArgs p) {
 // 64 KiB instead of 96 KiB of fragment reads per half-step and CU -- the LDS pipe (DMA writes + fragment reads) is what bounds
 // the eight-wave main loop (profiles/r2_experiments.md section 5).  With a single wave per SIMD nothing hides a stall of that
 // wave, so: every wait is explicit (the compiler's own wait insertion degrades to vmcnt(0)/lgkmcnt(0) next to LDS-DMA, see
-// the note there), the fragment reads are issued in the first six of the eight MFMA groups of a half-step (>= 16 MFMAs before
-// they are waited for), the DMA ops in the last six.
+// the note there), the accumulators are pinned in the 256 AGPRs by issuing the MFMAs as inline asm ("+a"; with the builtin the
+// register allocator split them between VGPRs and AGPRs and copied them around the loop), and the steady-state loop is free of
+// branches (what a half-step issues is a compile-time tag; the last two K-tiles are peeled).  Every MFMA group of a half-step
+// carries two fragment reads and one LDS-DMA op.
 // =====================================================================================================================
 #define WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
 

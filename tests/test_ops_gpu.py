@@ -186,6 +186,29 @@ def test_weight_gradient_with_row_count_not_a_multiple_of_64(rows, N):
         assert calls == []
 
 
+@pytest.mark.parametrize("K,M,N", [(256, 256, 256), (4096, 1536, 512), (16448, 1536, 1536), (8192, 264, 4608)])
+def test_gemm_tn_four_wave_flavour_is_bit_identical_to_eight_waves(K, M, N):
+    """Weight-gradient kernel: the flavour with four waves of 128 x 128 (auto-selected for <= 108 output tiles at K >= 16384)
+    and the one with eight waves of 128 x 64 accumulate every element in the same order -- fresh output, accumulation into an
+    existing bf16 gradient and the split-K path must agree bit for bit, and match the fp32 product."""
+    hip = hipmod()
+    L = hip.lib()
+    A, Bm = rnd(K, M, seed=1, scale=0.5), rnd(K, N, seed=2, scale=0.5)
+    base = dev_bf16(rnd(M, N, seed=3))
+    outs = {}
+    try:
+        for flavour in (21, 23):
+            L.op_gemm_set_tile(flavour)
+            acc = base.clone()
+            outs[flavour] = (hip.gemm_tn(dev_bf16(A), dev_bf16(Bm)), hip.gemm_tn(dev_bf16(A), dev_bf16(Bm), acc, True))
+        torch.cuda.synchronize()
+    finally:
+        L.op_gemm_set_tile(22)
+    for x, y in zip(outs[21], outs[23]):
+        assert torch.equal(x, y), float((x.float() - y.float()).abs().max())
+    assert_close(outs[23][0], A.t() @ Bm, what="gemm_tn four waves")
+
+
 @pytest.mark.parametrize("glds", [1, 0])
 def test_gemm_three_segments_qkv(glds, tile_mode):
     hip = hipmod()

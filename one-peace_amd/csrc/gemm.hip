@@ -995,7 +995,42 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(const GemmArgs p) {
 // free, the n-operand reads are 2-way by construction).
 // =====================================================================================================================
 __device__ __forceinline__ int swzA_tn(int k) { return ((k & 3) | (((k >> 3) & 1) << 2)) << 1; }
-__device__ __forceinline__ int swzB_tn(int k) { return (k & 1) | (((k >> 1) & 1) << 3); }
+
+// Epilogue of the TN kernels.  Both operands' fragments hold 16 CONSECUTIVE columns (the n-operand reads of the NT-style
+// "16 contiguous output columns per lane" permutation use half of every 16-byte LDS chunk and are 2-way bank conflicts by
+// construction: a quarter of the kernel's LDS cycles, profiles/pmc/r2_gemm256_tn_wgrad_b128.txt), so lane (g, t) holds
+// acc[f][mi][r] = C[mrow0 + mi*16 + t][nbase + f*16 + g*4 + r]: four consecutive columns per fragment.  fp32 slab (split-K),
+// plain bf16 or accumulation into the existing bf16 gradient (C += acc; `resid` = C).
+template <int EPI, int NF>
+__device__ __forceinline__ void tn_epilogue(const GemmArgs& p, void* Cout, f32x4 (&acc)[NF][8], int mrow0, int nbase, int g, int t) {
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int m = mrow0 + mi * 16 + t;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const int n = nbase + f * 16 + g * 4;
+      if (n >= p.N) continue;  // N % 8 == 0: a group of four never straddles the edge
+      const f32x4 a = acc[f][mi];
+      if (EPI == EPI_F32) {
+        *reinterpret_cast<f32x4*>((float*)Cout + (int64_t)m * p.ldc + n) = a;
+      } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+        bf16_t* c = (bf16_t*)Cout + (int64_t)m * p.ldc + n;
+        float o[4] = {a[0], a[1], a[2], a[3]};
+        if (EPI == EPI_RESID) {
+          const bf16x4v r = *reinterpret_cast<const bf16x4v*>(p.resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (float)r[j] + o[j];
+        }
+        bf16x4v w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (bf16_t)o[j];
+        *reinterpret_cast<bf16x4v*>(c) = w;
+      }
+    }
+  }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
@@ -1033,7 +1068,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
     const int q = i * 512 + tid;
     const int kr = q >> 5, pc = q & 31;
     const int ca = min(m0 + (pc ^ swzA_tn(kr)) * 8, p.M - 8);
-    const int cb = min(n0 + (pc ^ swzB_tn(kr)) * 8, p.N - 8);
+    const int cb = min(n0 + (pc ^ swzA_tn(kr)) * 8, p.N - 8);
     offA[i] = (unsigned)(((int64_t)kr * p.lda + ca) * 2);
     offB[i] = (unsigned)(((int64_t)kr * p.ldb + cb) * 2);
   }
@@ -1056,8 +1091,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
   }
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni) {
-    const int chunk = wn * 8 + (t & 3) * 2 + (ni >> 1);
-    rdW[ni] = OPER2_BYTES + rowoff + ((chunk ^ swzB_tn(krow)) << 4) + (ni & 1) * 8;
+    const int chunk = wn * 8 + ni * 2 + ((t & 3) >> 1);  // 16 consecutive n per fragment, like the m-operand: conflict free
+    rdW[ni] = OPER2_BYTES + rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
   }
 
   auto issue = [&](int slot) {
@@ -1162,7 +1197,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
     step_tail(kt, fA, fB);
     step_tail(kt + 1, fB, fA);
   }
-  gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, 0, g, t);
+  tn_epilogue<EPI, 4>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, g, t);
 }
 
 // Four-wave flavour of the TN kernel (one wave per SIMD, 128 x 128 per wave; see gemm256w_kernel): the same four-stage
@@ -1204,7 +1239,7 @@ __global__ __launch_bounds__(256) void gemm256w_tn_kernel(const GemmArgs p) {
     const int q = i * 256 + tid;
     const int kr = q >> 5, pc = q & 31;
     const int ca = min(m0 + (pc ^ swzA_tn(kr)) * 8, p.M - 8);
-    const int cb = min(n0 + (pc ^ swzB_tn(kr)) * 8, p.N - 8);
+    const int cb = min(n0 + (pc ^ swzA_tn(kr)) * 8, p.N - 8);
     offA[i] = (unsigned)(((int64_t)kr * p.lda + ca) * 2);
     offB[i] = (unsigned)(((int64_t)kr * p.ldb + cb) * 2);
   }
@@ -1228,8 +1263,8 @@ __global__ __launch_bounds__(256) void gemm256w_tn_kernel(const GemmArgs p) {
   }
 #pragma unroll
   for (int f = 0; f < 8; ++f) {  // f = blk * 4 + ni
-    const int chunk = (wn * 2 + (f >> 2)) * 8 + (t & 3) * 2 + ((f & 3) >> 1);
-    rdW[f] = OPER2_BYTES + rowoff + ((chunk ^ swzB_tn(krow)) << 4) + (f & 1) * 8;
+    const int chunk = wn * 16 + f * 2 + ((t & 3) >> 1);  // 16 consecutive n per fragment, like the m-operand: conflict free
+    rdW[f] = OPER2_BYTES + rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
   }
 
   auto dma = [&](char* la, int j) {  // op j = 0..7 of a stage: A ops 0..3, B ops 4..7
@@ -1314,8 +1349,8 @@ __global__ __launch_bounds__(256) void gemm256w_tn_kernel(const GemmArgs p) {
     step_tail(kt + 1, fB, fA);
   }
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the inline-asm MFMAs are invisible to the hazard recogniser
-  gemm_epilogue<EPI, 8>(p, Cout, acc[0], m0 + wm * 128, n0 + wn * 128, 0, g, t);
-  gemm_epilogue<EPI, 8>(p, Cout, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, 0, g, t);
+  tn_epilogue<EPI, 4>(p, Cout, acc[0], m0 + wm * 128, n0 + wn * 128, g, t);
+  tn_epilogue<EPI, 4>(p, Cout, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, g, t);
 }
 
 template <int EPI>

@@ -8,7 +8,10 @@
 //   * fused_dropout_res  residual + droppath(gamma * y), transformer_layer.py:70-88 -> EPI_RESID
 //   * scale * local @ all^T of the contrastive head, image_text_pretrain_loss.py:171-172 -> EPI_F32
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+// Kernels (chosen per launch by plan_gemm / launch256): gemm_nt_kernel 128x128 (small launches, described next);
+// gemm256_kernel 256x256 BK = 32 four-stage; gemm256b_kernel 256x256 BK = 64, eight waves of 128x64; gemm256w_kernel the same
+// with four waves of 128x128 (one wave per SIMD); gemm256_tn_kernel / gemm256w_tn_kernel the weight-gradient (TN) pair.
+// Tiling of the 128x128 kernel: one output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
 // 16x16x32 accumulators), BK = 64, two LDS buffers (2 x 32 KiB), one barrier per K-tile.  Operand tiles
 // are [128 rows][64 k] bf16 (128-byte rows) with the 16-byte slot index XOR-ed by (row & 7): the
 // ds_read_b128 fragment reads are then bank-conflict free (each 16-lane group covers all 64 banks once).

@@ -77,13 +77,25 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
  * accumulate != 0: C += A^T B.  workspace: optional fp32 scratch enabling split-K. */
 int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                int accumulate, void* workspace, int64_t workspace_bytes, int64_t tune, void* stream);
+/* Grouped form of op_gemm_nt: up to three problems C_p[M_p,N] = epilogue(A_p[M_p,K] . W_p[N,K]^T) that share N, K, the leading
+ * dimensions and the epilogue (0 bias, 2 GeGLU, 3 residual) in ONE launch of the persistent 256x256 kernel -- replaces the three
+ * per-modality FFN launches of an encoder layer (transformer_layer.py:203-226: text / image / audio rows go through their own
+ * text_ffn / image_ffn / audio_ffn).  Every array argument is a HOST array: A, M, C, h0, h1, resid, gamma, rowscale,
+ * rows_per_sample have nprob entries; B and bias have 2 * nprob ([2p] = the weight / its bias, [2p + 1] = wi_1 of a GeGLU problem).
+ * h0 / h1 / resid / gamma / rowscale / bias (arrays or entries) may be NULL.  Results are bit-identical to nprob op_gemm_nt calls.
+ * Needs N % 256 == 0 (GeGLU: % 128), K % 64 == 0, K >= 128, lda / ldb / ldc % 8 == 0, operands < 2 GiB; else returns -95. */
+int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, int64_t lda, const void* const* B, int64_t ldb,
+                       const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
+                       const void* const* resid, int64_t ldr, const void* const* gamma, const float* const* rowscale,
+                       const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream);
 /* `tune` (op_gemm_nt, op_gemm_tn, op_gemm_plan): per-call tuning word, 0 = what production uses.  The library keeps NO tuning
  * state, so every entry point is a pure function of its arguments; tests and tools select a kernel flavour with the call:
  * bits 0-1 tile (0 auto: a cost model picks 128x128 or 256x256 tiles, K-splits and the tail-rows split; 1 force 128x128;
  * 2 force 256x256); bits 2-3 flavour of the 256x256 NT kernel (0 auto, 1 BK = 32, 2 eight-wave full-line, 3 four-wave full-line); bits 4-6 tail-rows split (0 default, 1 off,
  * 3 whenever it saves a round, 4 always); bits 7-11 M-tiles per L2 group (0 auto); bits 12-14 timing ablations of the 256x256
  * kernel (tools; wrong results); bits 15-18 forced K-split count of small problems (tools); bit 19 register-staged operands
- * instead of LDS-DMA (global_load_lds). */
+ * instead of LDS-DMA (global_load_lds); bits 20-22 kernel of the four-wave NT launches (0 auto, 1 / 3 one-tile workgroups with
+ * that instruction schedule, 6 persistent workgroups, 7 the round-2 kernel). */
 /* Host-only query (no GPU needed): the launch decision op_gemm_nt takes for a dense, single-segment problem.
  * plan[0] = tile (128 | 256), plan[1] = K-splits, plan[2] = 1 if the epilogue runs in the split-K fold kernel,
  * plan[3] = leftover rows (M % 256) split off into a second, small launch (0 = none). */

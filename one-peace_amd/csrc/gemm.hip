@@ -26,6 +26,7 @@
 //
 // Roofline: MFMA (dense bf16, 2.5 PFLOP/s).  Algorithmic work = 2*M*N*K flops per launch.
 #include "common.h"
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -988,6 +989,418 @@ __global__ __launch_bounds__(256) void gemm256w_kernel(const GemmArgs p) {
 }
 
 // =====================================================================================================================
+// gemm256v_kernel: the four-wave kernel above with (a) LDS-DMA through buffer descriptors -- `buffer_load_dwordx4 v, s[rsrc],
+// s_off offen lds`: the K position travels in the descriptor's base address (scalar adds), so the steady loop has no per-load
+// 64-bit VALU address add -- and (b) an
+// instruction stream in which every gap between two MFMAs carries AT MOST ONE memory instruction, placed by a compile-time table
+// (vs_read / vs_dma): with one wave per SIMD the matrix pipe is fed by a single in-order instruction stream, a 16x16x32 MFMA
+// occupies it for 16 cycles, and whatever the wave has to issue between two MFMAs beyond ~12 cycles idles it.  PMC of
+// gemm256w_kernel (profiles/pmc/r2_gemm256w_nt_qkv_b128.txt): matrix pipe 56 % busy, 26 % of the wave's cycles are the issue of
+// non-MFMA instructions -- it issues 8 MFMAs back to back and then a burst {address add, M0, 2 ds_read_b128, LDS-DMA}.
+// Same LDS image, slot rotation, barrier protocol and per-accumulator MFMA order as gemm256w_kernel / gemm256b_kernel:
+// bit-identical results.  SCHED selects where a half-step's 16 fragment reads and 8 LDS-DMA ops go (tools/gemm_sched_ab.py;
+// five placements were measured, profiles/r3_gemm_sched_ab.txt: all within 1 % of each other, all 1 ... 2.5 % ahead of gemm256w):
+//   1  after every 8th MFMA: 2 reads + 1 DMA (gemm256w's placement; isolates the effect of the buffer loads)
+//   3  per 8 MFMAs: read after the 1st, read after the 4th, DMA after the 6th (production)
+// =====================================================================================================================
+__host__ __device__ constexpr int vs_read(int S, int i, int which) {  // fragment read `which` (0/1) issued after MFMA i, or -1
+  if (S == 1) return (i & 7) == 7 ? 2 * (i >> 3) + which : -1;
+  return which != 0 ? -1 : (i & 7) == 0 ? 2 * (i >> 3) : (i & 7) == 3 ? 2 * (i >> 3) + 1 : -1;
+}
+__host__ __device__ constexpr int vs_dma(int S, int i) {  // LDS-DMA op issued after MFMA i, or -1
+  if (S == 1) return (i & 7) == 7 ? i >> 3 : -1;
+  return (i & 7) == 5 ? i >> 3 : -1;
+}
+
+template <int EPI, int SCHED>
+__global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int GM = p.gm;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * BM2, n0 = pid_n * BN_OUT;
+  const int nk = p.K / 64;
+
+  // ---- staging: op j (0..7) of an operand tile covers LDS rows j*32 + (tid >> 3), 16-byte slot tid & 7 ----
+  // Both operands go through buffer descriptors whose BASE is the operand's first element of the K-tile being fetched and whose
+  // size is what is left of the matrix from there (0 for K-tiles past the end: the loop below issues tiles i+2 unconditionally,
+  // those fetch nothing).  Activations: per-lane byte offset of the (clamped) row in a VGPR per op; weights: per-lane offset of
+  // the lane's row inside a 32-row group in ONE VGPR + the group's first row as an SGPR offset per op.
+  const int srow = tid >> 3;                       // 0..31
+  const int sc = (tid & 7) ^ (srow & 7);
+  unsigned offA[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gm = min(m0 + j * 32 + srow, p.M - 1);
+    offA[j] = (unsigned)(((int64_t)gm * p.lda + sc * 8) * 2);
+  }
+  const int nrecA = (int)((((int64_t)p.M - 1) * p.lda + p.K) * 2);
+  unsigned offB;
+  unsigned soffB[8];
+  const char* ptrB[2];
+  {
+    const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;
+    const int lanecol = (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
+                                           : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
+    offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col0 = (EPI == EPI_GEGLU) ? n0 + (j & 3) * 32 : n0 - seg * p.n_seg + (j >> 1) * 64 + (j & 1) * 8;
+      soffB[j] = (unsigned)((int64_t)col0 * p.ldb * 2);
+    }
+    ptrB[0] = (const char*)((EPI == EPI_GEGLU) ? p.B[0] : p.B[seg]);
+    ptrB[1] = (const char*)((EPI == EPI_GEGLU) ? p.B[1] : p.B[seg]);
+  }
+  const int rowsB = (EPI == EPI_GEGLU) ? p.N : min(p.n_seg, p.N);
+  const int nrecB = (int)((((int64_t)rowsB - 1) * p.ldb + p.K) * 2);
+  int ktA = 0, ktB = 0;  // next K-tile of each operand to be fetched
+
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+  const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
+  auto w_off = [&](int f) {  // byte offset of weight fragment f = blk * 4 + ni inside the operand tile
+    const int blk = f >> 2, ni = f & 3;
+    if (EPI == EPI_GEGLU) return ((ni >> 1) * 128 + (wn * 2 + blk) * 32 + (ni & 1) * 16 + t) * 128;
+    return (wn * 128 + blk * 64 + ni * 16 + t) * 128;
+  };
+
+  int qslot_issue = 0;
+  struct Rsrc { __amdgpu_buffer_rsrc_t a, b0, b1; };
+  auto rsrc_a = [&]() {  // descriptor of activation K-tile ktA (empty past the end)
+    return __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (int64_t)ktA * 128), 0, ktA < nk ? nrecA - ktA * 128 : 0, 0x00020000);
+  };
+  auto rsrc_b = [&](int which) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(ptrB[which] + (int64_t)ktB * 128), 0, ktB < nk ? nrecB - ktB * 128 : 0, 0x00020000);
+  };
+  auto dma_a = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offA[j], 0, 0, 0);
+  };
+  auto dma_b = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((EPI == EPI_GEGLU && j >= 4) ? r1 : r0, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16,
+                                             offB, soffB[j], 0, 0);
+  };
+  auto advance = [&](bool is_b) {
+    if (is_b) ++ktB; else ++ktA;
+    qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
+  };
+  auto issue_tile = [&](bool is_b) {
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_a(), rb0 = rsrc_b(0), rb1 = rsrc_b(1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (is_b) dma_b(rb0, rb1, dst, j); else dma_a(ra, dst, j);
+    }
+    advance(is_b);
+  };
+
+  // One half-step: 64 MFMAs on `cur` (complete), the 16 fragment reads of the next half-step into `nxt` and the 8 LDS-DMA ops of
+  // one operand tile (IS_B: a weight tile, else an activation tile), each between the two MFMAs the SCHED table names.
+  auto half_step = [&](auto b_tag, const bf16x8 (&cur_w)[8], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[8], bf16x8 (&nxt_x)[8],
+                       const char* sa, const char* sb, int h) {
+    constexpr bool IS_B = decltype(b_tag)::value;
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+    const __amdgpu_buffer_rsrc_t r0 = IS_B ? rsrc_b(0) : rsrc_a(), r1 = (IS_B && EPI == EPI_GEGLU) ? rsrc_b(1) : r0;
+    auto rd = [&](int r) {  // r = 0..15: weight fragments first (the first MFMAs of the next half-step need all eight of them)
+      if (r < 8) nxt_w[r] = *reinterpret_cast<const bf16x8*>(sb + w_off(r) + fsw[h]);
+      else nxt_x[r - 8] = *reinterpret_cast<const bf16x8*>(sa + rowX + (r - 8) * 2048 + fsw[h]);
+    };
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int k = i >> 3, f = i & 7;
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
+      const int rd0 = vs_read(SCHED, i, 0), rd1 = vs_read(SCHED, i, 1), d = vs_dma(SCHED, i);
+      if (rd0 >= 0 || rd1 >= 0 || d >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (rd0 >= 0) rd(rd0);
+        if (rd1 >= 0) rd(rd1);
+        if (d >= 0) { if (IS_B) dma_b(r0, r1, dst, d); else dma_a(r0, dst, d); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    advance(IS_B);
+  };
+  using IsA = std::integral_constant<bool, false>;
+  using IsB = std::integral_constant<bool, true>;
+
+  // ---- prologue: A0 B0 A1 B1 (nk >= 2); fragments of (0,0) ----
+  issue_tile(false);
+  issue_tile(true);
+  issue_tile(false);
+  issue_tile(true);
+  WAIT_VM(16);
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfA[8], xfA[8], wfB[8], xfB[8];
+  int sa = 0, sb = 1;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) wfA[r] = *reinterpret_cast<const bf16x8*>(smem + sb * SLOT3_BYTES + w_off(r) + fsw[0]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) xfA[r] = *reinterpret_cast<const bf16x8*>(smem + sa * SLOT3_BYTES + rowX + r * 2048 + fsw[0]);
+  // ONE loop over all K-tiles, no peeled tail: tile i issues tiles i+2 also when they do not exist (empty descriptors: nothing is
+  // fetched) and its second half-step reads the "next tile's" fragments also when there is none (never used).  A peeled tail made
+  // the register allocator shuffle accumulators (v_accvgpr_read / _mov) on the loop-exit edge, i.e. right behind inline-asm MFMAs
+  // it cannot see: those copies read accumulators whose MFMAs were still in flight (tools/check_mfma_hazards.py looks for that).
+  int nk_last = nk;
+  asm volatile("" : "+s"(nk_last));
+  for (int i = 0; i < nk; ++i) {
+    const int sa1 = sa + 2 >= SLOTS3 ? sa + 2 - SLOTS3 : sa + 2, sb1 = sb + 2 >= SLOTS3 ? sb + 2 - SLOTS3 : sb + 2;
+    WAIT_LGKM(0);
+    asm volatile("s_nop 0");
+    __builtin_amdgcn_sched_barrier(0);
+    half_step(IsA{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);   // (i,0): A(i+2)
+    WAIT_LGKM(0);
+    WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    half_step(IsB{}, wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0);  // (i,1): B(i+2)
+    sa = sa1;
+    sb = sb1;
+    // The accumulators are written by inline-asm MFMAs the hazard recogniser does not see, and on the loop-exit edge the register
+    // allocator reads / moves accumulators (v_accvgpr_read / _mov; neither a "memory" clobber nor operand dependences of a later
+    // statement keep those copies away from the edge): the last MFMAs retire INSIDE the loop body, on the last trip only.  The
+    // trip test goes through a value the optimiser cannot equate with the exit condition, or it would sink the statement
+    // behind the edge again.
+    if (i + 1 >= nk_last) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+  }
+  // the empty fetches and the unused fragment reads of the last tile must be gone before the registers / the LDS get their next owner
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  gemm_epilogue<EPI, 8>(p, p.C, acc[0], m0 + wm * 128, n0 + wn * 128, n0 + (wn * 2) * 32, g, t);
+  gemm_epilogue<EPI, 8>(p, p.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, n0 + (wn * 2 + 1) * 32, g, t);
+}
+
+// =====================================================================================================================
+// gemm256p_kernel: PERSISTENT, GROUPED form of gemm256v_kernel (schedule 3).  One workgroup per CU walks the tile list
+// b = blockIdx, blockIdx + gridDim, ... (the same tile -> CU assignment the hardware dispatcher produces for one-tile
+// workgroups, so the panels shared through L2 and the K-lockstep of a round are unchanged), and the K-tile stream never stops
+// at a tile boundary: the loop that issues K-tile i+2 of the current tile issues K-tiles 0 and 1 of the NEXT tile during its
+// last two trips, and the last half-step reads the next tile's first fragments.  What a one-tile workgroup pays per tile --
+// dispatch, kernel-argument loads, address set-up, the latency of the first operand tiles, and an epilogue whose stores have
+// to drain before the CU gets its next workgroup (K-scan of gemm256w_kernel: 26 us per three-round launch, 20 % of a
+// K = 1536 launch) -- is paid once per launch or overlaps with the next tile's main loop.
+// Grouped: the tile list may span up to three PROBLEMS that share N, K and the epilogue but have their own activation
+// matrix, row count, weights, bias, layer-scale vector, residual and outputs -- the three modality FFNs of an encoder layer as
+// ONE launch (a text pass alone is 192 tiles on 256 CUs), transformer_layer.py:203-226.  M-tiles of the problems are
+// concatenated; rows past a problem's end are fetched as zeros (buffer descriptor sized to the problem) and never stored.
+// =====================================================================================================================
+struct GroupArgs {
+  int nprob;
+  const bf16_t* A[3]; int M[3]; int mt_end[3];  // mt_end: running sum of 256-row tiles (entries >= nprob - 1 hold tiles_m)
+  const bf16_t* B[3][3];                         // [problem][weight segment along N]; GeGLU: 0 = wi_0, 1 = wi_1
+  const bf16_t* bias[3][3];
+  void* C[3]; bf16_t* H0[3]; bf16_t* H1[3];
+  const bf16_t* resid[3]; const bf16_t* gamma[3]; const float* rowscale[3]; int rows_per_sample[3];
+  int64_t lda, ldb, ldc, ldr;
+  const float* alpha;
+  int n_seg, N, K, tiles_m, tiles_n, gm;
+};
+
+template <class T>
+__device__ __forceinline__ T sel3(const T (&a)[3], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : a[2]; }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SCHED = 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+  const int nk = p.K / 64;
+  const int ntiles = p.tiles_m * p.tiles_n;
+  const int stride_b = gridDim.x;
+
+  // ---- tile b -> problem, first row, first column; descriptors of its operand panels (all wave-uniform) ----
+  struct Tile { int prob, m0, n0; const char* a; int na; const char* b0; const char* b1; int nb; };
+  auto locate = [&](int b) {
+    Tile T;
+    const bool valid = b < ntiles;
+    const int pid = xcd_remap(valid ? b : 0, ntiles);
+    const int per_group = p.gm * p.tiles_n;
+    const int first_m = (pid / per_group) * p.gm;
+    const int gsz = min(p.tiles_m - first_m, p.gm);
+    const int in_group = pid % per_group;
+    const int pid_m = first_m + in_group % gsz, pid_n = in_group / gsz;
+    T.prob = (pid_m >= p.mt_end[0] ? 1 : 0) + (pid_m >= p.mt_end[1] ? 1 : 0);
+    T.m0 = (pid_m - (T.prob == 0 ? 0 : T.prob == 1 ? p.mt_end[0] : p.mt_end[1])) * BM2;
+    T.n0 = pid_n * BN_OUT;
+    const int Mp = sel3(p.M, T.prob);
+    T.a = (const char*)(sel3(p.A, T.prob) + (int64_t)T.m0 * p.lda);
+    T.na = valid ? (int)((((int64_t)Mp - 1 - T.m0) * p.lda + p.K) * 2) : 0;  // bytes from the tile's first row to the matrix end
+    if (EPI == EPI_GEGLU) {
+      const bf16_t* w0 = T.prob == 0 ? p.B[0][0] : T.prob == 1 ? p.B[1][0] : p.B[2][0];
+      const bf16_t* w1 = T.prob == 0 ? p.B[0][1] : T.prob == 1 ? p.B[1][1] : p.B[2][1];
+      T.b0 = (const char*)(w0 + (int64_t)T.n0 * p.ldb);
+      T.b1 = (const char*)(w1 + (int64_t)T.n0 * p.ldb);
+      T.nb = valid ? (int)((((int64_t)p.N - 1 - T.n0) * p.ldb + p.K) * 2) : 0;
+    } else {
+      const int seg = T.n0 / p.n_seg, c0 = T.n0 - seg * p.n_seg;
+      const bf16_t* w = T.prob == 0 ? (seg == 0 ? p.B[0][0] : seg == 1 ? p.B[0][1] : p.B[0][2])
+                      : T.prob == 1 ? (seg == 0 ? p.B[1][0] : seg == 1 ? p.B[1][1] : p.B[1][2])
+                                    : (seg == 0 ? p.B[2][0] : seg == 1 ? p.B[2][1] : p.B[2][2]);
+      T.b0 = T.b1 = (const char*)(w + (int64_t)c0 * p.ldb);
+      T.nb = valid ? (int)((((int64_t)min(p.n_seg, p.N) - 1 - c0) * p.ldb + p.K) * 2) : 0;
+    }
+    return T;
+  };
+
+  // ---- staging (see gemm256v_kernel): op j covers LDS rows j*32 + (tid >> 3); nothing here depends on the tile ----
+  const int srow = tid >> 3;
+  const int sc = (tid & 7) ^ (srow & 7);
+  unsigned offA[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) offA[j] = (unsigned)(((int64_t)(j * 32 + srow) * p.lda + sc * 8) * 2);
+  const int lanecol = (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
+                                         : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
+  const unsigned offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
+  unsigned soffB[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    soffB[j] = (unsigned)((int64_t)((EPI == EPI_GEGLU) ? (j & 3) * 32 : (j >> 1) * 64 + (j & 1) * 8) * p.ldb * 2);
+
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+  const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
+  auto w_off = [&](int f) {
+    const int blk = f >> 2, ni = f & 3;
+    if (EPI == EPI_GEGLU) return ((ni >> 1) * 128 + (wn * 2 + blk) * 32 + (ni & 1) * 16 + t) * 128;
+    return (wn * 128 + blk * 64 + ni * 16 + t) * 128;
+  };
+
+  int qslot_issue = 0;
+  auto rsrc = [&](const char* base, int nrec, int kt) {  // K-tile kt of a panel: base + kt*128 bytes, what is left of it (or nothing)
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)kt * 128), 0, nrec > 0 ? nrec - kt * 128 : 0, 0x00020000);
+  };
+  auto dma_a = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offA[j], 0, 0, 0);
+  };
+  auto dma_b = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((EPI == EPI_GEGLU && j >= 4) ? r1 : r0, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16,
+                                             offB, soffB[j], 0, 0);
+  };
+  auto next_slot = [&]() { qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1; };
+  auto issue_tile = [&](bool is_b, const Tile& T, int kt) {
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+    const __amdgpu_buffer_rsrc_t ra = rsrc(T.a, T.na, kt), rb0 = rsrc(T.b0, T.nb, kt), rb1 = rsrc(T.b1, T.nb, kt);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (is_b) dma_b(rb0, rb1, dst, j); else dma_a(ra, dst, j);
+    }
+    next_slot();
+  };
+  auto half_step = [&](auto b_tag, const Tile& T, int kt, const bf16x8 (&cur_w)[8], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[8],
+                       bf16x8 (&nxt_x)[8], const char* sa, const char* sb, int h) {
+    constexpr bool IS_B = decltype(b_tag)::value;
+    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
+    const __amdgpu_buffer_rsrc_t r0 = IS_B ? rsrc(T.b0, T.nb, kt) : rsrc(T.a, T.na, kt);
+    const __amdgpu_buffer_rsrc_t r1 = (IS_B && EPI == EPI_GEGLU) ? rsrc(T.b1, T.nb, kt) : r0;
+    auto rd = [&](int r) {
+      if (r < 8) nxt_w[r] = *reinterpret_cast<const bf16x8*>(sb + w_off(r) + fsw[h]);
+      else nxt_x[r - 8] = *reinterpret_cast<const bf16x8*>(sa + rowX + (r - 8) * 2048 + fsw[h]);
+    };
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int k = i >> 3, f = i & 7;
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
+      const int rd0 = vs_read(SCHED, i, 0), rd1 = vs_read(SCHED, i, 1), d = vs_dma(SCHED, i);
+      if (rd0 >= 0 || rd1 >= 0 || d >= 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (rd0 >= 0) rd(rd0);
+        if (rd1 >= 0) rd(rd1);
+        if (d >= 0) { if (IS_B) dma_b(r0, r1, dst, d); else dma_a(r0, dst, d); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    next_slot();
+  };
+  using IsA = std::integral_constant<bool, false>;
+  using IsB = std::integral_constant<bool, true>;
+
+  int b = blockIdx.x;
+  Tile cur = locate(b);
+  // ---- prologue of the FIRST tile only: A0 B0 A1 B1, fragments of (0,0) ----
+  issue_tile(false, cur, 0);
+  issue_tile(true, cur, 0);
+  issue_tile(false, cur, 1);
+  issue_tile(true, cur, 1);
+  WAIT_VM(16);
+  __builtin_amdgcn_s_barrier();
+  bf16x8 wfA[8], xfA[8], wfB[8], xfB[8];
+  int sa = 0, sb = 1;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) wfA[r] = *reinterpret_cast<const bf16x8*>(smem + sb * SLOT3_BYTES + w_off(r) + fsw[0]);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) xfA[r] = *reinterpret_cast<const bf16x8*>(smem + sa * SLOT3_BYTES + rowX + r * 2048 + fsw[0]);
+  int nk_last = nk;
+  asm volatile("" : "+s"(nk_last));
+
+  for (; b < ntiles; b += stride_b) {
+    const Tile nxt = locate(b + stride_b);  // past the list: empty descriptors, nothing is fetched
+    for (int i = 0; i < nk; ++i) {
+      const bool wrap = i + 2 >= nk;       // K-tile i+2 of this tile, or K-tile i+2-nk of the next one
+      const int kt = wrap ? i + 2 - nk : i + 2;
+      const Tile& src = wrap ? nxt : cur;
+      const int sa1 = sa + 2 >= SLOTS3 ? sa + 2 - SLOTS3 : sa + 2, sb1 = sb + 2 >= SLOTS3 ? sb + 2 - SLOTS3 : sb + 2;
+      WAIT_LGKM(0);
+      asm volatile("s_nop 0");
+      __builtin_amdgcn_sched_barrier(0);
+      half_step(IsA{}, src, kt, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);
+      WAIT_LGKM(0);
+      WAIT_VM(8);
+      __builtin_amdgcn_s_barrier();
+      half_step(IsB{}, src, kt, wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0);
+      sa = sa1;
+      sb = sb1;
+      // last trip: the inline-asm MFMAs retire before the loop exit, where the register allocator may read / move accumulators
+      // (see gemm256v_kernel)
+      if (i + 1 >= nk_last) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+    }
+    {  // epilogue of the finished tile; its stores drain while the next tile's main loop runs
+      GemmArgs q;
+      q.M = sel3(p.M, cur.prob); q.N = p.N; q.K = p.K; q.n_seg = p.n_seg; q.ldc = p.ldc; q.ldr = p.ldr; q.m_off = 0;
+      q.C = sel3(p.C, cur.prob); q.H0 = sel3(p.H0, cur.prob); q.H1 = sel3(p.H1, cur.prob);
+      q.resid = sel3(p.resid, cur.prob); q.gamma = sel3(p.gamma, cur.prob); q.rowscale = sel3(p.rowscale, cur.prob);
+      q.rows_per_sample = sel3(p.rows_per_sample, cur.prob); q.alpha = p.alpha;
+#pragma unroll
+      for (int sgi = 0; sgi < 3; ++sgi)
+        q.bias[sgi] = cur.prob == 0 ? p.bias[0][sgi] : cur.prob == 1 ? p.bias[1][sgi] : p.bias[2][sgi];
+      gemm_epilogue<EPI, 8>(q, q.C, acc[0], cur.m0 + wm * 128, cur.n0 + wn * 128, cur.n0 + (wn * 2) * 32, g, t);
+      gemm_epilogue<EPI, 8>(q, q.C, acc[1], cur.m0 + wm * 128, cur.n0 + wn * 128 + 64, cur.n0 + (wn * 2 + 1) * 32, g, t);
+    }
+    zero_acc();
+    cur = nxt;
+  }
+  // the empty fetches and the unused fragment reads behind the last tile must be gone before the LDS / registers get their next owner
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+
+// =====================================================================================================================
 // TN variant of the 256x256 kernel:  C[M,N] = sum_k A[k][m] * B[k][n]  with BOTH operands stored K-major ([K, M] and
 // [K, N] row-major) -- the weight-gradient GEMM dW = dy^T x straight from the activation matrices, no transposed copies.
 // Same four-stage LDS-DMA pipeline and epilogue; operand tiles are [32 k][256] (512-byte rows) and the MFMA fragments
@@ -1391,7 +1804,9 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) 
 //   bits 12-14 timing ablation of the 256x256 BK = 32 kernel (tools only; wrong results)
 //   bits 15-18 forced K-split count of small problems (tools only)
 //   bit  19    register-staged operand path instead of LDS-DMA (128x128 kernel; tests)
-struct GemmTune { int tile_mode, fullline, tail_rows, gm, ablation, force_splits, glds; };
+//   bits 20-22 four-wave NT launches: 0 auto, 1 / 3 gemm256v_kernel with that instruction schedule, 6 gemm256p_kernel (persistent),
+//              7 gemm256w_kernel (tools, tests)
+struct GemmTune { int tile_mode, fullline, tail_rows, gm, ablation, force_splits, glds, sched; };
 static GemmTune decode_tune(int64_t t) {
   GemmTune T;
   T.tile_mode = (int)(t & 3);
@@ -1403,7 +1818,75 @@ static GemmTune decode_tune(int64_t t) {
   T.ablation = (int)((t >> 12) & 7);
   T.force_splits = (int)((t >> 15) & 15);
   T.glds = ((t >> 19) & 1) ? 0 : 1;
+  T.sched = (int)((t >> 20) & 7);
   return T;
+}
+
+constexpr int V_SCHED_DEFAULT = 3;  // kernel of the four-wave NT launches when the tune word does not name one: gemm256v_kernel, schedule 3
+                                    // (-1.3 ... -1.9 % over gemm256w_kernel = 7 on the 4B shapes, profiles/r3_gemm_sched_ab.txt)
+
+template <int EPI, int SCHED>
+int launch256v(const GemmArgs& a, hipStream_t s, dim3 grid, size_t sh) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256v_kernel<EPI, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) { op_set_error("gemm256v: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256v_kernel<EPI, SCHED>), grid, dim3(256), sh, s, a);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// persistent grouped kernel: one workgroup per CU (or per tile when there are fewer tiles)
+static int num_cus() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n - n % 8;  // a multiple of the 8 XCDs: workgroup w stays on XCD w % 8 over its whole tile list
+    if (cached[dev] <= 0) cached[dev] = 8;
+  }
+  return cached[dev];
+}
+
+template <int EPI>
+int launch256p(const GroupArgs& ga, hipStream_t s, bool persistent = true) {
+  const size_t sh = (size_t)SLOTS3 * SLOT3_BYTES;
+  hipError_t e = hipFuncSetAttribute((const void*)gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (e != hipSuccess) { op_set_error("gemm256p: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+  const int ntiles = ga.tiles_m * ga.tiles_n;
+  hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3((!persistent || ntiles < num_cus()) ? ntiles : num_cus()), dim3(256), sh, s, ga);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+static int launch256p_any(const GroupArgs& ga, int epi, hipStream_t s, bool persistent) {
+  switch (epi) {
+    case EPI_BIAS: return launch256p<EPI_BIAS>(ga, s, persistent);
+    case EPI_F32: return launch256p<EPI_F32>(ga, s, persistent);
+    case EPI_GEGLU: return launch256p<EPI_GEGLU>(ga, s, persistent);
+    default: return launch256p<EPI_RESID>(ga, s, persistent);
+  }
+}
+
+// single-problem GroupArgs of a plain launch
+static GroupArgs group_of(const GemmArgs& a, int epi) {
+  GroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.nprob = 1;
+  ga.A[0] = a.A; ga.M[0] = a.M;
+  ga.tiles_m = ceil_div(a.M, 256);
+  ga.tiles_n = ceil_div(a.N, epi == EPI_GEGLU ? 128 : 256);
+  ga.mt_end[0] = ga.mt_end[1] = ga.mt_end[2] = ga.tiles_m;
+  for (int i = 0; i < 3; ++i) { ga.B[0][i] = a.B[i]; ga.bias[0][i] = a.bias[i]; }
+  ga.C[0] = a.C; ga.H0[0] = a.H0; ga.H1[0] = a.H1; ga.resid[0] = a.resid; ga.gamma[0] = a.gamma; ga.rowscale[0] = a.rowscale;
+  ga.rows_per_sample[0] = a.rows_per_sample;
+  ga.lda = a.lda; ga.ldb = a.ldb; ga.ldc = a.ldc; ga.ldr = a.ldr; ga.alpha = a.alpha;
+  ga.n_seg = a.n_seg; ga.N = a.N; ga.K = a.K; ga.gm = a.gm;
+  return ga;
 }
 
 template <int EPI>
@@ -1423,6 +1906,15 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
   if ((T.fullline == 3 || (T.fullline == 2 && fills && EPI != EPI_GEGLU)) && splits == 1 &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0 && a.K >= 128) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
+    const int sched = T.sched == 0 ? V_SCHED_DEFAULT : T.sched;
+    switch (sched) {
+      case 1: return launch256v<EPI, 1>(a, s, grid, sh5);
+      case 3: return launch256v<EPI, 3>(a, s, grid, sh5);
+      case 6:
+        if (a.m_off == 0) return launch256p<EPI>(group_of(a, EPI), s, true);
+        return launch256v<EPI, 3>(a, s, grid, sh5);
+      default: break;
+    }
     static bool attr6 = false;
     if (!attr6) {
       hipError_t e = hipFuncSetAttribute((const void*)gemm256w_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
@@ -1799,6 +2291,67 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
                       rows_per_sample, alpha, M, N, K, epilogue, workspace, workspace_bytes, stream, 0, true, decode_tune(tune));
 }
 
+
+// Grouped NT GEMM: up to three problems C_p[M_p, N] = epilogue(A_p[M_p, K] . W_p[N, K]^T) that share N, K, the leading dimensions
+// and the epilogue, in ONE launch of the persistent kernel -- the text / image / audio FFN of an encoder layer
+// (transformer_layer.py:203-226; each modality's rows go through its own weights).  All array arguments are HOST arrays with
+// nprob entries (B / bias: nprob x 2, [p*2 + 0] = the weight (GeGLU: wi_0), [p*2 + 1] = wi_1 for GeGLU, else unused); h0, h1, resid,
+// gamma, rowscale, bias entries may be null, a whole array pointer may be null.  Epilogues 0 (bias), 2 (GeGLU), 3 (residual).
+// Requirements: N % 256 == 0 (GeGLU: N % 128 == 0), K % 64 == 0, K >= 128, lda / ldb / ldc % 8 == 0, every operand below 2 GiB.
+// Returns OP_ENOTSUP when the shape does not qualify (the caller then launches the problems one by one).
+int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, int64_t lda, const void* const* B, int64_t ldb,
+                       const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
+                       const void* const* resid, int64_t ldr, const void* const* gamma, const float* const* rowscale,
+                       const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream) {
+  const GemmTune T = decode_tune(tune);
+  OP_CHECK_ARG(nprob >= 1 && nprob <= 3 && A && M && B && C, "gemm_nt_grouped: 1..3 problems, non-null A / M / B / C arrays");
+  OP_CHECK_ARG(epilogue == EPI_BIAS || epilogue == EPI_GEGLU || epilogue == EPI_RESID, "gemm_nt_grouped: epilogue %d", epilogue);
+  const int bn = epilogue == EPI_GEGLU ? 128 : 256;
+  if (N <= 0 || K < 128 || N % bn != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 ||
+      N * ldb >= ((int64_t)1 << 30)) {
+    op_set_error("gemm_nt_grouped: shape N=%lld K=%lld not supported by the persistent kernel", (long long)N, (long long)K);
+    return OP_ENOTSUP;
+  }
+  GroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.nprob = (int)nprob;
+  int tiles = 0;
+  double rows = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (i < nprob) {
+      OP_CHECK_ARG(M[i] > 0 && A[i] && C[i] && B[i * 2], "gemm_nt_grouped: problem %d: empty or null operand", i);
+      if (M[i] * lda >= ((int64_t)1 << 30) || M[i] * ldc >= ((int64_t)1 << 30)) {
+        op_set_error("gemm_nt_grouped: problem %d too large for 32-bit offsets", i);
+        return OP_ENOTSUP;
+      }
+      ga.A[i] = (const bf16_t*)A[i]; ga.M[i] = (int)M[i];
+      ga.B[i][0] = (const bf16_t*)B[i * 2]; ga.B[i][1] = (const bf16_t*)B[i * 2 + 1];
+      if (epilogue == EPI_GEGLU) OP_CHECK_ARG(ga.B[i][1], "gemm_nt_grouped: GeGLU needs two weights per problem");
+      ga.bias[i][0] = bias ? (const bf16_t*)bias[i * 2] : nullptr;
+      ga.C[i] = C[i]; ga.H0[i] = h0 ? (bf16_t*)h0[i] : nullptr; ga.H1[i] = h1 ? (bf16_t*)h1[i] : nullptr;
+      OP_CHECK_ARG((ga.H0[i] == nullptr) == (ga.H1[i] == nullptr) || epilogue != EPI_GEGLU, "gemm_nt_grouped: GeGLU h0/h1 both or neither");
+      ga.resid[i] = resid ? (const bf16_t*)resid[i] : nullptr;
+      if (epilogue == EPI_RESID) OP_CHECK_ARG(ga.resid[i], "gemm_nt_grouped: residual epilogue needs resid");
+      ga.gamma[i] = gamma ? (const bf16_t*)gamma[i] : nullptr;
+      ga.rowscale[i] = rowscale ? rowscale[i] : nullptr;
+      ga.rows_per_sample[i] = rows_per_sample && rows_per_sample[i] > 0 ? (int)rows_per_sample[i] : 1;
+      tiles += ceil_div(M[i], 256);
+      rows += (double)M[i];
+    } else {
+      ga.rows_per_sample[i] = 1;
+    }
+    ga.mt_end[i] = tiles;
+  }
+  ga.tiles_m = tiles;
+  ga.tiles_n = (int)(N / bn);
+  ga.lda = lda; ga.ldb = ldb; ga.ldc = ldc; ga.ldr = ldr; ga.alpha = nullptr;
+  ga.n_seg = (int)N; ga.N = (int)N; ga.K = (int)K;
+  ga.gm = ga.tiles_n <= 8 ? 1 : 8;
+  const int slot = op_prof_begin(0, 2.0 * rows * (double)N * (double)K * (epilogue == EPI_GEGLU ? 2.0 : 1.0), stream);
+  const int rc = launch256p_any(ga, epilogue, (hipStream_t)stream, T.sched == 6);
+  op_prof_end(slot, stream);
+  return rc;
+}
 
 // C[M,N] (bf16, ldc) = A^T B with A [K, M] (lda) and B [K, N] (ldb) both row-major bf16: the weight-gradient GEMM
 // dW[out,in] = dy[tokens,out]^T x[tokens,in] (autograd of nn.Linear) without transposed operand copies.

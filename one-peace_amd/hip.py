@@ -36,6 +36,7 @@ SIGNATURES = {
     "op_gemm_plan": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int64, I64, P]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
                            c_int, P, I64, I64, P]),
+    "op_gemm_nt_grouped": (c_int, [I64, P, P, I64, P, I64, P, P, I64, P, P, P, I64, P, P, P, I64, I64, c_int, I64, P]),
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
@@ -89,14 +90,15 @@ class Tuning:
         self.ablation = 0        # timing ablations of the 256x256 kernel (tools)
         self.force_splits = 0    # forced K-split count of small problems (tools)
         self.glds = 1            # 1 LDS-DMA staging, 0 register-staged operands
+        self.sched = 0           # four-wave NT launches: 0 auto, 1-5 gemm256v_kernel instruction schedule, 7 gemm256w_kernel
         self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
 
     def gemm(self):
-        fl = {2: 0, 0: 1, 1: 2, 3: 3}[self.fullline]
+        fl = {2: 0, 0: 1, 1: 2, 3: 3}.get(self.fullline, 0)
         tr = 0 if self.tail_rows == 1 else self.tail_rows + 1
         return (self.tile_mode | fl << 2 | tr << 4 | (self.gm & 31) << 7 | (self.ablation & 7) << 12 | (self.force_splits & 15) << 15
-                | (0 if self.glds else 1) << 19)
+                | (0 if self.glds else 1) << 19 | (self.sched & 7) << 20)
 
     def attn_fwd(self):
         return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1
@@ -128,7 +130,8 @@ class _LibProxy:
         elif mode >= 40:
             TUNE.gm = mode - 40
         elif mode >= 20:
-            TUNE.fullline = mode - 20
+            if 0 <= mode - 20 <= 3:  # other values were ignored by the round-1 C knob as well
+                TUNE.fullline = mode - 20
         elif mode >= 10:
             TUNE.ablation = mode - 10
         else:
@@ -290,6 +293,49 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
                             rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, TUNE.gemm(), stream()), "op_gemm_nt")
     return out
+
+
+def _ptr_array(items, n):
+    arr = (c_void_p * n)()
+    for i, t in enumerate(items or ()):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def gemm_nt_grouped(As, Ws, biases=None, outs=None, epilogue=EPI_BIAS, h0s=None, h1s=None, resids=None, gammas=None,
+                    rowscales=None, rows_per_sample=None):
+    """One launch for up to three problems out_p = epilogue(A_p @ W_p^T) with a common N, K (the per-modality FFNs of a layer).
+    As: [M_p, K] tensors with a common row stride; Ws: per problem one weight, or (wi_0, wi_1) for the GeGLU epilogue.
+    Returns the list of outputs, or None when the shape does not qualify for the persistent kernel (caller falls back)."""
+    n = len(As)
+    K = As[0].shape[1]
+    pairs = [w if isinstance(w, (tuple, list)) else (w, None) for w in Ws]
+    N = pairs[0][0].shape[0]
+    if outs is None:
+        outs = [torch.empty(a.shape[0], N, dtype=torch.bfloat16, device=a.device) for a in As]
+    lda, ldb, ldc = As[0].stride(0), pairs[0][0].stride(0), outs[0].stride(0)
+    ldr = resids[0].stride(0) if resids and resids[0] is not None else 0
+    if any(a.stride(0) != lda or a.shape[1] != K for a in As) or any(w[0].stride(0) != ldb or w[0].shape != (N, K) for w in pairs) \
+            or any(o.stride(0) != ldc for o in outs) or (ldr and any(r.stride(0) != ldr for r in resids)):
+        return None
+    flatB, flatb = [], []
+    for i, (w0, w1) in enumerate(pairs):
+        flatB += [w0, w1]
+        flatb += [biases[i] if biases else None, None]
+    Ms = (c_int64 * n)(*[a.shape[0] for a in As])
+    rps = (c_int64 * n)(*[(rows_per_sample[i] if rows_per_sample else 0) for i in range(n)])
+    for i, a in enumerate(As):
+        outs_n = 1 + (2 if h1s and h1s[i] is not None else (1 if h0s and h0s[i] is not None else 0))
+        GEMM_ALGO_BYTES[0] += 2 * (a.shape[0] * K + N * K * (2 if epilogue == EPI_GEGLU else 1)
+                                   + (a.shape[0] * N if resids and resids[i] is not None else 0)) + 2 * a.shape[0] * N * outs_n
+    GEMM_ALGO_BYTES[1] += 1
+    rc = lib().op_gemm_nt_grouped(n, _ptr_array(As, n), Ms, lda, _ptr_array(flatB, 2 * n), ldb, _ptr_array(flatb, 2 * n),
+                                  _ptr_array(outs, n), ldc, _ptr_array(h0s, n), _ptr_array(h1s, n), _ptr_array(resids, n), ldr,
+                                  _ptr_array(gammas, n), _ptr_array(rowscales, n), rps, N, K, epilogue, TUNE.gemm(), stream())
+    if rc == -95:
+        return None
+    _check(rc, "op_gemm_nt_grouped")
+    return outs
 
 
 def quant_fp8_rows(x2d):

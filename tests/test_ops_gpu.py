@@ -92,22 +92,27 @@ def test_gemm_bias(M, N, K, glds, tile_mode):
         hip.lib().op_gemm_set_staging(1)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 1536, 1536), (4099, 256, 3072), (8192, 1536, 6144)])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 128), (1000, 1536, 1536), (4099, 256, 3072), (8192, 1536, 6144), (32896, 1536, 192)])
 def test_gemm_four_wave_flavour_is_bit_identical_to_eight_waves(M, N, K):
-    """The two BK = 64 flavours of the 256x256 kernel accumulate every output element in the same order (k ascending, one MFMA
+    """Every BK = 64 flavour of the 256x256 kernel accumulates every output element in the same order (k ascending, one MFMA
     per 32 k): bias, residual (+ branch output), GeGLU (+ pre-activations) and fp32 outputs must agree bit for bit, so the
-    planner may pick either one per launch (four waves when K >= 3072) without changing results."""
+    planner may pick any of them per launch without changing results.  Four-wave kernels: round 2's gemm256w (sched 7), the
+    buffer-load / one-memory-op-per-MFMA-gap kernel gemm256v with its two instruction schedules (1, 3 = production) and the
+    persistent kernel gemm256p (6).  (Round 3 found accumulator registers read stale behind inline-asm MFMAs in a peeled-loop
+    variant of gemm256v: a few registers per wave, deterministic per binary -- this test is what catches that class.)"""
     hip = hipmod()
-    L = hip.lib()
     a = dev_bf16(rnd(M, K, seed=1))
     w, w1 = dev_bf16(rnd(N, K, seed=2, scale=K ** -0.5)), dev_bf16(rnd(N, K, seed=3, scale=K ** -0.5))
     b, gamma, res = dev_bf16(rnd(N, seed=4)), dev_bf16(rnd(N, seed=5)), dev_bf16(rnd(M, N, seed=6))
     ps = torch.rand((M + 6) // 7, device=DEV)
     outs = {}
-    old = L.op_gemm_set_tile(2)
+    T = hip.TUNE
     try:
-        for flavour in (21, 23):
-            L.op_gemm_set_tile(flavour)
+        for flavour in ("eight", 7, 1, 3, 6):
+            T.reset()
+            T.tile_mode = 2
+            T.fullline = 1 if flavour == "eight" else 3
+            T.sched = 0 if flavour == "eight" else flavour
             h0, h1, y = (torch.empty(M, N, dtype=torch.bfloat16, device=DEV) for _ in range(3))
             outs[flavour] = [
                 hip.gemm_nt(a, [w], [b]),
@@ -120,11 +125,56 @@ def test_gemm_four_wave_flavour_is_bit_identical_to_eight_waves(M, N, K):
                 outs[flavour].append(hip.gemm_nt(a, [w[:seg], w[seg:2 * seg], w[2 * seg:]], [b[:seg], None, b[:seg]], n_seg=seg, N=N))
         torch.cuda.synchronize()
     finally:
-        L.op_gemm_set_tile(22)
-        L.op_gemm_set_tile(old)
-    for i, (x, y) in enumerate(zip(outs[21], outs[23])):
-        assert torch.equal(x, y), (i, float((x.float() - y.float()).abs().max()))
-    assert_close(outs[23][0], rnd(M, K, seed=1) @ rnd(N, K, seed=2, scale=K ** -0.5).t() + rnd(N, seed=4), what="four-wave bias")
+        T.reset()
+    for flavour in (7, 1, 3, 6):
+        for i, (x, y) in enumerate(zip(outs["eight"], outs[flavour])):
+            assert torch.equal(x, y), (flavour, i, float((x.float() - y.float()).abs().max()))
+    assert_close(outs[3][0], rnd(M, K, seed=1) @ rnd(N, K, seed=2, scale=K ** -0.5).t() + rnd(N, seed=4), what="four-wave bias")
+
+
+@pytest.mark.parametrize("Ms", [(300, 257, 64), (2048, 4096, 1000), (512, 8192 + 128, 1250)])
+@pytest.mark.parametrize("persistent", [False, True])
+def test_gemm_grouped_launch_is_bit_identical_to_separate_launches(Ms, persistent):
+    """op_gemm_nt_grouped: the three modality FFNs of a layer (own rows, weights, bias, layer scale, residual, drop-path row
+    scales with their own rows-per-sample) as ONE launch, ragged row counts included, against three op_gemm_nt launches."""
+    hip = hipmod()
+    H, F = 256, 512
+    T = hip.TUNE
+    xs = [dev_bf16(rnd(m, H, seed=10 + i)) for i, m in enumerate(Ms)]
+    w0 = [dev_bf16(rnd(F, H, seed=20 + i, scale=H ** -0.5)) for i in range(3)]
+    w1 = [dev_bf16(rnd(F, H, seed=30 + i, scale=H ** -0.5)) for i in range(3)]
+    w2 = [dev_bf16(rnd(H, F, seed=40 + i, scale=F ** -0.5)) for i in range(3)]
+    b2 = [dev_bf16(rnd(H, seed=50 + i)) for i in range(3)]
+    gam = [dev_bf16(rnd(H, seed=60 + i)) for i in range(3)]
+    res = [dev_bf16(rnd(m, H, seed=70 + i)) for i, m in enumerate(Ms)]
+    rps = [3, 7, 5]
+    ps = [torch.rand(m // r + 1, device=DEV) for m, r in zip(Ms, rps)]
+
+    def bf(m, n):
+        return torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+    try:
+        T.reset()
+        ref_g, ref_o = [], []
+        for i, m in enumerate(Ms):
+            h0, h1, y = bf(m, F), bf(m, F), bf(m, H)
+            g = hip.gemm_nt(xs[i], [w0[i], w1[i]], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
+            ref_g.append((g, h0, h1))
+            o = hip.gemm_nt(g, [w2[i]], [b2[i]], epilogue=hip.EPI_RESID, resid=res[i], gamma=gam[i], rowscale=ps[i], rows_per_sample=rps[i],
+                            h0=y, splitk=False)
+            ref_o.append((o, y, hip.gemm_nt(g, [w2[i]], [b2[i]], splitk=False)))
+        T.sched = 6 if persistent else 0
+        h0s, h1s, ys = [bf(m, F) for m in Ms], [bf(m, F) for m in Ms], [bf(m, H) for m in Ms]
+        gs = hip.gemm_nt_grouped(xs, list(zip(w0, w1)), epilogue=hip.EPI_GEGLU, h0s=h0s, h1s=h1s)
+        assert gs is not None
+        os_ = hip.gemm_nt_grouped(gs, w2, biases=b2, epilogue=hip.EPI_RESID, h0s=ys, resids=res, gammas=gam, rowscales=ps, rows_per_sample=rps)
+        plain = hip.gemm_nt_grouped(gs, w2, biases=b2)
+        torch.cuda.synchronize()
+    finally:
+        T.reset()
+    for i in range(3):
+        assert torch.equal(gs[i], ref_g[i][0]) and torch.equal(h0s[i], ref_g[i][1]) and torch.equal(h1s[i], ref_g[i][2]), i
+        assert torch.equal(os_[i], ref_o[i][0]) and torch.equal(ys[i], ref_o[i][1]) and torch.equal(plain[i], ref_o[i][2]), i
+    assert hip.gemm_nt_grouped([xs[0][:, :72]], [w0[0][:, :72]]) is None  # K % 64 != 0: the caller falls back
 
 
 @pytest.mark.parametrize("M,N,K", [(1536, 1536, 8192), (384, 256, 16448 - 16448 % 64), (4608, 1536, 4096)])

@@ -2116,22 +2116,28 @@ NtDecision decide_nt(int64_t M, int64_t N, int64_t K, int epilogue, bool has_bia
   // bias / residual epilogues, applied by the fold kernel.  plan_gemm's cost model decides whether a split pays.
   d.fold_epi = (epilogue == EPI_RESID || (epilogue == EPI_BIAS && has_bias0)) && M <= 1024 && fold_layout_ok;
   const bool allow_split = ((epilogue == EPI_BIAS && !has_bias0) || d.fold_epi) && have_ws && N % 8 == 0;
-  d.plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, ws_bytes, T);
-  if (T.tile_mode == 2 && allow_256 && d.plan.tile != 256) d.plan = {256, 1, 0};
-  // Tail rows.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
-  // every CU (M = 128 x 257: 774 tiles = 3.02 rounds for N = 1536).  If dropping them saves a round, the full M-tiles run
-  // as one launch and the <= 128 leftover rows as a second, small one (128 x 128 tiles).
+  // Tail rows first.  When M is not a multiple of 256, the N-tiles of the partial last M-tile can cost a whole extra round of
+  // every CU (M = 128 x 257: 774 tiles = 3.02 rounds for N = 1536).  If dropping them saves a round, the full M-tiles run as
+  // one launch and the <= 128 leftover rows as a second, small one (128 x 128 tiles).  This is decided on the UNSPLIT plan: a
+  // K-split of the whole problem would also hide the fourth round (7 half-length rounds instead of 4) but pays fp32 slabs of the
+  // whole output for it (the K = 12 288 FFN input gradient at 32 896 tokens: 1.34 ms split against 0.87 ms tail-split, round 3).
   d.tail_split = false;
   d.m_main = M;
-  if (allow_tail_split && T.tail_rows && d.plan.tile == 256 && d.plan.splits == 1 && M > 256) {
+  const GemmPlan unsplit = plan_gemm(M, N, K, epilogue, allow_256, false, 0, T);
+  if (allow_tail_split && T.tail_rows && (unsplit.tile == 256 || (T.tile_mode == 2 && allow_256)) && M > 256) {
     const int64_t m_rem = M % 256;
     const int64_t tn = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
     const int64_t r_full = ceil_div(ceil_div(M, 256) * tn, 256), r_main = ceil_div(((M - m_rem) / 256) * tn, 256);
     if (m_rem > 0 && m_rem <= 128 && (T.tail_rows == 3 || (r_main < r_full && (T.tail_rows == 2 || K >= 1024)))) {
       d.tail_split = true;
       d.m_main = M - m_rem;
+      d.plan = unsplit;
+      if (T.tile_mode == 2 && allow_256 && d.plan.tile != 256) d.plan = {256, 1, 0};
+      return d;
     }
   }
+  d.plan = plan_gemm(M, N, K, epilogue, allow_256, allow_split, ws_bytes, T);
+  if (T.tile_mode == 2 && allow_256 && d.plan.tile != 256) d.plan = {256, 1, 0};
   return d;
 }
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
                                                            const bf16_t* __restrict__ h1, const bf16_t* __restrict__ w,
                                                            const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, bf16_t* __restrict__ dh0,
-                                                           bf16_t* __restrict__ dh1, float* __restrict__ ws, int64_t rows,
+                                                           bf16_t* __restrict__ dh1, int64_t ldd, float* __restrict__ ws, int64_t rows,
                                                            int cols) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // NW==1: [4][cols] ; NW==4: [4]
   float* red = smem;
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
           o0[j] = dg * b[j] * (cdf + a[j] * pdf);
           o1[j] = dg * ge;
         }
-        Vec8<bf16_t>::store(dh0 + base + c, o0);
-        Vec8<bf16_t>::store(dh1 + base + c, o1);
+        Vec8<bf16_t>::store(dh0 + row * ldd + c, o0);
+        Vec8<bf16_t>::store(dh1 + row * ldd + c, o1);
       }
     }
 #pragma unroll
@@ -506,9 +506,11 @@ int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b
 // forward statistics of g = gelu(h0) * h1.  Replaces the LayerNorm backward + GeGLU backward pair of the FFN
 // (one_peace/models/transformer/transformer_layer.py:64-67,111-118); g itself is not needed.
 int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* w, const float* mean, const float* rstd,
-                    void* dh0, void* dh1, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int accumulate,
+                    void* dh0, void* dh1, int64_t ldd, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int accumulate,
                     void* stream) {
   OP_CHECK_ARG(dy && h0 && h1 && dh0 && dh1 && mean && rstd, "ln_geglu_bwd: null pointer");
+  if (ldd <= 0) ldd = cols;
+  OP_CHECK_ARG(ldd >= cols && ldd % 8 == 0, "ln_geglu_bwd: output row stride %lld", (long long)ldd);
   OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192, "ln_geglu_bwd: cols=%lld unsupported", (long long)cols);
   OP_CHECK_ARG(!(dw || db) || workspace, "ln_geglu_bwd: dw/db requested without workspace");
   if (rows == 0) return OP_OK;
@@ -521,7 +523,7 @@ int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* 
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                                 \
     hipLaunchKernelGGL((ln_geglu_bwd_kernel<CH, NW>), dim3(grid), dim3(NW == 1 ? 256 : 64 * NW), sh, s,           \
                        (const bf16_t*)dy, (const bf16_t*)h0, (const bf16_t*)h1, (const bf16_t*)w, mean, rstd,      \
-                       (bf16_t*)dh0, (bf16_t*)dh1, wsk, rows, (int)cols);                                          \
+                       (bf16_t*)dh0, (bf16_t*)dh1, ldd, wsk, rows, (int)cols);                                     \
   } while (0)
   if (cols <= 512) LNG_B(1, 1);
   else if (cols <= 1024) LNG_B(2, 1);

@@ -45,7 +45,7 @@ SIGNATURES = {
     "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
     "op_resid_bwd_workspace_bytes": (I64, [I64]),
     "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, I64, I64, c_int, P]),
-    "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, P]),
+    "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, I64, P, P, P, I64, I64, c_int, P]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
     "op_geglu_bwd": (c_int, [P, P, P, P, P, I64, P]),
     "op_scale_rows": (c_int, [P, P, P, I64, P, I64, I64, P]),
@@ -459,15 +459,22 @@ def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma
     return out, dgamma, dbias
 
 
-def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False):
-    """Backward of LayerNorm_F(gelu(h0)*h1): returns dh0, dh1, dw, db (dw/db allocated unless given)."""
+def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False, need_wgrad=True, dh0=None, dh1=None):
+    """Backward of LayerNorm_F(gelu(h0)*h1): returns dh0, dh1, dw, db (dw/db allocated unless given; None with need_wgrad=False).
+    dh0 / dh1 may be given as column blocks of one wider matrix (same row stride, last dim contiguous)."""
     rows, cols = h0.shape
-    dh0, dh1 = torch.empty_like(h0), torch.empty_like(h1)
-    if dw is None:
-        dw, db, accumulate = torch.empty_like(w), torch.empty_like(w), False
-    ws = workspace(lib().op_layernorm_bwd_workspace_bytes(rows, cols), h0.device, "ln")
-    _check(lib().op_ln_geglu_bwd(ptr(dy), ptr(h0), ptr(h1), ptr(w), ptr(mean), ptr(rstd), ptr(dh0), ptr(dh1), ptr(dw), ptr(db),
-                                 ptr(ws), rows, cols, int(accumulate), stream()), "op_ln_geglu_bwd")
+    if dh0 is None:
+        dh0, dh1 = torch.empty_like(h0), torch.empty_like(h1)
+    assert dh0.stride(0) == dh1.stride(0) and dh0.stride(1) == 1 and dh1.stride(1) == 1
+    ws = None
+    if need_wgrad:
+        if dw is None:
+            dw, db, accumulate = torch.empty_like(w), torch.empty_like(w), False
+        ws = workspace(lib().op_layernorm_bwd_workspace_bytes(rows, cols), h0.device, "ln")
+    else:
+        dw = db = None
+    _check(lib().op_ln_geglu_bwd(ptr(dy), ptr(h0), ptr(h1), ptr(w), ptr(mean), ptr(rstd), ptr(dh0), ptr(dh1), dh0.stride(0),
+                                 ptr(dw), ptr(db), ptr(ws), rows, cols, int(accumulate), stream()), "op_ln_geglu_bwd")
     return dh0, dh1, dw, db
 
 

@@ -421,8 +421,9 @@ FFN_PARAMS = ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
 LAYER_PARAMS = ATTN_PARAMS + FFN_PARAMS
 
 
-def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_frag=None):
-    """x_mid = x + ps1 * g1 * out_proj(subLN(attention(LN1(x))))  on x2 [B*S, H]."""
+def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_frag=None, want_y=True):
+    """x_mid = x + ps1 * g1 * out_proj(subLN(attention(LN1(x))))  on x2 [B*S, H].  want_y: also write the branch output y1 (only the
+    gradient of gamma_1 needs it)."""
     H = x2.shape[1]
     xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
     if H % 128 == 0:
@@ -438,7 +439,7 @@ def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_
         aln, mean_a, rstd_a = hip.layernorm_fwd(attn, P["aln_w"], P["aln_b"], want_stats=keep)
     else:
         aln, mean_a, rstd_a = attn, None, None
-    y1 = torch.empty_like(x2) if keep else None
+    y1 = torch.empty_like(x2) if keep and want_y else None
     x_mid = hip.gemm_nt(aln, [P["wo"]], [P["bo"]], epilogue=hip.EPI_RESID, resid=x2, gamma=P["g1"], rowscale=ps1,
                         rows_per_sample=S, h0=y1)
     if not keep:
@@ -447,7 +448,7 @@ def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_
                        rstd_a=rstd_a, y1=y1)
 
 
-def _ffn_forward(x_mid, P, S, ps2, keep):
+def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True):
     """out = x_mid + ps2 * g2 * W2(LN_F(gelu(LN2(x_mid) W0^T) * (LN2(x_mid) W1^T)))  on x_mid [B*S, H]."""
     xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
     Fd = P["w0"].shape[0]
@@ -466,7 +467,7 @@ def _ffn_forward(x_mid, P, S, ps2, keep):
         gln, mean_f, rstd_f = hip.layernorm_fwd(g, P["fln_w"], P["fln_b"], want_stats=keep)
     else:
         gln, mean_f, rstd_f = g, None, None
-    y2 = torch.empty_like(x_mid) if keep else None
+    y2 = torch.empty_like(x_mid) if keep and want_y else None
     if fp8:
         gq, gs = hip.quant_fp8_rows(gln)
         w2q, w2s = _fp8_weight(P["w2"])
@@ -519,15 +520,37 @@ def _return_grads(names, params, G, direct):
     return out
 
 
-def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G):
-    """Gradient of  resid + ps * gamma * (y)  w.r.t. the branch output, gamma and the last Linear's bias in one pass."""
-    names = (gname, bname) if gamma is not None else (bname,)
-    tgt, acc = _targets(direct, *names)
-    dgamma = None if gamma is None else (tgt[0] if acc else True)
-    dy, dg, dbias = hip.resid_bwd(dout, y if gamma is not None else None, gamma, ps, S, dgamma=dgamma,
-                                  dbias=tgt[-1] if acc else True, accumulate=acc)
-    _finish(direct, G, names, (dg, dbias) if gamma is not None else (dbias,), acc)
+def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs):
+    """Gradient of  resid + ps * gamma * (y)  w.r.t. the branch output and -- where they are wanted -- gamma and the last
+    Linear's bias, in one pass."""
+    names = tuple(n for n, present in ((gname, gamma is not None), (bname, True)) if present and needs.get(n))
+    tgt, acc = _targets(direct, *names) if names else ([], False)
+    t = dict(zip(names, tgt))
+    dgamma = (t[gname] if acc else True) if gname in t else None
+    dbias = (t[bname] if acc else True) if bname in t else None
+    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc)
+    _finish(direct, G, names, tuple({gname: dg, bname: db}[n] for n in names), acc)
     return dy
+
+
+def _adjacent_grads(direct, names):
+    """The parameters `names` in the memory order of their flat gradient views when those views tile ONE contiguous range
+    (distributed.FlatParameters lays a layer's decayed weights out back to back), else None.  A merged weight-gradient GEMM
+    then writes all of them with one launch (and one split-K fold) instead of one launch each."""
+    if not all(n in direct for n in names):
+        return None
+    order = sorted(names, key=lambda n: direct[n].grad.data_ptr())
+    for a, b in zip(order, order[1:]):
+        ga, gb = direct[a].grad, direct[b].grad
+        if not ga.is_contiguous() or ga.data_ptr() + ga.numel() * ga.element_size() != gb.data_ptr() or ga.shape[1:] != gb.shape[1:]:
+            return None
+    return order
+
+
+def _span(direct, order):
+    """One [sum rows, cols] view over the adjacent gradient views of `order`."""
+    g0 = direct[order[0]].grad
+    return torch.as_strided(g0, (sum(direct[n].grad.shape[0] for n in order), g0.shape[1]), (g0.shape[1], 1))
 
 
 def _weight_grad_fn(ctx, G):
@@ -575,12 +598,18 @@ class AttnBranchFn(torch.autograd.Function):
         bias_img = bias.image.detach() if bias is not None else None
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
+        needs = dict(zip(ATTN_PARAMS, ctx.needs_input_grad[7:]))
         x_mid, acts = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, keep,
-                                    bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None)
+                                    bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None, want_y=needs["g1"])
         ctx.bias, ctx.dims, ctx.n_params = bias, (B, S, H, heads, scale), len(params)
         ctx.direct = ()
         if need_grad:
             _register_direct(ctx, ATTN_PARAMS, params, ctx.needs_input_grad[7:])
+        if keep:  # activations only a frozen parameter's gradient would read are not kept
+            if not needs["wo"]:
+                acts["aln"] = None if P["aln_w"] is not None else acts["aln"]
+            if not (needs["wq"] or needs["wk"] or needs["wv"]):
+                acts["xln1"] = None
         _save(ctx, keep, acts, x2, key_pad, ps, *params)
         return x_mid.view(B, S, H)
 
@@ -590,12 +619,15 @@ class AttnBranchFn(torch.autograd.Function):
         params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
         B, S, H, heads, scale = ctx.dims
         P = dict(zip(ATTN_PARAMS, params))
+        # what autograd actually asks for (frozen parameters -- stage-2 audio-language pretraining freezes the whole attention
+        # branch, one_peace_pretrain.py:98-104 -- cost no weight-gradient GEMM, column sum or LayerNorm parameter reduction)
+        needs = {n: bool(ng) and q is not None for n, q, ng in zip(ATTN_PARAMS, params, ctx.needs_input_grad[7:])}
+        need_x = bool(ctx.needs_input_grad[0])
         bias = ctx.bias
         bias_img = bias.image.detach() if bias is not None else None
-        biasT = bias.imageT if bias is not None else None
         want_dbias = bias is not None and bias.image.requires_grad
         if ctx.act_names is not None:
-            A = _restore(ctx, saved_acts, ("mean_a", "rstd_a"))
+            A = _restore(ctx, saved_acts, ("mean_a", "rstd_a", "y1", "xln1", "aln"))
         else:  # recompute (the reference's checkpoint_activations behaviour)
             _, A = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, True,
                                  bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None)
@@ -604,42 +636,75 @@ class AttnBranchFn(torch.autograd.Function):
             dx_mid = dx_mid.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], ps, S, "g1", "bo", direct, G)
-        weight_grad("wo", dy1, A["aln"])
-        daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
-        if P["aln_w"] is not None:
-            (tw, tb), acc = _targets(direct, "aln_w", "aln_b")
-            dattn, dw_, db_ = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"], A["rstd_a"], dw=tw, db=tb,
-                                                accumulate=acc)
-            _finish(direct, G, ("aln_w", "aln_b"), (dw_, db_), acc)
-        else:
-            dattn = daln
-        dqkv, _ = _attn_backward(A["qkv"], dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, biasT, key_pad,
-                                 bias.grad_accumulator(B) if want_dbias else None,
-                                 bias.frag if bias is not None and S <= 384 else None)
-        (tq, tv), acc = _targets(direct, "bq", "bv")
-        if H % 8 == 0:
-            sums = hip.colsum_segments(dqkv, H, [tq, None, tv] if acc else None, accumulate=acc)
-            _finish(direct, G, ("bq", "bv"), (sums[0], sums[2]), acc)
-        else:
-            dbias_cols = hip.colsum(dqkv)
-            G["bq"], G["bv"] = dbias_cols[:H], dbias_cols[2 * H:]
-        if direct.keys() & {"wq", "wk", "wv"}:
-            for i, n in enumerate(("wq", "wk", "wv")):
-                weight_grad(n, dqkv[:, i * H:(i + 1) * H], A["xln1"])
-        else:
-            dW = wgrad(dqkv, A["xln1"])  # [3H, H]
-            G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
-        dxln1 = hip.gemm_nt(dqkv, [_transposed((P["wq"], P["wk"], P["wv"]))])
-        (tw, tb), acc = _targets(direct, "ln1_w", "ln1_b")
-        dx, dw_, db_ = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"], add=dx_mid, dw=tw, db=tb,
-                                         accumulate=acc)
-        _finish(direct, G, ("ln1_w", "ln1_b"), (dw_, db_), acc)
+        dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], ps, S, "g1", "bo", direct, G, needs)
+        if needs["wo"]:
+            weight_grad("wo", dy1, A["aln"])
+        upstream = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b")
+        dx = None
+        if need_x or want_dbias or any(needs[n] for n in upstream):
+            daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
+            if P["aln_w"] is not None:
+                want = needs["aln_w"] or needs["aln_b"]
+                (tw, tb), acc = _targets(direct, "aln_w", "aln_b") if want else ((None, None), False)
+                dattn, dw_, db_ = hip.layernorm_bwd(daln, A["attn"], P["aln_w"], P["aln_b"], A["mean_a"], A["rstd_a"], dw=tw, db=tb,
+                                                    accumulate=acc, need_wgrad=want)
+                if want:
+                    _finish(direct, G, ("aln_w", "aln_b"), (dw_, db_), acc)
+            else:
+                dattn = daln
+            # column order of the packed q|k|v gradient: the memory order of the three weights' flat gradient views when those
+            # are adjacent (then ONE weight-gradient launch writes all three), q, k, v otherwise
+            qkv_names = ("wq", "wk", "wv")
+            order = _adjacent_grads(direct, qkv_names) if all(needs[n] for n in qkv_names) and H % 8 == 0 else None
+            cols = tuple(order) if order else qkv_names
+            slot = {n: i for i, n in enumerate(cols)}
+            qkv = A["qkv"]
+            dqkv = torch.empty_like(qkv)
+            dparts = {n: dqkv[:, slot[n] * H:(slot[n] + 1) * H] for n in qkv_names}
+            _attn_backward(qkv, dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, bias.imageT if bias is not None else None,
+                           key_pad, bias.grad_accumulator(B) if want_dbias else None,
+                           bias.frag if bias is not None and S <= 384 else None, dparts["wq"], dparts["wk"], dparts["wv"])
+            bias_of = {"wq": "bq", "wv": "bv"}
+            bnames = tuple(bias_of[n] for n in cols if n in bias_of and needs[bias_of[n]])
+            if bnames:
+                tgt, acc = _targets(direct, *bnames)
+                if H % 8 == 0:
+                    outs = [None, None, None]
+                    for n, t_ in zip(bnames, tgt):
+                        outs[slot["wq" if n == "bq" else "wv"]] = t_ if acc else torch.empty(H, dtype=dqkv.dtype, device=dqkv.device)
+                    hip.colsum_segments(dqkv, H, outs, accumulate=acc)
+                    _finish(direct, G, bnames, tuple(outs[slot["wq" if n == "bq" else "wv"]] for n in bnames), acc)
+                else:
+                    sums = hip.colsum(dqkv)
+                    for n in bnames:
+                        i = slot["wq" if n == "bq" else "wv"]
+                        G[n] = sums[i * H:(i + 1) * H]
+            if order:  # one launch, one fold: dW[3H, H] straight into the three adjacent flat gradient views
+                wgrad(dqkv, A["xln1"], out=_span(direct, order), accumulate=True)
+                for n in order:
+                    _direct_grad_done(direct[n])
+            elif any(n in direct for n in qkv_names) or not all(needs[n] for n in qkv_names):
+                for n in qkv_names:
+                    if needs[n]:
+                        weight_grad(n, dparts[n], A["xln1"])
+            else:
+                dW = wgrad(dqkv, A["xln1"])  # [3H, H]
+                G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
+            if need_x or needs["ln1_w"] or needs["ln1_b"]:
+                dxln1 = hip.gemm_nt(dqkv, [_transposed(tuple(P[n] for n in cols))])
+                want = needs["ln1_w"] or needs["ln1_b"]
+                (tw, tb), acc = _targets(direct, "ln1_w", "ln1_b") if want else ((None, None), False)
+                dx, dw_, db_ = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"], add=dx_mid, dw=tw, db=tb,
+                                                 accumulate=acc, need_wgrad=want)
+                if want:
+                    _finish(direct, G, ("ln1_w", "ln1_b"), (dw_, db_), acc)
+        if dx is None and need_x:  # nothing upstream of the residual wanted a gradient: only the skip connection carries one
+            dx = dx_mid
         grads = _return_grads(ATTN_PARAMS, params, G, direct)
         dimg = None
         if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
             dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
-        return (dx.view(B, S, H), dimg, None, None, None, None, None, *grads)
+        return (dx.view(B, S, H) if dx is not None else None, dimg, None, None, None, None, None, *grads)
 
 
 class FfnBranchFn(torch.autograd.Function):
@@ -653,11 +718,17 @@ class FfnBranchFn(torch.autograd.Function):
         x2 = x.reshape(B * S, H)
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
-        out, acts = _ffn_forward(x2, P, S, ps, keep)
+        needs = dict(zip(FFN_PARAMS, ctx.needs_input_grad[3:]))
+        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"])
         ctx.dims, ctx.n_params = (B, S, H), len(params)
         ctx.direct = ()
         if need_grad:
             _register_direct(ctx, FFN_PARAMS, params, ctx.needs_input_grad[3:])
+        if keep:
+            if not needs["w2"] and P["fln_w"] is not None:
+                acts["gln"] = None
+            if not (needs["w0"] or needs["w1"]):
+                acts["xln2"] = None
         _save(ctx, keep, acts, x2, ps, *params)
         return out.view(B, S, H)
 
@@ -667,8 +738,10 @@ class FfnBranchFn(torch.autograd.Function):
         params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
         B, S, H = ctx.dims
         P = dict(zip(FFN_PARAMS, params))
+        needs = {n: bool(ng) and q is not None for n, q, ng in zip(FFN_PARAMS, params, ctx.needs_input_grad[3:])}
+        need_x = bool(ctx.needs_input_grad[0])
         if ctx.act_names is not None:
-            A = _restore(ctx, saved_acts, ("mean_f", "rstd_f"))
+            A = _restore(ctx, saved_acts, ("mean_f", "rstd_f", "y2", "gln", "xln2"))
         else:
             _, A = _ffn_forward(x_mid, P, S, ps, True)
         N = B * S
@@ -678,39 +751,54 @@ class FfnBranchFn(torch.autograd.Function):
             dout2 = dout2.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy2 = _resid_backward(dout2, A["y2"], P["g2"], ps, S, "g2", "b2", direct, G)
-        weight_grad("w2", dy2, A["gln"])
-        dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
-        if P["fln_w"] is not None:  # sub-LayerNorm(F) and GeGLU backward in one pass; g is recomputed from h0, h1
-            (tw, tb), acc = _targets(direct, "fln_w", "fln_b")
-            dh0, dh1, dw_, db_ = hip.ln_geglu_bwd(dgln, A["h0"], A["h1"], P["fln_w"], A["mean_f"], A["rstd_f"], dw=tw, db=tb,
-                                                  accumulate=acc)
-            _finish(direct, G, ("fln_w", "fln_b"), (dw_, db_), acc)
-        else:
-            dh0, dh1 = hip.geglu_bwd(dgln, A["h0"], A["h1"])
-        if ("w0" in direct and "w1" in direct) or (USE_TN_WGRAD and N >= 64 and hip.gemm_tn_supported(wgrad_tn_rows(N), Fd, H, Fd, H)):
-            weight_grad("w0", dh0, A["xln2"])
-            weight_grad("w1", dh1, A["xln2"])
-        else:
-            xln2T = _t_pad(A["xln2"])
-            dhT = torch.empty(2 * Fd, xln2T.shape[1], dtype=dh0.dtype, device=dh0.device)  # [dh0^T ; dh1^T] -> one GEMM
-            if xln2T.shape[1] != N:
-                dhT[:, N:].zero_()
-            hip.transpose(dh0, dhT[:Fd])
-            hip.transpose(dh1, dhT[Fd:])
-            dW01 = _wgrad(dhT, xln2T)
-            G["w0"], G["w1"] = dW01[:Fd], dW01[Fd:]
-        dxln2 = hip.gemm_nt(dh0, [_transposed(P["w0"])])
-        hip.gemm_nt(dh1, [_transposed(P["w1"])], out=dxln2, epilogue=hip.EPI_RESID, resid=dxln2)
-        (tw, tb), acc = _targets(direct, "ln2_w", "ln2_b")
-        dx, dw_, db_ = hip.layernorm_bwd(dxln2, x_mid, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"], add=dout2, dw=tw, db=tb,
-                                         accumulate=acc)
-        _finish(direct, G, ("ln2_w", "ln2_b"), (dw_, db_), acc)
+        dy2 = _resid_backward(dout2, A["y2"], P["g2"], ps, S, "g2", "b2", direct, G, needs)
+        if needs["w2"]:
+            weight_grad("w2", dy2, A["gln"])
+        dx = None
+        if need_x or any(needs[n] for n in ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b")):
+            dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
+            # dh0 | dh1 as the two halves of ONE [N, 2F] matrix, in the memory order of the two weights' flat gradient views:
+            # one weight-gradient launch (288 output tiles, one fold) when those views are adjacent, and always one K = 2F
+            # input-gradient GEMM instead of two K = F launches chained through a residual epilogue
+            order = _adjacent_grads(direct, ("w0", "w1")) if needs["w0"] and needs["w1"] and Fd % 8 == 0 else None
+            cols = tuple(order) if order else ("w0", "w1")
+            dh = torch.empty(N, 2 * Fd, dtype=dgln.dtype, device=dgln.device)
+            dpart = {n: dh[:, i * Fd:(i + 1) * Fd] for i, n in enumerate(cols)}
+            if P["fln_w"] is not None:  # sub-LayerNorm(F) and GeGLU backward in one pass; g is recomputed from h0, h1
+                want = needs["fln_w"] or needs["fln_b"]
+                (tw, tb), acc = _targets(direct, "fln_w", "fln_b") if want else ((None, None), False)
+                _, _, dw_, db_ = hip.ln_geglu_bwd(dgln, A["h0"], A["h1"], P["fln_w"], A["mean_f"], A["rstd_f"], dw=tw, db=tb,
+                                                  accumulate=acc, need_wgrad=want, dh0=dpart["w0"], dh1=dpart["w1"])
+                if want:
+                    _finish(direct, G, ("fln_w", "fln_b"), (dw_, db_), acc)
+            else:
+                d0, d1 = hip.geglu_bwd(dgln, A["h0"], A["h1"])
+                dpart["w0"].copy_(d0)
+                dpart["w1"].copy_(d1)
+            if order:
+                wgrad(dh, A["xln2"], out=_span(direct, order), accumulate=True)
+                for n in order:
+                    _direct_grad_done(direct[n])
+            else:
+                for n in ("w0", "w1"):
+                    if needs[n]:
+                        weight_grad(n, dpart[n], A["xln2"])
+            if need_x or needs["ln2_w"] or needs["ln2_b"]:
+                dxln2 = hip.gemm_nt(dh, [_transposed(tuple(P[n] for n in cols))])
+                want = needs["ln2_w"] or needs["ln2_b"]
+                (tw, tb), acc = _targets(direct, "ln2_w", "ln2_b") if want else ((None, None), False)
+                dx, dw_, db_ = hip.layernorm_bwd(dxln2, x_mid, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"], add=dout2, dw=tw, db=tb,
+                                                 accumulate=acc, need_wgrad=want)
+                if want:
+                    _finish(direct, G, ("ln2_w", "ln2_b"), (dw_, db_), acc)
+        if dx is None and need_x:
+            dx = dout2
         grads = _return_grads(FFN_PARAMS, params, G, direct)
-        return (dx.view(B, S, H), None, None, *grads)
+        return (dx.view(B, S, H) if dx is not None else None, None, None, *grads)
 
 
-def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag=None):
+def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag, dq, dk, dv):
+    """Attention backward; dq / dk / dv: [N, H] column blocks of one packed [N, 3H] gradient matrix (any block order)."""
     H = heads * 64
     dev = qkv.device
     Spad = hip.attn_spad(S)
@@ -718,11 +806,8 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
     L = hip.lib()
     hip._check(L.op_attn_bwd_delta(hip.ptr(dattn), hip.ptr(attn), dattn.stride(0), hip.ptr(delta), B, S, Spad, heads,
                                    hip.stream()), "op_attn_bwd_delta")
-    dqkv = torch.empty_like(qkv)
-    dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     hip.attn_bwd_launch(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, bias_img, biasT, key_pad, lse, delta, dq, dk,
-                        dv, 3 * H, dbias_acc, B, S, Spad, heads, scale, bias_frag)
-    return dqkv, dbias_acc
+                        dv, dq.stride(0), dbias_acc, B, S, Spad, heads, scale, bias_frag)
 
 
 def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):

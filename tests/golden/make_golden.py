@@ -213,10 +213,12 @@ PRETRAIN_AL_ENC = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_hea
 PRETRAIN_AL_DEC = dict(embed_dim=64, ffn_embed_dim=128, layers=1, attention_heads=1, use_image_moe=False, use_attn_bias=False)
 
 
-def pretrain_al_fixture():
+def pretrain_al_fixture(stage2=False):
     """The audio-language pretraining objective (ATC + three DCL terms, audio_text_pretrain_loss.py:73-157): frozen text
     teacher, audio / joint 'al' students with preserve ids, decoder with the spec-less fixed-position audio adapter and
-    without layer scale (pretrain_al_3B.yaml:138-176)."""
+    without layer scale (pretrain_al_3B.yaml:138-176).  stage2: the same with `stage2_pretrain: true`
+    (one_peace_pretrain.py:98-104: text_proj and the encoder frozen except the audio adapter, audio_layer_norm and every
+    layer's audio_ffn) -> micro_pretrain_al_stage2.pt: which parameters receive a gradient, and those gradients."""
     from types import SimpleNamespace
     pm = R.ref("one_peace.models.one_peace.one_peace_pretrain")
     crit_mod = R.ref("one_peace.criterions.audio_text_pretrain_loss")
@@ -227,7 +229,7 @@ def pretrain_al_fixture():
     dec.audio_adapter.bucket_size = 256
     dec.use_layer_scale = False
     cfg = SimpleNamespace(encoder=R.make_cfg(**PRETRAIN_AL_ENC).encoder, decoder=dec, copy_rel_pos_table=False,
-                          reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
+                          reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=bool(stage2))
     torch.manual_seed(0)
     m = pm.OnePeacePretrainModel(cfg, R.TinyDictionary(vocab))
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -255,8 +257,12 @@ def pretrain_al_fixture():
             "encoder_wrapper.fusion_model.layers.0.self_attn.q_proj.weight"}
     fx = dict(enc=PRETRAIN_AL_ENC, dec=PRETRAIN_AL_DEC, vocab=vocab, shapes=shapes, net_input=ni, loss=loss.detach(),
               log={k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in log.items()}, grads=grads_summary(m, keep))
-    torch.save(fx, os.path.join(HERE, "micro_pretrain_al.pt"))
-    print("pretrain al: loss %.6f " % loss.item(), {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
+    if stage2:
+        fx["trainable"] = sorted(n for n, q in m.named_parameters() if q.requires_grad)
+        fx["with_grad"] = sorted(n for n, q in m.named_parameters() if q.grad is not None)
+    torch.save(fx, os.path.join(HERE, "micro_pretrain_al_stage2.pt" if stage2 else "micro_pretrain_al.pt"))
+    print("pretrain al%s: loss %.6f " % (" (stage 2)" if stage2 else "", loss.item()),
+          {k: round(float(v), 5) for k, v in log.items() if "loss" in k})
 
 
 DEEP = dict(embed_dim=1536, ffn_embed_dim=6144, layers=8, attention_heads=24, image_rel_bucket_size=16,
@@ -286,6 +292,25 @@ def deep_vision_fixture():
               feats_head=feats[:, :4].detach().clone(), grads=grads)
     torch.save(fx, os.path.join(HERE, "deep_vision.pt"))
     print("deep vision: logits norm %.4f, %d grads" % (float(logits.norm()), len(fx["grads"])))
+
+
+DEEP40 = dict(DEEP, layers=40)
+
+
+def deep_vision40_fixture():
+    """The reference's FULL-DEPTH image tower: 40 layers at the 4B layer dimensions (the vision branch of ONE-PEACE-4B, 1.5 B
+    parameters, BASELINE configs[1]), one 256^2 image, forward only (2 s on CPU): the normalised CLS embedding, three probe rows
+    of the final features and the residual-stream norm after the last layer.  Weights are the deterministic synthetic ones of
+    oracle/synth.py and are never stored."""
+    m, shapes = build_ref_model(DEEP40, 1000, head_type="image")
+    imgs = synth.synth_inputs(1, image_res=256, vocab=1000)["src_images"]
+    with torch.no_grad():
+        logits = m(src_images=imgs, encoder_type="image")
+        feats = m.encoder_wrapper(src_images=imgs, encoder_type="image")[1]
+    fx = dict(cfg=DEEP40, vocab=1000, nparams=sum(int(torch.tensor(v).prod()) for v in shapes.values()), batch=1, image_res=256,
+              logits=logits.detach(), feats_rows=feats[0, [0, 1, 128, 256]].detach().clone(), feats_norm=feats.double().norm().float())
+    torch.save(fx, os.path.join(HERE, "deep_vision40.pt"))
+    print("deep vision 40: logits norm %.4f, feats norm %.4f" % (float(logits.norm()), float(fx["feats_norm"])))
 
 
 OPTIM = dict(lr=[1e-3, 2e-3, 1.5e-3], betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, layer_decay=0.8, clip_norm=0.7)
@@ -335,16 +360,19 @@ def optim_fixture():
 
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
-    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep"):
-        {"optim": optim_fixture, "deep": deep_vision_fixture}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep", "stage2", "deep40"):
+        {"optim": optim_fixture, "deep": deep_vision_fixture, "stage2": lambda: pretrain_al_fixture(stage2=True),
+         "deep40": deep_vision40_fixture}[sys.argv[1]]()
         sys.exit(0)
     micro_fixture()
     tiny_text_fixture()
     layer_fixture()
     pretrain_fixture()
     pretrain_al_fixture()
+    pretrain_al_fixture(stage2=True)
     optim_fixture()
     deep_vision_fixture()
+    deep_vision40_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

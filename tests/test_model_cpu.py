@@ -184,7 +184,7 @@ def test_hub_process_audio_follows_reference_collation(golden_dir):
     assert torch.allclose(wavs[2], torch.nn.functional.layer_norm(clips[2], clips[2].shape)[: 16000 * 15])
 
 
-def _build_pretrain(fx, audio_language=False):
+def _build_pretrain(fx, audio_language=False, stage2=False):
     from types import SimpleNamespace
     from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel
     from one_peace_amd.unify_model_config import one_peace_encoder_config
@@ -200,7 +200,7 @@ def _build_pretrain(fx, audio_language=False):
         dec.audio_adapter.abs_pos_type = "fixed"
         dec.audio_adapter.bucket_size = 256
         dec.use_layer_scale = False
-    cfg = SimpleNamespace(encoder=enc, decoder=dec, reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=False)
+    cfg = SimpleNamespace(encoder=enc, decoder=dec, reset_logit_scale=False, logit_scale_init=1 / 0.07, stage2_pretrain=stage2)
     return load_synth(OnePeacePretrainModel(cfg, TinyDictionary(fx["vocab"])), fx["shapes"]).eval()
 
 
@@ -263,6 +263,35 @@ def test_audio_language_pretraining_objective_matches_reference(golden_dir):
         elif not k.endswith("#rows4"):
             assert torch.allclose(named[k].grad, v, atol=2e-5, rtol=2e-4), k
     assert checked > 40
+
+
+def test_stage2_audio_language_pretraining_freezes_what_the_reference_freezes(golden_dir):
+    """`stage2_pretrain: true` (one_peace_pretrain.py:98-104): text_proj and the whole encoder frozen except the audio adapter,
+    audio_layer_norm and every layer's audio_ffn.  tests/golden/micro_pretrain_al_stage2.pt (written by the unmodified reference):
+    the same set of parameters is trainable here, the same set receives a gradient, the loss is unchanged and every stored
+    gradient matches."""
+    from one_peace_amd.criterions.pretrain import AudioTextPretrainLossCriterion
+    fx = torch.load(os.path.join(golden_dir, "micro_pretrain_al_stage2.pt"), weights_only=False)
+    m = _build_pretrain(fx, audio_language=True, stage2=True)
+    assert sorted(n for n, q in m.named_parameters() if q.requires_grad) == fx["trainable"]
+    frozen = [n for n, q in m.named_parameters() if not q.requires_grad]
+    assert any("self_attn.q_proj" in n for n in frozen) and any("text_ffn" in n for n in frozen) and "text_proj.weight" in frozen
+    assert not any("audio_ffn" in n or "audio_adapter" in n or n.startswith("decoder_") for n in frozen)
+    crit = AudioTextPretrainLossCriterion(None, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0)
+    loss, _, log = crit(m, {"net_input": fx["net_input"], "nsentences": 4})
+    assert abs(float(loss) - float(fx["loss"])) < 2e-5 * abs(float(fx["loss"]))
+    m.zero_grad()
+    loss.backward()
+    named = dict(m.named_parameters())
+    assert sorted(n for n, q in named.items() if q.grad is not None) == fx["with_grad"]
+    checked = 0
+    for k, v in fx["grads"].items():
+        if k.endswith("#norm"):
+            assert abs(float(named[k[:-5]].grad.double().norm()) - float(v)) <= 2e-4 * max(float(v), 1e-3), k
+            checked += 1
+        elif not k.endswith("#rows4"):
+            assert torch.allclose(named[k].grad, v, atol=2e-5, rtol=2e-4), k
+    assert checked > 30
 
 
 def test_flat_parameter_groups_follow_reference_param_groups(golden_dir):

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 3: the GPU test suite + a short bench of the headline config in one call (argument: output sub-directory)
+d=gpurun_out/${1:-r3}
+mkdir -p $d
+timeout 1500 python -m pytest tests -m gpu -x -q > $d/pytest.txt 2>&1; tail -15 $d/pytest.txt
+timeout 400 python bench.py --steps 8 --warmup 3 --no-cpu-baseline > $d/bench.txt 2>&1
+tail -1 $d/bench.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'], d['roofline']['frac'], d['roofline']['launches'])" || tail -5 $d/bench.txt

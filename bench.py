@@ -54,7 +54,7 @@ class _Dict:
         return 1
 
 
-def build_model(layers, device, recompute=False, head="val", image_grid=16):
+def build_model(layers, device, recompute=False, head="val", image_grid=16, extra=None):
     """ONE-PEACE-4B encoder as the retrieval model (contrastive heads) with the FFN sets of `head` ('val': text + image +
     audio, 'vl': text + image, 'image': image only); image_grid = patches per side (16: 256^2, 28: 448^2, 32: 512^2)."""
     from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
@@ -63,6 +63,7 @@ def build_model(layers, device, recompute=False, head="val", image_grid=16):
               layer_scale_init_value=1e-6, audio_bucket_size=512, checkpoint_activations=recompute)
     if image_grid != 16:  # larger grid: position / relative-position buckets sized for it (ViT-style resolution change)
         kw.update(image_bucket_size=image_grid, image_rel_bucket_size=image_grid)
+    kw.update(extra or {})
     enc = one_peace_encoder_config(**kw)
     cfg = SimpleNamespace(encoder=enc, copy_rel_pos_table=False)
     with torch.device(device):
@@ -86,6 +87,61 @@ def build_pretrain_vl_model(layers, device, recompute=False):
     with torch.device(device):
         model = OnePeacePretrainModel(cfg, _Dict())
     return model.to(torch.bfloat16).train()
+
+
+def build_pretrain_al_model(layers, device, recompute=False, stage2=True):
+    """pretrain_al_3B.yaml: the 4B encoder with text + audio towers, the 2-layer 768-wide decoder with the spec-less fixed-position
+    audio adapter and no layer scale, `stage2_pretrain: true` (one_peace_pretrain.py:98-104: only the audio adapter, the audio
+    FFNs and audio_layer_norm of the encoder train; text_proj frozen)."""
+    from one_peace_amd.one_peace.one_peace_pretrain import OnePeacePretrainModel
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    enc = one_peace_encoder_config(embed_dim=H, ffn_embed_dim=FFN, layers=layers, attention_heads=HEADS, drop_path_rate=0.4,
+                                   layer_scale_init_value=1e-6, use_image_moe=False, audio_bucket_size=512,
+                                   checkpoint_activations=recompute)
+    dec = one_peace_encoder_config(embed_dim=768, ffn_embed_dim=2048, layers=2, attention_heads=12, drop_path_rate=0.0,
+                                   use_image_moe=False, checkpoint_activations=recompute)
+    dec.text_adapter.use_attn_bias = dec.audio_adapter.use_attn_bias = False
+    dec.audio_adapter.feature_encoder_spec = None
+    dec.audio_adapter.abs_pos_type = "fixed"
+    dec.audio_adapter.bucket_size = 256
+    dec.use_layer_scale = False
+    cfg = SimpleNamespace(encoder=enc, decoder=dec, copy_rel_pos_table=False, reset_logit_scale=True,
+                          logit_scale_init=1 / 0.07, stage2_pretrain=stage2)
+    with torch.device(device):
+        model = OnePeacePretrainModel(cfg, _Dict())
+    return model.to(torch.bfloat16).train()
+
+
+def add_pretrain_al_masks(batch, seed):
+    """Preserve ids / mask indices of the audio-language stage with the mask ratios of pretrain_al_3B.yaml:12-14 (position 0 = CLS
+    is always kept; synthetic clips have no padding)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tok = batch["src_tokens"].cpu()
+    b = tok.shape[0]
+    dev = batch["src_tokens"].device
+
+    def make(valid, ratio):
+        S = valid.shape[1]
+        rows, mask = [], torch.zeros(b, S, dtype=torch.bool)
+        for i in range(b):
+            cand = torch.nonzero(valid[i, 1:]).flatten() + 1
+            n_mask = int(len(cand) * ratio)
+            perm = cand[torch.randperm(len(cand), generator=g)]
+            mask[i, perm[:n_mask]] = True
+            rows.append(torch.cat([torch.zeros(1, dtype=torch.long), perm[n_mask:].sort().values]))
+        K = max(len(r) for r in rows)
+        ids = torch.full((b, K), -1, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = r
+        return ids.to(dev), mask.to(dev)
+    text_valid = torch.cat([torch.ones(b, 1, dtype=torch.bool), tok.ne(1)], dim=1)
+    audio_valid = ~batch["audio_padding_masks"].cpu()
+    out = dict(batch)
+    out["audio_preserve_ids"], out["audio_mask_indices"] = make(audio_valid, 0.55)
+    out["al_text_preserve_ids"], out["al_text_mask_indices"] = make(text_valid, 0.4)
+    out["al_audio_preserve_ids"], out["al_audio_mask_indices"] = make(audio_valid, 0.45)
+    out.pop("src_images", None)
+    return out
 
 
 def add_pretrain_masks(batch, seed):
@@ -120,23 +176,23 @@ def add_pretrain_masks(batch, seed):
     return out
 
 
-def synthetic_batch(b, device, seed, res=256, audio_seconds=None, text=True):
+def synthetic_batch(b, device, seed, res=256, audio_seconds=None, text=True, text_len=63, dtype=torch.bfloat16):
     """SURVEY.md 8d synthetic inputs: tokens uniform in [4, 50264] with r % 8 trailing pads, N(0,1) pixels / waveforms."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     out = {}
     if text:
-        tok = torch.randint(4, 50265, (b, 63), generator=g)
+        tok = torch.randint(4, 50265, (b, text_len), generator=g)
         for i in range(b):
             k = i % 8
             if k:
-                tok[i, 63 - k:] = 1
+                tok[i, text_len - k:] = 1
         out["src_tokens"] = tok.to(device)
-    out["src_images"] = torch.randn(b, 3, res, res, generator=g).to(device).to(torch.bfloat16)
+    out["src_images"] = torch.randn(b, 3, res, res, generator=g).to(device).to(dtype)
     audio_S = 0
     if audio_seconds:
         n_wav = int(16000 * audio_seconds)
         audio_S = audio_frames(n_wav) + 1
-        out["src_audios"] = torch.randn(b, n_wav, generator=g).to(device).to(torch.bfloat16)
+        out["src_audios"] = torch.randn(b, n_wav, generator=g).to(device).to(dtype)
         out["audio_padding_masks"] = torch.zeros(b, audio_S, dtype=torch.bool, device=device)
     return out, audio_S
 
@@ -223,6 +279,7 @@ def auto_batch(device, tokens_per_sample, layers, recompute, candidates, fixed_g
 
 
 def main():
+    global H, FFN, LAYERS, HEADS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -237,9 +294,11 @@ def main():
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--objective", choices=["contrastive", "pretrain-vl"], default="contrastive",
+    ap.add_argument("--objective", choices=["contrastive", "pretrain-vl", "pretrain-al"], default="contrastive",
                     help="config 3 only: contrastive = the headline tri-modal ITC+ATC step; pretrain-vl = the full image-text "
-                         "pretraining objective (ITC + four DCL terms, six passes incl. the masked students and the decoder)")
+                         "pretraining objective (ITC + four DCL terms, six passes incl. the masked students and the decoder); "
+                         "pretrain-al = the stage-2 audio-language objective (ATC + three DCL terms; everything but the audio "
+                         "adapter / audio FFNs / audio_layer_norm of the encoder frozen, pretrain_al_3B.yaml)")
     ap.add_argument("--check-replicas", action="store_true",
                     help="after the run, compare a checksum of all parameters across ranks (every rank sees different data, so the "
                          "replicas only stay identical if every gradient was all-reduced after its last contribution)")
@@ -247,6 +306,10 @@ def main():
                     help="every step takes its batch from host memory through staging.SamplePrefetcher (PCIe-inclusive rate; "
                          "the headline value keeps inputs resident in HBM)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--debug-cpu-micro", action="store_true",
+                    help="NOT a measurement: the same control flow (init, broadcast, bucketed reducer, fused all-gather criterion, "
+                         "replica / launch-order checks, max-over-ranks timing, JSON line) on CPU over gloo with a 2-layer H=128 model, "
+                         "the torch path of the mirrors and optim.TorchAdamW -- what the world-size-4 test of tests/ runs")
     ap.add_argument("--graphs", action="store_true",
                     help="single process, training configs: zero-grad + forwards + loss + backward of a step replayed as ONE "
                          "hipGraph (graphs.TrainStepGraph; the optimiser step stays eager).  For launch-bound small batches; the "
@@ -256,19 +319,29 @@ def main():
     from one_peace_amd import hip
     from one_peace_amd.criterions.contrastive import ImageTextRetrievalCriterion, TriModalContrastiveCriterion
     from one_peace_amd.distributed import BucketedGradReducer, FlatParameters, init_distributed
-    from one_peace_amd.optim import FusedAdamW
+    from one_peace_amd.optim import FusedAdamW, TorchAdamW
 
-    if not torch.cuda.is_available():
+    micro = args.debug_cpu_micro
+    if micro:
+        H, FFN, LAYERS, HEADS = 128, 256, 2, 2
+        args.layers, args.no_profile, args.no_cpu_baseline, args.audio_seconds = LAYERS, True, True, 0.5
+        args.batch = args.batch or 4
+        if args.config != 3 or args.objective != "contrastive" or args.graphs or args.host_inputs or args.fp8:
+            raise SystemExit("--debug-cpu-micro runs the headline control flow only")
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
-    hip.lib()
-    rank, world, local = init_distributed(os.environ.get("ONEPEACE_DIST_BACKEND"))
+    else:
+        hip.lib()
+    rank, world, local = init_distributed("gloo" if micro else os.environ.get("ONEPEACE_DIST_BACKEND"))
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
     if os.environ.get("ONEPEACE_SINGLE_DEVICE_DEBUG"):  # functional test of the N>1 control flow on a 1-GPU box (gloo)
         local = 0
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    device = torch.device("cpu") if micro else torch.device("cuda", local)
+    if not micro:
+        torch.cuda.set_device(device)
     torch.manual_seed(3407 + rank)
-    full = args.config == 3 and args.objective == "pretrain-vl"
+    full = args.config == 3 and args.objective in ("pretrain-vl", "pretrain-al")
+    al = args.config == 3 and args.objective == "pretrain-al"
     train = args.config != 1
     rccl_reserve = 6.0 if world > 1 else 0.0  # GB kept free for RCCL transport buffers / rings on a multi-GPU node
 
@@ -302,20 +375,28 @@ def main():
                 "grad all-reduce, grad-norm clip, AdamW%s" % (res, S_img, "; FFN GEMMs in fp8 (e4m3, per-row scales)" if args.fp8 else ""))
         metric = "long-sequence (%d-token image) contrastive step samples/s ONE-PEACE-4B" % S_img
     else:
-        S_img, audio_s, head, res = 257, (None if full else args.audio_seconds), "val", 256
-        audio_S = 0 if full else audio_frames(int(16000 * audio_s)) + 1
+        S_img, audio_s, head, res = (17 if micro else 257), (None if full and not al else args.audio_seconds), "val", (64 if micro else 256)
+        if micro:
+            S_txt = 16
+        audio_S = 0 if full and not al else audio_frames(int(16000 * audio_s)) + 1
         if args.batch <= 0:
             args.batch = auto_batch(device, S_img + S_txt + audio_S, args.layers, args.recompute, (128, 64, 32, 16, 8), 50.0,
                                     rccl_reserve)
         if full and args.batch > 64:
             args.batch = 64  # five passes keep activations (two teachers, three students): 64 tuples fit
-        modal = {"text": S_txt, "image": S_img} if full else {"text": S_txt, "image": S_img, "audio": audio_S}
+        modal = ({"text": S_txt, "audio": audio_S} if al else {"text": S_txt, "image": S_img} if full else
+                 {"text": S_txt, "image": S_img, "audio": audio_S})
         name = ("BASELINE configs[3]: ONE-PEACE-4B tri-modal (image 256^2 + text 64 + audio %.0fs) contrastive pretrain step: 3 forwards, "
                 "ITC+ATC, backward, grad all-reduce, grad-norm clip, AdamW" % args.audio_seconds) if not full else (
+                "ONE-PEACE-4B STAGE-2 audio-language pretraining step, objective of pretrain_al_3B.yaml (audio %.0fs): frozen text teacher and "
+                "joint al teacher (no grad), audio pass, masked audio / al students (mask ratios .55/.4/.45) through the 2-layer decoder, "
+                "ATC + 3 DCL terms; only the audio adapter, audio FFNs and audio_layer_norm of the encoder train (no weight-gradient GEMM "
+                "for frozen parameters), backward, grad-norm clip, AdamW" % args.audio_seconds) if al else (
                 "ONE-PEACE-4B image-text pretraining step, full objective of pretrain_vl_3B.yaml: text + image teachers, joint vl "
                 "teacher (no grad), masked text / image / vl students (mask ratios .15/.75/.4/.6875) through the 2-layer decoder, "
                 "ITC + 4 DCL terms, backward, grad-norm clip, AdamW")
         metric = ("pretrain samples/s (tri-modal global batch) ONE-PEACE-4B" if not full else
+                  "EXTRA: stage-2 audio-language pretraining objective (ATC + 3 DCL terms) samples/s ONE-PEACE-4B" if al else
                   "EXTRA: full image-text pretraining objective (ITC + 4 DCL terms) samples/s ONE-PEACE-4B")
 
     if args.fp8:
@@ -324,15 +405,21 @@ def main():
         from one_peace_amd import ops
         ops.set_fp8_ffn(True)  # opt-in: FFN GEMMs (GeGLU up-projection, down-projection and their dgrads) on e4m3 operands
 
-    if full:
+    if al:
+        model = build_pretrain_al_model(args.layers, device, args.recompute)
+    elif full:
         model = build_pretrain_vl_model(args.layers, device, args.recompute)
     else:
-        model = build_model(args.layers, device, args.recompute, head=head, image_grid=res // 16)
+        model = build_model(args.layers, device, args.recompute, head=head, image_grid=res // 16,
+                            extra=dict(text_bucket_size=256) if micro else None)
+    if micro:
+        model = model.float()  # CPU: the torch path of the mirrors in fp32
     model = model.train() if train else model.eval()
     nparams = sum(p.numel() for p in model.parameters())
-    batch, audio_S = synthetic_batch(args.batch, device, 3407 + rank, res=res, audio_seconds=audio_s, text=args.config != 1)
+    bkw = dict(text_len=15, dtype=torch.float32) if micro else {}
+    batch, audio_S = synthetic_batch(args.batch, device, 3407 + rank, res=res, audio_seconds=audio_s, text=args.config != 1, **bkw)
     if full:
-        batch = add_pretrain_masks(batch, 3407 + rank)
+        batch = (add_pretrain_al_masks if al else add_pretrain_masks)(batch, 3407 + rank)
     sample = {"net_input": batch, "nsentences": args.batch}
 
     reducer = opt = flat = None
@@ -341,9 +428,12 @@ def main():
         flat = FlatParameters(model, no_decay=lambda n, p: p.dim() <= 1 or n in no_decay_names)
         if dist.is_initialized():  # replicas start from rank 0's weights (fairseq: distributed_utils.broadcast of the initial state)
             dist.broadcast(flat.params, src=0)
-        reducer = BucketedGradReducer(flat)
-        opt = FusedAdamW(flat, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)  # pretrain_vl_3B.yaml:24-36
-        if full:
+        reducer = BucketedGradReducer(flat, bucket_bytes=(64 << 10) if micro else (256 << 20))
+        opt = (TorchAdamW if micro else FusedAdamW)(flat, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)  # pretrain_vl_3B.yaml:24-36
+        if al:
+            from one_peace_amd.criterions.pretrain import AudioTextPretrainLossCriterion
+            crit = AudioTextPretrainLossCriterion(None, 1.0, 0.5, 0.5, 2.5, 0.1)  # pretrain_al_3B.yaml criterion block
+        elif full:
             from one_peace_amd.criterions.pretrain import ImageTextPretrainLossCriterion
             crit = ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, 0.0)  # pretrain_vl_3B.yaml criterion block
         elif args.config == 3:
@@ -391,14 +481,15 @@ def main():
     def sync():
         if dist.is_initialized():
             dist.barrier()
-        torch.cuda.synchronize()
+        if not micro:
+            torch.cuda.synchronize()
 
     def fit_batch_to_free_memory():
         """First-contact safety: after the model, the optimiser state and RCCL's own buffers exist, compare what is actually
         free on the device (minimum over ranks) with the activation estimate and halve the batch until it fits -- every rank
         takes the same decision, so no rank can run out of memory in the middle of a collective."""
         nonlocal batch, sample, audio_S
-        if not train:
+        if not train or micro:
             return
         free_b, _ = torch.cuda.mem_get_info(device)
         free_t = torch.tensor([free_b / 1e9], dtype=torch.float64, device=device)
@@ -416,7 +507,7 @@ def main():
                 free_gb, args.batch), file=sys.stderr, flush=True)
             batch, audio_S = synthetic_batch(args.batch, device, 3407 + rank, res=res, audio_seconds=audio_s, text=True)
             if full:
-                batch = add_pretrain_masks(batch, 3407 + rank)
+                batch = (add_pretrain_al_masks if al else add_pretrain_masks)(batch, 3407 + rank)
             sample = {"net_input": batch, "nsentences": args.batch}
 
     def warm(n):
@@ -437,7 +528,7 @@ def main():
                 torch.cuda.empty_cache()
                 batch, audio_S = synthetic_batch(args.batch, device, 3407 + rank, res=res, audio_seconds=audio_s, text=True)
                 if full:
-                    batch = add_pretrain_masks(batch, 3407 + rank)
+                    batch = (add_pretrain_al_masks if al else add_pretrain_masks)(batch, 3407 + rank)
                 sample = {"net_input": batch, "nsentences": args.batch}
                 print("bench: warm-up ran out of memory, per-GPU batch halved to %d" % args.batch, file=sys.stderr, flush=True)
 
@@ -491,14 +582,22 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = hip.profile_kernels.collect(4) if profiled_steps else None
+    order_same = None
     if args.check_replicas and world > 1:
         chk = torch.stack([flat.params.double().sum(), flat.params.double().abs().sum(), opt.exp_avg.double().sum()])
         allc = [torch.empty_like(chk) for _ in range(world)]
         dist.all_gather(allc, chk)
         same = all(torch.equal(allc[0], c) for c in allc[1:])
+        # collectives pair up by issue order: every rank must have issued its bucket all-reduces in the same order
+        dig = torch.tensor([reducer.launch_order_digest(), len(reducer.launch_order)], dtype=torch.int64, device=device)
+        alld = [torch.empty_like(dig) for _ in range(world)]
+        dist.all_gather(alld, dig)
+        order_same = all(torch.equal(alld[0], d) for d in alld[1:])
         if rank == 0:
-            print("replica check: %s (param checksums %s)" % ("IDENTICAL" if same else "DIVERGED", [c.tolist() for c in allc]),
-                  file=sys.stderr, flush=True)
+            print("replica check: %s (param checksums %s); bucket launch order on every rank: %s (%d launches)" % (
+                "IDENTICAL" if same else "DIVERGED", [c.tolist() for c in allc], "IDENTICAL" if order_same else "DIFFERENT",
+                int(alld[0][1])), file=sys.stderr, flush=True)
+        assert order_same, "ranks issued their gradient-bucket all-reduces in different orders: %s" % [d.tolist() for d in alld]
         assert same, "data-parallel replicas diverged: a gradient bucket was reduced before its last contribution"
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if dist.is_initialized():
@@ -536,6 +635,18 @@ def main():
         }
         if sweep:
             out["config"]["sweep"] = sweep
+        if micro:
+            out["metric"] = "NOT A MEASUREMENT: CPU control-flow run of the data-parallel step (micro model, gloo)"
+            out["dtype"], out["roofline"] = "f32 (torch path on CPU)", None
+        if dist.is_initialized():
+            k_mod = len(modal)
+            out["config"]["distributed"] = {
+                "backend": dist.get_backend(), "world_size_seen_by_backend": dist.get_world_size(),
+                "grad_buckets": len(reducer.buckets) if reducer is not None else 0,
+                "grad_bucket_bytes": [(e - s0) * flat.grads.element_size() for s0, e, _ in reducer.buckets][:4] if reducer is not None else [],
+                "grad_allreduce_bytes_per_step": flat.numel * flat.grads.element_size() if flat is not None else 0,
+                "embedding_allgather_bytes_per_step": k_mod * args.batch * H * (4 if micro else 2) * dist.get_world_size(),
+                "bucket_launch_order_identical_on_all_ranks": order_same}
         if reducer is not None and (world > 1 or reducer.active):
             rep = reducer.overlap_report()
             out["config"]["grad_allreduce_overlap"] = rep

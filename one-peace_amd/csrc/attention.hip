@@ -1347,13 +1347,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 template <bool HAS_BIAS, bool HAS_PAD>
 int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, size_t sh, int rows_pad, int qb_per_wg, int abl,
                    hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_res_kernel<HAS_BIAS, HAS_PAD>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RES_MAX_S * 128);
-    if (e != hipSuccess) { op_set_error("attn_fwd: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  OP_ENSURE_LDS((attn_fwd_res_kernel<HAS_BIAS, HAS_PAD>), 2 * RES_MAX_S * 128, "attn_fwd");
   hipLaunchKernelGGL((attn_fwd_res_kernel<HAS_BIAS, HAS_PAD>), grid, dim3(nw * 64), sh, s, a, frag, rows_pad, qb_per_wg, abl);
   return OP_OK;
 }

@@ -32,6 +32,20 @@ extern "C" void op_set_error(const char* fmt, ...);
     }                                      \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute is per device, and a process may
+// drive more than one (the deployment model is one process per GPU, but nothing here may rely on it).
+#define OP_ENSURE_LDS(kernel, bytes, what)                                                                          \
+  do {                                                                                                              \
+    static unsigned long long done_ = 0;                                                                            \
+    int dev_ = 0;                                                                                                   \
+    if (hipGetDevice(&dev_) != hipSuccess) dev_ = 0;                                                                \
+    if (!((done_ >> (dev_ & 63)) & 1ull)) {                                                                         \
+      hipError_t e_ = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+      if (e_ != hipSuccess) { op_set_error(what ": hipFuncSetAttribute failed: %s", hipGetErrorString(e_)); return (int)e_; } \
+      done_ |= 1ull << (dev_ & 63);                                                                                 \
+    }                                                                                                               \
+  } while (0)
+
 #define OP_LAUNCH_CHECK()                                                  \
   do {                                                                     \
     hipError_t e__ = hipGetLastError();                                    \

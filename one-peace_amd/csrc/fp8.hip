@@ -272,12 +272,7 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
 template <int EPI>
 int launch_fp8(const Fp8Args& a, hipStream_t s) {
   const size_t sh = 4 * 128 * 128;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) { op_set_error("gemm_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  OP_ENSURE_LDS((gemm_fp8_kernel<EPI>), (int)sh, "gemm_fp8");
   hipLaunchKernelGGL((gemm_fp8_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(256), sh, s, a);
   OP_LAUNCH_CHECK();
   return OP_OK;
@@ -330,17 +325,19 @@ int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0,
   a.tiles_m = ceil_div(M, 128);
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)M * (double)N * (double)K * (epilogue == F8_EPI_GEGLU ? 2.0 : 1.0);
+  if (epilogue == F8_EPI_GEGLU) {  // every argument check comes before the profiler slot is taken: an early return must not leak it
+    OP_CHECK_ARG(B1 && sb1, "gemm_nt_fp8: GeGLU needs two weights and two scale vectors");
+    OP_CHECK_ARG((h0 == nullptr) == (h1 == nullptr), "gemm_nt_fp8: GeGLU h0/h1 must both be given or both null");
+  }
+  if (epilogue == F8_EPI_RESID) OP_CHECK_ARG(resid, "gemm_nt_fp8: residual epilogue needs resid");
   const int slot = op_prof_begin(3, flops, stream);
   int rc;
   if (epilogue == F8_EPI_GEGLU) {
-    OP_CHECK_ARG(B1 && sb1, "gemm_nt_fp8: GeGLU needs two weights and two scale vectors");
-    OP_CHECK_ARG((h0 == nullptr) == (h1 == nullptr), "gemm_nt_fp8: GeGLU h0/h1 must both be given or both null");
     a.tiles_n = ceil_div(N, 64);
     rc = launch_fp8<F8_EPI_GEGLU>(a, s);
   } else {
     a.tiles_n = ceil_div(N, 128);
     if (epilogue == F8_EPI_RESID) {
-      OP_CHECK_ARG(resid, "gemm_nt_fp8: residual epilogue needs resid");
       rc = launch_fp8<F8_EPI_RESID>(a, s);
     } else {
       rc = launch_fp8<F8_EPI_BIAS>(a, s);

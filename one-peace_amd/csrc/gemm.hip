@@ -1773,19 +1773,9 @@ template <int EPI>
 int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = STAGES2 * STAGE2_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) { op_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  OP_ENSURE_LDS((gemm256_tn_kernel<EPI>), (int)sh, "gemm_tn");
   if (four_waves) {
-    static bool attr_w = false;
-    if (!attr_w) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm256w_tn_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      if (e != hipSuccess) { op_set_error("gemm_tn: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-      attr_w = true;
-    }
+    OP_ENSURE_LDS((gemm256w_tn_kernel<EPI>), (int)sh, "gemm_tn");
     hipLaunchKernelGGL((gemm256w_tn_kernel<EPI>), grid, dim3(256), sh, s, a);
   } else {
     hipLaunchKernelGGL((gemm256_tn_kernel<EPI>), grid, dim3(512), sh, s, a);
@@ -1827,12 +1817,7 @@ constexpr int V_SCHED_DEFAULT = 3;  // kernel of the four-wave NT launches when 
 
 template <int EPI, int SCHED>
 int launch256v(const GemmArgs& a, hipStream_t s, dim3 grid, size_t sh) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256v_kernel<EPI, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) { op_set_error("gemm256v: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  OP_ENSURE_LDS((gemm256v_kernel<EPI, SCHED>), (int)sh, "gemm256v");
   hipLaunchKernelGGL((gemm256v_kernel<EPI, SCHED>), grid, dim3(256), sh, s, a);
   OP_LAUNCH_CHECK();
   return OP_OK;
@@ -1855,8 +1840,7 @@ static int num_cus() {
 template <int EPI>
 int launch256p(const GroupArgs& ga, hipStream_t s, bool persistent = true) {
   const size_t sh = (size_t)SLOTS3 * SLOT3_BYTES;
-  hipError_t e = hipFuncSetAttribute((const void*)gemm256p_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  if (e != hipSuccess) { op_set_error("gemm256p: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+  OP_ENSURE_LDS((gemm256p_kernel<EPI>), sh, "gemm256p");
   const int ntiles = ga.tiles_m * ga.tiles_n;
   hipLaunchKernelGGL((gemm256p_kernel<EPI>), dim3((!persistent || ntiles < num_cus()) ? ntiles : num_cus()), dim3(256), sh, s, ga);
   OP_LAUNCH_CHECK();
@@ -1893,12 +1877,7 @@ template <int EPI>
 int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 1) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = STAGES2 * STAGE2_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) { op_set_error("gemm256: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set = true;
-  }
+  OP_ENSURE_LDS((gemm256_kernel<EPI>), (int)sh, "gemm256");
   const bool fills = (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1;
   // four-wave flavour (one wave per SIMD, 128 x 128 per wave): +9 ... +14 % at K = 6144, +1 ... +5 % at K = 1536 (bias and
   // residual epilogues); the GeGLU launch (VALU-heavy epilogue on half as many waves) is 2 % slower and stays on eight waves;
@@ -1915,12 +1894,7 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
         return launch256v<EPI, 3>(a, s, grid, sh5);
       default: break;
     }
-    static bool attr6 = false;
-    if (!attr6) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm256w_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
-      if (e != hipSuccess) { op_set_error("gemm256w: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-      attr6 = true;
-    }
+    OP_ENSURE_LDS((gemm256w_kernel<EPI>), (int)sh5, "gemm256w");
     hipLaunchKernelGGL((gemm256w_kernel<EPI>), grid, dim3(256), sh5, s, a);
     OP_LAUNCH_CHECK();
     return OP_OK;
@@ -1929,12 +1903,7 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
   if ((T.fullline == 1 || (T.fullline == 2 && fills)) &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
-    static bool attr5 = false;
-    if (!attr5) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm256b_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
-      if (e != hipSuccess) { op_set_error("gemm256b: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-      attr5 = true;
-    }
+    OP_ENSURE_LDS((gemm256b_kernel<EPI>), (int)sh5, "gemm256b");
     hipLaunchKernelGGL((gemm256b_kernel<EPI>), grid, dim3(512), sh5, s, a);
   } else if (EPI == EPI_BIAS && T.ablation == 1) {
     hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -1965,15 +1934,8 @@ template <int EPI>
 int launch(const GemmArgs& a, int glds, hipStream_t s, int splits = 1) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = 4 * TILE_BYTES;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[glds ? 1 : 0]) {
-    hipError_t e = glds ? hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, true>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh)
-                        : hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, false>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) { op_set_error("gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-    attr_set[glds ? 1 : 0] = true;
-  }
+  if (glds) OP_ENSURE_LDS((gemm_nt_kernel<EPI, true>), sh, "gemm");
+  else OP_ENSURE_LDS((gemm_nt_kernel<EPI, false>), sh, "gemm");
   if (glds)
     hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), sh, s, a);
   else

@@ -7,6 +7,7 @@ backward, divides by the world size and all-reduces ~15 sequential 512 MiB bucke
 buffers (no pack/unpack), buckets are contiguous slices that are all-reduced asynchronously as soon as autograd has
 finished the last parameter of the bucket (post-accumulate-grad hooks -> overlap with the rest of backward), and the
 1/world division is folded into the fused AdamW kernel."""
+import collections
 import os
 
 import torch
@@ -151,7 +152,8 @@ class BucketedGradReducer:
         self._sync = True
         self._unused = None  # indices of parameters that took no part in the first step (learned in its finish())
         self.stats = {"steps": 0, "buckets": len(self.buckets), "launched_in_backward": 0, "launched_in_finish": 0}
-        self._exposed = []  # (event before the waits, event after) per step on the compute stream (nccl only)
+        self.launch_order = []  # bucket indices in the order their all-reduce was issued, all steps (see launch_order_digest)
+        self._exposed = collections.deque(maxlen=64)  # (event before the waits, event after) of the last steps (nccl only)
         if self.active:
             for idx, (n, p, o, k) in enumerate(flat.entries):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(idx, from_autograd=True)))
@@ -161,6 +163,9 @@ class BucketedGradReducer:
     def _launch(self, b):
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        self.launch_order.append(b)
+        if len(self.launch_order) > 1 << 16:  # bounded: the digest below is for first-contact checks, not for long runs
+            del self.launch_order[: 1 << 15]
         self._handles.append(dist.all_reduce(self.flat.grads[s:e], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def _make_hook(self, idx, from_autograd):
@@ -238,11 +243,21 @@ class BucketedGradReducer:
             self._exposed.append((e0, e1))
         self._handles = []
 
+    def launch_order_digest(self):
+        """A 63-bit digest of the order in which this rank issued its bucket all-reduces so far.  Collectives match up across
+        ranks by ISSUE ORDER, not by bucket: ranks that issue the same buckets in different orders all-reduce unrelated slices
+        into each other (or deadlock when the sizes differ).  The order follows from autograd's execution order, which is the same
+        on every rank for the same graph -- `bench.py --check-replicas` all-gathers this digest and fails loudly if it is not."""
+        h = 1469598103934665603
+        for b in self.launch_order:
+            h = ((h ^ (b + 1)) * 1099511628211) & ((1 << 63) - 1)
+        return h
+
     def overlap_report(self):
         """After a synchronize: how the buckets went out and how long the compute stream sat in finish() waiting for RCCL
         (the part of the gradient all-reduce that backward did NOT hide), averaged per step."""
         rep = dict(self.stats)
         if self._exposed:
             rep["exposed_allreduce_ms_per_step"] = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
-        self._exposed = []
+        self._exposed.clear()
         return rep

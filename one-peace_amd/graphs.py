@@ -78,6 +78,17 @@ class TrainStepGraph:
     def __init__(self, fwd_bwd, warmup=2):
         if not torch.cuda.is_available():
             raise RuntimeError("TrainStepGraph: hipGraph capture has no CPU path")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the bucketed gradient reducer works through Python hooks that only run at capture time: a replay would launch no
+            # all-reduce (or the captured ones, out of step with reset() / finish()) -- data-parallel steps stay eager
+            raise RuntimeError("TrainStepGraph: single-process only (world size %d): the gradient reducer's hooks do not run on "
+                               "replay" % dist.get_world_size())
+        from . import ops
+        if ops.FP8_FFN:
+            # the fp8 copies of the FFN weights are re-quantised by refresh_weight_cache() after every optimiser step, in place,
+            # so a replay reads current weights; the capture below must therefore see them already cached (the warm-up does that)
+            pass
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # autograd's stream bookkeeping, workspaces and derived buffers settle on a side stream

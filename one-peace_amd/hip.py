@@ -338,11 +338,15 @@ def gemm_nt_grouped(As, Ws, biases=None, outs=None, epilogue=EPI_BIAS, h0s=None,
     return outs
 
 
-def quant_fp8_rows(x2d):
-    """bf16 [rows, cols] -> (fp8 e4m3 bytes [rows, cols] as uint8, fp32 row scales [rows]) with x ~= q * scale[row]."""
+def quant_fp8_rows(x2d, out=None):
+    """bf16 [rows, cols] -> (fp8 e4m3 bytes [rows, cols] as uint8, fp32 row scales [rows]) with x ~= q * scale[row].
+    out: an earlier result to overwrite in place (derived weight copies keep their addresses across optimiser steps)."""
     rows, cols = x2d.shape
-    q = torch.empty(rows, cols, dtype=torch.uint8, device=x2d.device)
-    scale = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    if out is not None:
+        q, scale = out
+    else:
+        q = torch.empty(rows, cols, dtype=torch.uint8, device=x2d.device)
+        scale = torch.empty(rows, dtype=torch.float32, device=x2d.device)
     _check(lib().op_quant_fp8_rows(ptr(x2d), x2d.stride(0), ptr(q), q.stride(0), ptr(scale), rows, cols, stream()), "op_quant_fp8_rows")
     return q, scale
 

@@ -37,6 +37,15 @@ def refresh_weight_cache():
     one launch per matrix plus a concatenation per q/k/v triple, they cost 14 ms per step) and mark them current."""
     global _cache_epoch, _refresh_plan
     _cache_epoch += 1
+    # fp8 copies of the FFN weights (opt-in variant): re-quantised IN PLACE into the same buffers -- a replayed TrainStepGraph keeps
+    # reading these addresses, and an eager step must not pay a cache miss per weight either
+    for k, (ref, _, qs) in list(_fp8_cache.items()):
+        w = ref()
+        if w is None:
+            del _fp8_cache[k]
+            continue
+        hip.quant_fp8_rows(w.detach(), out=qs)
+        _fp8_cache[k] = (ref, (w._version, w.data_ptr(), _cache_epoch), qs)
     live = [(k, v) for k, v in _wt_cache.items() if all(r() is not None for r in v[0])]
     if not live:
         return

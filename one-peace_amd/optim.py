@@ -83,3 +83,45 @@ class FusedAdamW:
 
     def zero_grad(self):
         self.flat.zero_grad()
+
+
+class TorchAdamW:
+    """The same update over ``FlatParameters`` written with torch ops (fp32 math on the flat buffers, any device / dtype): the
+    optimiser of the CPU control-flow runs of the data-parallel step (``bench.py --debug-cpu-micro``, world-size-4 gloo test) and
+    a readable statement of what the fused kernel computes.  Same interface as ``FusedAdamW``."""
+
+    def __init__(self, flat: FlatParameters, lr=5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05):
+        self.flat = flat
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros(flat.numel, dtype=torch.float32, device=flat.params.device)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
+        self.step_count = 0
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0, clip_norm=0.0):
+        self.step_count += 1
+        f, (b1, b2) = self.flat, self.betas
+        g = f.grads.float() * grad_scale
+        norm = g.norm() if clip_norm > 0 else None
+        if norm is not None:
+            g = g * (clip_norm / (norm + 1e-6)).clamp(max=1.0)  # fairseq/utils.py:349-397
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        update = self.exp_avg / (self.exp_avg_sq.sqrt() + self.eps)
+        bias = (1 - b2 ** self.step_count) ** 0.5 / (1 - b1 ** self.step_count)
+        for start, end, scale, decays in f.groups:
+            if end <= start:
+                continue
+            pf = f.params[start:end].float()
+            if decays and self.weight_decay != 0:
+                pf = pf + pf * (-self.weight_decay * self.lr * scale)
+            f.params[start:end].copy_(pf - self.lr * scale * bias * update[start:end])
+        if f.params.is_cuda:
+            ops.refresh_weight_cache()
+        return norm
+
+    def zero_grad(self):
+        self.flat.zero_grad()

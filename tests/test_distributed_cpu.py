@@ -141,3 +141,38 @@ def test_world2_gather_loss_and_grad_allreduce():
         mp.spawn(_worker, args=(world, initfile, d), nprocs=world, join=True)
         r0, r1 = torch.load(os.path.join(d, "r0.pt")), torch.load(os.path.join(d, "r1.pt"))
         assert torch.equal(r0["avg"], r1["avg"]), "ranks disagree after the all-reduce"
+
+
+def test_world4_bench_control_flow_on_cpu():
+    """bench.py's own data-parallel control flow -- env:// initialisation, parameter broadcast, three forwards, the fused [k,b,H]
+    all-gather criterion, backward with the bucketed gradient all-reduce (46 buckets here) overlapped, clip + optimiser step,
+    max-over-ranks timing and the JSON line -- at WORLD SIZE 4 over gloo (`--debug-cpu-micro`: 2-layer H=128 model, torch path,
+    optim.TorchAdamW).  Every rank sees different data, so identical replicas after three steps mean every gradient was reduced
+    after its last contribution; and because collectives pair up by issue order, every rank must have issued its bucket
+    all-reduces in the same order (digest all-gathered by --check-replicas).  The multi-GPU tier is RCCL's first contact with
+    more than one rank: this is what can be proven about it without the hardware."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--debug-cpu-micro", "--check-replicas"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "replica check: IDENTICAL" in r.stderr and "bucket launch order on every rank: IDENTICAL" in r.stderr, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line: %r" % lines
+    out = json.loads(lines[0])
+    d = out["config"]["distributed"]
+    assert out["n_gpus"] == 4 and d["world_size_seen_by_backend"] == 4 and d["bucket_launch_order_identical_on_all_ranks"] is True
+    assert out["config"]["global_batch"] == 4 * out["config"]["per_gpu_batch"] and out["scaling"] == "weak"
+    ov = out["config"]["grad_allreduce_overlap"]
+    assert ov["buckets"] == d["grad_buckets"] > 8 and ov["steps"] == 3
+    # after the first step (which learns the parameters without a gradient) every bucket goes out DURING backward
+    assert ov["launched_in_finish"] <= ov["buckets"] and ov["launched_in_backward"] >= 2 * ov["buckets"]

@@ -737,11 +737,23 @@ def test_stage2_pretraining_skips_frozen_weight_gradients(golden_dir):
     assert n > 20
 
 
-def test_train_step_graph_replay_matches_eager_training():
+@pytest.mark.parametrize("fp8", [False, True])
+def test_train_step_graph_replay_matches_eager_training(fp8):
     """graphs.TrainStepGraph: zero-grad + three forwards + ITC/ATC + the whole backward (custom autograd functions, in-place
     accumulation into the flat gradient buffer, autograd's own accumulation for the adapters) recorded into ONE hipGraph and
     replayed, optimiser step eager in between: losses and parameters must follow eager training bit for bit, also when the
-    static batch is overwritten with new data between replays."""
+    static batch is overwritten with new data between replays.  fp8: the opt-in e4m3 forward FFN GEMMs -- their quantised weight
+    copies are derived buffers a replay reads by address, so the optimiser step has to re-quantise them in place (a
+    replay kept reading the step-0 weights)."""
+    from one_peace_amd import ops as _ops
+    old_fp8 = _ops.set_fp8_ffn(fp8)
+    try:
+        _graph_vs_eager()
+    finally:
+        _ops.set_fp8_ffn(old_fp8)
+
+
+def _graph_vs_eager():
     from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
     from one_peace_amd.distributed import BucketedGradReducer, FlatParameters
     from one_peace_amd.graphs import TrainStepGraph

@@ -135,15 +135,23 @@ class TriModalContrastiveCriterion(FairseqCriterion):
     transformer_encoder.py:136-137): VL and AL are separate stages with exactly these two losses, which this criterion
     sums so that all three FFN sets train in one step.  One fused all-gather of [3, b, H]."""
 
-    def __init__(self, task, label_smoothing=0.0):
+    def __init__(self, task, label_smoothing=0.0, lock_step=True):
         super().__init__(task)
         self.label_smoothing = label_smoothing
+        self.lock_step = lock_step  # False: always one model call per modality, exactly the reference's call pattern
 
     def forward(self, model, sample, reduce=True):
         ni = sample["net_input"]
-        text = _first(model(src_tokens=ni["src_tokens"], encoder_type="text"))
-        image = _first(model(src_images=ni["src_images"], encoder_type="image"))
-        audio = _first(model(src_audios=ni["src_audios"], audio_padding_masks=ni["audio_padding_masks"], encoder_type="audio"))
+        multi = None
+        if self.lock_step and hasattr(model, "forward_multi"):  # the three streams layer by layer in lock-step (MI355X path)
+            multi = model.forward_multi(src_tokens=ni["src_tokens"], src_images=ni["src_images"], src_audios=ni["src_audios"],
+                                        audio_padding_masks=ni["audio_padding_masks"])
+        if multi is not None:
+            text, image, audio = multi["text"], multi["image"], multi["audio"]
+        else:
+            text = _first(model(src_tokens=ni["src_tokens"], encoder_type="text"))
+            image = _first(model(src_images=ni["src_images"], encoder_type="image"))
+            audio = _first(model(src_audios=ni["src_audios"], audio_padding_masks=ni["audio_padding_masks"], encoder_type="audio"))
         text_all, image_all, audio_all = gather_without_grad(text, image, audio)
         scale = model(return_logit_scale=True)
         itc, i2t, t2i = contrastive_pair_loss(image, text, image_all, text_all, scale, self.label_smoothing)

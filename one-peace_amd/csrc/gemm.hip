@@ -1066,13 +1066,7 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   const int nrecB = (int)((((int64_t)rowsB - 1) * p.ldb + p.K) * 2);
   int ktA = 0, ktB = 0;  // next K-tile of each operand to be fetched
 
-  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi]; cleared while the first operand tiles are in flight (below)
 
   const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
   const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
@@ -1145,6 +1139,16 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   issue_tile(true);
   issue_tile(false);
   issue_tile(true);
+  {  // clear the accumulators UNDER the latency of the loads above: 64 MFMAs 0 x 0 + 0 (as compiler-generated v_accvgpr_write
+     // the 256 writes are rematerialised constants the scheduler places wherever it likes -- it put them behind the wait)
+    const bf16x8 zf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[a][b][c]) : "v"(zf));
+  }
   WAIT_VM(16);
   __builtin_amdgcn_s_barrier();
   bf16x8 wfA[8], xfA[8], wfB[8], xfB[8];

@@ -65,6 +65,25 @@ class ModelWrapper(nn.Module):
         return tf, imf, af
 
 
+def _wrapper_forward_multi(self, src_tokens=None, src_images=None, src_audios=None, audio_padding_masks=None):
+    """ModelWrapper.forward_multi: the single-modality passes of the given inputs as one lock-step pass (see
+    TransformerEncoder.forward_multi); returns {modality: features [B, S, H]}, or None when the configuration / inputs do not
+    qualify (the caller then runs one forward per modality)."""
+    infos = {}
+    if src_tokens is not None and hasattr(self, "text_adapter"):
+        infos["text"] = self.text_adapter(src_tokens, None, None, None)
+    if src_images is not None and hasattr(self, "image_adapter"):
+        infos["image"] = self.image_adapter(src_images, None, None, None, False)
+    if src_audios is not None and hasattr(self, "audio_adapter"):
+        infos["audio"] = self.audio_adapter(src_audios, audio_padding_masks, preserve_ids=None, preserve_embed=None, mask_token=None)
+    if not self.fusion_model.multi_ok(infos):
+        return None
+    return self.fusion_model.forward_multi(infos)
+
+
+ModelWrapper.forward_multi = _wrapper_forward_multi
+
+
 @register_model("one_peace_base", dataclass=UnifyModelConfig)
 class OnePeaceBaseModel(BaseFairseqModel):
     def __init__(self, cfg, src_dict):

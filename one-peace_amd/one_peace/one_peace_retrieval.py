@@ -89,6 +89,15 @@ class OnePeaceRetrievalModel(OnePeaceBaseModel):
         tower = feats[MODALITIES.index(encoder_type)]
         return normalized_projection(getattr(self, encoder_type + "_proj"), tower[:, 0, :])
 
+    def forward_multi(self, src_tokens=None, src_images=None, src_audios=None, audio_padding_masks=None):
+        """{modality: normalised CLS embedding} of the given inputs -- the same results as one `forward(..., encoder_type=m)` per
+        modality -- from ONE lock-step pass through the shared encoder (MI355X path); None when that pass does not apply."""
+        feats = self.encoder_wrapper.forward_multi(src_tokens=src_tokens, src_images=src_images, src_audios=src_audios,
+                                                   audio_padding_masks=audio_padding_masks)
+        if feats is None:
+            return None
+        return {m: normalized_projection(getattr(self, m + "_proj"), f[:, 0, :]) for m, f in feats.items()}
+
     # ---- checkpoints ------------------------------------------------------------------------------------------------
     def remove_pretraining_modules(self, state_dict):
         """Drop the towers this head type does not have (a pretraining checkpoint carries all of them)."""

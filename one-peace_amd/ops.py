@@ -430,9 +430,32 @@ FFN_PARAMS = ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b", "w2", "b2", "g2")
 LAYER_PARAMS = ATTN_PARAMS + FFN_PARAMS
 
 
-def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_frag=None, want_y=True):
-    """x_mid = x + ps1 * g1 * out_proj(subLN(attention(LN1(x))))  on x2 [B*S, H].  want_y: also write the branch output y1 (only the
-    gradient of gamma_1 needs it)."""
+class StreamSeg:
+    """One stream's rows inside a packed [sum B*S, H] activation matrix: B samples of S tokens starting at row `row0`, with their
+    own relative-position bias handle (RelPosBias-like or None) and key-padding bytes.  A single-stream layer is one segment;
+    a lock-step pass over several modalities (transformer_encoder.forward_multi) has one per modality."""
+    __slots__ = ("name", "B", "S", "row0", "bias", "key_pad")
+
+    def __init__(self, name, B, S, row0, bias=None, key_pad=None):
+        self.name, self.B, self.S, self.row0, self.bias, self.key_pad = name, B, S, row0, bias, key_pad
+
+    @property
+    def rows(self):
+        return self.B * self.S
+
+    @property
+    def end(self):
+        return self.row0 + self.B * self.S
+
+    def frag(self, limit):
+        return self.bias.frag if self.bias is not None and self.S <= limit else None
+
+
+def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
+    """x_mid = x + rowscale * g1 * out_proj(subLN(attention(LN1(x))))  on the packed rows x2 [N, H]: LayerNorm, the fused q|k|v
+    projection, the sub-LayerNorm and the output projection run over ALL rows in one launch each, the attention core per
+    segment.  rowscale: fp32 drop-path multipliers indexed by row // rps (None = 1).  want_y: also write the branch output y1
+    (only the gradient of gamma_1 needs it)."""
     H = x2.shape[1]
     xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
     if H % 128 == 0:
@@ -441,20 +464,27 @@ def _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps1, keep, bias_
         qkv = torch.empty(x2.shape[0], 3 * H, dtype=x2.dtype, device=x2.device)
         for i, (w, b) in enumerate(((P["wq"], P["bq"]), (P["wk"], None), (P["wv"], P["bv"]))):
             hip.gemm_nt(xln1, [w], [b] if b is not None else None, out=qkv[:, i * H:(i + 1) * H], ldc=3 * H)
-    Spad = hip.attn_spad(S)
-    attn, lse = hip.attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, B, S, heads, scale, bias_img, key_pad,
-                             Spad, want_lse=keep, bias_frag=bias_frag)
+    attn = torch.empty_like(x2)
+    lses = []
+    for sg in segs:
+        r = slice(sg.row0, sg.end)
+        _, lse = hip.attn_fwd(qkv[r, :H], qkv[r, H:2 * H], qkv[r, 2 * H:], 3 * H, sg.B, sg.S, heads, scale,
+                              sg.bias.image.detach() if sg.bias is not None else None, sg.key_pad, hip.attn_spad(sg.S), out=attn[r],
+                              want_lse=keep, bias_frag=sg.frag(hip.ATTN_RESIDENT_MAX_S))
+        lses.append(lse)
     if P["aln_w"] is not None:
         aln, mean_a, rstd_a = hip.layernorm_fwd(attn, P["aln_w"], P["aln_b"], want_stats=keep)
     else:
         aln, mean_a, rstd_a = attn, None, None
     y1 = torch.empty_like(x2) if keep and want_y else None
-    x_mid = hip.gemm_nt(aln, [P["wo"]], [P["bo"]], epilogue=hip.EPI_RESID, resid=x2, gamma=P["g1"], rowscale=ps1,
-                        rows_per_sample=S, h0=y1)
+    x_mid = hip.gemm_nt(aln, [P["wo"]], [P["bo"]], epilogue=hip.EPI_RESID, resid=x2, gamma=P["g1"], rowscale=rowscale,
+                        rows_per_sample=rps, h0=y1)
     if not keep:
         return x_mid, None
-    return x_mid, dict(xln1=xln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, aln=aln, mean_a=mean_a,
-                       rstd_a=rstd_a, y1=y1)
+    acts = dict(xln1=xln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn=attn, aln=aln, mean_a=mean_a, rstd_a=rstd_a, y1=y1)
+    for i, lse in enumerate(lses):
+        acts["lse%d" % i] = lse
+    return x_mid, acts
 
 
 def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True):
@@ -592,65 +622,64 @@ def _restore(ctx, saved_acts, optional):
 
 
 class AttnBranchFn(torch.autograd.Function):
-    """First half of transformer_layer.py:165-228: x + droppath(gamma_1 * self_attn(LN(x))), forward + backward in HIP.
+    """First half of transformer_layer.py:165-228: x + droppath(gamma_1 * self_attn(LN(x))), forward + backward in HIP, over the
+    packed rows of one or more streams.
 
-    x: [B, S, H] bf16 contiguous (batch-major; S may be a joint text+image / text+audio stream).  bias: RelPosBias-like
-    handle or None (bias_image = bias.image only puts the table(s) into the autograd graph).  key_pad: uint8 [B, Spad] or
-    None.  ps: fp32 [B] drop-path multipliers (0 or 1/keep) or None."""
+    x2: [N, H] bf16 contiguous rows (batch-major per segment; a segment may itself be a joint text+image / text+audio
+    stream).  segs: [StreamSeg] covering the N rows.  rowscale: fp32 drop-path multipliers (0 or 1/keep) indexed by
+    row // rps, or None.  imgs: one bias image per segment (or None) -- only there to put the tables into the autograd graph."""
 
     @staticmethod
-    def forward(ctx, x, bias_image, bias, key_pad, ps, heads, save_acts, *params):
-        B, S, H = x.shape
+    def forward(ctx, x2, segs, rowscale, rps, heads, save_acts, *rest):
+        nseg = len(segs)
+        params = rest[nseg:]
+        N, H = x2.shape
         P = dict(zip(ATTN_PARAMS, params))
-        x2 = x.reshape(B * S, H)
         scale = (H // heads) ** -0.5
-        bias_img = bias.image.detach() if bias is not None else None
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
-        needs = dict(zip(ATTN_PARAMS, ctx.needs_input_grad[7:]))
-        x_mid, acts = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, keep,
-                                    bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None, want_y=needs["g1"])
-        ctx.bias, ctx.dims, ctx.n_params = bias, (B, S, H, heads, scale), len(params)
+        first_param = 6 + nseg
+        needs = dict(zip(ATTN_PARAMS, ctx.needs_input_grad[first_param:]))
+        x_mid, acts = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"])
+        ctx.segs, ctx.dims, ctx.n_params, ctx.first_param = segs, (N, H, heads, scale, rps), len(params), first_param
         ctx.direct = ()
         if need_grad:
-            _register_direct(ctx, ATTN_PARAMS, params, ctx.needs_input_grad[7:])
+            _register_direct(ctx, ATTN_PARAMS, params, ctx.needs_input_grad[first_param:])
         if keep:  # activations only a frozen parameter's gradient would read are not kept
             if not needs["wo"]:
                 acts["aln"] = None if P["aln_w"] is not None else acts["aln"]
             if not (needs["wq"] or needs["wk"] or needs["wv"]):
                 acts["xln1"] = None
-        _save(ctx, keep, acts, x2, key_pad, ps, *params)
-        return x_mid.view(B, S, H)
+        _save(ctx, keep, acts, x2, rowscale, *params)
+        return x_mid
 
     @staticmethod
     def backward(ctx, dx_mid):
-        x2, key_pad, ps, *rest = ctx.saved_tensors
+        x2, rowscale, *rest = ctx.saved_tensors
         params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
-        B, S, H, heads, scale = ctx.dims
+        N, H, heads, scale, rps = ctx.dims
+        segs = ctx.segs
+        nseg = len(segs)
         P = dict(zip(ATTN_PARAMS, params))
         # what autograd actually asks for (frozen parameters -- stage-2 audio-language pretraining freezes the whole attention
         # branch, one_peace_pretrain.py:98-104 -- cost no weight-gradient GEMM, column sum or LayerNorm parameter reduction)
-        needs = {n: bool(ng) and q is not None for n, q, ng in zip(ATTN_PARAMS, params, ctx.needs_input_grad[7:])}
+        needs = {n: bool(ng) and q is not None for n, q, ng in zip(ATTN_PARAMS, params, ctx.needs_input_grad[ctx.first_param:])}
         need_x = bool(ctx.needs_input_grad[0])
-        bias = ctx.bias
-        bias_img = bias.image.detach() if bias is not None else None
-        want_dbias = bias is not None and bias.image.requires_grad
+        want_dbias = [sg.bias is not None and sg.bias.image.requires_grad for sg in segs]
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_a", "rstd_a", "y1", "xln1", "aln"))
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = _attn_forward(x2, P, B, S, heads, scale, bias_img, key_pad, ps, True,
-                                 bias.frag if bias is not None and S <= hip.ATTN_RESIDENT_MAX_S else None)
-        dx_mid = dx_mid.reshape(B * S, H)
+            _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True)
         if not dx_mid.is_contiguous():
             dx_mid = dx_mid.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], ps, S, "g1", "bo", direct, G, needs)
+        dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs)
         if needs["wo"]:
             weight_grad("wo", dy1, A["aln"])
         upstream = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b")
         dx = None
-        if need_x or want_dbias or any(needs[n] for n in upstream):
+        if need_x or any(want_dbias) or any(needs[n] for n in upstream):
             daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
             if P["aln_w"] is not None:
                 want = needs["aln_w"] or needs["aln_b"]
@@ -669,10 +698,13 @@ class AttnBranchFn(torch.autograd.Function):
             slot = {n: i for i, n in enumerate(cols)}
             qkv = A["qkv"]
             dqkv = torch.empty_like(qkv)
-            dparts = {n: dqkv[:, slot[n] * H:(slot[n] + 1) * H] for n in qkv_names}
-            _attn_backward(qkv, dattn, A["attn"], A["lse"], B, S, heads, scale, bias_img, bias.imageT if bias is not None else None,
-                           key_pad, bias.grad_accumulator(B) if want_dbias else None,
-                           bias.frag if bias is not None and S <= 384 else None, dparts["wq"], dparts["wk"], dparts["wv"])
+            for i, sg in enumerate(segs):
+                r = slice(sg.row0, sg.end)
+                dparts = {n: dqkv[r, slot[n] * H:(slot[n] + 1) * H] for n in qkv_names}
+                _attn_backward(qkv[r], dattn[r], A["attn"][r], A["lse%d" % i], sg.B, sg.S, heads, scale,
+                               sg.bias.image.detach() if sg.bias is not None else None, sg.bias.imageT if sg.bias is not None else None,
+                               sg.key_pad, sg.bias.grad_accumulator(sg.B) if want_dbias[i] else None, sg.frag(384),
+                               dparts["wq"], dparts["wk"], dparts["wv"])
             bias_of = {"wq": "bq", "wv": "bv"}
             bnames = tuple(bias_of[n] for n in cols if n in bias_of and needs[bias_of[n]])
             if bnames:
@@ -695,7 +727,7 @@ class AttnBranchFn(torch.autograd.Function):
             elif any(n in direct for n in qkv_names) or not all(needs[n] for n in qkv_names):
                 for n in qkv_names:
                     if needs[n]:
-                        weight_grad(n, dparts[n], A["xln1"])
+                        weight_grad(n, dqkv[:, slot[n] * H:(slot[n] + 1) * H], A["xln1"])
             else:
                 dW = wgrad(dqkv, A["xln1"])  # [3H, H]
                 G["wq"], G["wk"], G["wv"] = dW[:H], dW[H:2 * H], dW[2 * H:]
@@ -710,10 +742,11 @@ class AttnBranchFn(torch.autograd.Function):
         if dx is None and need_x:  # nothing upstream of the residual wanted a gradient: only the skip connection carries one
             dx = dx_mid
         grads = _return_grads(ATTN_PARAMS, params, G, direct)
-        dimg = None
-        if want_dbias:  # placeholder (see _RelPosImageFn.backward); the real gradient went into bias.acc
-            dimg = torch.zeros((), dtype=bias_img.dtype, device=bias_img.device).expand(bias_img.shape)
-        return (dx.view(B, S, H) if dx is not None else None, dimg, None, None, None, None, None, *grads)
+        dimgs = []
+        for sg, w in zip(segs, want_dbias):  # placeholders (see _RelPosImageFn.backward); the real gradients went into bias.acc
+            img = sg.bias.image if sg.bias is not None else None
+            dimgs.append(torch.zeros((), dtype=img.dtype, device=img.device).expand(img.shape) if w else None)
+        return (dx, None, None, None, None, None, *dimgs, *grads)
 
 
 class FfnBranchFn(torch.autograd.Function):
@@ -806,6 +839,194 @@ class FfnBranchFn(torch.autograd.Function):
         return (dx.view(B, S, H) if dx is not None else None, None, None, *grads)
 
 
+FFN_SHARED = ("ln2_w", "ln2_b", "g2")                       # shared by every modality (final_layer_norm, gamma_2)
+FFN_OWN = ("w0", "w1", "fln_w", "fln_b", "w2", "b2")          # one set per modality (text_ffn / image_ffn / audio_ffn)
+
+
+class FfnBranchMultiFn(torch.autograd.Function):
+    """Second half of transformer_layer.py:165-228 for a lock-step pass: x + droppath(gamma_2 * <modality>_ffn(LN(x))) on the packed
+    rows of several modalities, each segment through its OWN FFN weights.  final_layer_norm (forward and backward) runs over all
+    rows in one launch; the two narrow GEMMs of the branch -- down-projection + residual (N = H, K = F) and the input gradient of
+    wi_0 | wi_1 (N = H, K = 2F) -- are ONE grouped launch over the modalities (op_gemm_nt_grouped: a text pass alone is 192 tiles
+    on 256 CUs, the image pass 3.02 rounds); the wide ones (GeGLU up-projection, its LN(F), the input gradient of the
+    down-projection) and the weight gradients stay per modality.
+
+    x2: [N, H]; segs: [StreamSeg] (only row0 / B / S are used); pss: per segment fp32 [B] drop-path multipliers or None;
+    params: ln2_w, ln2_b, g2, then (w0, w1, fln_w, fln_b, w2, b2) per segment."""
+
+    @staticmethod
+    def _compute(x2, segs, pss, params, keep, want_y):
+        nseg = len(segs)
+        shared = dict(zip(FFN_SHARED, params[:3]))
+        own = [dict(zip(FFN_OWN, params[3 + 6 * i:9 + 6 * i])) for i in range(nseg)]
+        N, H = x2.shape
+        Fd = own[0]["w0"].shape[0]
+        xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep)
+        dev, dt = x2.device, x2.dtype
+        g = torch.empty(N, Fd, dtype=dt, device=dev)
+        h0 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
+        h1 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
+        has_fln = own[0]["fln_w"] is not None
+        gln = torch.empty(N, Fd, dtype=dt, device=dev) if has_fln else g
+        mean_f = torch.empty(N, dtype=torch.float32, device=dev) if keep and has_fln else None
+        rstd_f = torch.empty(N, dtype=torch.float32, device=dev) if keep and has_fln else None
+        L = hip.lib()
+        for sg, P in zip(segs, own):
+            r = slice(sg.row0, sg.end)
+            hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0[r] if keep else None, h1=h1[r] if keep else None, out=g[r])
+            if has_fln:
+                hip._check(L.op_layernorm_fwd(hip.ptr(g[r]), hip.ptr(P["fln_w"]), hip.ptr(P["fln_b"]), hip.ptr(gln[r]),
+                                              hip.ptr(mean_f[r]) if keep else None, hip.ptr(rstd_f[r]) if keep else None, sg.rows, Fd, 1e-5, 0,
+                                              hip.DT_BF16, hip.stream()), "op_layernorm_fwd")
+        y2 = torch.empty_like(x2) if keep and want_y else None
+        out = torch.empty_like(x2)
+        rs = [slice(sg.row0, sg.end) for sg in segs]
+        grouped = hip.gemm_nt_grouped([gln[r] for r in rs], [P["w2"] for P in own], biases=[P["b2"] for P in own], outs=[out[r] for r in rs],
+                                      epilogue=hip.EPI_RESID, h0s=[y2[r] for r in rs] if y2 is not None else None,
+                                      resids=[x2[r] for r in rs], gammas=[shared["g2"]] * nseg, rowscales=list(pss),
+                                      rows_per_sample=[sg.S for sg in segs])
+        if grouped is None:  # shape outside the persistent kernel: one launch per modality
+            for sg, P, r, ps in zip(segs, own, rs, pss):
+                hip.gemm_nt(gln[r], [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x2[r], gamma=shared["g2"], rowscale=ps,
+                            rows_per_sample=sg.S, h0=y2[r] if y2 is not None else None, out=out[r])
+        acts = dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2) if keep else None
+        return out, acts
+
+    @staticmethod
+    def forward(ctx, x2, segs, pss, save_acts, *params):
+        nseg = len(segs)
+        N, H = x2.shape
+        Fd = params[3].shape[0]
+        need_grad = any(ctx.needs_input_grad)
+        keep = bool(save_acts) and need_grad
+        needs = ctx.needs_input_grad[4:]
+        has_fln = params[5] is not None
+        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]))
+        ctx.segs, ctx.n_params, ctx.dims = segs, len(params), (N, H, Fd)
+        ctx.direct = ()
+        names = list(FFN_SHARED) + ["%s@%d" % (n, i) for i in range(nseg) for n in FFN_OWN]
+        ctx.names = names
+        if need_grad:
+            _register_direct(ctx, names, params, needs)
+        if keep:  # activations only a frozen parameter's gradient would read are not kept
+            nd = dict(zip(names, needs))
+            if not any(nd["w0@%d" % i] or nd["w1@%d" % i] for i in range(nseg)):
+                acts["xln2"] = None
+            if has_fln and not any(nd["w2@%d" % i] for i in range(nseg)):
+                acts["gln"] = None
+        _save(ctx, keep, acts or {}, x2, *[ps for ps in pss], *params)
+        ctx.n_ps = len(pss)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, *rest = ctx.saved_tensors
+        pss, rest = rest[:ctx.n_ps], rest[ctx.n_ps:]
+        params, saved_acts = rest[:ctx.n_params], rest[ctx.n_params:]
+        segs, names = ctx.segs, ctx.names
+        nseg = len(segs)
+        N, H, Fd = ctx.dims
+        P = dict(zip(names, params))
+        needs = {n: bool(ng) and q is not None for n, q, ng in zip(names, params, ctx.needs_input_grad[4:])}
+        need_x = bool(ctx.needs_input_grad[0])
+        if ctx.act_names is not None:
+            A = _restore(ctx, saved_acts, ("mean_f", "rstd_f", "y2", "gln", "xln2"))
+        else:  # recompute (the reference's checkpoint_activations behaviour)
+            _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, True)
+        if not dout.is_contiguous():
+            dout = dout.contiguous()
+        G = {}
+        weight_grad, direct = _weight_grad_fn(ctx, G)
+        has_fln = P["fln_w@0"] is not None
+        dev, dt = dout.device, dout.dtype
+        upstream = need_x or needs["ln2_w"] or needs["ln2_b"] or any(
+            needs["%s@%d" % (n, i)] for i in range(nseg) for n in ("w0", "w1", "fln_w", "fln_b"))
+        dh = torch.empty(N, 2 * Fd, dtype=dt, device=dev) if upstream else None
+        dgln = torch.empty(N, Fd, dtype=dt, device=dev) if upstream else None
+        colsets, dg_tmp = [], None
+        for i, sg in enumerate(segs):
+            r = slice(sg.row0, sg.end)
+            k = lambda n: "%s@%d" % (n, i)  # noqa: E731
+            # residual branch: gamma_2 is shared (its gradient accumulates over the segments), the bias is the modality's own
+            want_g, want_b = needs["g2"], needs[k("b2")]
+            acc_g, acc_b = "g2" in direct, k("b2") in direct
+            tg = direct["g2"].grad if acc_g else (True if want_g else None)
+            tb = direct[k("b2")].grad if acc_b else (True if want_b else None)
+            if want_g and want_b and acc_g != acc_b:  # one in the flat buffer, one not: two temporaries, folded below
+                tg = tb = True
+                acc_g = acc_b = False
+            dy2, dg_, db_ = hip.resid_bwd(dout[r], A["y2"][r] if want_g else None, P["g2"], pss[i], sg.S, dgamma=tg if want_g else None,
+                                          dbias=tb if want_b else None, accumulate=(acc_g and want_g) or (acc_b and want_b))
+            if want_g and not acc_g:
+                dg_tmp = dg_.float() if dg_tmp is None else dg_tmp + dg_.float()
+            if want_b:
+                if acc_b:
+                    _direct_grad_done(direct[k("b2")])
+                else:
+                    G[k("b2")] = db_
+            if needs[k("w2")]:
+                weight_grad(k("w2"), dy2, A["gln"][r])
+            if not upstream:
+                colsets.append(None)
+                continue
+            hip.gemm_nt(dy2, [_transposed(P[k("w2")])], out=dgln[r])
+            pair = (k("w0"), k("w1"))
+            order = _adjacent_grads(direct, pair) if needs[pair[0]] and needs[pair[1]] and Fd % 8 == 0 else None
+            cols = tuple(order) if order else pair
+            colsets.append(cols)
+            dpart = {n: dh[r, j * Fd:(j + 1) * Fd] for j, n in enumerate(cols)}
+            if has_fln:
+                want = needs[k("fln_w")] or needs[k("fln_b")]
+                (tw, tb2), acc = _targets(direct, k("fln_w"), k("fln_b")) if want else ((None, None), False)
+                _, _, dw_, db2_ = hip.ln_geglu_bwd(dgln[r], A["h0"][r], A["h1"][r], P[k("fln_w")], A["mean_f"][r], A["rstd_f"][r], dw=tw,
+                                                   db=tb2, accumulate=acc, need_wgrad=want, dh0=dpart[pair[0]], dh1=dpart[pair[1]])
+                if want:
+                    _finish(direct, G, (k("fln_w"), k("fln_b")), (dw_, db2_), acc)
+            else:
+                d0, d1 = hip.geglu_bwd(dgln[r], A["h0"][r], A["h1"][r])
+                dpart[pair[0]].copy_(d0)
+                dpart[pair[1]].copy_(d1)
+            if order:
+                wgrad(dh[r], A["xln2"][r], out=_span(direct, order), accumulate=True)
+                for n in order:
+                    _direct_grad_done(direct[n])
+            else:
+                for n in pair:
+                    if needs[n]:
+                        weight_grad(n, dpart[n], A["xln2"][r])
+        if needs["g2"]:
+            if "g2" in direct and dg_tmp is None:
+                _direct_grad_done(direct["g2"])
+            else:
+                G["g2"] = dg_tmp.to(dt)
+        dx = None
+        if upstream and (need_x or needs["ln2_w"] or needs["ln2_b"]):
+            dxln2 = torch.empty(N, H, dtype=dt, device=dev)
+            rs = [slice(sg.row0, sg.end) for sg in segs]
+            wts = [_transposed(tuple(P[n] for n in cols)) for cols in colsets]
+            if hip.gemm_nt_grouped([dh[r] for r in rs], wts, outs=[dxln2[r] for r in rs]) is None:
+                for r, wt in zip(rs, wts):
+                    hip.gemm_nt(dh[r], [wt], out=dxln2[r])
+            want = needs["ln2_w"] or needs["ln2_b"]
+            (tw, tb), acc = _targets(direct, "ln2_w", "ln2_b") if want else ((None, None), False)
+            dx, dw_, db_ = hip.layernorm_bwd(dxln2, x2, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"], add=dout, dw=tw, db=tb,
+                                             accumulate=acc, need_wgrad=want)
+            if want:
+                _finish(direct, G, ("ln2_w", "ln2_b"), (dw_, db_), acc)
+        if dx is None and need_x:
+            dx = dout
+        grads = _return_grads(names, params, G, direct)
+        return (dx, None, None, None, *grads)
+
+
+def ffn_branch_multi(x2, segs, pss, shared, own, save_acts=True):
+    """shared: (ln2_w, ln2_b, g2); own: per segment (w0, w1, fln_w, fln_b, w2, b2); save_acts False: recompute in backward."""
+    flat = list(shared)
+    for o in own:
+        flat += list(o)
+    return FfnBranchMultiFn.apply(x2, segs, tuple(pss), save_acts, *flat)
+
+
 def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag, dq, dk, dv):
     """Attention backward; dq / dk / dv: [N, H] column blocks of one packed [N, 3H] gradient matrix (any block order)."""
     H = heads * 64
@@ -820,7 +1041,20 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
 
 
 def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):
-    return AttnBranchFn.apply(x, bias.image if bias is not None else None, bias, key_pad, ps, heads, save_acts, *params)
+    """Single stream: x [B, S, H] contiguous; bias: RelPosBias-like handle or None; key_pad: uint8 [B, Spad] or None; ps: fp32 [B]
+    drop-path multipliers or None."""
+    B, S, H = x.shape
+    seg = StreamSeg("x", B, S, 0, bias, key_pad)
+    out = AttnBranchFn.apply(x.reshape(B * S, H), [seg], ps, S, heads, save_acts, bias.image if bias is not None else None, *params)
+    return out.view(B, S, H)
+
+
+def attn_branch_multi(x2, segs, ps_rows, heads, params, save_acts=False):
+    """Lock-step pass: x2 [sum rows, H] holds the rows of several streams (segs); ps_rows: fp32 [sum rows] per-row drop-path
+    multipliers or None.  The attention-branch weights are modality-shared (transformer_layer.py:111-138), so LayerNorm, q|k|v,
+    sub-LayerNorm and out-proj (and, in backward, their input- and weight-gradient GEMMs) are ONE launch over all rows."""
+    return AttnBranchFn.apply(x2, segs, ps_rows, 1, heads, save_acts, *[sg.bias.image if sg.bias is not None else None for sg in segs],
+                              *params)
 
 
 def ffn_branch(x, ps, params, save_acts=False):

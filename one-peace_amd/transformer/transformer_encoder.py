@@ -132,6 +132,62 @@ class TransformerEncoder(nn.Module):
         return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": [],
                 "image_encoder_states": [], "audio_encoder_states": []}
 
+    # ------------------------------------------------------------------------------------------------------
+    def multi_ok(self, infos):
+        """Can the single-modality streams `infos` ({modality: (x, pad, biases)}) run as ONE lock-step pass?"""
+        if len(infos) < 2:
+            return False
+        xs = [p[0] for p in infos.values()]
+        if not all(ops.hip_eligible(x) and x.device == xs[0].device for x in xs):
+            return False
+        return all(self._fused_ok(m, [p]) and not any(torch.is_tensor(b) or getattr(b, "ids", None) is not None for b in (p[2] or ()))
+                   for m, p in infos.items())
+
+    def forward_multi(self, infos):
+        """The single-modality passes of `infos` ({modality: adapter tuple (x [B,S,H], pad [B,S], bias list)}) advanced through the
+        layers in LOCK-STEP on one packed activation matrix [sum B*S, H]: what the reference computes with one forward per
+        modality (image_text_pretrain_loss.py:76-105 calls the model once per stream), with every modality-shared GEMM / LayerNorm
+        of the attention branch launched once over all rows and the per-modality FFN weights applied to their own row ranges.
+        Returns {modality: features [B, S, H]} -- per row the same arithmetic as `forward(..., encoder_type=modality)`."""
+        segs, xs, row0, samples = [], [], 0, 0
+        per_layer = []
+        for m, (x, pad, biases) in infos.items():
+            B, S, H = x.shape
+            handles = [b.handle() for b in biases] if biases else []
+            key_pad = None
+            if not getattr(pad, "_all_false", False):
+                x = x * (~pad).unsqueeze(-1).to(x.dtype)  # transformer_encoder.py:141-142
+                if handles:
+                    key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=x.device)
+                    key_pad[:, :S] = pad.to(torch.uint8)
+            xs.append(x.reshape(B * S, H))
+            segs.append((m, B, S, row0, key_pad, samples))
+            per_layer.append(handles)
+            row0 += B * S
+            samples += B
+        x2 = torch.cat(xs, dim=0)
+        dev = x2.device
+        scales = self._draw_path_scales(samples, dev)
+        row2sample = None
+        if scales is not None:
+            row2sample = torch.cat([torch.arange(B, device=dev).repeat_interleave(S) + s0 for (_, B, S, _, _, s0) in segs])
+        for idx, layer in enumerate(self.layers):
+            lsegs = []
+            for (m, B, S, r0, key_pad, _), handles in zip(segs, per_layer):
+                h = None if not handles else (handles[0] if len(handles) == 1 else handles[idx])
+                lsegs.append(ops.StreamSeg(m, B, S, r0, h, key_pad))
+            ps1 = ps2 = None
+            if scales is not None:
+                ps1, ps2 = scales[idx]
+            ps1_rows = ps1.index_select(0, row2sample) if ps1 is not None else None
+            ps2s = [ps2[s0:s0 + B] if ps2 is not None else None for (_, B, _, _, _, s0) in segs]
+            x2 = layer.forward_fused_multi(x2, lsegs, ps1_rows, ps2s)
+        out = {}
+        for (m, B, S, r0, _, _) in segs:
+            norm, rows = getattr(self, m + "_layer_norm"), x2[r0:r0 + B * S]
+            out[m] = (norm(rows) if norm is not None else rows).view(B, S, -1)
+        return out
+
     def _draw_path_scales(self, B, device):
         """Per-sample stochastic-depth multipliers of the whole stack in ONE draw (transformer_layer.py:78-85 draws a fresh
         Bernoulli mask per residual branch: 2 per layer; same distribution, 2 launches instead of 4 per layer)."""

@@ -138,6 +138,16 @@ class TransformerEncoderLayer(nn.Module):
         parts = (x[:, :n_text].contiguous(), x[:, n_text:].contiguous())
         return torch.cat([ops.ffn_branch(part, ps2, self.ffn_params(m), keep) for part, m in zip(parts, streams)], dim=1)
 
+    def forward_fused_multi(self, x2, segs, ps1_rows, ps2s):
+        """Lock-step pass over several single-modality streams: x2 [sum rows, H] packs the rows of the streams in `segs`
+        (ops.StreamSeg, named by modality).  The attention branch is modality-shared, so it runs once over all rows; every segment
+        then goes through its own FFN.  ps1_rows: fp32 [sum rows] per-row drop-path multipliers of the attention branch or None;
+        ps2s: per segment fp32 [B] multipliers of the FFN branch or None."""
+        keep = not getattr(self.cfg, "checkpoint_activations", False)
+        x2 = ops.attn_branch_multi(x2, segs, ps1_rows, self.self_attn.num_heads, self.attn_params(), keep)
+        own = [self.ffn_params(sg.name)[2:8] for sg in segs]
+        return ops.ffn_branch_multi(x2, segs, ps2s, (self.final_layer_norm.weight, self.final_layer_norm.bias, self.gamma_2), own, keep)
+
     def upgrade_state_dict_named(self, state_dict, name):
         """Legacy key renames + fill-in of missing keys (reference transformer_layer.py:230-248)."""
         for old, new in (("0", "self_attn_layer_norm"), ("1", "final_layer_norm")):

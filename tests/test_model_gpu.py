@@ -674,6 +674,87 @@ def test_deep_vision_branch_8_layers_4b_dimensions(golden_dir):
         "\n".join(report) + "\n")
 
 
+@pytest.mark.parametrize("flat,drop_path,recompute", [(False, 0.0, False), (True, 0.0, True), (True, 0.3, False), (False, 0.3, True)])
+def test_lock_step_pass_matches_one_forward_per_modality(flat, drop_path, recompute):
+    """TransformerEncoder.forward_multi: the text, image and audio streams of a tri-modal step advanced layer by layer in lock-step
+    on one packed activation matrix (shared attention-branch GEMMs / LayerNorms once over all rows, grouped launches for the narrow
+    FFN GEMMs) against one forward per modality (the reference's call pattern, image_text_pretrain_loss.py:76-105):
+    the embeddings and the loss must be BIT-IDENTICAL (per row the same kernels do the same arithmetic), so must every gradient of
+    the per-modality parameters (FFN sets, adapters' own weights are reached through bit-identical input gradients); the gradients
+    of the modality-SHARED parameters are one fp32 sum over all rows instead of three sums rounded to bf16 and added -- equal within
+    bf16 rounding (stated deviation, closer to fp32).  flat: gradients accumulated in place in FlatParameters (merged weight-gradient
+    launches); drop_path: the same per-sample drop-path draws in both runs; recompute: checkpoint_activations (layer activations
+    recomputed in backward) or kept."""
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.transformer import transformer_encoder as TE
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=3, attention_heads=2, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B = 6
+    inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    L = cfg["layers"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    table = (torch.bernoulli(torch.full((L, 2, 3 * B), 0.7), generator=g) / 0.7).to(DEV)  # fixed per-sample drop-path multipliers
+    calls = {"n": 0}
+    orig = TE.TransformerEncoder._draw_path_scales
+
+    def fixed_draw(self, nb, device):
+        if drop_path <= 0.0:
+            return None
+        o = 0 if nb == 3 * B else calls["n"] * B   # lock-step: all samples at once; separate passes: text, image, audio in turn
+        calls["n"] += 1
+        return [(table[i, 0, o:o + nb], table[i, 1, o:o + nb]) for i in range(L)]
+    TE.TransformerEncoder._draw_path_scales = fixed_draw
+    res = {}
+    try:
+        for lock in (False, True):
+            enc = one_peace_encoder_config(drop_path_rate=drop_path, layer_scale_init_value=1e-2, checkpoint_activations=recompute, **cfg)
+            torch.manual_seed(0)
+            m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+            m = m.to(DEV).to(torch.bfloat16).train()
+            fl = FlatParameters(m) if flat else None
+            calls["n"] = 0
+            used = {"multi": 0}
+            if lock:
+                orig_multi = TE.TransformerEncoder.forward_multi
+
+                def counted(self, infos):
+                    used["multi"] += 1
+                    return orig_multi(self, infos)
+                TE.TransformerEncoder.forward_multi = counted
+            try:
+                loss, _, log = TriModalContrastiveCriterion(None, 0.0, lock_step=lock)(m, {"net_input": inp, "nsentences": B})
+                if fl is not None:
+                    fl.zero_grad()
+                else:
+                    m.zero_grad()
+                loss.backward()
+                torch.cuda.synchronize()
+            finally:
+                if lock:
+                    TE.TransformerEncoder.forward_multi = orig_multi
+            assert used["multi"] == (1 if lock else 0)
+            res[lock] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+    finally:
+        TE.TransformerEncoder._draw_path_scales = orig
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    shared_tags = ("self_attn.", "self_attn_layer_norm", "final_layer_norm", "gamma_1", "gamma_2", "logit_scale")
+    n_exact = n_close = 0
+    for n, gs in res[False][1].items():
+        gm = res[True][1][n]
+        if any(t in n for t in shared_tags):
+            assert float((gm - gs).norm()) <= 2e-2 * float(gs.norm()) + 1e-5, (n, float((gm - gs).norm()), float(gs.norm()))
+            n_close += 1
+        else:
+            assert torch.equal(gm, gs), (n, float((gm - gs).abs().max()))
+            n_exact += 1
+    assert n_exact > 40 and n_close > 20
+
+
 def test_vision_tower_40_layers_matches_reference(golden_dir):
     """tests/golden/deep_vision40.pt: the reference's FULL-DEPTH image tower -- 40 layers at the 4B layer dimensions (1.5 B
     parameters, BASELINE configs[1]) -- one 256^2 image, forward, run on CPU in fp32 through ref_shim.  The HIP path in bf16 against

@@ -1,0 +1,13 @@
+# rocprofv3 kernel trace of the headline bench (3 timed steps) + last-step summary; outputs under gpurun_out/r3prof
+set -x
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3prof
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/prof_r3
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+find /tmp/prof_r3 -name "*.csv" | head
+KT=$(find /tmp/prof_r3 -name "*kernel_trace.csv" | head -1)
+ST=$(find /tmp/prof_r3 -name "*kernel_stats.csv" | head -1)
+cp $ST $OUT/bench_kernel_stats.csv
+python $GRAFT_REPO_ROOT/tools/trace_summary.py $KT $OUT/bench_last_step.json 1 > $OUT/trace_summary.txt 2>&1
+head -60 $OUT/trace_summary.txt

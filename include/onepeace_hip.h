@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, ldd of op_ln_geglu_bwd */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -194,11 +194,17 @@ int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float
                  void* stream);
 /* Backward of LayerNorm_F(gelu(h0) * h1) w.r.t. h0, h1 and the LayerNorm affine in one pass (the FFN's GeGLU + inner
  * sub-LayerNorm, transformer_layer.py:64-67,111-118); mean/rstd: forward statistics.  workspace: op_layernorm_bwd_workspace_bytes.
- * ldd: row stride (elements) of dh0 / dh1, 0 = cols -- the two gradients may be the halves of one [rows, 2 * cols] matrix, which
+ * ldh: row stride of h0 / h1 (0 = cols).  ldd: row stride (elements) of dh0 / dh1, 0 = cols -- the two gradients may be the halves of one [rows, 2 * cols] matrix, which
  * is then ONE operand for the merged wi_0 | wi_1 weight-gradient and input-gradient GEMMs. */
 int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* w, const float* mean, const float* rstd,
-                    void* dh0, void* dh1, int64_t ldd, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
-                    int accumulate, void* stream);
+                    void* dh0, void* dh1, int64_t ldd, int64_t ldh, void* dw, void* db, void* workspace, int64_t rows,
+                    int64_t cols, int accumulate, void* stream);
+/* Forward of the same pair: y [rows, cols] = LayerNorm_F(bf16(gelu(h0) * h1)) with exact-erf GELU, + mean / rstd (nullable).
+ * h0 / h1: row stride ldh (0 = cols) -- the halves of the [rows, 2 * cols] output of ONE plain two-segment up-projection GEMM
+ * (wi_0 | wi_1).  Used by the training path instead of the GEMM's EPI_GEGLU epilogue: the erf costs the GEMM more than this
+ * HBM-bound pass costs in total. */
+int op_ln_geglu_fwd(const void* h0, const void* h1, int64_t ldh, const void* w, const void* b, void* y, float* mean, float* rstd,
+                    int64_t rows, int64_t cols, float eps, void* stream);
 /* out[n] = (accumulate ? out[n] : 0) + mul[n] * sum_m rowscale[m/rps] * x[m][n] * (y ? y[m][n] : 1); y/rowscale/mul NULL ok */
 int op_colsum(const void* x, const void* y, const float* rowscale, int64_t rows_per_sample, const void* mul, void* out,
               void* workspace, int64_t M, int64_t N, int accumulate, int out_dtype, void* stream);

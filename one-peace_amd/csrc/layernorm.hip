@@ -120,6 +120,106 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
+// y = LayerNorm_F(bf16(gelu(h0) * h1)) straight from the two pre-activations of the GeGLU up-projection (row stride ldh: they are
+// the halves of one [rows, 2 * cols] matrix written by a PLAIN two-segment GEMM).  Takes the exact-erf GELU (16 VALU instructions
+// per element, 13 % of the fused-epilogue GEMM: one wave per SIMD cannot hide it) out of the GEMM's epilogue and into a kernel
+// that is HBM-bound with VALU to spare; the product is rounded to bf16 before the statistics, exactly as the backward
+// (ln_geglu_bwd_kernel) re-creates it.  Algorithmic bytes: 2 reads + 1 write of [rows, cols] bf16.
+template <int CH, int NW>
+__global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(const bf16_t* __restrict__ h0, const bf16_t* __restrict__ h1,
+                                                           int64_t ldh, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
+                                                           bf16_t* __restrict__ y, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, int64_t rows, int cols, float eps) {
+  __shared__ float red[4];
+  constexpr int G = 64 * NW;
+  const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
+  const int64_t row0 = (NW == 1) ? ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) : blockIdx.x;
+  const int64_t rstep = (NW == 1) ? (int64_t)gridDim.x * 4 : gridDim.x;
+  const float inv = 1.0f / (float)cols;
+  float wv[CH][8], bv[CH][8];
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = (tig + G * i) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wv[i][j] = 1.f; bv[i][j] = 0.f; }
+    if (c < cols) {
+      if (w) Vec8<bf16_t>::load(w + c, wv[i]);
+      if (b) Vec8<bf16_t>::load(b + c, bv[i]);
+    }
+  }
+  bf16x8 c0[CH], c1[CH], n0[CH], n1[CH];
+  if (row0 < rows) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        c0[i] = Vec8<bf16_t>::ldraw(h0 + row0 * ldh + c);
+        c1[i] = Vec8<bf16_t>::ldraw(h1 + row0 * ldh + c);
+      }
+    }
+  }
+  for (int64_t row = row0; row < rows; row += rstep) {
+    const int64_t nrow = row + rstep;
+    if (nrow < rows) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) {
+          n0[i] = Vec8<bf16_t>::ldraw(h0 + nrow * ldh + c);
+          n1[i] = Vec8<bf16_t>::ldraw(h1 + nrow * ldh + c);
+        }
+      }
+    }
+    float v[CH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        float a[8], bb[8];
+        Vec8<bf16_t>::cvt(c0[i], a);
+        Vec8<bf16_t>::cvt(c1[i], bb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[i][j] = (float)(bf16_t)(gelu_erf(a[j]) * bb[j]);
+          s += v[i][j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+      }
+    }
+    const float mean = group_sum<NW>(s, red) * inv;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; ss += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(group_sum<NW>(ss, red) * inv + eps);
+    bf16_t* yr = y + row * (int64_t)cols;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = (tig + G * i) * 8;
+      if (c < cols) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[i][j] + bv[i][j];
+        Vec8<bf16_t>::store(yr + c, o);
+      }
+    }
+    if (tig == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { c0[i] = n0[i]; c1[i] = n1[i]; }
+  }
+}
+
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw = sum_rows dy*xhat;  db = sum_rows dy.
 // Partial dw/db of each workgroup go to ws[gridDim.x][2][cols] (fp32); ln_bwd_reduce_kernel folds them.
 template <typename T, int CH, int NW, bool GELU>
@@ -258,8 +358,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
                                                            const bf16_t* __restrict__ h1, const bf16_t* __restrict__ w,
                                                            const float* __restrict__ mean_in,
                                                            const float* __restrict__ rstd_in, bf16_t* __restrict__ dh0,
-                                                           bf16_t* __restrict__ dh1, int64_t ldd, float* __restrict__ ws, int64_t rows,
-                                                           int cols) {
+                                                           bf16_t* __restrict__ dh1, int64_t ldd, int64_t ldh, float* __restrict__ ws,
+                                                           int64_t rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) float smem[];  // NW==1: [4][cols] ; NW==4: [4]
   float* red = smem;
   constexpr int G = 64 * NW;
@@ -284,8 +384,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        r0[i] = Vec8<bf16_t>::ldraw(h0 + row0 * (int64_t)cols + c);
-        r1[i] = Vec8<bf16_t>::ldraw(h1 + row0 * (int64_t)cols + c);
+        r0[i] = Vec8<bf16_t>::ldraw(h0 + row0 * ldh + c);
+        r1[i] = Vec8<bf16_t>::ldraw(h1 + row0 * ldh + c);
         rg[i] = Vec8<bf16_t>::ldraw(dy + row0 * (int64_t)cols + c);
       }
     }
@@ -299,8 +399,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
       for (int i = 0; i < CH; ++i) {
         const int c = (tig + G * i) * 8;
         if (c < cols) {
-          n0[i] = Vec8<bf16_t>::ldraw(h0 + nrow * (int64_t)cols + c);
-          n1[i] = Vec8<bf16_t>::ldraw(h1 + nrow * (int64_t)cols + c);
+          n0[i] = Vec8<bf16_t>::ldraw(h0 + nrow * ldh + c);
+          n1[i] = Vec8<bf16_t>::ldraw(h1 + nrow * ldh + c);
           ng[i] = Vec8<bf16_t>::ldraw(dy + nrow * (int64_t)cols + c);
         }
       }
@@ -505,12 +605,38 @@ int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b
 // Backward of  y = LayerNorm_F(gelu(h0) * h1) * w + b  w.r.t. h0, h1, w, b in one pass (bf16 only); mean/rstd are the
 // forward statistics of g = gelu(h0) * h1.  Replaces the LayerNorm backward + GeGLU backward pair of the FFN
 // (one_peace/models/transformer/transformer_layer.py:64-67,111-118); g itself is not needed.
+// y [rows, cols] = LayerNorm(bf16(gelu(h0) * h1)) (+ mean / rstd, nullable); h0, h1: row stride ldh (0 = cols).
+int op_ln_geglu_fwd(const void* h0, const void* h1, int64_t ldh, const void* w, const void* b, void* y, float* mean, float* rstd,
+                    int64_t rows, int64_t cols, float eps, void* stream) {
+  OP_CHECK_ARG(h0 && h1 && y, "ln_geglu_fwd: null pointer");
+  if (ldh <= 0) ldh = cols;
+  OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192 && ldh >= cols && ldh % 8 == 0, "ln_geglu_fwd: cols=%lld ldh=%lld unsupported",
+               (long long)cols, (long long)ldh);
+  if (rows == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define LNG_F(CH, NW)                                                                                                       \
+  hipLaunchKernelGGL((ln_geglu_fwd_kernel<CH, NW>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(NW == 1 ? 256 : 64 * NW), 0, s, \
+                     (const bf16_t*)h0, (const bf16_t*)h1, ldh, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, \
+                     (int)cols, eps)
+  if (cols <= 512) LNG_F(1, 1);
+  else if (cols <= 1024) LNG_F(2, 1);
+  else if (cols <= 1536) LNG_F(3, 1);
+  else if (cols <= 2048) LNG_F(4, 1);
+  else if (cols <= 4096) LNG_F(2, 4);
+  else if (cols <= 6144) LNG_F(3, 4);
+  else LNG_F(4, 4);
+#undef LNG_F
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
 int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* w, const float* mean, const float* rstd,
-                    void* dh0, void* dh1, int64_t ldd, void* dw, void* db, void* workspace, int64_t rows, int64_t cols, int accumulate,
-                    void* stream) {
+                    void* dh0, void* dh1, int64_t ldd, int64_t ldh, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
+                    int accumulate, void* stream) {
   OP_CHECK_ARG(dy && h0 && h1 && dh0 && dh1 && mean && rstd, "ln_geglu_bwd: null pointer");
   if (ldd <= 0) ldd = cols;
-  OP_CHECK_ARG(ldd >= cols && ldd % 8 == 0, "ln_geglu_bwd: output row stride %lld", (long long)ldd);
+  if (ldh <= 0) ldh = cols;
+  OP_CHECK_ARG(ldd >= cols && ldd % 8 == 0 && ldh >= cols && ldh % 8 == 0, "ln_geglu_bwd: row strides %lld / %lld", (long long)ldd, (long long)ldh);
   OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192, "ln_geglu_bwd: cols=%lld unsupported", (long long)cols);
   OP_CHECK_ARG(!(dw || db) || workspace, "ln_geglu_bwd: dw/db requested without workspace");
   if (rows == 0) return OP_OK;
@@ -523,7 +649,7 @@ int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* 
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                                 \
     hipLaunchKernelGGL((ln_geglu_bwd_kernel<CH, NW>), dim3(grid), dim3(NW == 1 ? 256 : 64 * NW), sh, s,           \
                        (const bf16_t*)dy, (const bf16_t*)h0, (const bf16_t*)h1, (const bf16_t*)w, mean, rstd,      \
-                       (bf16_t*)dh0, (bf16_t*)dh1, ldd, wsk, rows, (int)cols);                                     \
+                       (bf16_t*)dh0, (bf16_t*)dh1, ldd, ldh, wsk, rows, (int)cols);                                \
   } while (0)
   if (cols <= 512) LNG_B(1, 1);
   else if (cols <= 1024) LNG_B(2, 1);

@@ -45,7 +45,8 @@ SIGNATURES = {
     "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
     "op_resid_bwd_workspace_bytes": (I64, [I64]),
     "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, I64, I64, c_int, P]),
-    "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, I64, P, P, P, I64, I64, c_int, P]),
+    "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, P, P, P, I64, I64, c_int, P]),
+    "op_ln_geglu_fwd": (c_int, [P, P, I64, P, P, P, P, P, I64, I64, c_float, P]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
     "op_geglu_bwd": (c_int, [P, P, P, P, P, I64, P]),
     "op_scale_rows": (c_int, [P, P, P, I64, P, I64, I64, P]),
@@ -470,6 +471,7 @@ def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False, 
     if dh0 is None:
         dh0, dh1 = torch.empty_like(h0), torch.empty_like(h1)
     assert dh0.stride(0) == dh1.stride(0) and dh0.stride(1) == 1 and dh1.stride(1) == 1
+    assert h0.stride(0) == h1.stride(0) and h0.stride(1) == 1 and h1.stride(1) == 1
     ws = None
     if need_wgrad:
         if dw is None:
@@ -478,8 +480,21 @@ def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False, 
     else:
         dw = db = None
     _check(lib().op_ln_geglu_bwd(ptr(dy), ptr(h0), ptr(h1), ptr(w), ptr(mean), ptr(rstd), ptr(dh0), ptr(dh1), dh0.stride(0),
-                                 ptr(dw), ptr(db), ptr(ws), rows, cols, int(accumulate), stream()), "op_ln_geglu_bwd")
+                                 h0.stride(0), ptr(dw), ptr(db), ptr(ws), rows, cols, int(accumulate), stream()), "op_ln_geglu_bwd")
     return dh0, dh1, dw, db
+
+
+def ln_geglu_fwd(h0, h1, w, b, eps=1e-5, want_stats=True, out=None, mean=None, rstd=None):
+    """LayerNorm_F(bf16(gelu(h0) * h1)); h0 / h1 may be column blocks of one wider matrix.  Returns y, mean, rstd."""
+    rows, cols = h0.shape
+    assert h0.stride(0) == h1.stride(0) and h0.stride(1) == 1 and h1.stride(1) == 1
+    y = out if out is not None else torch.empty(rows, cols, dtype=h0.dtype, device=h0.device)
+    if want_stats and mean is None:
+        mean = torch.empty(rows, dtype=torch.float32, device=h0.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=h0.device)
+    _check(lib().op_ln_geglu_fwd(ptr(h0), ptr(h1), h0.stride(0), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream()),
+           "op_ln_geglu_fwd")
+    return y, mean, rstd
 
 
 def geglu_bwd(dg, h0, h1):

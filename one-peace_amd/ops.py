@@ -10,6 +10,7 @@ keeps only its input and recomputes the intermediates in backward -- the referen
 keeps them, which 288 GB of HBM affords even for the 4B model at batch 64.
 """
 import math
+import os
 import weakref
 
 import torch
@@ -487,22 +488,39 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
     return x_mid, acts
 
 
+GEGLU_SPLIT = os.environ.get("ONEPEACE_GEGLU_SPLIT", "1") != "0"
+
+
+def _geglu_split(Fd, fln_w):
+    """Training forward of the GeGLU: plain two-segment GEMM writing h0 | h1 + op_ln_geglu_fwd instead of the EPI_GEGLU epilogue
+    (which keeps the erf on the GEMM's critical path: one wave per SIMD cannot hide ~16 VALU per output element) followed by a
+    LayerNorm pass over g.  Needs the inner sub-LayerNorm (scale_fc) and whole 256-column tiles per weight segment."""
+    return GEGLU_SPLIT and fln_w is not None and Fd % 256 == 0
+
+
 def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True):
     """out = x_mid + ps2 * g2 * W2(LN_F(gelu(LN2(x_mid) W0^T) * (LN2(x_mid) W1^T)))  on x_mid [B*S, H]."""
     xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
     Fd = P["w0"].shape[0]
     h0 = h1 = None
-    if keep:
+    fp8 = FP8_FFN and x_mid.shape[1] % 128 == 0 and Fd % 128 == 0
+    split = keep and not fp8 and _geglu_split(Fd, P["fln_w"])
+    if keep and not split:
         h0 = torch.empty(x_mid.shape[0], Fd, dtype=x_mid.dtype, device=x_mid.device)
         h1 = torch.empty_like(h0)
-    fp8 = FP8_FFN and x_mid.shape[1] % 128 == 0 and Fd % 128 == 0
-    if fp8:  # opt-in: e4m3 operands with per-row scales, fp32 accumulation (csrc/fp8.hip)
+    if split:  # plain wi_0 | wi_1 up-projection; GELU, gate and the inner LayerNorm in one HBM-bound pass
+        hh = hip.gemm_nt(xln2, [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd)
+        h0, h1 = hh[:, :Fd], hh[:, Fd:]
+        gln, mean_f, rstd_f = hip.ln_geglu_fwd(h0, h1, P["fln_w"], P["fln_b"])
+    elif fp8:  # opt-in: e4m3 operands with per-row scales, fp32 accumulation (csrc/fp8.hip)
         xq, xs = hip.quant_fp8_rows(xln2)
         (w0q, w0s), (w1q, w1s) = _fp8_weight(P["w0"]), _fp8_weight(P["w1"])
         g = hip.gemm_nt_fp8(xq, xs, [w0q, w1q], [w0s, w1s], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
     else:
         g = hip.gemm_nt(xln2, [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1)
-    if P["fln_w"] is not None:
+    if split:
+        pass
+    elif P["fln_w"] is not None:
         gln, mean_f, rstd_f = hip.layernorm_fwd(g, P["fln_w"], P["fln_b"], want_stats=keep)
     else:
         gln, mean_f, rstd_f = g, None, None
@@ -863,16 +881,25 @@ class FfnBranchMultiFn(torch.autograd.Function):
         Fd = own[0]["w0"].shape[0]
         xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep)
         dev, dt = x2.device, x2.dtype
-        g = torch.empty(N, Fd, dtype=dt, device=dev)
-        h0 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
-        h1 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
         has_fln = own[0]["fln_w"] is not None
+        split = keep and _geglu_split(Fd, own[0]["fln_w"])
+        if split:
+            hh = torch.empty(N, 2 * Fd, dtype=dt, device=dev)
+            g, h0, h1 = None, hh[:, :Fd], hh[:, Fd:]
+        else:
+            g = torch.empty(N, Fd, dtype=dt, device=dev)
+            h0 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
+            h1 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
         gln = torch.empty(N, Fd, dtype=dt, device=dev) if has_fln else g
         mean_f = torch.empty(N, dtype=torch.float32, device=dev) if keep and has_fln else None
         rstd_f = torch.empty(N, dtype=torch.float32, device=dev) if keep and has_fln else None
         L = hip.lib()
         for sg, P in zip(segs, own):
             r = slice(sg.row0, sg.end)
+            if split:
+                hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd, out=hh[r])
+                hip.ln_geglu_fwd(h0[r], h1[r], P["fln_w"], P["fln_b"], out=gln[r], mean=mean_f[r], rstd=rstd_f[r])
+                continue
             hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0[r] if keep else None, h1=h1[r] if keep else None, out=g[r])
             if has_fln:
                 hip._check(L.op_layernorm_fwd(hip.ptr(g[r]), hip.ptr(P["fln_w"]), hip.ptr(P["fln_b"]), hip.ptr(gln[r]),

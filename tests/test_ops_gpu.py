@@ -396,6 +396,31 @@ def test_colsum_segments_qkv_bias_gradients(accumulate):
             assert_close(outs[i], ref[i * H:(i + 1) * H], what="seg%d" % i)
 
 
+@pytest.mark.parametrize("M,F_", [(130, 1024), (37, 256), (70, 6144), (9, 2048), (261, 1536)])
+def test_ln_geglu_fwd_fused(M, F_):
+    """LayerNorm_F(gelu(h0) * h1) from the two halves of one [M, 2F] matrix: against the oracle's formulas
+    (transformer_layer.py:64-67,111-118), and against the unfused pair it replaces (bf16 product, then op_layernorm_fwd): same
+    statistics and output up to the few bf16 ulps by which torch's erf and the device's differ."""
+    hip = hipmod()
+    hh = dev_bf16(torch.cat([rnd(M, F_, seed=2, scale=2.0), rnd(M, F_, seed=3)], 1))
+    h0, h1 = hh[:, :F_], hh[:, F_:]
+    w, b = dev_bf16(1 + 0.1 * rnd(F_, seed=4)), dev_bf16(0.1 * rnd(F_, seed=5))
+    y, mean, rstd = hip.ln_geglu_fwd(h0, h1, w, b)
+    g = (O.gelu_erf(h0.float()) * h1.float()).bfloat16()
+    y2, mean2, rstd2 = hip.layernorm_fwd(g, w, b, want_stats=True)
+    assert_close(y, y2.float().cpu(), fro=1e-3, mx=2e-2, what="vs unfused")
+    torch.testing.assert_close(mean, mean2, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(rstd, rstd2, rtol=1e-3, atol=1e-4)
+    ref = O.layer_norm(O.gelu_erf(h0.float().cpu()) * h1.float().cpu(), w.float().cpu(), b.float().cpu())
+    assert_close(y, ref, what="ln(geglu)")
+    # strided inputs of the backward: same result as from contiguous copies
+    dy = dev_bf16(rnd(M, F_, seed=1))
+    a = hip.ln_geglu_bwd(dy, h0, h1, w, mean, rstd)
+    c = hip.ln_geglu_bwd(dy, h0.contiguous(), h1.contiguous(), w, mean, rstd)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("M,F_", [(130, 1024), (37, 256), (70, 6144), (9, 2048)])
 def test_ln_geglu_bwd_fused(M, F_):
     """LayerNorm(F) backward + GeGLU backward in one pass vs autograd through the oracle's formulas

@@ -58,6 +58,10 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// resid + rowscale * gamma * y with the roundings pinned (product of the two scales, then one fused multiply-add): every epilogue
+// that applies the residual form -- in-kernel or in the split-K fold -- gives the same bits whatever the optimiser would contract.
+__device__ __forceinline__ float resid_out(float r, float rs, float gv, float y) { return __builtin_fmaf(__fmul_rn(rs, gv), y, r); }
+
 // LDS row p of the weight tile -> output column (relative to the tile) it feeds.
 template <int EPI>
 __device__ __forceinline__ int w_row_to_col(int p) {
@@ -195,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
         if (second) Vec8<bf16_t>::store(p.H0 + (int64_t)m * p.ldc + nc0 + 8, hi);
       }
 #pragma unroll
-      for (int j = 0; j < 16; ++j) o[j] = rv[j] + rs * gv[j] * o[j];
+      for (int j = 0; j < 16; ++j) o[j] = resid_out(rv[j], rs, gv[j], o[j]);
     }
     if (EPI == EPI_F32) {
       float* C = (float*)Cout + (int64_t)m * p.ldc + nc0;
@@ -211,6 +215,170 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
       for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
       Vec8<bf16_t>::store(C, lo);
       if (second) Vec8<bf16_t>::store(C + 8, hi);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Epilogue of the FOUR-WAVE kernels (gemm256v / gemm256p; plain / bias and residual forms): same arithmetic, operation for
+// operation, as gemm_epilogue above (bit-identical output), with the accumulators in the OTHER orientation.
+//
+// What the time stamps inside gemm256v_kernel said (tools/gemm_timeline.py, profiles/r3_gemm_timeline.txt): the shared epilogue
+// costs 4.3 us per tile in its plain form and 13 us in the residual form even with 48 workgroups on the chip, 5-6 / 16-18 us
+// with 256 -- 11 % of a K = 1536 launch.  Ablations of the same build: the arithmetic alone (accumulator reads, bias, bf16
+// conversion; stores replaced by a register sink) takes 0.9 us, the 32 stores alone (of a constant) take 4.2 us.  Re-writing the
+// arithmetic (1425 -> 630 instructions) and making the four lanes of a row cover 64 contiguous bytes changed nothing: the
+// texture addresser coalesces ADJACENT lanes only, and in the "weights as first operand" orientation adjacent lanes (t, t + 1)
+// are different ROWS -- every lane's 16 bytes went to the L2 as a request of their own, 64 requests per instruction, ~69 cycles
+// per store instruction and CU.
+//
+// So the kernels that end here issue their MFMAs with the ACTIVATION fragment as first operand (same fragments, same LDS
+// reads, operands swapped): accumulator acc[blk][ni][mi][r] of lane (g, t) is then row mi*16 + g*4 + r of the wave's 128 rows
+// and the weight-tile row blk*64 + ni*16 + t, and the weight rows are staged so that this is COLUMN t*8 + blk*4 + ni of the
+// wave's 128 columns (VMAP).  Per (mi, r) a lane holds 8 contiguous columns = one 16-byte store; the 16 lanes of a g-group
+// write one whole 256-byte row segment, a store instruction writes four of them: fully coalesced, 32 stores per wave.
+// C, the residual and the branch output go through buffer descriptors based at the wave's first row / column whose size ends
+// at the last valid row (rows >= M are dropped / read as zero by the hardware: no guards); the per-lane offset is ONE VGPR,
+// the row of a (mi, r) pair an SGPR offset.  N % 256 == 0 and n_seg % 256 == 0 (launch conditions).
+//
+// NOTE on the stores: `buffer_store_dwordx4 ... s_off offen` reads its data VGPRs late, and hipcc (ROCm 7.2) does not keep a
+// following VALU write of those VGPRs away from it -- neither across a block boundary nor inside a block (its hazard table has
+// the rule for an immediate offset only).  Seen as dword 1 of lanes 12-15 of every 16-lane row of a store going out overwritten
+// (tools/gemm_epi_debug.py), first behind a per-store branch, then in straight-line code with a separate `s_nop` statement that
+// the scheduler had moved behind the overwriting instruction.  Every store here is therefore ONE asm statement that contains
+// its own wait states (store_b128_padded) -- behind it for the data VGPRs, and in front of it for its SGPR operands, which an
+// opaque asm statement does not get from the compiler either -- and tools/check_mfma_hazards.py looks for both patterns in the
+// compiled ISA.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void unpack_bf16x8(const u32x4& raw, float (&f)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
+    f[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(const float (&f)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (bf16_t)f[j];
+  return __builtin_bit_cast(u32x4, v);
+}
+
+// 16-byte buffer store + the wait states that keep the next writer of its data VGPRs away (one asm statement: a separate
+// s_nop was scheduled BEHIND such writers; see the note above).  Descriptor: raw buffer, base / size in bytes.
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, int nbytes) {
+  const uint64_t a = (uint64_t)base;
+  return (u32x4){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffffu,
+                 (unsigned)__builtin_amdgcn_readfirstlane(nbytes), 0x00020000u};
+}
+__device__ __forceinline__ void store_b128_padded(const u32x4& data, const u32x4& rsrc, int voff, int soff) {
+  // (s_nop 4 in front: the SGPR operands may have been written by the SALU / v_readfirstlane just before -- 5 wait states that the
+  // hazard recogniser cannot insert for an instruction it does not see; without them a store went out with the PREVIOUS row offset)
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4][8], int mrow0, int ncol0, int g, int t) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "epilogue_v: plain / bias and residual epilogues only");
+  const int rows_left = min(p.M - mrow0, 128);  // wave-uniform
+  if (rows_left <= 0) return;
+  const int ldc = (int)p.ldc;
+  const int nrec = ((rows_left - 1) * ldc + 128) * 2;
+  const u32x4 rc = raw_rsrc((bf16_t*)p.C + (int64_t)mrow0 * p.ldc + ncol0, nrec);
+  const int voff = (g * 4 * ldc + t * 8) * 2;  // + ((mi*16 + r) * ldc) * 2 as the scalar offset
+  const int seg = ncol0 / p.n_seg;
+  const bf16_t* bp = p.bias[seg];
+  // the lane's 8 columns: acc[j >> 2][j & 3][mi][r] <-> column t*8 + j
+  auto row_of = [&](int mi, int r, float (&o)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = acc[j >> 2][j & 3][mi][r];
+  };
+
+  if constexpr (EPI == EPI_BIAS) {
+    auto stores = [&](auto bias_tag) {
+      constexpr bool BIAS = decltype(bias_tag)::value;
+      float bv[8];
+      if constexpr (BIAS) unpack_bf16x8(*reinterpret_cast<const u32x4*>(bp + (ncol0 - seg * p.n_seg) + t * 8), bv);
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float o[8];
+          row_of(mi, r, o);
+          if constexpr (BIAS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += bv[j];
+          }
+#if defined(OP_EXP_EPI) && OP_EXP_EPI == 1  // (tools/gemm_timeline.py ablations: 1 = arithmetic without the stores, 2 = stores without arithmetic)
+          { const u32x4 pk = pack_bf16x8(o); asm volatile("" ::"v"(pk)); }
+#elif defined(OP_EXP_EPI) && OP_EXP_EPI == 2
+          store_b128_padded((u32x4){0u, 0u, 0u, 0u}, rc, voff, (mi * 16 + r) * ldc * 2);
+#else
+          store_b128_padded(pack_bf16x8(o), rc, voff, (mi * 16 + r) * ldc * 2);
+#endif
+        }
+    };
+    if (bp) stores(std::true_type{});
+    else stores(std::false_type{});
+  } else {
+    const int ldr = (int)p.ldr;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + (int64_t)mrow0 * p.ldr + ncol0), 0,
+                                                                        ((rows_left - 1) * ldr + 128) * 2, 0x00020000);
+    const int voff_r = (g * 4 * ldr + t * 8) * 2;
+    // rowscale index of a row by multiply-high: exact while (rows + m_off) * rows_per_sample < 2^32 (else a true division)
+    const unsigned rps = (unsigned)p.rows_per_sample;
+    const bool exact = p.rowscale && (uint64_t)((unsigned)(p.M + p.m_off)) * rps < (1ull << 32) && rps > 1;
+    const unsigned magic = exact ? 0xffffffffu / rps + 1u : 0u;
+    // residual rows (and their row scales) in chunks of two 16-row fragments (8 rows per lane: 8 loads, 32 + 8 VGPRs), one chunk
+    // ahead of the arithmetic: the first chunk's latency is exposed (together with the bias / gamma loads), the later ones hide
+    u32x4 rraw[2][2][4];
+    float rsv[2][2][4];
+    auto load_chunk = [&](int c, u32x4 (&dst)[2][4], float (&rs)[2][4]) {  // chunk c: fragments mi = 2c, 2c + 1
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (c * 2 + m2) * 16 + r;  // + g * 4 in the lane offset
+          dst[m2][r] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff_r, row * ldr * 2, 0);
+          if (p.rowscale) {
+            const unsigned mc = (unsigned)(min(mrow0 + row + g * 4, p.M - 1) + p.m_off);
+            rs[m2][r] = p.rowscale[exact ? __umulhi(mc, magic) : mc / rps];
+          } else {
+            rs[m2][r] = 1.f;
+          }
+        }
+    };
+    load_chunk(0, rraw[0], rsv[0]);
+    float bv[8], gv[8];
+    {
+      u32x4 braw = (u32x4){0u, 0u, 0u, 0u}, graw = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      if (bp) braw = *reinterpret_cast<const u32x4*>(bp + (ncol0 - seg * p.n_seg) + t * 8);
+      if (p.gamma) graw = *reinterpret_cast<const u32x4*>(p.gamma + ncol0 + t * 8);
+      unpack_bf16x8(braw, bv);
+      unpack_bf16x8(graw, gv);
+    }
+    const bool has_y = p.H0 != nullptr;
+    const u32x4 ry = raw_rsrc(p.H0 + (int64_t)mrow0 * p.ldc + ncol0, has_y ? nrec : 0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c + 1 < 4) load_chunk(c + 1, rraw[(c + 1) & 1], rsv[(c + 1) & 1]);
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int mi = c * 2 + m2;
+          const int soff = (mi * 16 + r) * ldc * 2;
+          const float rs = rsv[c & 1][m2][r];
+          float o[8], rv[8];
+          row_of(mi, r, o);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += bv[j];
+          if (has_y) store_b128_padded(pack_bf16x8(o), ry, voff, soff);  // branch output y (pre layer-scale)
+          unpack_bf16x8(rraw[c & 1][m2][r], rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = resid_out(rv[j], rs, gv[j], o[j]);
+          store_b128_padded(pack_bf16x8(o), rc, voff, soff);
+        }
     }
   }
 }
@@ -1012,14 +1180,30 @@ __host__ __device__ constexpr int vs_dma(int S, int i) {  // LDS-DMA op issued a
   return (i & 7) == 5 ? i >> 3 : -1;
 }
 
+#ifdef OP_GEMM_TIMELINE  // tools/gemm_timeline.py only: per-workgroup time stamps (100 MHz s_memrealtime) of gemm256v_kernel
+__device__ unsigned long long* g_timeline = nullptr;
+#define TL_MARK(k)                                                                                       \
+  do {                                                                                                   \
+    if (g_timeline && threadIdx.x == 0) g_timeline[(int64_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define TL_MARK(k)
+#endif
+
 template <int EPI, int SCHED>
 __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  TL_MARK(1);
+#ifdef OP_GEMM_TIMELINE
+  if (g_timeline && threadIdx.x == 0)
+    g_timeline[(int64_t)blockIdx.x * 8] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int g = lane >> 4, t = lane & 15;
   constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+  constexpr bool VMAP = EPI == EPI_BIAS || EPI == EPI_RESID;  // ends in epilogue_v: its operand order and column map
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int GM = p.gm;
@@ -1051,12 +1235,16 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   const char* ptrB[2];
   {
     const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;
-    const int lanecol = (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
-                                           : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
+    // (VMAP, the column map of epilogue_v: LDS row j*32 + srow = wave (j >> 2), block (j >> 1) & 1, ni (j & 1)*2 + (srow >> 4),
+    // t = srow & 15  ->  column (j >> 2)*128 + t*8 + block*4 + ni)
+    const int lanecol = VMAP ? (srow & 15) * 8 + (srow >> 4)
+                             : (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
+                                                  : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
     offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int col0 = (EPI == EPI_GEGLU) ? n0 + (j & 3) * 32 : n0 - seg * p.n_seg + (j >> 1) * 64 + (j & 1) * 8;
+      const int col0 = (EPI == EPI_GEGLU) ? n0 + (j & 3) * 32
+                       : n0 - seg * p.n_seg + (VMAP ? (j >> 2) * 128 + ((j >> 1) & 1) * 4 + (j & 1) * 2 : (j >> 1) * 64 + (j & 1) * 8);
       soffB[j] = (unsigned)((int64_t)col0 * p.ldb * 2);
     }
     ptrB[0] = (const char*)((EPI == EPI_GEGLU) ? p.B[0] : p.B[seg]);
@@ -1119,7 +1307,8 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
       const int k = i >> 3, f = i & 7;
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
+      if constexpr (VMAP) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_x[k]), "v"(cur_w[f]));
+      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
       const int rd0 = vs_read(SCHED, i, 0), rd1 = vs_read(SCHED, i, 1), d = vs_dma(SCHED, i);
       if (rd0 >= 0 || rd1 >= 0 || d >= 0) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1149,8 +1338,10 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[a][b][c]) : "v"(zf));
   }
+  TL_MARK(2);
   WAIT_VM(16);
   __builtin_amdgcn_s_barrier();
+  TL_MARK(3);
   bf16x8 wfA[8], xfA[8], wfB[8], xfB[8];
   int sa = 0, sb = 1;
 #pragma unroll
@@ -1184,8 +1375,18 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   }
   // the empty fetches and the unused fragment reads of the last tile must be gone before the registers / the LDS get their next owner
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  gemm_epilogue<EPI, 8>(p, p.C, acc[0], m0 + wm * 128, n0 + wn * 128, n0 + (wn * 2) * 32, g, t);
-  gemm_epilogue<EPI, 8>(p, p.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, n0 + (wn * 2 + 1) * 32, g, t);
+  TL_MARK(4);
+  if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+    epilogue_v<EPI>(p, acc, m0 + wm * 128, n0 + wn * 128, g, t);
+  } else {
+    gemm_epilogue<EPI, 8>(p, p.C, acc[0], m0 + wm * 128, n0 + wn * 128, n0 + (wn * 2) * 32, g, t);
+    gemm_epilogue<EPI, 8>(p, p.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, n0 + (wn * 2 + 1) * 32, g, t);
+  }
+  TL_MARK(5);
+#ifdef OP_GEMM_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TL_MARK(6);
+#endif
 }
 
 // =====================================================================================================================
@@ -1270,13 +1471,16 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
   unsigned offA[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) offA[j] = (unsigned)(((int64_t)(j * 32 + srow) * p.lda + sc * 8) * 2);
-  const int lanecol = (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
-                                         : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
+  constexpr bool VMAP = EPI == EPI_BIAS || EPI == EPI_RESID;  // ends in epilogue_v: its operand order and column map
+  const int lanecol = VMAP ? (srow & 15) * 8 + (srow >> 4)
+                           : (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
+                                                : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
   const unsigned offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
   unsigned soffB[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    soffB[j] = (unsigned)((int64_t)((EPI == EPI_GEGLU) ? (j & 3) * 32 : (j >> 1) * 64 + (j & 1) * 8) * p.ldb * 2);
+    soffB[j] = (unsigned)((int64_t)((EPI == EPI_GEGLU) ? (j & 3) * 32
+                                    : VMAP ? (j >> 2) * 128 + ((j >> 1) & 1) * 4 + (j & 1) * 2 : (j >> 1) * 64 + (j & 1) * 8) * p.ldb * 2);
 
   f32x4 acc[2][4][8];  // [64-column block][ni][mi]
   auto zero_acc = [&]() {
@@ -1331,7 +1535,8 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
       const int k = i >> 3, f = i & 7;
-      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
+      if constexpr (VMAP) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_x[k]), "v"(cur_w[f]));
+      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
       const int rd0 = vs_read(SCHED, i, 0), rd1 = vs_read(SCHED, i, 1), d = vs_dma(SCHED, i);
       if (rd0 >= 0 || rd1 >= 0 || d >= 0) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1394,8 +1599,12 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
 #pragma unroll
       for (int sgi = 0; sgi < 3; ++sgi)
         q.bias[sgi] = cur.prob == 0 ? p.bias[0][sgi] : cur.prob == 1 ? p.bias[1][sgi] : p.bias[2][sgi];
-      gemm_epilogue<EPI, 8>(q, q.C, acc[0], cur.m0 + wm * 128, cur.n0 + wn * 128, cur.n0 + (wn * 2) * 32, g, t);
-      gemm_epilogue<EPI, 8>(q, q.C, acc[1], cur.m0 + wm * 128, cur.n0 + wn * 128 + 64, cur.n0 + (wn * 2 + 1) * 32, g, t);
+      if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+        epilogue_v<EPI>(q, acc, cur.m0 + wm * 128, cur.n0 + wn * 128, g, t);
+      } else {
+        gemm_epilogue<EPI, 8>(q, q.C, acc[0], cur.m0 + wm * 128, cur.n0 + wn * 128, cur.n0 + (wn * 2) * 32, g, t);
+        gemm_epilogue<EPI, 8>(q, q.C, acc[1], cur.m0 + wm * 128, cur.n0 + wn * 128 + 64, cur.n0 + (wn * 2 + 1) * 32, g, t);
+      }
     }
     zero_acc();
     cur = nxt;
@@ -2009,7 +2218,7 @@ __global__ __launch_bounds__(256) void splitk_fold_epilogue_kernel(const FoldArg
       if (p.gamma) {
         Vec8<bf16_t>::load(p.gamma + c, gv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = r[j] + rs * gv[j] * a[j];
+        for (int j = 0; j < 8; ++j) a[j] = resid_out(r[j], rs, gv[j], a[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = r[j] + rs * a[j];
@@ -2399,3 +2608,9 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 }
 
 }  // extern "C"
+
+#ifdef OP_GEMM_TIMELINE
+extern "C" int op_debug_gemm_timeline(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf));
+}
+#endif

@@ -12,7 +12,7 @@ from ctypes import c_double, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libonepeace_hip.so")
+LIB_PATH = os.environ.get("ONEPEACE_HIP_LIB") or os.path.join(_HERE, "lib", "libonepeace_hip.so")  # (override: instrumented builds of tools/)
 _lib = None
 
 DT_BF16, DT_F32 = 0, 1

@@ -11,6 +11,14 @@ a few accumulator registers per wave were read stale, deterministically per bina
 every kernel's instruction stream in program order (every loop body a second time, for hazards across its back edge) and
 reports any compiler-generated instruction that touches an AGPR fewer than NEED wait states after the inline-asm MFMA that
 writes that AGPR.  Without an argument it compiles csrc/gemm.hip with -save-temps in a temporary directory first.
+
+Second check (round 3, csrc/gemm.hip epilogue_v): `buffer_store_dwordx3/x4 v[a:b], v, s[..], sN offen` reads its data VGPRs
+late; this hipcc does not keep a following VALU write of v[a:b] away from it when the offset is an SGPR (dword 1 of lanes 12-15
+of each 16-lane row went out overwritten).  Reported: any instruction that writes one of the data VGPRs fewer than STORE_NEED
+wait states behind such a store, in fall-through order (labels are walked through: the miss was first seen across one).
+Third check: those stores are inline asm, so the compiler does not give them the SGPR_NEED wait states a VMEM instruction needs
+behind an SALU / v_readfirstlane write of an SGPR it reads (row offset, descriptor) -- a store went out with the previous row's
+offset; reported when the asm block does not supply them itself.
 Exit status 0 = clean.
 """
 import os
@@ -20,8 +28,55 @@ import sys
 import tempfile
 
 NEED = 18  # wait states between an 8-pass XDL write and a non-MFMA read / overwrite of the result
+SGPR_NEED = 5   # wait states between an SALU / v_readfirstlane write of an SGPR and an inline-asm VMEM instruction that reads it
+STORE_NEED = 2  # wait states between a >= 12-byte buffer store with an SGPR offset and a VALU write of its data VGPRs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AGPR = re.compile(r"\ba(?:\[(\d+):(\d+)\]|(\d+)\b)")
+VGPR = re.compile(r"\bv(?:\[(\d+):(\d+)\]|(\d+)\b)")
+WIDE_STORE = re.compile(r"^buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*v\d+,\s*s\[\d+:\d+\],\s*s\d+")
+
+
+def vgprs(text):
+    out = []
+    for m in VGPR.finditer(text):
+        if m.group(3) is not None:
+            out.append(int(m.group(3)))
+        else:
+            out.extend(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check_store_data(lines):
+    """The store-data rule over the whole file, fall-through order.  Returns [problem strings]."""
+    problems, name = [], None
+    pending = []  # (set of data VGPRs, wait states since the store, text)
+    for n, raw in enumerate(lines, 1):
+        line = raw.strip()
+        m = re.match(r"^(_Z\w+):", raw)
+        if m:
+            name, pending = m.group(1), []
+            continue
+        if not line or line.startswith((".", ";")) or line.endswith(":"):
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        op = code.split()[0]
+        if op == "s_nop":
+            step = int(code.split()[1]) + 1
+        else:
+            step = 1
+            if op.startswith("v_") and not op.startswith("v_cmp") and len(code.split(None, 1)) > 1:
+                dest = set(vgprs(code.split(None, 1)[1].split(",")[0]))
+                for regs, since, text in pending:
+                    if since < STORE_NEED and dest & regs:
+                        problems.append("%s: line %d: `%s` overwrites data of `%s` %d wait states behind it" % (name, n, code, text, since))
+        pending = [(r, since + step, t) for r, since, t in pending if since + step < STORE_NEED]
+        m = WIDE_STORE.match(code)
+        if m:
+            pending.append((set(range(int(m.group(1)), int(m.group(2)) + 1)), 0, code))
+    return problems
+
 
 
 def agprs(text):
@@ -92,8 +147,59 @@ def check_lines(lines):
     return kernels, problems
 
 
+SGPR = re.compile(r"\bs(?:\[(\d+):(\d+)\]|(\d+)\b)")
+
+
+def sgprs(text):
+    out = []
+    for m in SGPR.finditer(text):
+        if m.group(3) is not None:
+            out.append(int(m.group(3)))
+        else:
+            out.extend(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check_asm_vmem_sgprs(lines):
+    """SGPR write -> inline-asm VMEM read, fall-through order.  Returns [problem strings]."""
+    problems, name, in_asm, now, wrote = [], None, False, 0, {}
+    for n, raw in enumerate(lines, 1):
+        line = raw.strip()
+        m = re.match(r"^(_Z\w+):", raw)
+        if m:
+            name, in_asm, now, wrote = m.group(1), False, 0, {}
+            continue
+        if ";;#ASMSTART" in line:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in line:
+            in_asm = False
+            continue
+        if not line or line.startswith((".", ";")) or line.endswith(":"):
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        op = code.split()[0]
+        if in_asm and op.startswith(("buffer_", "global_", "flat_")):
+            for r in sgprs(code):
+                if r in wrote and now - wrote[r] < SGPR_NEED:
+                    problems.append("%s: line %d: inline-asm `%s` reads s%d %d wait states after it was written" % (name, n, code, r, now - wrote[r]))
+                    break
+        elif (op.startswith("s_") and not op.startswith(("s_nop", "s_waitcnt", "s_cmp", "s_cbranch", "s_branch", "s_barrier", "s_endpgm", "s_load", "s_sleep", "s_setprio"))) \
+                or op == "v_readfirstlane_b32" or op == "v_readlane_b32":
+            rest = code.split(None, 1)
+            if len(rest) > 1:
+                for r in sgprs(rest[1].split(",")[0]):
+                    wrote[r] = now
+        now += (int(code.split()[1]) + 1) if op == "s_nop" else 1
+    return problems
+
+
 def check(path):
-    return check_lines(open(path).read().split("\n"))
+    lines = open(path).read().split("\n")
+    kernels, problems = check_lines(lines)
+    return kernels, problems + check_store_data(lines) + check_asm_vmem_sgprs(lines)
 
 
 def main():

@@ -1330,6 +1330,10 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   using IsB = std::integral_constant<bool, true>;
 
   // ---- prologue: A0 B0 A1 B1 (nk >= 2); fragments of (0,0) ----
+  // (tools/gemm_timeline.py: 2.6 ... 4.1 us from kernel entry to the first fragments, 0.6 of it index math; the rest is the latency
+  // of the first operand tiles when all 256 CUs start a round together -- issuing the second tile pair behind the accumulator
+  // clear instead of in front of it changed nothing, round 3)
+  TL_MARK(7);
   issue_tile(false);
   issue_tile(true);
   issue_tile(false);
@@ -1648,6 +1652,7 @@ __device__ __forceinline__ void tn_epilogue(const GemmArgs& p, void* Cout, f32x4
       if (n >= p.N) continue;  // N % 8 == 0: a group of four never straddles the edge
       const f32x4 a = acc[f][mi];
       if (EPI == EPI_F32) {
+        // (plain stores on purpose: the fold kernel re-reads the slabs right away -- non-temporal stores measured +3 % on the launch)
         *reinterpret_cast<f32x4*>((float*)Cout + (int64_t)m * p.ldc + n) = a;
       } else {
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;

@@ -34,6 +34,16 @@ cases = [
     ("dgrad N6144", lambda: hip.gemm_nt(x, [w2t], out=o_f, splitk=False), 2.0 * M * F * H),
     ("dgrad K4608", lambda: hip.gemm_nt(x3, [w3t], out=o_h, splitk=False), 2.0 * M * H * 3 * H),
 ]
+if os.environ.get("TN", "1") != "0":  # weight-gradient launches of the lock-step step (accumulate into bf16 gradients)
+    KA = 73216
+    dyf, dyq, xa, gf = torch.randn(M, 2 * F, **bf), torch.randn(KA, 3 * H, **bf), torch.randn(KA, H, **bf), torch.randn(M, F, **bf)
+    a_w01, a_w2, a_qkv, a_o = torch.zeros(2 * F, H, **bf), torch.zeros(H, F, **bf), torch.zeros(3 * H, H, **bf), torch.zeros(H, H, **bf)
+    cases += [
+        ("tn w01", lambda: hip.gemm_tn(dyf, x, a_w01, True), 2.0 * M * 2 * F * H),
+        ("tn w2", lambda: hip.gemm_tn(x, gf, a_w2, True), 2.0 * M * F * H),
+        ("tn qkv", lambda: hip.gemm_tn(dyq, xa, a_qkv, True), 2.0 * KA * 3 * H * H),
+        ("tn out", lambda: hip.gemm_tn(xa, xa, a_o, True), 2.0 * KA * H * H),
+    ]
 best = {}
 for _ in range(ROUNDS):
     for name, fn, fl in cases:

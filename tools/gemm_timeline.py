@@ -73,6 +73,7 @@ def run(name, M, N, K, fn):
     if os.environ.get('RAW'):
         print([hex(int(v)) for v in hw[:12]])
     t = d[:, 1:7].double() * 0.01  # us
+    index_math = float(((d[:, 7] - d[:, 1]).double() * 0.01).median())  # kernel entry -> first LDS-DMA instruction
     t0 = t[:, 0].min()
     med = lambda x: float(x.median())
     seg = dict(setup=med(t[:, 1] - t[:, 0]), wait=med(t[:, 2] - t[:, 1]), loop=med(t[:, 3] - t[:, 2]), epilogue=med(t[:, 4] - t[:, 3]),
@@ -85,9 +86,9 @@ def run(name, M, N, K, fn):
             gaps.append(rows[1:, 0] - rows[:-1, 5])
     gaps = torch.cat(gaps) if gaps else torch.zeros(1, dtype=torch.double)
     total = float(t[:, 5].max() - t0)
-    print("%-28s M=%6d N=%5d K=%5d | %4d workgroups on %3d CUs, launch %.1f us | set-up %.2f  wait %.2f  loop %.2f  epilogue %.2f  drain %.2f | "
+    print("%-28s M=%6d N=%5d K=%5d | %4d workgroups on %3d CUs, launch %.1f us | set-up %.2f (of which kernel arguments + index math %.2f)  wait %.2f  loop %.2f  epilogue %.2f  drain %.2f | "
           "gap to next workgroup on the CU: median %.2f  p90 %.2f us | first entry spread %.2f us" % (
-              name, M, N, K, d.shape[0], len(cu.unique()), total, seg["setup"], seg["wait"], seg["loop"], seg["epilogue"], seg["drain"],
+              name, M, N, K, d.shape[0], len(cu.unique()), total, seg["setup"], index_math, seg["wait"], seg["loop"], seg["epilogue"], seg["drain"],
               med(gaps), float(gaps.quantile(0.9)), float(t[:, 0].sort().values[min(255, d.shape[0] - 1)] - t0)), flush=True)
 
 

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -145,9 +145,12 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
  * the matrix pipe too.  dq/dk/dv rows have stride ldg; dbias fp32 [slabs][heads][S][Spad] (optional, accumulated into:
  * pre-zero it; the gradient is the sum over slabs, slabs = op_attn_bwd_dbias_slabs(B, S, heads, tune)). */
 int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune);
-int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
-                const void* biasT, const void* bias_frag, int64_t bias_batch_stride, const void* key_pad, const float* lse,
-                const float* delta, void* dq,
+/* out (nullable): the forward output rows (same stride ldo as dout).  Given, `delta` is a WORKSPACE of the call: the dQ kernels
+ * compute delta = rowsum(dout o out) per head from fragments they load anyway and the dK/dV kernel, launched behind them, reads
+ * it -- op_attn_bwd_delta's pass over both matrices is not needed.  NULL: `delta` must hold op_attn_bwd_delta's result. */
+int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, const void* out, int64_t ldo,
+                const void* bias, const void* biasT, const void* bias_frag, int64_t bias_batch_stride, const void* key_pad,
+                const float* lse, float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
                 int64_t head_dim, float scale, int64_t tune, void* stream);
 

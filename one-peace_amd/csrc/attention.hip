@@ -557,6 +557,8 @@ struct AttnBwdArgs {
   const uint8_t* key_pad;            // [B][Spad]
   const float* lse;                  // [B][heads][Spad]
   const float* delta;                // [B][heads][Spad]
+  const bf16_t* out;                 // forward output rows [B*S][ldo], or null.  Given: the dQ kernels compute delta = rowsum(dO o O) per
+  float* delta_w;                    // head themselves and store it here (= delta) for the dK/dV kernel, which then runs after them
   bf16_t* dq; bf16_t* dk; bf16_t* dv; int64_t ldg;  // gradient rows (same packing as q/k/v)
   float* dbias;                      // [heads][S][Spad] fp32, pre-zeroed
   int B, S, Spad, heads, bchunk;
@@ -588,6 +590,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     const int qi = (int)(row - bb * S);
     delta[(bb * heads + h) * Spad + qi] = s;
   }
+}
+
+// delta[q] = sum_d dO[q][d] * O[q][d] of one head from the first-operand fragments of a 16-query block (lane (g, t): row t, dims
+// kk*32 + g*8 .. +7): 16 products per lane, then the four g-groups.  Every lane of a row ends up with the row's sum.
+__device__ __forceinline__ float delta_from_frags(const bf16x8 (&dO)[2], const bf16x8 (&O)[2]) {
+  float s = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = __builtin_fmaf((float)dO[kk][i], (float)O[kk][i], s);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  return s;
 }
 
 // Softmax part rewritten in round 2 like the resident forward kernel (profiles/r2_experiments.md: these kernels are bound by
@@ -903,7 +918,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
       of[qb][kk] = *reinterpret_cast<const bf16x8*>(p.dout + (row_base + qi) * p.ldo + h * HD + kk * 32 + g * 8);
     }
     lse[qb] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
-    del[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+    if (p.out) {  // (uniform) delta from dO and O, stored for the dK/dV kernel
+      bf16x8 oo[2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) oo[kk] = *reinterpret_cast<const bf16x8*>(p.out + (row_base + qi) * p.ldo + h * HD + kk * 32 + g * 8);
+      del[qb] = delta_from_frags(of[qb], oo);
+      if (g == 0 && q0w + qb * 16 + t < p.S) p.delta_w[((int64_t)b * p.heads + h) * p.Spad + qi] = del[qb];
+    } else {
+      del[qb] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+    }
   }
   f32x4 dqT[2][4];
 #pragma unroll
@@ -1042,17 +1065,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
       *reinterpret_cast<u32x4*>(ldsV + off) = rv[i];
     }
   };
-  bf16x8 qn[1][2], on[1][2];
+  bf16x8 qn[1][2], on[1][2], oon[2];
   float lsen[1], deln[1];
+  const bool own_delta = p.out != nullptr;  // delta from dO and O here, stored for the dK/dV kernel (which then runs after this one)
   auto load_q = [&](int b) {
     const int64_t row = (int64_t)b * p.S + qi;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       qn[0][kk] = *reinterpret_cast<const bf16x8*>(p.q + row * p.ld + h * HD + kk * 32 + g * 8);
       on[0][kk] = *reinterpret_cast<const bf16x8*>(p.dout + row * p.ldo + h * HD + kk * 32 + g * 8);
+      if (own_delta) oon[kk] = *reinterpret_cast<const bf16x8*>(p.out + row * p.ldo + h * HD + kk * 32 + g * 8);
     }
     lsen[0] = p.lse[((int64_t)b * p.heads + h) * p.Spad + qi];
-    deln[0] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
+    if (!own_delta) deln[0] = p.delta[((int64_t)b * p.heads + h) * p.Spad + qi];
   };
   int trsw[4];
 #pragma unroll
@@ -1083,7 +1108,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) { qf[0][kk] = qn[0][kk]; of[0][kk] = on[0][kk]; }
     lse[0] = lsen[0];
-    del[0] = deln[0];
+    if (own_delta) {
+      del[0] = delta_from_frags(of[0], oon);
+      if (g == 0 && q0w + t < p.S) p.delta_w[((int64_t)b * p.heads + h) * p.Spad + qi] = del[0];
+    } else {
+      del[0] = deln[0];
+    }
     if (b + 1 < b_end) load_q(b + 1);
     // The bias fragments do not depend on the sample; left alone the compiler hoists all NT x 4 of them out of this loop
     // (8 VGPRs per key tile) and spills accumulators instead.  They are L2-resident: reload per sample.
@@ -1459,9 +1489,11 @@ int op_attn_bwd_delta(const void* dout, const void* out, int64_t ldo, float* del
 // dbias (fp32 [op_attn_bwd_dbias_slabs()][heads][S][Spad], pre-zeroed by the caller, accumulated into) is optional.
 // bias_batch_stride != 0: bias / biasT hold one image per sample (that many elements apart; the masked-pretraining
 // branch gathers a different token subset per sample, adapter/image.py:229-246); dbias then has B slabs, one per sample.
-int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* bias,
+// out (nullable): the forward output rows (stride ldo).  Given, `delta` is a WORKSPACE: the dQ kernels compute it from dout and
+// out and the dK/dV kernel (launched after them) reads it -- op_attn_bwd_delta's pass over both matrices is not needed.
+int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const void* dout, const void* out, int64_t ldo, const void* bias,
                 const void* biasT, const void* bias_frag, int64_t bias_batch_stride, const void* key_pad, const float* lse,
-                const float* delta, void* dq,
+                float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
                 int64_t head_dim, float scale, int64_t tune, void* stream) {
   const bool merge_dbias = !(tune & 1);
@@ -1478,7 +1510,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   a.bias_bs = bias ? bias_batch_stride : 0;
   OP_CHECK_ARG(!(dbias && a.bias_bs != 0) || (merge_dbias && ceil_div(S, BKV) <= 6),
                "attn_bwd: the gradient of a per-sample bias needs the merged dQ + dBias kernel (S <= 384)");
-  a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta;
+  a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta; a.out = (const bf16_t*)out; a.delta_w = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
   {  // batch chunk per workgroup: enough workgroups to fill the chip, as few atomic rounds as possible
@@ -1490,11 +1522,20 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   }
   hipStream_t s = (hipStream_t)stream;
   const double fl = 4.0 * (double)B * (double)heads * (double)S * (double)S * HD;
-  int slot = op_prof_begin(2, 2.0 * fl, stream);
-  if (bias) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
-  op_prof_end(slot, stream);
-  OP_LAUNCH_CHECK();
+  int slot;
+  const int bchunk_dkdv = a.bchunk;
+  auto launch_dkdv = [&]() {
+    AttnBwdArgs d = a;
+    d.bchunk = bchunk_dkdv;
+    const int sl = op_prof_begin(2, 2.0 * fl, stream);
+    if (bias) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+    op_prof_end(sl, stream);
+  };
+  if (!out) {  // delta precomputed (op_attn_bwd_delta): the kernels are independent
+    launch_dkdv();
+    OP_LAUNCH_CHECK();
+  }
   const int nt = ceil_div(S, BKV);
   if (dbias && nt <= 6 && merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
     // per-sample bias: every sample is its own chunk, slab b of dbias is the gradient of sample b's bias image
@@ -1523,6 +1564,10 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
 #undef DQDB
     op_prof_end(slot, stream);
     OP_LAUNCH_CHECK();
+    if (out) {
+      launch_dkdv();
+      OP_LAUNCH_CHECK();
+    }
     return OP_OK;
   }
   slot = op_prof_begin(2, 1.5 * fl, stream);
@@ -1530,6 +1575,10 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(ceil_div(S, BQ), (unsigned)heads, (unsigned)B), dim3(256), 0, s, a);
   op_prof_end(slot, stream);
   OP_LAUNCH_CHECK();
+  if (out) {
+    launch_dkdv();
+    OP_LAUNCH_CHECK();
+  }
   if (dbias) {
     const int chunks = ceil_div(B, a.bchunk);
     hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(ceil_div(S, BQ), ceil_div(S, BKV), (unsigned)(heads * chunks)), dim3(256), 0,

@@ -64,7 +64,7 @@ SIGNATURES = {
     "op_attn_bias_frag_elems": (I64, [I64, I64]),
     "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
-    "op_attn_bwd": (c_int, [P, P, P, I64, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
+    "op_attn_bwd": (c_int, [P, P, P, I64, P, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
     "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
@@ -637,24 +637,24 @@ def attn_bwd(q, k, v, ld, dout, out, lse, B, S, heads, scale, bias=None, biasT=N
     dev = q.device
     H = heads * 64
     Spad = Spad or attn_spad(S)
-    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)
-    _check(lib().op_attn_bwd_delta(ptr(dout), ptr(out), dout.stride(0), ptr(delta), B, S, Spad, heads, stream()),
-           "op_attn_bwd_delta")
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)  # workspace: filled by the dQ kernels (out is passed)
+    assert out.stride(0) == dout.stride(0)
     if dqkv is None:
         dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=dev)
     per_sample = bias is not None and bias.dim() == 4
     dbias = attn_dbias_buffer(B, S, heads, Spad, dev, per_sample) if want_dbias else None
     dq, dk, dv = dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:]
     attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, dqkv.stride(0), dbias, B, S, Spad, heads, scale,
-                    bias_frag)
+                    bias_frag, out=out)
     if dbias is None:
         return dqkv, None
     return dqkv, (dbias if per_sample else dbias.sum(0))
 
 
 def attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk, dv, ldg, dbias, B, S, Spad, heads, scale,
-                    bias_frag=None):
-    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(bias), ptr(biasT), ptr(bias_frag),
+                    bias_frag=None, out=None):
+    """out (the forward output, row stride as dout): delta is then only a workspace, computed inside the call."""
+    _check(lib().op_attn_bwd(ptr(q), ptr(k), ptr(v), ld, ptr(dout), ptr(out), dout.stride(0), ptr(bias), ptr(biasT), ptr(bias_frag),
                              _bias_bstride(bias),
                              ptr(key_pad), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldg, ptr(dbias), B, S, Spad, heads,
                              64, scale, TUNE.attn_bwd(), stream()), "op_attn_bwd")

@@ -489,6 +489,7 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
 
 
 GEGLU_SPLIT = os.environ.get("ONEPEACE_GEGLU_SPLIT", "1") != "0"
+SEPARATE_DELTA = os.environ.get("ONEPEACE_SEPARATE_DELTA", "0") == "1"  # A/B switch: op_attn_bwd_delta pass instead of the fused one
 
 
 def _geglu_split(Fd, fln_w):
@@ -1059,12 +1060,13 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, k
     H = heads * 64
     dev = qkv.device
     Spad = hip.attn_spad(S)
-    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)
-    L = hip.lib()
-    hip._check(L.op_attn_bwd_delta(hip.ptr(dattn), hip.ptr(attn), dattn.stride(0), hip.ptr(delta), B, S, Spad, heads,
-                                   hip.stream()), "op_attn_bwd_delta")
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)  # workspace of the call (rowsum(dO o O), from the dQ kernels)
+    if attn.stride(0) != dattn.stride(0) or SEPARATE_DELTA:  # (the fused delta reads both with one row stride)
+        hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dattn), hip.ptr(attn), dattn.stride(0), hip.ptr(delta), B, S, Spad, heads,
+                                               hip.stream()), "op_attn_bwd_delta")
+        attn = None
     hip.attn_bwd_launch(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, bias_img, biasT, key_pad, lse, delta, dq, dk,
-                        dv, dq.stride(0), dbias_acc, B, S, Spad, heads, scale, bias_frag)
+                        dv, dq.stride(0), dbias_acc, B, S, Spad, heads, scale, bias_frag, out=attn)
 
 
 def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):

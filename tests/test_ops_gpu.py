@@ -685,12 +685,10 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
     clean, clean_dbias = hip.attn_bwd(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, out, lse, B, S, heads, 0.125,
                                       bias_d, biasT_d, pad_d, Spad, want_dbias=True, bias_frag=hip.attn_bias_pack(bias_d, S))
     assert clean.isfinite().all() and clean_dbias[:, :, :S].isfinite().all()
-    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=DEV)
-    hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dout), hip.ptr(out), dout.stride(0), hip.ptr(delta), B, S, Spad, heads,
-                                           hip.stream()), "op_attn_bwd_delta")
+    # delta is a workspace of the call (the dQ kernels fill its live part from dout and out): poison all of it
+    delta = torch.full((B, heads, Spad), float("inf"), dtype=torch.float32, device=DEV)
     lse_p = lse.clone()
     lse_p[:, :, S:] = float("nan")
-    delta[:, :, S:] = float("inf")
     bias_p, biasT_p = bias_d.clone(), biasT_d.clone()
     bias_p[:, :, S:] = float("nan")
     biasT_p[:, :, S:] = 3.0e4  # the transposed image's pad columns must be finite (the dK/dV kernel adds the bias with an MFMA)
@@ -698,8 +696,18 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
     dbias = hip.attn_dbias_buffer(B, S, heads, Spad, DEV)
     hip.attn_bwd_launch(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, bias_p, biasT_p, pad_d, lse_p, delta,
                         dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], 3 * H, dbias, B, S, Spad, heads, 0.125,
-                        hip.attn_bias_pack(bias_p, S))
+                        hip.attn_bias_pack(bias_p, S), out=out)
     assert torch.equal(dqkv, clean)
+    # the separate delta pass (op_attn_bwd_delta, out = NULL) gives the same gradients up to the order of its fp32 row sums
+    delta2 = torch.empty(B, heads, Spad, dtype=torch.float32, device=DEV)
+    hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dout), hip.ptr(out), dout.stride(0), hip.ptr(delta2), B, S, Spad, heads,
+                                           hip.stream()), "op_attn_bwd_delta")
+    torch.testing.assert_close(delta[:, :, :S], delta2[:, :, :S], rtol=1e-4, atol=1e-4)
+    dqkv2 = torch.empty_like(dqkv)
+    hip.attn_bwd_launch(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, dout, bias_d, biasT_d, pad_d, lse, delta2,
+                        dqkv2[:, :H], dqkv2[:, H:2 * H], dqkv2[:, 2 * H:], 3 * H, None, B, S, Spad, heads, 0.125,
+                        hip.attn_bias_pack(bias_d, S))
+    assert_close(dqkv2, clean.float().cpu(), fro=2e-3, mx=2e-2, what="separate delta pass")
     got = dbias.sum(0)[:, :, :S]
     assert got.isfinite().all()
     if merge_dbias:  # slabs with plain read-modify-write: deterministic

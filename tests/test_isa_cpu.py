@@ -35,10 +35,36 @@ def test_hazard_checker_sees_a_stale_accumulator_read():
     assert len(C.check_lines(loop.split("\n"))[1]) == 1  # only visible across the back edge
 
 
+def test_hazard_checker_sees_an_overwritten_store_operand():
+    """Round 3: the two misses of hipcc around `buffer_store_dwordx4 ... sN offen` (csrc/gemm.hip epilogue_v)."""
+    bad = """_Z3foov:
+	v_cvt_pk_bf16_f32 v13, v0, v1
+	buffer_store_dwordx4 v[12:15], v144, s[12:15], s2 offen
+.LBB0_7:
+	v_pk_mul_f32 v[12:13], v[80:81], v[96:97]
+	s_endpgm"""
+    assert len(C.check_store_data(bad.split("\n"))) == 1                      # across a label, as first seen
+    assert len(C.check_store_data(bad.replace(".LBB0_7:\n", "").split("\n"))) == 1  # and inside a block
+    assert C.check_store_data(bad.replace(".LBB0_7:", "\ts_nop 1\n.LBB0_7:").split("\n")) == []
+    assert C.check_store_data(bad.replace("v[12:13], v[80:81]", "v[16:17], v[80:81]").split("\n")) == []
+    asm = """_Z3barv:
+	s_mul_i32 s2, s10, 6
+	;;#ASMSTART
+	buffer_store_dwordx4 v[0:3], v6, s[4:7], s2 offen
+	s_nop 1
+	;;#ASMEND
+	s_endpgm"""
+    assert len(C.check_asm_vmem_sgprs(asm.split("\n"))) == 1   # the SALU result is read one wait state later
+    assert C.check_asm_vmem_sgprs(asm.replace("\tbuffer_store", "\ts_nop 4\n\tbuffer_store").split("\n")) == []
+    assert len(C.check_asm_vmem_sgprs(asm.replace("s_mul_i32 s2, s10, 6", "v_readfirstlane_b32 s5, v3").split("\n"))) == 1  # descriptor word
+
+
 @pytest.mark.skipif(shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None, reason="needs hipcc")
 def test_no_compiler_instruction_touches_an_accumulator_behind_an_inline_asm_mfma(tmp_path):
     """The four-wave kernels pin their accumulators in AGPRs through inline-asm MFMAs the compiler's hazard recogniser cannot
-    see; copies it places on control-flow edges must come at least 18 wait states after the MFMA that writes the register."""
+    see; copies it places on control-flow edges must come at least 18 wait states after the MFMA that writes the register.
+    Same compile: no VALU write of a wide buffer store's data registers right behind it, and every inline-asm VMEM instruction
+    brings the wait states for its SGPR operands itself."""
     kernels, problems = C.check(C.compile_isa(str(tmp_path)))
     assert kernels > 20
     assert problems == [], problems[:5]

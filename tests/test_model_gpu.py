@@ -1,11 +1,15 @@
 """Model-level parity on MI355X: the HIP path (bf16) against the reference-generated golden fixtures / the fp32 oracle.
 
-Stated tolerance (north_star: "within a stated fp tolerance"): for every compared tensor
-    rel_fro(hip_bf16, fp32_reference) <= max(2 x rel_fro(torch_bf16_path, fp32_reference), floor)
-where torch_bf16_path is the reference algorithm executed op-by-op in bf16 (our mirrors' torch path = the numerics
-the reference itself has in bf16 training, trainer.py:86-88), and floor = 1.5e-2 for activations/embeddings,
-5e-2 for gradients.  The fused kernels keep fp32 accumulators across ops the reference rounds to bf16 in between, so
-they are normally *closer* to fp32 than the yardstick."""
+Stated tolerance (north_star: "within a stated fp tolerance"), ABSOLUTE since round 3: for every compared tensor
+    rel_fro(hip_bf16, fp32_reference) <= bound
+with bound = 1.5e-2 for activations / embeddings / logits and 5e-2 for gradients (6e-2 for the masked-pretraining objectives,
+whose per-sample token subsets leave fewer summands per weight), plus the few named exceptions of BOUND_EXCEPTIONS -- tensors
+whose error is a property of the problem, not of the kernels (the bf16 torch path of the reference algorithm lands at the same
+value).  The bounds were read off the measured reports (profiles/r*_parity_report*.txt, gpurun_out/*_parity_report*.txt: largest
+activation error 1.2e-2, largest regular gradient error 4.0e-2 micro / 5.3e-2 pretraining) -- until round 2 the gate was relative
+to the torch-bf16 path (2 x its error), which let both drift together.  That path (the reference algorithm executed op-by-op in
+bf16, trainer.py:86-88) is still run and its error printed next to ours in the reports, as context only.  The fused kernels keep
+fp32 accumulators across ops the reference rounds to bf16 in between, so they are normally *closer* to fp32 than it is."""
 import os
 
 import pytest
@@ -24,14 +28,24 @@ def _fx(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
 
-def _check(name, hip_val, torch_val, ref, floor, report, abs_err=0.0):
-    """abs_err: absolute Frobenius slack for ill-conditioned tensors (small-norm gradients whose bf16 error does not scale
-    with their norm): the gate is  |hip - ref|_F <= max(2 x torch-bf16 error, floor) * |ref|_F + abs_err."""
+# name fragment -> bound that replaces the default one (measured value in brackets; torch-bf16 lands at the same error)
+BOUND_EXCEPTIONS = {
+    "audio_adapter.rel_pos_table_list.0.weight": 1.3e-1,  # [1.02e-1; torch-bf16 0.98e-1] tiny table gradient: sums of strongly cancelling bf16 dS entries
+    "al_audio": 2.5e-2,                                    # [1.86e-2; torch-bf16 2.0e-2] audio CLS embedding of the joint pretraining step
+}
+
+
+def _check(name, hip_val, torch_val, ref, bound, report, abs_err=0.0):
+    """Absolute gate:  |hip - ref|_F <= bound * |ref|_F + abs_err  (abs_err: Frobenius slack for small-norm gradients whose bf16
+    error does not scale with their norm).  The torch-bf16 error is reported, not gated on."""
     e_hip, e_t = rel_fro(hip_val.float(), ref), rel_fro(torch_val.float(), ref)
-    report.append("%-60s hip %.3e  torch-bf16 %.3e" % (name, e_hip, e_t))
+    for frag, b in BOUND_EXCEPTIONS.items():
+        if frag in name:
+            bound = b
+    report.append("%-60s hip %.3e  torch-bf16 %.3e  (bound %.1e)" % (name, e_hip, e_t, bound))
     nref = float(ref.double().norm())
-    assert e_hip * nref <= max(2 * e_t, floor) * nref + abs_err, "%s: hip %.3e vs torch-bf16 %.3e (floor %.1e, abs %.1e, |ref| %.3e)" % (
-        name, e_hip, e_t, floor, abs_err, nref)
+    assert e_hip * nref <= bound * nref + abs_err, "%s: hip %.3e > bound %.1e (torch-bf16 %.3e, abs %.1e, |ref| %.3e)" % (
+        name, e_hip, bound, e_t, abs_err, nref)
 
 
 def _force_torch_path(model, flag):
@@ -75,7 +89,7 @@ def test_micro_model_forward_backward(golden_dir):
     h, tt = results["hip"], results["torch"]
     for key, ref in (("t", "text_logits"), ("i", "image_logits"), ("a", "audio_logits")):
         _check(ref, h[key], tt[key], fx[ref], 1.5e-2, report)
-    assert abs(float(h["itc"]) - float(fx["itc_loss"])) <= max(2 * abs(float(tt["itc"]) - float(fx["itc_loss"])), 2e-2)
+    assert abs(float(h["itc"]) - float(fx["itc_loss"])) <= 2e-2  # absolute (loss ~ 1.4; measured 3e-3)
     # gradients: the golden file holds the ITC + ATC(label smoothing 0.1) objective; here the criterion uses 0.0 for both,
     # so compare against the oracle's gradient of exactly this objective
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth.synth_state_dict(fx["shapes"]).items()}
@@ -479,7 +493,7 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
         if "loss" in k:
             eh, et = abs(res["hip"]["log"][k] - float(ref)), abs(res["torch"]["log"][k] - float(ref))
             report.append("%-20s ref %.5f hip err %.2e torch-bf16 err %.2e" % (k, float(ref), eh, et))
-            assert eh <= max(2 * et, 3e-2 * max(1.0, abs(float(ref)))), (k, eh, et)
+            assert eh <= 3e-2 * max(1.0, abs(float(ref))), (k, eh, et)  # absolute
     n_checked = 0
     for k, v in fx["grads"].items():
         if k.endswith("#norm") or k.endswith("#rows4"):
@@ -494,7 +508,7 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
             # (norm 0.5) gradient of this model (measured 1.2e-2 / 4e-3).  The attention kernels themselves reproduce colsum(dV) to 9e-4.
             e_abs = float((gh - v).norm())
             report.append("%-60s |hip - ref| %.3e (|ref| %.3e)" % ("grad " + k, e_abs, float(v.norm())))
-            assert e_abs <= max(2 * float((gt - v).norm()), 2e-2), (k, e_abs)
+            assert e_abs <= 2e-2, (k, e_abs)
         else:
             _check("grad " + k, gh, gt, v, 6e-2, report)
         n_checked += 1

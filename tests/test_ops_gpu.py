@@ -834,11 +834,16 @@ def test_audio_feature_extractor_matches_conv_stack():
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(16448, 4608, 1536, "qkv"), (16448, 6144, 1536, "geglu"), (16000, 1536, 6144, "resid"),
-                                       (32896, 1536, 1536, "bias")])
+                                       (32896, 1536, 1536, "bias"),
+                                       # the EXACT launches of the headline step (128 x 257 image tokens per pass), fp32-checked:
+                                       (32896, 4608, 1536, "qkv"), (32896, 6144, 1536, "geglu"), (32896, 12288, 1536, "up2"),
+                                       (32896, 1536, 6144, "resid"), (32896, 1536, 1536, "resid"), (32896, 1536, 12288, "plain")])
 def test_gemm_full_size_launches_match_torch(M, N, K, epi):
-    """BASELINE-size launches (every CU busy, the auto-selected kernel flavours: 256x256 BK=64 full-line, 128x128 for
-    M = 16000) against torch's bf16 matmul with fp32 accumulation on the same device -- the oracle is too slow at this
-    size, so the yardstick is an independent GEMM; epilogues are applied to its fp32 result as the oracle defines them."""
+    """BASELINE-size launches (every CU busy, the auto-selected kernel flavours: the four-wave 256x256 kernels + tail-rows launch
+    at M = 32896, 128x128 for M = 16000) against an fp32 matmul of the same bf16 operands on the same device -- the oracle is
+    too slow at this size, so the yardstick is an independent fp32 GEMM; epilogues are applied to its result as the oracle
+    defines them.  "up2" is the training path of the FFN up-projection since round 3 (plain wi_0 | wi_1 launch writing h0 | h1,
+    then op_ln_geglu_fwd), "plain" the merged K = 2F input gradient of the FFN."""
     hip = hipmod()
     g = torch.Generator(device=DEV).manual_seed(7)
     a = torch.randn(M, K, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
@@ -857,12 +862,31 @@ def test_gemm_full_size_launches_match_torch(M, N, K, epi):
         ref = torch.nn.functional.gelu(r0) * r1
         assert_close(h0, r0, what="h0")
         assert_close(h1, r1, what="h1")
+    elif epi == "up2":
+        Fd = N // 2
+        w0, w1 = mk(Fd, K), mk(Fd, K)
+        lw, lb = (1 + mk(Fd)).to(torch.bfloat16), mk(Fd)
+        out = hip.gemm_nt(a, [w0, w1], n_seg=Fd, N=N)
+        ref = torch.cat([a.float() @ w0.float().t(), a.float() @ w1.float().t()], 1)
+        gln, mean, rstd = hip.ln_geglu_fwd(out[:, :Fd], out[:, Fd:], lw, lb)
+        gref = torch.nn.functional.layer_norm(torch.nn.functional.gelu(ref[:, :Fd]) * ref[:, Fd:], (Fd,), lw.float(), lb.float(), 1e-5)
+        # (h0 / h1 are rounded to bf16 before the GELU, as the reference's bf16 modules round them: one more rounding than a single op)
+        assert_close(gln, gref, fro=8e-3, mx=6e-2, what="LayerNorm(gelu(h0) * h1)")
+        del gref
     elif epi == "resid":
+        rps = 257 if M % 257 == 0 else 250
         w, b, gamma = mk(N, K), mk(N), mk(N)
         res = torch.randn(M, N, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16)
-        ps = (torch.rand(M // 250, generator=g, device=DEV) > 0.3).float() / 0.7
-        out = hip.gemm_nt(a, [w], [b], epilogue=hip.EPI_RESID, resid=res, gamma=gamma, rowscale=ps, rows_per_sample=250)
-        ref = res.float() + ps.repeat_interleave(250)[:, None] * gamma.float() * (a.float() @ w.float().t() + b.float())
+        ps = (torch.rand(M // rps, generator=g, device=DEV) > 0.3).float() / 0.7
+        y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        out = hip.gemm_nt(a, [w], [b], epilogue=hip.EPI_RESID, resid=res, gamma=gamma, rowscale=ps, rows_per_sample=rps, h0=y)
+        yref = a.float() @ w.float().t() + b.float()
+        assert_close(y, yref, what="branch output")
+        ref = res.float() + ps.repeat_interleave(rps)[:, None] * gamma.float() * yref
+    elif epi == "plain":
+        w = mk(N, K)
+        out = hip.gemm_nt(a, [w])
+        ref = a.float() @ w.float().t()
     else:
         w, b = mk(N, K), mk(N)
         out = hip.gemm_nt(a, [w], [b])
@@ -870,11 +894,13 @@ def test_gemm_full_size_launches_match_torch(M, N, K, epi):
     assert_close(out, ref, what=epi)
 
 
-def test_weight_gradient_full_size_matches_torch():
-    """dW = dy^T x at BASELINE size (tokens = 16448) with in-place accumulation, transpose-read kernel + split-K."""
+@pytest.mark.parametrize("M,No,Ni", [(16448, 1536, 6144), (32896, 1536, 6144), (32896, 12288, 1536), (73216, 4608, 1536)])
+def test_weight_gradient_full_size_matches_torch(M, No, Ni):
+    """dW = dy^T x at BASELINE size with in-place accumulation, transpose-read kernels + split-K: tokens = 16448 (round 1),
+    and the exact launches of the headline step -- K = 32896 image tokens for the per-modality FFN weights (w2; the merged
+    wi_0 | wi_1 launch), K = 73216 rows of the lock-step pass for the merged q | k | v weights -- fp32-checked."""
     from one_peace_amd import ops
     g = torch.Generator(device=DEV).manual_seed(9)
-    M, No, Ni = 16448, 1536, 6144
     dy = torch.randn(M, No, generator=g, device=DEV).to(torch.bfloat16)
     x = torch.randn(M, Ni, generator=g, device=DEV).to(torch.bfloat16)
     base = torch.randn(No, Ni, generator=g, device=DEV).to(torch.bfloat16)

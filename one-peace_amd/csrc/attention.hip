@@ -1256,7 +1256,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
 }
 
 // grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
-// same for every sample and is loaded once; each sample's K/V tile goes through LDS once for all four waves (next
+// same for every sample of the chunk (per-sample bias images: chunks of ONE sample, gradient slab b for sample b -- the path of
+// masked pretraining with more kept tokens than the merged kernel's 384) and is loaded once; each sample's K/V tile goes through LDS once for all four waves (next
 // sample's tile in flight during the MFMAs); dS is accumulated in registers over the chunk, chunks combine by fp32 atomics.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
@@ -1276,8 +1277,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       acc[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias)
-        breg[qb][kb] = *reinterpret_cast<const bf16x4*>(p.bias + ((int64_t)h * p.S + qi) * p.Spad + k0 + kb * 16 + g * 4);
+      if (p.bias)  // (per-sample images: this workgroup's chunk is ONE sample, launch condition)
+        breg[qb][kb] = *reinterpret_cast<const bf16x4*>(p.bias + (int64_t)(chunk * p.bchunk) * p.bias_bs + ((int64_t)h * p.S + qi) * p.Spad +
+                                                        k0 + kb * 16 + g * 4);
     }
   }
   u32x4 rk[2], rv[2];
@@ -1362,7 +1364,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
     if (qi >= p.S) continue;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      float* dst = p.dbias + ((int64_t)h * p.S + qi) * p.Spad + k0 + kb * 16 + g * 4;
+      // shared image: every chunk adds into the one slab; per-sample images: slab b of sample b, written by this workgroup alone
+      float* dst = p.dbias + ((p.bias_bs != 0 ? (int64_t)chunk * p.heads : 0) + h) * ((int64_t)p.S * p.Spad) + (int64_t)qi * p.Spad + k0 +
+                   kb * 16 + g * 4;
+      if (k0 + kb * 16 >= p.Spad) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[qb][kb][r]);
     }
@@ -1508,8 +1513,6 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   a.dout = (const bf16_t*)dout; a.ldo = ldo; a.bias = (const bf16_t*)bias; a.biasT = (const bf16_t*)biasT;
   a.bias_frag = bias ? (const bf16_t*)bias_frag : nullptr;
   a.bias_bs = bias ? bias_batch_stride : 0;
-  OP_CHECK_ARG(!(dbias && a.bias_bs != 0) || (merge_dbias && ceil_div(S, BKV) <= 6),
-               "attn_bwd: the gradient of a per-sample bias needs the merged dQ + dBias kernel (S <= 384)");
   a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta; a.out = (const bf16_t*)out; a.delta_w = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
@@ -1580,6 +1583,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
     OP_LAUNCH_CHECK();
   }
   if (dbias) {
+    if (a.bias_bs != 0) a.bchunk = 1;  // per-sample bias images: one sample per workgroup, slab b of dbias for sample b
     const int chunks = ceil_div(B, a.bchunk);
     hipLaunchKernelGGL(attn_bwd_dbias_kernel, dim3(ceil_div(S, BQ), ceil_div(S, BKV), (unsigned)(heads * chunks)), dim3(256), 0,
                        s, a);

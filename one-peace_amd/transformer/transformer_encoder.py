@@ -77,9 +77,6 @@ class TransformerEncoder(nn.Module):
                 if n_bias is not None and len(biases) != n_bias:
                     return False
                 n_bias = len(biases)
-        if any(p[2] is not None for p in parts) and sum(p[0].shape[1] for p in parts) > 384 and any(
-                torch.is_tensor(b) or getattr(b, "ids", None) is not None for p in parts if p[2] is not None for b in p[2]):
-            return False  # the per-sample bias gradient needs the merged dQ + dBias kernel (<= 384 kept tokens)
         if len(parts) > 1 and any(p[0].dtype != parts[0][0].dtype or not p[0].is_cuda for p in parts):
             return False
         if self.encoder_layerdrop > 0.0 and self.training:

@@ -602,6 +602,63 @@ def test_batched_weight_cache_refresh_after_optimizer_step():
     assert losses["batched"] == losses["lazy"], losses
 
 
+def test_masked_image_pass_with_more_than_384_kept_tokens_takes_the_fused_path():
+    """Masked image pass of the pretraining objective at 448^2 (785 tokens) keeping CLS + 499 patches per sample -- a different
+    subset per sample, so the relative-position bias is one image per sample and its gradient one slab per sample
+    (adapter/image.py:188-204,229-246).  Up to round 2 more than 384 kept tokens fell back to the torch layers (the per-sample
+    bias gradient existed only in the merged dQ + dBias kernel); now the separate dQ / dBias kernels write per-sample slabs.
+    Checked: the fused layers run (no torch fallback), and features + every gradient (incl. the relative-position table's)
+    against the mirror's reference-algorithm path in fp32 on the same weights; the masked passes' parity with the reference
+    itself is pinned at small sizes by the golden pretraining fixtures."""
+    from one_peace_amd.transformer import transformer_encoder as TE
+    grid, keep = 28, 500
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=2, attention_heads=2, image_bucket_size=grid,
+               image_rel_bucket_size=grid, text_bucket_size=256, audio_bucket_size=512)
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.randn(3, 3, 448, 448, generator=g)
+    # preserve ids index the token sequence WITH its CLS token at 0, which is always kept (data side of the reference)
+    ids = torch.stack([torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(grid * grid, generator=g)[:keep - 1].sort().values])
+                       for _ in range(3)])
+    w = torch.randn(3, keep, 128, generator=g)
+    calls = {"fused": 0, "torch": 0}
+    of, ot = TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch
+
+    def cf(self, *a, **k):
+        calls["fused"] += 1
+        return of(self, *a, **k)
+
+    def ct(self, *a, **k):
+        calls["torch"] += 1
+        return ot(self, *a, **k)
+
+    res = {}
+    TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch = cf, ct
+    try:
+        for mode, dt in (("hip", torch.bfloat16), ("torch", torch.bfloat16), ("fp32", torch.float32)):
+            m = load_synth(build_retrieval(cfg, 1000)).to(DEV).to(dt).eval()
+            _force_torch_path(m, mode != "hip")
+            calls["fused"] = calls["torch"] = 0
+            feats = m.encoder_wrapper(src_images=imgs.to(DEV).to(dt), image_preserve_ids=ids.to(DEV), encoder_type="image")[1]
+            assert feats.shape == (3, keep, 128)
+            if mode == "hip":
+                assert calls == {"fused": 1, "torch": 0}, calls
+            m.zero_grad()
+            (feats.float() * w.to(DEV)).sum().backward()
+            res[mode] = (feats.detach().float().cpu(),
+                         {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch = of, ot
+    report = []
+    _check("masked 448^2 image features (500 kept tokens)", res["hip"][0], res["torch"][0], res["fp32"][0], 1.5e-2, report)
+    n = 0
+    for k, ref in res["fp32"][1].items():
+        if k in res["hip"][1] and float(ref.norm()) > 1e-7:
+            _check("grad " + k, res["hip"][1][k], res["torch"][1][k], ref, 5e-2, report, abs_err=1.5e-3)
+            n += 1
+    assert n > 30 and any("rel_pos_table" in k for k in res["hip"][1])
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "masked_448_parity_report.txt"), "w").write("\n".join(report) + "\n")
+
+
 @pytest.mark.parametrize("res_px", [448, 512])
 def test_long_sequence_image_on_hip(res_px):
     """BASELINE configs[4] shape class: 448^2 images -> 28 x 28 patches + CLS = 785 tokens and 512^2 -> 1025 tokens (the

@@ -726,10 +726,11 @@ def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_d
     assert torch.equal(out_sp, out_s)
 
 
-@pytest.mark.parametrize("B,S,heads,use_pad", [(3, 70, 2, True), (5, 83, 3, False), (2, 257, 2, True)])
+@pytest.mark.parametrize("B,S,heads,use_pad", [(3, 70, 2, True), (5, 83, 3, False), (2, 257, 2, True), (3, 401, 2, True), (2, 530, 1, False)])
 def test_attention_per_sample_bias(B, S, heads, use_pad):
     """Masked pretraining gathers a different token subset per sample, so the additive bias is [B, heads, S, S]
-    (adapter/image.py:229-246): one bias image per sample in the kernels, one gradient slab per sample back."""
+    (adapter/image.py:229-246): one bias image per sample in the kernels, one gradient slab per sample back.  More than 384
+    kept tokens (448^2 images and up) take the separate dQ and dBias kernels, one sample per dBias workgroup (round 3)."""
     hip = hipmod()
     H = heads * 64
     qkv = rnd(B * S, 3 * H, seed=1)

@@ -14,7 +14,7 @@ from tools.bench_ops import timeit  # noqa: E402
 H, heads = 1536, 24
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 bf = dict(dtype=torch.bfloat16, device="cuda")
-for S in (257, 250, 64, 320, 327):
+for S in [int(v) for v in os.environ.get("SS", "257,250,64,320,327").split(",")]:
     Spad = hip.attn_spad(S)
     qkv = torch.randn(B * S, 3 * H, **bf)
     bias = torch.randn(heads, S, Spad, **bf)

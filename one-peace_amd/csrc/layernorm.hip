@@ -14,6 +14,15 @@ namespace {
 
 constexpr int LN_MAX_BLOCKS = 4096;       // workspace bound for the dw/db partials
 constexpr int g_ln_blocks_fwd = 512, g_ln_blocks_bwd = 512;  // persistent-grid caps (round-1 sweep: tools/ln_sweep.py, profiles/)
+// The fused GeGLU + LayerNorm(F) passes have their own caps (tools/ln_geglu_sweep.py, 32 896 x 6144, round 3): forward 256 / 512 /
+// 1024 / 2048 / 4096 workgroups -> 0.389 / 0.265 / 0.240 / 0.237 / 0.236 ms; backward (dw / db partials per workgroup) 0.530 /
+// 0.403 / 0.417 / 0.448 / 0.507 ms.
+#ifndef OP_LN_GEGLU_BLOCKS_FWD
+#define OP_LN_GEGLU_BLOCKS_FWD 2048
+#endif
+#ifndef OP_LN_GEGLU_BLOCKS_BWD
+#define OP_LN_GEGLU_BLOCKS_BWD 512
+#endif
 
 template <int NW>
 __device__ __forceinline__ float group_sum(float v, float* red) {
@@ -615,7 +624,7 @@ int op_ln_geglu_fwd(const void* h0, const void* h1, int64_t ldh, const void* w, 
   if (rows == 0) return OP_OK;
   hipStream_t s = (hipStream_t)stream;
 #define LNG_F(CH, NW)                                                                                                       \
-  hipLaunchKernelGGL((ln_geglu_fwd_kernel<CH, NW>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(NW == 1 ? 256 : 64 * NW), 0, s, \
+  hipLaunchKernelGGL((ln_geglu_fwd_kernel<CH, NW>), dim3(ln_grid(rows, NW, OP_LN_GEGLU_BLOCKS_FWD)), dim3(NW == 1 ? 256 : 64 * NW), 0, s, \
                      (const bf16_t*)h0, (const bf16_t*)h1, ldh, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, \
                      (int)cols, eps)
   if (cols <= 512) LNG_F(1, 1);
@@ -645,7 +654,7 @@ int op_ln_geglu_bwd(const void* dy, const void* h0, const void* h1, const void* 
   int grid = 0;
 #define LNG_B(CH, NW)                                                                                              \
   do {                                                                                                             \
-    grid = ln_grid(rows, NW, g_ln_blocks_bwd);                                                                     \
+    grid = ln_grid(rows, NW, OP_LN_GEGLU_BLOCKS_BWD);                                                                     \
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                                 \
     hipLaunchKernelGGL((ln_geglu_bwd_kernel<CH, NW>), dim3(grid), dim3(NW == 1 ? 256 : 64 * NW), sh, s,           \
                        (const bf16_t*)dy, (const bf16_t*)h0, (const bf16_t*)h1, (const bf16_t*)w, mean, rstd,      \

@@ -347,10 +347,13 @@ __global__ __launch_bounds__(RES_MAX_NW * 64, 5) void attn_fwd_res_kernel(AttnAr
     }
   }
 
-  // ---- this wave's 16-query block ----
+  // ---- this wave's 16-query blocks: wid, wid + nw, ... of the workgroup's qb_per_wg (normally one: nw = qb_per_wg; the launch may
+  // give a workgroup fewer waves than blocks -- S = 257: 17 blocks as 9 + 8 on workgroups of EIGHT waves, which spread evenly over
+  // the four SIMDs, the ninth block being a second trip of wave 0) ----
   const int nqb = (p.S + 15) >> 4, nkp = (p.S + 31) >> 5;
-  const int qblk = bx * qb_per_wg + wid;
-  const bool active = wid < qb_per_wg && qblk < nqb;
+  for (int lblk = wid, trip = 0; trip == 0 || lblk < qb_per_wg; lblk += nw, ++trip) {
+  const int qblk = bx * qb_per_wg + lblk;
+  const bool active = lblk < qb_per_wg && qblk < nqb;
   const int q0 = min(qblk, nqb - 1) * 16;
   const int qi = min(q0 + t, p.S - 1);
 
@@ -379,9 +382,11 @@ __global__ __launch_bounds__(RES_MAX_NW * 64, 5) void attn_fwd_res_kernel(AttnAr
     }
   }
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // the only barrier: K and V are resident
-  if (!active || (abl & 2)) return;
+  if (trip == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the only barrier: K and V are resident
+  }
+  if (!active || (abl & 2)) continue;
 
   f32x4 ot[4];
   float m2_run = -INFINITY, l_run = 0.f;  // running max in the exp2 domain (scores * scale * log2 e), running sum
@@ -496,7 +501,7 @@ __global__ __launch_bounds__(RES_MAX_NW * 64, 5) void attn_fwd_res_kernel(AttnAr
   float l = l_run;
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
-  if (q0 + t >= p.S) return;
+  if (q0 + t >= p.S) continue;
   const float inv = 1.f / l;
   bf16_t* op = p.out + (row_base + q0 + t) * p.ldo + h * HD;
 #pragma unroll
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(RES_MAX_NW * 64, 5) void attn_fwd_res_kernel(AttnAr
     *reinterpret_cast<bf16x4*>(op + db * 16 + g * 4) = o;
   }
   if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.lse_ld + q0 + t] = m2_run * (1.0f / LOG2E) + logf(l);
+  }
 }
 
 // Fragment-major bias image (what attn_fwd_res_kernel's bias MFMA reads): for every 16-query block qb and 32-key pair-block
@@ -1434,17 +1440,20 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   if (!(tune & 1) && S <= RES_MAX_S && (!bias || (bias_frag && inv_exact))) {
     const int nqb = ceil_div(S, 16);
     const int nwg = ceil_div(nqb, RES_MAX_NW);
-    const int qb_per_wg = ceil_div(nqb, nwg);              // = waves per workgroup
+    const int qb_per_wg = ceil_div(nqb, nwg);              // 16-query blocks per workgroup
+    int nwaves = qb_per_wg;                                  // waves per workgroup (a wave takes blocks wid, wid + nwaves, ...)
+    if ((tune >> 3) & 15) nwaves = min(qb_per_wg, (int)((tune >> 3) & 15));   // (tests / A-B timing)
+    else if (qb_per_wg == 9) nwaves = 8;                     // S = 257 ... 272: see the kernel
     const int rows_pad = ceil_div(S, 32) * 32;
     const size_t sh = (size_t)2 * rows_pad * 128;
     const dim3 rgrid(nwg, (unsigned)heads, (unsigned)B);
     const int abl = (int)((tune >> 1) & 3);
     const bf16_t* fr = (const bf16_t*)bias_frag;
     int rc;
-    if (bias && key_pad) rc = launch_fwd_res<true, true>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
-    else if (bias) rc = launch_fwd_res<true, false>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
-    else if (key_pad) rc = launch_fwd_res<false, true>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
-    else rc = launch_fwd_res<false, false>(a, fr, rgrid, qb_per_wg, sh, rows_pad, qb_per_wg, abl, s);
+    if (bias && key_pad) rc = launch_fwd_res<true, true>(a, fr, rgrid, nwaves, sh, rows_pad, qb_per_wg, abl, s);
+    else if (bias) rc = launch_fwd_res<true, false>(a, fr, rgrid, nwaves, sh, rows_pad, qb_per_wg, abl, s);
+    else if (key_pad) rc = launch_fwd_res<false, true>(a, fr, rgrid, nwaves, sh, rows_pad, qb_per_wg, abl, s);
+    else rc = launch_fwd_res<false, false>(a, fr, rgrid, nwaves, sh, rows_pad, qb_per_wg, abl, s);
     op_prof_end(slot, stream);
     if (rc != OP_OK) return rc;
     OP_LAUNCH_CHECK();

@@ -94,6 +94,7 @@ class Tuning:
         self.sched = 0           # four-wave NT launches: 0 auto, 1-5 gemm256v_kernel instruction schedule, 7 gemm256w_kernel
         self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
+        self.attn_waves = 0      # resident forward kernel: waves per workgroup (0 = production rule; tests / A-B timing)
 
     def gemm(self):
         fl = {2: 0, 0: 1, 1: 2, 3: 3}.get(self.fullline, 0)
@@ -102,7 +103,7 @@ class Tuning:
                 | (0 if self.glds else 1) << 19 | (self.sched & 7) << 20)
 
     def attn_fwd(self):
-        return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1
+        return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1 | (self.attn_waves & 15) << 3
 
     def attn_bwd(self):
         return 0 if self.merge_dbias else 1

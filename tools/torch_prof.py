@@ -14,7 +14,7 @@ flat = FlatParameters(model, no_decay=lambda n, p: p.dim() <= 1)
 red = BucketedGradReducer(flat)
 opt = FusedAdamW(flat)
 crit = TriModalContrastiveCriterion(None, 0.0)
-batch, _ = bench.synthetic_batch(64, 5.0, dev, 1)
+batch, _ = bench.synthetic_batch(64, dev, 1, audio_seconds=5.0)
 sample = {"net_input": batch, "nsentences": 64}
 
 def step():

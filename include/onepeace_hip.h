@@ -95,7 +95,7 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
  * 3 whenever it saves a round, 4 always); bits 7-11 M-tiles per L2 group (0 auto); bits 12-14 timing ablations of the 256x256
  * kernel (tools; wrong results); bits 15-18 forced K-split count of small problems (tools); bit 19 register-staged operands
  * instead of LDS-DMA (global_load_lds); bits 20-22 kernel of the four-wave NT launches (0 auto, 1 / 3 one-tile workgroups with
- * that instruction schedule, 6 persistent workgroups, 7 the round-2 kernel). */
+ * that instruction schedule, 6 persistent workgroups, 7 the round-2 kernel; op_gemm_nt_grouped: persistent workgroups unless 7). */
 /* Host-only query (no GPU needed): the launch decision op_gemm_nt takes for a dense, single-segment problem.
  * plan[0] = tile (128 | 256), plan[1] = K-splits, plan[2] = 1 if the epilogue runs in the split-K fold kernel,
  * plan[3] = leftover rows (M % 256) split off into a second, small launch (0 = none). */

@@ -162,7 +162,7 @@ def test_gemm_grouped_launch_is_bit_identical_to_separate_launches(Ms, persisten
             o = hip.gemm_nt(g, [w2[i]], [b2[i]], epilogue=hip.EPI_RESID, resid=res[i], gamma=gam[i], rowscale=ps[i], rows_per_sample=rps[i],
                             h0=y, splitk=False)
             ref_o.append((o, y, hip.gemm_nt(g, [w2[i]], [b2[i]], splitk=False)))
-        T.sched = 6 if persistent else 0
+        T.sched = 6 if persistent else 7  # (op_gemm_nt_grouped: persistent unless 7; production = 0 = persistent since round 3)
         h0s, h1s, ys = [bf(m, F) for m in Ms], [bf(m, F) for m in Ms], [bf(m, H) for m in Ms]
         gs = hip.gemm_nt_grouped(xs, list(zip(w0, w1)), epilogue=hip.EPI_GEGLU, h0s=h0s, h1s=h1s)
         assert gs is not None

@@ -48,7 +48,7 @@ for name, (sep, grp, flops) in cases.items():
     for rnd in range(3):
         T.reset(); r["separate (auto)"] = min(r.get("separate (auto)", 1e9), timeit(sep, iters=20, warmup=3))
         T.reset(); T.sched = 3; r["separate v3"] = min(r.get("separate v3", 1e9), timeit(sep, iters=20, warmup=3))
-        T.reset(); r["grouped one-tile"] = min(r.get("grouped one-tile", 1e9), timeit(grp, iters=20, warmup=3))
+        T.reset(); T.sched = 7; r["grouped one-tile"] = min(r.get("grouped one-tile", 1e9), timeit(grp, iters=20, warmup=3))
         T.reset(); T.sched = 6; r["grouped persistent"] = min(r.get("grouped persistent", 1e9), timeit(grp, iters=20, warmup=3))
     T.reset()
     print("%-22s " % name + "  ".join("%s %.4f ms (%.0f TF)" % (k, v, flops / v / 1e9) for k, v in r.items()), flush=True)

@@ -1,0 +1,41 @@
+"""Round 3: merged dQ + dBias kernel, batch chunks chosen by round quantisation vs round 2's ">= 768 workgroups" rule.
+python tools/attn_chunks_ab.py [B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from one_peace_amd import hip  # noqa: E402
+from tools.bench_ops import timeit  # noqa: E402
+
+bf = dict(dtype=torch.bfloat16, device="cuda")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+heads, H = 24, 1536
+torch.manual_seed(0)
+L = hip.lib()
+for S in (257, 250, 65):
+    Spad = hip.attn_spad(S)
+    qkv = torch.randn(B * S, 3 * H, **bf)
+    bias = torch.randn(heads, S, Spad, **bf)
+    biasT = torch.randn(heads, S, Spad, **bf)
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    frag = hip.attn_bias_pack(bias, S)
+    out, lse = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, None, Spad, want_lse=True, bias_frag=frag)
+    dout = torch.randn_like(out)
+    res = {}
+    for r2 in (1, 0, 1, 0):
+        hip.TUNE.dbias_chunks_r2 = r2
+        n = L.op_attn_bwd_dbias_slabs(B, S, heads, hip.TUNE.attn_bwd())
+        fn = lambda: hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias, biasT, None, Spad, want_dbias=True, bias_frag=frag)
+        d, db = fn()
+        t = timeit(fn, iters=20)
+        key = "round-2 rule (%d chunks)" % n if r2 else "new rule (%d chunks)" % n
+        res[key] = min(res.get(key, 1e9), t)
+        if r2:
+            ref = (d.clone(), db.clone())
+        else:
+            assert torch.equal(d, ref[0])
+            err = float((db - ref[1]).norm() / ref[1].norm())
+    hip.TUNE.dbias_chunks_r2 = 0
+    print("B=%d S=%d backward + dBias: " % (B, S) + "   ".join("%s %.4f ms" % kv for kv in res.items()) + "   (dq/dk/dv identical, dbias rel diff %.1e)" % err, flush=True)

@@ -618,8 +618,8 @@ __device__ __forceinline__ float delta_from_frags(const bf16x8 (&dO)[2], const b
 // score instead of 11.  Keys that do not exist or are padded need NO masking here: a key is a COLUMN of every product of this
 // kernel, so whatever its P / dS columns hold only reaches its own dK / dV rows, which are written as zeros (padded keys) or
 // not at all (keys >= S).  Query rows >= S of the last tile get lse = +inf (P = 0) and delta = 0.
-template <bool HAS_BIAS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+template <bool HAS_BIAS, int KB>  // KB: 16-key blocks per wave (2: 128 keys per workgroup; 1: 64 -- see op_attn_bwd)
+__global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
   char* ldsQ = smem;
   char* ldsO = smem + 64 * 128;
@@ -627,15 +627,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   const int g = lane >> 4, t = lane & 15;
   int bx, h, b;
   xcd_work_item(bx, h, b);
-  const int kbase = bx * 128 + wid * 32;
+  const int kbase = bx * (64 * KB) + wid * (16 * KB);
   const bool wave_active = kbase < p.S;
   const int64_t row_base = (int64_t)b * p.S;
 
   // K, V fragments (second operand): lane (g,t) <- X[kbase + kb*16 + t][kk*32 + g*8 ..]
-  bf16x8 kf[2][2], vf[2][2];
-  bool kdead[2];
+  bf16x8 kf[KB][2], vf[KB][2];
+  bool kdead[KB];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
+  for (int kb = 0; kb < KB; ++kb) {
     const int key = kbase + kb * 16 + t;
     const int kc = min(key, p.S - 1);
     const int64_t off = (row_base + kc) * p.ld + h * HD;
@@ -646,9 +646,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     }
     kdead[kb] = p.key_pad && key < p.S && p.key_pad[(int64_t)b * p.Spad + key];  // padded key: its dK / dV rows are zero
   }
-  f32x4 dvT[2][4], dkT[2][4];
+  f32x4 dvT[KB][4], dkT[KB][4];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+  for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
     for (int db = 0; db < 4; ++db) { dvT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
@@ -680,11 +680,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   const float* lse_b = p.lse + ((int64_t)b * p.heads + h) * p.Spad;
   const float* del_b = p.delta + ((int64_t)b * p.heads + h) * p.Spad;
   // transposed bias image rows of this lane's two keys: 8 consecutive queries at g*8 = one second-operand fragment
-  const bf16_t* brow[2] = {nullptr, nullptr};
+  const bf16_t* brow[KB] = {};
   bf16x8 sel_lo, sel_hi;  // first operand that copies second-operand row j = t (j = 16 + t) into output row t, times 1/scale
   if constexpr (HAS_BIAS) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < KB; ++kb) {
       const int key = min(kbase + kb * 16 + t, p.S - 1);
       brow[kb] = p.biasT + (int64_t)b * p.bias_bs + ((int64_t)h * p.S + key) * p.Spad + g * 8;
     }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     // lse / delta / bias fragments of both 32-query halves first, THEN the next tile's Q / dO prefetch: s_waitcnt vmcnt
     // counts in issue order, so small loads issued behind the prefetch would make their wait a wait for the prefetch.
     f32x4 l4[2][2], d4[2][2];
-    bf16x8 bfr[2][2];
+    bf16x8 bfr[2][KB];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
       }
       if constexpr (HAS_BIAS) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) bfr[m][kb] = *reinterpret_cast<const bf16x8*>(brow[kb] + q0 + m * 32);
+        for (int kb = 0; kb < KB; ++kb) bfr[m][kb] = *reinterpret_cast<const bf16x8*>(brow[kb] + q0 + m * 32);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -732,11 +732,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (q0 + m * 32 >= p.S) break;  // uniform: no valid query in this half of the tile
-      f32x4 s[2][2], dp[2][2];
+      f32x4 s[2][KB], dp[2][KB];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        for (int kb = 0; kb < KB; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int qb = 2 * m + j;
@@ -746,14 +746,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
           const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(ldsQ + off);
           const bf16x8 ofr = *reinterpret_cast<const bf16x8*>(ldsO + off);
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
+          for (int kb = 0; kb < KB; ++kb) {
             s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[kb][kk], s[j][kb], 0, 0, 0);
             dp[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vf[kb][kk], dp[j][kb], 0, 0, 0);
           }
         }
         if constexpr (HAS_BIAS) {
 #pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
+          for (int kb = 0; kb < KB; ++kb)
             s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j ? sel_hi : sel_lo, bfr[m][kb], s[j][kb], 0, 0, 0);
         }
       }
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
           dl[r] = live ? d4[m][j][r] : 0.f;
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][r], c1, -l2[r]));
@@ -777,9 +777,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
           }
         }
       }
-      bf16x8 pfr[2], dsf[2];
+      bf16x8 pfr[KB], dsf[KB];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < KB; ++kb) {
         float a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
         const bf16x8 oT = join_tr(tr_read(ldsO + trsw[db] + (2 * m) * 2048), tr_read(ldsO + trsw[db] + (2 * m + 1) * 2048));
         const bf16x8 qT = join_tr(tr_read(ldsQ + trsw[db] + (2 * m) * 2048), tr_read(ldsQ + trsw[db] + (2 * m + 1) * 2048));
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < KB; ++kb) {
           dvT[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT, pfr[kb], dvT[kb][db], 0, 0, 0);
           dkT[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsf[kb], dkT[kb][db], 0, 0, 0);
         }
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
   }
   if (!wave_active) return;
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
+  for (int kb = 0; kb < KB; ++kb) {
     const int key = kbase + kb * 16 + t;
     if (key >= p.S) continue;
     bf16_t* kp = p.dk + (row_base + key) * p.ldg + h * HD;
@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 //   op_attn_fwd:  bit 0 = always the streaming kernel (tests / A-B timing); bits 1-2 = timing ablations of the resident kernel
 //                 (tools only: 1 no K/V staging, 2 no compute)
 //   op_attn_bwd / op_attn_bwd_dbias_slabs:  bit 0 = separate dQ and dBias kernels instead of the merged one (tests);
-//                 bit 1 = round 2's batch-chunk rule of the merged kernel (A/B timing)
+//                 bit 1 = round 2's batch-chunk rule of the merged kernel (A/B timing); bits 2-3 = 2: dK/dV kernel with 64 keys per workgroup
 
 template <bool HAS_BIAS, bool HAS_PAD>
 int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, size_t sh, int rows_pad, int qb_per_wg, int abl,
@@ -1563,8 +1563,18 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
     AttnBwdArgs d = a;
     d.bchunk = bchunk_dkdv;
     const int sl = op_prof_begin(2, 2.0 * fl, stream);
-    if (bias) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+    // keys per workgroup: 128 (two 16-key blocks per wave, 243 VGPRs, 2 waves/SIMD) or 64 (one block, 164 VGPRs, 3 waves/SIMD, a
+    // third less padding at S = 257).  Measured (tools/attn_dkdv_ab.py, backward + dBias, B = 128): S = 257 0.6708 vs 0.6733 ms,
+    // S = 250 0.5179 vs 0.5467, S = 65 0.1233 vs 0.1445, S = 785 1.436 vs 1.470 -- the narrower wave reads every Q / dO fragment
+    // for half as many MFMAs; 128 stays.  tune bits 2-3: 2 forces 64 (A/B timing).
+    const bool kb1 = ((tune >> 2) & 3) == 2;
+    if (kb1) {
+      if (bias) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, 1>), dim3(ceil_div(S, 64), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+      else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, 1>), dim3(ceil_div(S, 64), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+    } else {
+      if (bias) hipLaunchKernelGGL((attn_bwd_dkdv_kernel<true, 2>), dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+      else hipLaunchKernelGGL((attn_bwd_dkdv_kernel<false, 2>), dim3(ceil_div(S, 128), (unsigned)heads, (unsigned)B), dim3(256), 0, s, d);
+    }
     op_prof_end(sl, stream);
   };
   if (!out) {  // delta precomputed (op_attn_bwd_delta): the kernels are independent

@@ -345,6 +345,7 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = (c * 2 + m2) * 16 + r;  // + g * 4 in the lane offset
+          // (plain loads: a non-temporal hint made the K = 1536 residual launch 7 % slower, tools/gemm_lib_ab.py)
           dst[m2][r] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff_r, row * ldr * 2, 0);
           if (p.rowscale) {
             const unsigned mc = (unsigned)(min(mrow0 + row + g * 4, p.M - 1) + p.m_off);

@@ -2181,11 +2181,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int c = (int)(i - m * n8) * 8;
     float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (accumulate) Vec8<bf16_t>::load(out + m * ldc + c, a);
-    for (int z = 0; z < splits; ++z) {
-      float v[8];
-      Vec8<float>::load(ws + z * slab + m * N + c, v);
+    // up to eight slabs requested before the first is added (a load -> add chain per slab left the fold at 4.2 TB/s, round 3);
+    // the slabs are added in the same order as before
+    for (int z0 = 0; z0 < splits; z0 += 8) {
+      typename Vec8<float>::raw_t raw[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) a[j] += v[j];
+      for (int z = 0; z < 8; ++z)
+        if (z0 + z < splits) raw[z] = Vec8<float>::ldraw(ws + (z0 + z) * slab + m * N + c);
+#pragma unroll
+      for (int z = 0; z < 8; ++z)
+        if (z0 + z < splits) {
+          float v[8];
+          Vec8<float>::cvt(raw[z], v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a[j] += v[j];
+        }
     }
     Vec8<bf16_t>::store(out + m * ldc + c, a);
   }

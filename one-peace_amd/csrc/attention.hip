@@ -1384,7 +1384,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 //   op_attn_fwd:  bit 0 = always the streaming kernel (tests / A-B timing); bits 1-2 = timing ablations of the resident kernel
 //                 (tools only: 1 no K/V staging, 2 no compute)
 //   op_attn_bwd / op_attn_bwd_dbias_slabs:  bit 0 = separate dQ and dBias kernels instead of the merged one (tests);
-//                 bit 1 = round 2's batch-chunk rule of the merged kernel (A/B timing); bits 2-3 = 2: dK/dV kernel with 64 keys per workgroup
+//                 bit 1 = round 2's batch-chunk rule of the merged kernel (A/B timing); bits 2-3 = 2: dK/dV kernel with 64 keys per workgroup;
+//                 bits 4-9 = forced number of batch chunks of the merged kernel (sweep of tools/attn_chunks_ab.py: the rule's choice is
+//                 within 1 % of the best of {2 ... 16} at S = 257 / 250 / 65)
 
 template <bool HAS_BIAS, bool HAS_PAD>
 int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, size_t sh, int rows_pad, int qb_per_wg, int abl,
@@ -1400,8 +1402,9 @@ int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, siz
 // ">= 768 workgroups", which at 257 tokens (5 query tiles x 24 heads) gave 7 chunks of 19 samples = 840 workgroups = 1.64 -> 2
 // rounds x 19 = 38 sample-times; 4 chunks of 32 (480 workgroups, one round) or 8 of 16 cost 32.  Chosen here: the chunk count with
 // the smallest cost (+ a little per chunk for the slab read-modify-write at the end of every workgroup; fewer slabs on a tie).
-inline int dbias_chunks(int64_t B, int64_t S, int64_t heads, bool merge, bool round2_rule = false) {
+inline int dbias_chunks(int64_t B, int64_t S, int64_t heads, bool merge, bool round2_rule = false, int forced = 0) {
   if (!merge || ceil_div(S, BKV) > 6) return 1;
+  if (forced > 0) return ceil_div(B, ceil_div(B, min((int64_t)forced, B)));  // (tune bits 4-9: A/B timing)
   if (round2_rule) {  // (tune bit 1: A/B timing)
     const int64_t base2 = (int64_t)ceil_div(S, 64) * heads;
     int chunks = (int)((768 + base2 - 1) / base2);
@@ -1436,7 +1439,7 @@ extern "C" {
 
 // dbias of op_attn_bwd is fp32 [slabs][heads][S][Spad], pre-zeroed, slabs = this value (the batch chunks of the merged
 // dQ + dBias kernel add into their own slab without atomics; sum the slabs afterwards).  `tune` as for op_attn_bwd.
-int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune) { return dbias_chunks(B, S, heads, !(tune & 1), (tune & 2) != 0); }
+int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune) { return dbias_chunks(B, S, heads, !(tune & 1), (tune & 2) != 0, (int)((tune >> 4) & 63)); }
 
 // q, k, v: bf16 rows of `ld` elements (row = b*S + s), head h occupies columns [h*64, h*64+64) of each pointer
 // (so one packed [B*S, 3H] projection output serves all three with pointer offsets 0, H, 2H).
@@ -1584,7 +1587,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   const int nt = ceil_div(S, BKV);
   if (dbias && nt <= 6 && merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
     // per-sample bias: every sample is its own chunk, slab b of dbias is the gradient of sample b's bias image
-    const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads, true, (tune & 2) != 0);
+    const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads, true, (tune & 2) != 0, (int)((tune >> 4) & 63));
     a.bchunk = ceil_div(B, chunks);
     const dim3 grid(ceil_div(S, 64), (unsigned)heads, (unsigned)chunks);
     const bool one_block = ceil_div(S - (nt - 1) * BKV, 16) == 1;  // last key tile = a single 16-key block (S = 257: 256 + CLS)

@@ -26,8 +26,10 @@ for S in (257, 250, 65):
     dqkv = torch.empty(B * S, 3 * H, **bf)
     delta = torch.empty(B, heads, Spad, dtype=torch.float32, device="cuda")
     res, ref = {}, None
-    for r2 in (1, 0, 1, 0):
-        hip.TUNE.dbias_chunks_r2 = r2
+    forced = [int(v) for v in os.environ.get("CHUNKS", "").split(",") if v]
+    for r2 in ([1, 0, 1, 0] if not forced else [-c for c in forced] * 2):
+        hip.TUNE.dbias_chunks_r2 = 1 if r2 == 1 else 0
+        hip.TUNE.dbias_chunks = -r2 if r2 < 0 else 0
         n = L.op_attn_bwd_dbias_slabs(B, S, heads, hip.TUNE.attn_bwd())
         slabs = torch.zeros(n, heads, S, Spad, dtype=torch.float32, device="cuda")
         fn = lambda: hip.attn_bwd_launch(q, k, v, 3 * H, dout, bias, biasT, None, lse, delta, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
@@ -36,7 +38,7 @@ for S in (257, 250, 65):
         if ref is None:
             ref = dqkv.clone()
         assert torch.equal(dqkv, ref)
-        key = "round-2 rule (%d chunks)" % n if r2 else "new rule (%d chunks)" % n
+        key = "round-2 rule (%d chunks)" % n if r2 == 1 else ("library rule (%d chunks)" % n if r2 == 0 else "%d chunks" % n)
         res[key] = min(res.get(key, 1e9), timeit(fn, iters=20))
-    hip.TUNE.dbias_chunks_r2 = 0
+    hip.TUNE.dbias_chunks_r2 = hip.TUNE.dbias_chunks = 0
     print("B=%d S=%d dK/dV + dQ/dBias kernels: " % (B, S) + "   ".join("%s %.4f ms" % kv for kv in res.items()) + "   (dq/dk/dv identical)", flush=True)

@@ -2009,6 +2009,259 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) 
   return OP_OK;
 }
 
+// =====================================================================================================================
+// gemm256w_tn_grouped_kernel: ALL weight gradients of an encoder layer as ONE persistent launch, no split-K.
+// A weight-gradient GEMM has few output tiles (36 ... 288 of 256 x 256) and a very long K (the token count: 8 192 ... 73 216),
+// so a launch per weight needs split-K to fill 256 CUs: fp32 slabs (the merged wi_0|wi_1 gradient wrote 7 slabs = 528 MB to
+// produce a 37.7 MB gradient) and a fold kernel that reads them back (20 ms of the 4B step).  Here up to TN_MAX_PROB problems
+// (own operands, sizes, K and output) form ONE tile list: a layer of the lock-step pass is q|k|v, out-proj and wi_0|wi_1, wo of
+// three modalities = 1440 tiles, 5.6 per CU, walked by one workgroup per CU -- every tile runs its WHOLE K and accumulates
+// straight into the bf16 gradient.  Scheduling: problems in the order given (the caller sorts by K, longest first), tiles dealt
+// to EIGHT queues, one per XCD, in groups that share the panel of the wide operand (all tiles along the short dimension of
+// the output, <= 8) so that the workgroups of one XCD read it through their L2 in K-lockstep; a workgroup draws from the queue
+// of its XCD (blockIdx & 7; speed only, any mapping is correct) with one returning atomic per tile -- issued at the START of
+// the tile it precedes, consumed after its main loop -- and steals from the other queues when its own is empty.  Greedy list
+// scheduling with the longest tiles first ends within a few per cent of the ideal makespan (1440 tiles of four lengths:
+// 0.96); the last workgroup to finish resets the counters for the next launch on the stream.
+// Main loop, LDS image, fragment order = gemm256w_tn_kernel (bit-identical per-tile results to its unsplit launch).
+// =====================================================================================================================
+constexpr int TN_MAX_PROB = 12;
+constexpr int TN_CTR_STRIDE = 16;  // counters 64 bytes apart: queue heads 0..7, then the exit counter
+struct TnProb {
+  const bf16_t* A; const bf16_t* B; bf16_t* C;  // C[M,N] (+)= A[K,M]^T B[K,N]
+  int64_t lda, ldb, ldc;
+  int M, N, K, tiles_m, tiles_n, accumulate;
+};
+struct TnGroupArgs { int nprob; int pad_; unsigned* ctr; TnProb pr[TN_MAX_PROB]; };
+
+// groups of a problem: all tiles along the SHORT dimension of its tile grid (chunks of <= 8 when that is longer)
+struct TnGeom { int along_n, gs, nch, csz, ng; };
+__host__ __device__ __forceinline__ TnGeom tn_geom(int tiles_m, int tiles_n) {
+  TnGeom G;
+  G.along_n = tiles_n <= tiles_m;
+  G.gs = G.along_n ? tiles_n : tiles_m;
+  G.nch = (G.gs + 7) >> 3;
+  G.csz = (G.gs + G.nch - 1) / G.nch;
+  G.ng = (G.along_n ? tiles_m : tiles_n) * G.nch;
+  return G;
+}
+// slots (tiles incl. the empty ones of a partial last chunk) in queue x
+__host__ __device__ __forceinline__ int tn_queue_len(const TnGroupArgs& p, int x) {
+  int n = 0, rot = 0;
+  for (int i = 0; i < p.nprob; ++i) {
+    const TnGeom G = tn_geom(p.pr[i].tiles_m, p.pr[i].tiles_n);
+    const int gi0 = (x - rot) & 7;
+    n += (gi0 < G.ng ? (G.ng - 1 - gi0) / 8 + 1 : 0) * G.csz;
+    rot = (rot + G.ng) & 7;
+  }
+  return n;
+}
+// slot q of queue x -> problem and tile; false for an empty slot
+__host__ __device__ __forceinline__ bool tn_decode(const TnGroupArgs& p, int x, int q, int& prob, int& tm, int& tn) {
+  int rot = 0;
+  for (int i = 0; i < p.nprob; ++i) {
+    const TnGeom G = tn_geom(p.pr[i].tiles_m, p.pr[i].tiles_n);
+    const int gi0 = (x - rot) & 7;
+    const int n = (gi0 < G.ng ? (G.ng - 1 - gi0) / 8 + 1 : 0) * G.csz;
+    if (q < n) {
+      const int j = q / G.csz, s = q - j * G.csz;
+      const int gi = gi0 + 8 * j;
+      const int li = gi / G.nch, c = gi - li * G.nch;
+      const int si = c * G.csz + s;
+      prob = i;
+      tm = G.along_n ? li : si;
+      tn = G.along_n ? si : li;
+      return si < G.gs;
+    }
+    q -= n;
+    rot = (rot + G.ng) & 7;
+  }
+  prob = 0; tm = tn = 0;
+  return false;
+}
+
+__global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int sh_next;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+
+  // ---- tile-independent: transpose-read provider addresses (see gemm256w_tn_kernel) ----
+  const int krow = g * 8 + (t >> 2);
+  const int rowoff = krow * 512;
+  int rdX[8], rdW[8];
+#pragma unroll
+  for (int mi = 0; mi < 8; ++mi) {
+    const int chunk = wm * 16 + mi * 2 + ((t & 3) >> 1);
+    rdX[mi] = rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int chunk = wn * 16 + f * 2 + ((t & 3) >> 1);
+    rdW[f] = OPER2_BYTES + rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
+  }
+
+  // ---- queue state of the fetching thread (thread 0): home queue first, then the others in turn ----
+  const int home = blockIdx.x & 7;
+  int tried = 0;          // queues found empty so far
+  int xn = home;          // queue of the ticket in flight
+  unsigned qn = 0;        // the ticket
+  auto draw = [&]() {     // one returning atomic on the current queue's head
+    xn = (home + tried) & 7;
+    qn = __hip_atomic_fetch_add(p.ctr + xn * TN_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto resolve = [&]() {  // ticket -> code (queue << 24 | slot), stealing while queues turn out empty; -1: nothing left anywhere
+    for (;;) {
+      if ((int)qn < tn_queue_len(p, xn)) return (xn << 24) | (int)qn;
+      if (++tried >= 8) return -1;
+      draw();
+    }
+  };
+  if (tid == 0) {
+    draw();
+    sh_next = resolve();
+  }
+  __syncthreads();
+  int code = __builtin_amdgcn_readfirstlane(sh_next);
+
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi], pinned in AGPRs by the inline-asm MFMAs
+
+  while (code >= 0) {
+    int prob, pid_m, pid_n;
+    const bool valid = tn_decode(p, code >> 24, code & 0xffffff, prob, pid_m, pid_n);
+    if (tid == 0 && tried < 8) draw();  // the NEXT tile's ticket: in flight during this tile's main loop
+    if (valid) {
+      const TnProb& q = p.pr[prob];
+      const int M = q.M, N = q.N;
+      const int64_t lda = q.lda, ldb = q.ldb;
+      const int m0 = pid_m * BM2, n0 = pid_n * 256;
+      const int nk = q.K / BK2;
+      const char* baseA = (const char*)q.A;
+      const char* baseB = (const char*)q.B;
+      unsigned offA[4], offB[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = i * 256 + tid;
+        const int kr = s >> 5, pc = s & 31;
+        const int ca = min(m0 + (pc ^ swzA_tn(kr)) * 8, M - 8);
+        const int cb = min(n0 + (pc ^ swzA_tn(kr)) * 8, N - 8);
+        offA[i] = (unsigned)(((int64_t)kr * lda + ca) * 2);
+        offB[i] = (unsigned)(((int64_t)kr * ldb + cb) * 2);
+      }
+      const int64_t stepA = (int64_t)BK2 * lda * 2, stepB = (int64_t)BK2 * ldb * 2;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+      auto dma = [&](char* la, int j) {  // op j = 0..7 of a stage: A ops 0..3, B ops 4..7
+        const int i = j & 3;
+        const int wbase = (i * 256 + wid * 64) * 16;
+        if (j < 4)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                           (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB + offB[i]),
+                                           (__attribute__((address_space(3))) void*)(la + OPER2_BYTES + wbase), 16, 0, 0);
+      };
+      auto issue = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma(smem + slot * STAGE2_BYTES, j);
+        baseA += stepA;
+        baseB += stepB;
+      };
+      auto wait_landed = [&](int younger) {  // 8 LDS-DMA ops per stage and wave
+        if (younger >= 3) WAIT_VM(24);
+        else if (younger == 2) WAIT_VM(16);
+        else if (younger == 1) WAIT_VM(8);
+        else WAIT_VM(0);
+      };
+      struct Frags { s16x4 w[8][2]; s16x4 x[8][2]; };
+      auto rd = [&](const char* st, Frags& f, int r) {
+        if (r < 16) f.w[r >> 1][r & 1] = tr_read16(lds_addr(st) + rdW[r >> 1], (r & 1) != 0);
+        else f.x[(r - 16) >> 1][r & 1] = tr_read16(lds_addr(st) + rdX[(r - 16) >> 1], (r & 1) != 0);
+      };
+      auto mfma1 = [&](const Frags& f, int j) {
+        const int mi = j >> 3, ff = j & 7;
+        const bf16x8 wv = join16(f.w[ff][0], f.w[ff][1]), xv = join16(f.x[mi][0], f.x[mi][1]);
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[ff >> 2][ff & 3][mi]) : "v"(wv), "v"(xv));
+      };
+      auto step_steady = [&](int kt, const Frags& cur, Frags& nxt) {
+        WAIT_LGKM(0);
+        WAIT_VM(16);
+        __builtin_amdgcn_s_barrier();
+        const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;
+        char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+          mfma1(cur, j);
+          if (j < 32) rd(st, nxt, j);
+          else if (j < 40) dma(la, j - 32);
+          if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        baseA += stepA;
+        baseB += stepB;
+      };
+      auto step_tail = [&](int kt, const Frags& cur, Frags& nxt) {
+        const bool has_next = kt + 1 < nk;
+        WAIT_LGKM(0);
+        if (has_next) wait_landed(min(nk - 2 - kt, STAGES2 - 2));
+        __builtin_amdgcn_s_barrier();
+        if (has_next) {
+          const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;
+#pragma unroll
+          for (int r = 0; r < 32; ++r) rd(st, nxt, r);
+        }
+#pragma unroll
+        for (int j = 0; j < 64; ++j) mfma1(cur, j);
+      };
+
+#pragma unroll
+      for (int s0 = 0; s0 < STAGES2; ++s0)
+        if (s0 < nk) issue(s0);
+      Frags fA, fB;
+      wait_landed(min(nk - 1, STAGES2 - 1));
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int r = 0; r < 32; ++r) rd(smem, fA, r);
+      int kt = 0;
+      for (; kt + STAGES2 + 1 < nk; kt += 2) {
+        step_steady(kt, fA, fB);
+        step_steady(kt + 1, fB, fA);
+      }
+      for (; kt < nk; kt += 2) {
+        step_tail(kt, fA, fB);
+        step_tail(kt + 1, fB, fA);
+      }
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the inline-asm MFMAs are invisible to the hazard recogniser
+      GemmArgs e;
+      e.M = M; e.N = N; e.ldc = q.ldc; e.resid = q.C; e.ldr = q.ldc;
+      if (q.accumulate) {
+        tn_epilogue<EPI_RESID, 4>(e, q.C, acc[0], m0 + wm * 128, n0 + wn * 128, g, t);
+        tn_epilogue<EPI_RESID, 4>(e, q.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, g, t);
+      } else {
+        tn_epilogue<EPI_BIAS, 4>(e, q.C, acc[0], m0 + wm * 128, n0 + wn * 128, g, t);
+        tn_epilogue<EPI_BIAS, 4>(e, q.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, g, t);
+      }
+    }
+    if (tid == 0) sh_next = tried < 8 ? resolve() : -1;
+    __syncthreads();  // the ticket is published, and every wave is done with the LDS stages the next tile overwrites
+    code = __builtin_amdgcn_readfirstlane(sh_next);
+    __syncthreads();  // ... and has read it before thread 0 publishes the one after
+  }
+  if (tid == 0) {  // the last workgroup to leave re-arms the counters for the next launch on this stream
+    const unsigned gone = __hip_atomic_fetch_add(p.ctr + 8 * TN_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == gridDim.x - 1) {
+#pragma unroll 1
+      for (int x = 0; x <= 8; ++x) __hip_atomic_store(p.ctr + x * TN_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // Per-call tuning word of the GEMM entry points (last argument before the stream; 0 = the defaults production uses).  The
 // library keeps NO tuning state: tests and tools that want a specific kernel flavour pass it with the call.
 //   bits 0-1   tile: 0 auto, 1 force 128x128, 2 force 256x256
@@ -2631,6 +2884,92 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   }
   op_prof_end(slot, stream);
   return rc;
+}
+
+// Bytes of the counter block op_gemm_tn_grouped needs: device memory the caller zeroes ONCE; every launch leaves it zeroed.
+// One block per stream that may run the op (launches on one stream are ordered, the block is re-armed by the launch itself).
+int64_t op_gemm_tn_grouped_counter_bytes(void) { return (int64_t)(9 * TN_CTR_STRIDE) * 4; }
+
+// Host-only query (works without a GPU): the tile queues op_gemm_tn_grouped builds for these problem sizes.  Writes, queue by queue
+// (0..7) and in draw order, one record of four int32 per tile: queue, problem (the caller's index), tile row, tile column; returns the
+// number of records (every output tile of every problem appears exactly once), or -22 when `cap` records do not suffice.
+int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int32_t* out, int64_t cap) {
+  if (nprob < 1 || nprob > TN_MAX_PROB || !M || !N || !K || !out) return OP_EINVAL;
+  int order[TN_MAX_PROB];
+  for (int i = 0; i < (int)nprob; ++i) order[i] = i;
+  for (int i = 1; i < (int)nprob; ++i)
+    for (int j = i; j > 0 && K[order[j]] > K[order[j - 1]]; --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+  TnGroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.nprob = (int)nprob;
+  for (int i = 0; i < (int)nprob; ++i) {
+    ga.pr[i].tiles_m = ceil_div(M[order[i]], 256);
+    ga.pr[i].tiles_n = ceil_div(N[order[i]], 256);
+  }
+  int64_t n = 0;
+  for (int x = 0; x < 8; ++x) {
+    const int len = tn_queue_len(ga, x);
+    for (int q = 0; q < len; ++q) {
+      int prob, tm, tn;
+      if (!tn_decode(ga, x, q, prob, tm, tn)) continue;
+      if (n >= cap) return OP_EINVAL;
+      out[4 * n] = x; out[4 * n + 1] = order[prob]; out[4 * n + 2] = tm; out[4 * n + 3] = tn;
+      ++n;
+    }
+  }
+  return n;
+}
+
+// Up to 12 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  (A_i [K_i, M_i], B_i [K_i, N_i] row-major bf16: dy and
+// x of nn.Linear, autograd's dW = dy^T x) as ONE persistent launch without split-K (gemm256w_tn_grouped_kernel): every output
+// tile runs its whole K and is written / accumulated once.  Shape rules per problem as op_gemm_tn; returns OP_ENOTSUP (nothing
+// launched) when a problem does not qualify -- the caller then uses op_gemm_tn per problem.  Problems may come in any order.
+// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile).
+int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
+                       const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
+                       void* counters, int64_t tune, void* stream) {
+  OP_CHECK_ARG(nprob >= 1 && nprob <= TN_MAX_PROB, "gemm_tn_grouped: %lld problems (1 ... %d)", (long long)nprob, TN_MAX_PROB);
+  OP_CHECK_ARG(A && lda && B && ldb && C && ldc && M && N && K && accumulate && counters, "gemm_tn_grouped: null pointer");
+  int order[TN_MAX_PROB];
+  for (int i = 0; i < (int)nprob; ++i) {
+    OP_CHECK_ARG(A[i] && B[i] && C[i], "gemm_tn_grouped: null operand of problem %d", i);
+    if (K[i] % 64 != 0 || K[i] < 64 || M[i] % 8 != 0 || N[i] % 8 != 0 || lda[i] % 8 != 0 || ldb[i] % 8 != 0 || M[i] < 8 || N[i] < 8 ||
+        31 * lda[i] + M[i] >= ((int64_t)1 << 30) || 31 * ldb[i] + N[i] >= ((int64_t)1 << 30) || ldc[i] % 4 != 0) {
+      op_set_error("gemm_tn_grouped: problem %d (M=%lld N=%lld K=%lld) not supported by the transpose-read kernel", i, (long long)M[i],
+                   (long long)N[i], (long long)K[i]);
+      return OP_ENOTSUP;
+    }
+    order[i] = i;
+  }
+  for (int i = 1; i < (int)nprob; ++i)  // longest K first (stable insertion sort): greedy list scheduling wants the long tiles early
+    for (int j = i; j > 0 && K[order[j]] > K[order[j - 1]]; --j) { const int tmp = order[j]; order[j] = order[j - 1]; order[j - 1] = tmp; }
+  TnGroupArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.nprob = (int)nprob;
+  ga.ctr = (unsigned*)counters;
+  double work = 0.0;
+  int64_t tiles = 0;
+  for (int i = 0; i < (int)nprob; ++i) {
+    const int s = order[i];
+    TnProb& q = ga.pr[i];
+    q.A = (const bf16_t*)A[s]; q.B = (const bf16_t*)B[s]; q.C = (bf16_t*)C[s];
+    q.lda = lda[s]; q.ldb = ldb[s]; q.ldc = ldc[s];
+    q.M = (int)M[s]; q.N = (int)N[s]; q.K = (int)K[s];
+    q.tiles_m = ceil_div(M[s], 256); q.tiles_n = ceil_div(N[s], 256);
+    q.accumulate = accumulate[s] != 0;
+    tiles += (int64_t)q.tiles_m * q.tiles_n;
+    work += 2.0 * (double)M[s] * (double)N[s] * (double)K[s];
+  }
+  int nwg = (int)(tune & 1023);
+  if (nwg <= 0) nwg = num_cus();
+  if (nwg > tiles) nwg = (int)tiles;
+  const size_t sh = STAGES2 * STAGE2_BYTES;
+  OP_ENSURE_LDS(gemm256w_tn_grouped_kernel, (int)sh, "gemm_tn_grouped");
+  const int slot = op_prof_begin(0, work, stream);
+  hipLaunchKernelGGL(gemm256w_tn_grouped_kernel, dim3(nwg), dim3(256), sh, (hipStream_t)stream, ga);
+  op_prof_end(slot, stream);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
 }
 
 }  // extern "C"

@@ -38,6 +38,9 @@ SIGNATURES = {
                            c_int, P, I64, I64, P]),
     "op_gemm_nt_grouped": (c_int, [I64, P, P, I64, P, I64, P, P, I64, P, P, P, I64, P, P, P, I64, I64, c_int, I64, P]),
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
+    "op_gemm_tn_grouped_counter_bytes": (I64, []),
+    "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, P, I64]),
+    "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
     "op_transpose_desc_bytes": (I64, []),
@@ -384,19 +387,62 @@ def gemm_tn_supported(K, M, N, lda, ldb):
             and 31 * lda + M < (1 << 30) and 31 * ldb + N < (1 << 30))
 
 
-def gemm_tn(A_km, B_kn, out=None, accumulate=False):
-    """C[M,N] (+)= A_km^T @ B_kn with A_km [K, M], B_kn [K, N] (row-major, last dim contiguous): dW = dy^T x without copies."""
+def gemm_tn_grouped_plan(sizes):
+    """[(M, N, K)] -> [(queue, problem, tile_m, tile_n)] in draw order: op_gemm_tn_grouped's schedule (host-only query)."""
+    n = len(sizes)
+    cap = sum(((m + 255) // 256) * ((nn + 255) // 256) for m, nn, _ in sizes)
+    out = (ctypes.c_int32 * (4 * cap))()
+    arr = lambda j: (c_int64 * n)(*[q[j] for q in sizes])  # noqa: E731
+    cnt = lib().op_gemm_tn_grouped_plan(n, arr(0), arr(1), arr(2), ctypes.cast(out, P), cap)
+    if cnt < 0:
+        raise RuntimeError("op_gemm_tn_grouped_plan failed (%d)" % cnt)
+    return [tuple(out[4 * i:4 * i + 4]) for i in range(cnt)]
+
+
+def gemm_tn(A_km, B_kn, out=None, accumulate=False, splitk=True):
+    """C[M,N] (+)= A_km^T @ B_kn with A_km [K, M], B_kn [K, N] (row-major, last dim contiguous): dW = dy^T x without copies.
+    splitk=False: no scratch is handed over, every output tile runs its whole K (tests: the grouped launch's yardstick)."""
     K, M = A_km.shape
     N = B_kn.shape[1]
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=A_km.device)
         accumulate = False
-    ws = workspace(SPLITK_WS_BYTES, A_km.device, "gemm_splitk")
+    ws = workspace(SPLITK_WS_BYTES, A_km.device, "gemm_splitk") if splitk else None
     GEMM_ALGO_BYTES[0] += 2 * (K * M + K * N + M * N * (2 if accumulate else 1))
     GEMM_ALGO_BYTES[1] += 1
     _check(lib().op_gemm_tn(ptr(A_km), A_km.stride(0), ptr(B_kn), B_kn.stride(0), ptr(out), out.stride(0), M, N, K,
-                            int(accumulate), ptr(ws), ws.numel(), TUNE.gemm(), stream()), "op_gemm_tn")
+                            int(accumulate), ptr(ws), ws.numel() if ws is not None else 0, TUNE.gemm(), stream()), "op_gemm_tn")
     return out
+
+
+_tn_counters = {}
+TN_GROUP_MAX = 12
+
+
+def gemm_tn_grouped(problems, tune=0):
+    """ONE persistent launch for up to 12 weight-gradient GEMMs, no split-K (csrc/gemm.hip: gemm256w_tn_grouped_kernel).
+    problems: [(A_km [K, M], B_kn [K, N], out [M, N] bf16, accumulate)].  Returns False (nothing launched) when a problem does not
+    qualify for the transpose-read kernel -- the caller then runs gemm_tn per problem."""
+    n = len(problems)
+    dev = problems[0][0].device
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ctr = _tn_counters.get(key)
+    if ctr is None:  # zeroed once; every launch re-arms it
+        ctr = _tn_counters[key] = torch.zeros(int(lib().op_gemm_tn_grouped_counter_bytes()), dtype=torch.uint8, device=dev)
+    arr = lambda vals: (c_int64 * n)(*vals)  # noqa: E731
+    As, Bs, Cs = [q[0] for q in problems], [q[1] for q in problems], [q[2] for q in problems]
+    acc = (ctypes.c_int32 * n)(*[int(bool(q[3])) for q in problems])
+    rc = lib().op_gemm_tn_grouped(n, _ptr_array(As, n), arr([a.stride(0) for a in As]), _ptr_array(Bs, n), arr([b.stride(0) for b in Bs]),
+                                  _ptr_array(Cs, n), arr([c.stride(0) for c in Cs]), arr([a.shape[1] for a in As]),
+                                  arr([b.shape[1] for b in Bs]), arr([a.shape[0] for a in As]), acc, ptr(ctr), int(tune), stream())
+    if rc == -95:
+        return False
+    _check(rc, "op_gemm_tn_grouped")
+    for a, b, c, ac in problems:
+        K, M = a.shape
+        GEMM_ALGO_BYTES[0] += 2 * (K * M + K * b.shape[1] + M * b.shape[1] * (2 if ac else 1))
+    GEMM_ALGO_BYTES[1] += 1
+    return True
 
 
 def transpose(x2d, out=None):

@@ -185,6 +185,65 @@ def wgrad(dy, x, out=None, accumulate=False):
     return hip.gemm_nt(_t_pad(dy), [_t_pad(x)], out=out)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# deferred weight gradients: all dW GEMMs of an encoder layer as ONE grouped launch (csrc/gemm.hip: gemm256w_tn_grouped_kernel)
+# --------------------------------------------------------------------------------------------------------------
+GROUPED_WGRAD = os.environ.get("ONEPEACE_GROUPED_WGRAD", "1") != "0"
+
+
+class _WgradQueue:
+    """Weight-gradient GEMMs that accumulate into flat gradient views, collected while a layer's backward runs (FFN branch
+    first, then the attention branch, which flushes): launched alone each of them has 36 ... 288 output tiles for 256 CUs and
+    needs split-K slabs + a fold; together they are 1440 tiles for one persistent launch without split-K.  The operands are
+    kept alive until the launch is enqueued; the reducer hears about a parameter only after that."""
+
+    def __init__(self):
+        self.items, self.done, self.armed = [], [], False
+
+    def add(self, dy, x, out, params):
+        self.items.append((dy, x, out, True))
+        self.done.extend(params)
+        if not self.armed:  # safety net: whatever is still queued when autograd finishes this backward pass goes out then
+            self.armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        if len(self.items) >= hip.TN_GROUP_MAX:
+            self.flush()
+
+    def _end_of_backward(self):
+        self.armed = False
+        self.flush()
+
+    def flush(self):
+        items, done = self.items, self.done
+        self.items, self.done = [], []
+        if items:
+            if len(items) == 1 or not hip.gemm_tn_grouped(items):  # a lone problem keeps the split-K launch of op_gemm_tn
+                for dy, x, out, _ in items:
+                    hip.gemm_tn(dy, x, out, True)
+        for q in done:
+            _direct_grad_done(q)
+
+
+_wgrad_queue = _WgradQueue()
+
+
+def wgrad_into(dy, x, grad_view, params):
+    """grad_view (+)= dy^T x for the flat-buffer gradient views of `params` (one view spanning all of them).  Deferred into the
+    layer's grouped launch when the shape allows, else launched now; either way every parameter's completion is signalled."""
+    K, M = dy.shape
+    if (GROUPED_WGRAD and USE_TN_WGRAD and K % 64 == 0 and K >= 64 and grad_view.stride(0) % 4 == 0 and grad_view.stride(1) == 1
+            and hip.gemm_tn_supported(K, M, x.shape[1], dy.stride(0), x.stride(0))):
+        _wgrad_queue.add(dy, x, grad_view, params)
+        return
+    wgrad(dy, x, out=grad_view, accumulate=True)
+    for q in params:
+        _direct_grad_done(q)
+
+
+def flush_wgrads():
+    _wgrad_queue.flush()
+
+
 def _direct_grad(param):
     """True when `param` lives in distributed.FlatParameters: its .grad is a pre-allocated, pre-zeroed view the weight
     gradient GEMM can accumulate into directly (no autograd accumulation pass, no temporary dW tensor)."""
@@ -617,8 +676,7 @@ def _weight_grad_fn(ctx, G):
     def weight_grad(name, dyv, xv):
         target = direct.get(name)
         if target is not None:
-            wgrad(dyv, xv, out=target.grad, accumulate=True)
-            _direct_grad_done(target)
+            wgrad_into(dyv, xv, target.grad, (target,))
         else:
             G[name] = wgrad(dyv, xv)
     return weight_grad, direct
@@ -739,10 +797,8 @@ class AttnBranchFn(torch.autograd.Function):
                     for n in bnames:
                         i = slot["wq" if n == "bq" else "wv"]
                         G[n] = sums[i * H:(i + 1) * H]
-            if order:  # one launch, one fold: dW[3H, H] straight into the three adjacent flat gradient views
-                wgrad(dqkv, A["xln1"], out=_span(direct, order), accumulate=True)
-                for n in order:
-                    _direct_grad_done(direct[n])
+            if order:  # one problem: dW[3H, H] straight into the three adjacent flat gradient views
+                wgrad_into(dqkv, A["xln1"], _span(direct, order), [direct[n] for n in order])
             elif any(n in direct for n in qkv_names) or not all(needs[n] for n in qkv_names):
                 for n in qkv_names:
                     if needs[n]:
@@ -760,6 +816,7 @@ class AttnBranchFn(torch.autograd.Function):
                     _finish(direct, G, ("ln1_w", "ln1_b"), (dw_, db_), acc)
         if dx is None and need_x:  # nothing upstream of the residual wanted a gradient: only the skip connection carries one
             dx = dx_mid
+        flush_wgrads()  # the layer's weight gradients (this branch's and the FFN branch's, which ran before it) as one launch
         grads = _return_grads(ATTN_PARAMS, params, G, direct)
         dimgs = []
         for sg, w in zip(segs, want_dbias):  # placeholders (see _RelPosImageFn.backward); the real gradients went into bias.acc
@@ -837,9 +894,7 @@ class FfnBranchFn(torch.autograd.Function):
                 dpart["w0"].copy_(d0)
                 dpart["w1"].copy_(d1)
             if order:
-                wgrad(dh, A["xln2"], out=_span(direct, order), accumulate=True)
-                for n in order:
-                    _direct_grad_done(direct[n])
+                wgrad_into(dh, A["xln2"], _span(direct, order), [direct[n] for n in order])
             else:
                 for n in ("w0", "w1"):
                     if needs[n]:
@@ -1015,9 +1070,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 dpart[pair[0]].copy_(d0)
                 dpart[pair[1]].copy_(d1)
             if order:
-                wgrad(dh[r], A["xln2"][r], out=_span(direct, order), accumulate=True)
-                for n in order:
-                    _direct_grad_done(direct[n])
+                wgrad_into(dh[r], A["xln2"][r], _span(direct, order), [direct[n] for n in order])
             else:
                 for n in pair:
                     if needs[n]:

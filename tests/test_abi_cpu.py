@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header(lib_path):
         assert len(hip.SIGNATURES[name][1]) == nargs, "%s: header has %d args, ctypes table %d" % (
             name, nargs, len(hip.SIGNATURES[name][1]))
     L = hip.lib()
-    assert L.op_abi_version() == 3  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3)
+    assert L.op_abi_version() == 4  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4)
 
 
 def test_no_silent_cpu_fallback():
@@ -91,3 +91,56 @@ def test_gemm_launch_planner_decisions(lib_path):
     assert hip.gemm_plan(2056, H, F, hip.EPI_RESID)[1] == 1
     with pytest.raises(RuntimeError):
         hip.gemm_plan(257, H, 100)  # K must be a multiple of 64
+
+
+LAYER_WGRADS = [  # (M = out features, N = in features, K = tokens) of the weight gradients of one lock-step layer at b = 128
+    (4608, 1536, 73088), (1536, 1536, 73088),                      # q|k|v, out-proj over all rows
+    (12288, 1536, 32896), (1536, 6144, 32896),                     # image wi_0|wi_1, wo
+    (12288, 1536, 32000), (1536, 6144, 32000),                     # audio
+    (12288, 1536, 8192), (1536, 6144, 8192),                       # text
+]
+
+
+def test_grouped_weight_gradient_schedule_covers_every_tile_once(lib_path):
+    """op_gemm_tn_grouped_plan (host-only): every 256 x 256 output tile of every problem sits in exactly one of the eight queues,
+    problems in order of decreasing K inside a queue, the tiles of a group (same row of the tile grid when that has <= 8 columns)
+    consecutive in ONE queue, queues balanced; also for ragged sizes and a grid wider than 8 in both directions."""
+    from one_peace_amd import hip
+    for sizes in (LAYER_WGRADS, [(264, 520, 128), (2304, 2560, 64), (8, 8, 64)], [(1536, 1536, 4096)] * 12):
+        plan = hip.gemm_tn_grouped_plan(sizes)
+        tiles = {(p, tm, tn) for _, p, tm, tn in plan}
+        want = {(p, tm, tn) for p, (M, N, _) in enumerate(sizes) for tm in range((M + 255) // 256) for tn in range((N + 255) // 256)}
+        assert len(plan) == len(want) and tiles == want
+        for x in range(8):
+            ks = [sizes[p][2] for q, p, _, _ in plan if q == x]
+            assert ks == sorted(ks, reverse=True)
+    plan = hip.gemm_tn_grouped_plan(LAYER_WGRADS)
+    per_queue = [sum(1 for q, *_ in plan if q == x) for x in range(8)]
+    assert max(per_queue) == min(per_queue) == 180
+    for x in range(8):  # groups of six tiles that share the 256-wide panel of the WIDE operand, consecutive in the queue
+        seq = [(p, tm, tn) for q, p, tm, tn in plan if q == x]
+        for i in range(0, len(seq), 6):
+            grp = seq[i:i + 6]
+            p = grp[0][0]
+            assert all(g[0] == p for g in grp)
+            M, N, _ = LAYER_WGRADS[p]
+            fixed = 1 if M >= N else 2  # tiles_n <= tiles_m: one tile row, all six columns
+            assert len({g[fixed] for g in grp}) == 1 and sorted(g[3 - fixed] for g in grp) == list(range(6))
+
+
+def test_grouped_weight_gradient_schedule_makespan(lib_path):
+    """Greedy list scheduling of that plan on 32 workgroups per queue (cost of a tile = its K + a fixed 400-row overhead): the
+    slowest workgroup is within 6 % of the ideal -- what replaces 7.9 rounds of split-K slabs plus the fold kernel."""
+    import heapq
+    from one_peace_amd import hip
+    plan = hip.gemm_tn_grouped_plan(LAYER_WGRADS)
+    worst, total = 0.0, 0.0
+    for x in range(8):
+        free = [0.0] * 32
+        heapq.heapify(free)
+        for q, p, _, _ in plan:
+            if q == x:
+                heapq.heappush(free, heapq.heappop(free) + LAYER_WGRADS[p][2] + 400.0)
+        worst = max(worst, max(free))
+        total += sum(LAYER_WGRADS[p][2] + 400.0 for q, p, _, _ in plan if q == x)
+    assert total / 256.0 / worst > 0.94, (total / 256.0, worst)

@@ -911,6 +911,76 @@ def test_weight_gradient_full_size_matches_torch(M, No, Ni):
     assert_close(grad, ref, what="dW accumulate")
 
 
+GROUPED_TN_SETS = {
+    "mixed": [(256, 512, 256, True), (128, 264, 520, False), (1024, 256, 1536, True), (64, 8, 8, True), (448, 2304, 2560, False)],
+    "twelve": [(320, 512, 384, bool(i & 1)) for i in range(12)],
+    "one": [(512, 768, 256, True)],
+}
+
+
+@pytest.mark.parametrize("name", sorted(GROUPED_TN_SETS))
+@pytest.mark.parametrize("nwg", [0, 3, 8, 37])
+def test_gemm_tn_grouped_is_bit_identical_to_unsplit_launches(name, nwg):
+    """op_gemm_tn_grouped: several weight-gradient GEMMs (own K, sizes, ragged edges, strided operands, fresh output or
+    accumulation) as one persistent launch -- every tile runs its whole K, so each problem must equal the UNSPLIT op_gemm_tn bit
+    for bit and the fp32 product within the bf16 tolerance; forced workgroup counts (fewer than queues, fewer than tiles, not a
+    multiple of eight) exercise work stealing, and a second launch on the same counter block the re-arm."""
+    hip = hipmod()
+    probs, want, refs = [], [], []
+    for i, (K, M, N, acc) in enumerate(GROUPED_TN_SETS[name]):
+        dy, x = rnd(K, M + 16, seed=10 + i, scale=0.5), rnd(K, N, seed=40 + i, scale=0.5)
+        base = rnd(M, N, seed=70 + i)
+        a = dev_bf16(dy)[:, 8:8 + M]  # a column block of a wider matrix, like the halves of the packed dh
+        out = dev_bf16(base).clone()
+        probs.append((a, dev_bf16(x), out, acc))
+        want.append(hip.gemm_tn(a, dev_bf16(x), dev_bf16(base).clone(), acc, splitk=False))
+        refs.append((base if acc else 0) + dy[:, 8:8 + M].t() @ x)
+    for rep in range(2):
+        if rep:
+            for (_, _, out, _), (K, M, N, acc), i in zip(probs, GROUPED_TN_SETS[name], range(99)):
+                out.copy_(dev_bf16(rnd(M, N, seed=70 + i)))
+        assert hip.gemm_tn_grouped(probs, tune=nwg)
+        torch.cuda.synchronize()
+        for (_, _, out, _), w, r in zip(probs, want, refs):
+            assert torch.equal(out, w), "grouped launch differs from the unsplit op_gemm_tn (launch %d)" % rep
+            assert_close(out, r, what="grouped dW")
+
+
+def test_gemm_tn_grouped_rejects_what_the_kernel_cannot_take():
+    hip = hipmod()
+    ok = (dev_bf16(rnd(128, 64)), dev_bf16(rnd(128, 64)), dev_bf16(rnd(64, 64)), False)
+    bad = (dev_bf16(rnd(96, 64)), dev_bf16(rnd(96, 64)), dev_bf16(rnd(64, 64)), False)  # K % 64 != 0
+    before = ok[2].clone()
+    assert hip.gemm_tn_grouped([ok, bad]) is False
+    torch.cuda.synchronize()
+    assert torch.equal(ok[2], before)  # nothing was launched
+    with pytest.raises(RuntimeError):
+        hip.gemm_tn_grouped([ok] * 13)
+
+
+def test_weight_gradients_of_a_headline_layer_grouped_match_torch():
+    """The eight weight gradients of one lock-step layer of the headline step (q|k|v and out-proj over 73 088 rows, wi_0|wi_1 and
+    wo of the image / audio / text FFNs) as ONE grouped launch, accumulated into existing gradients: fp32-checked, and equal to
+    what the per-problem split-K launches give within two bf16 roundings."""
+    hip = hipmod()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    H, F = 1536, 6144
+    rows = {"all": 73088, "img": 32896, "aud": 32000, "txt": 8192}
+    mk = lambda r, c: torch.randn(r, c, generator=g, device=DEV).to(torch.bfloat16)  # noqa: E731
+    sets = [("all", 3 * H, H), ("all", H, H)] + [(m, o, i) for m in ("img", "aud", "txt") for o, i in ((2 * F, H), (H, F))]
+    probs = []
+    for m, o, i in sets:
+        probs.append((mk(rows[m], o), mk(rows[m], i), mk(o, i), True))
+    base = [q[2].clone() for q in probs]
+    assert hip.gemm_tn_grouped(probs)
+    torch.cuda.synchronize()
+    for (dy, x, out, _), b in zip(probs, base):
+        ref = b.float() + dy.float().t() @ x.float()
+        assert_close(out, ref, what="grouped layer dW")
+        single = hip.gemm_tn(dy, x, b.clone(), True)
+        assert rel_fro(single, out) < 6e-3
+
+
 @pytest.mark.parametrize("epi", ["bias", "geglu", "resid"])
 def test_gemm_tail_rows_split(epi):
     """M = 2 x 256 + 77: the full M-tiles and the leftover rows run as two launches (forced here; in production only when

@@ -96,7 +96,8 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
  * modality FFN); per-tile results are bit-identical to an unsplit op_gemm_tn.  Every array argument is a HOST array of nprob
  * entries.  counters: op_gemm_tn_grouped_counter_bytes() bytes of device memory zeroed ONCE by the caller (the launch re-arms
  * it; one block per stream).  Shape rules per problem as op_gemm_tn (+ ldc % 4 == 0); returns -95 and launches nothing when a
- * problem does not qualify.  tune: bits 0-9 forced number of workgroups (0 = one per CU). */
+ * problem does not qualify.  tune: bits 0-9 forced number of workgroups (0 = one per CU); bit 10: every workgroup draws from the
+ * front of its queue (A/B timing of the solo workgroups, see the kernel). */
 int64_t op_gemm_tn_grouped_counter_bytes(void);
 /* Host-only (no GPU needed): the tile queues op_gemm_tn_grouped builds for these sizes -- records of four int32 (queue 0..7, problem
  * index of the caller, tile row, tile column) queue by queue in draw order; returns the record count (= the number of 256 x 256

@@ -2023,16 +2023,22 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) 
 // the tile it precedes, consumed after its main loop -- and steals from the other queues when its own is empty.  Greedy list
 // scheduling with the longest tiles first ends within a few per cent of the ideal makespan (1440 tiles of four lengths:
 // 0.96); the last workgroup to finish resets the counters for the next launch on the stream.
+// Groups only share their panel through L2 while their tiles run in K-lockstep, i.e. start together (tools/wgrad_grouped_timeline.py:
+// with 32 workgroups per XCD and groups of 6 the two odd workgroups break every group they touch -- start skews of up to a whole
+// tile, main loop 6 % slower; with 30 per XCD the skew stays below 20 us).  So only a multiple of the group size of an XCD's
+// workgroups draws from the FRONT of its queue; the others ("solo", p.solo_from) draw single tiles from its BACK, where the
+// shortest-K problems sit (the text FFN: small operands, little to share), until the two ends meet: one 64-bit counter per
+// queue holds both claim counts, a claim is good while their sum is below the queue length.
 // Main loop, LDS image, fragment order = gemm256w_tn_kernel (bit-identical per-tile results to its unsplit launch).
 // =====================================================================================================================
 constexpr int TN_MAX_PROB = 12;
-constexpr int TN_CTR_STRIDE = 16;  // counters 64 bytes apart: queue heads 0..7, then the exit counter
+constexpr int TN_CTR_STRIDE = 8;   // 64-bit counters 64 bytes apart: queues 0..7 (claims from the front | from the back << 32), then the exit counter
 struct TnProb {
   const bf16_t* A; const bf16_t* B; bf16_t* C;  // C[M,N] (+)= A[K,M]^T B[K,N]
   int64_t lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n, accumulate;
 };
-struct TnGroupArgs { int nprob; int pad_; unsigned* ctr; TnProb pr[TN_MAX_PROB]; };
+struct TnGroupArgs { int nprob; int solo_from; unsigned long long* ctr; TnProb pr[TN_MAX_PROB]; };  // solo_from: see the kernel
 
 // groups of a problem: all tiles along the SHORT dimension of its tile grid (chunks of <= 8 when that is longer)
 struct TnGeom { int along_n, gs, nch, csz, ng; };
@@ -2080,6 +2086,51 @@ __host__ __device__ __forceinline__ bool tn_decode(const TnGroupArgs& p, int x, 
   return false;
 }
 
+// Epilogue of a tile that lies inside the matrix (no guards): the 128 x 128 block of a wave, acc[blk][f][mi][r] =
+// C[mrow0 + mi*16 + t][nbase + blk*64 + f*16 + g*4 + r] (tn_epilogue's layout).  The old gradient values of two row blocks (16
+// fragments, 8 bytes per lane each) are requested before the first is used -- as one load -> add -> store chain per fragment
+// (tn_epilogue, 64 per wave) the epilogue took 26 us of a tile, a latency each (tools/wgrad_grouped_timeline.py).
+// `between`: called once after the first batch has been consumed (the caller's ticket atomic: outstanding in front of the first wait
+// it would turn the counted vmcnt into vmcnt(0) -- loads and returning atomics may complete out of order).
+template <bool ACCUM, typename F>
+__device__ __forceinline__ void tn_epilogue_full(bf16_t* C, int64_t ldc, f32x4 (&acc)[2][4][8], int mrow0, int nbase, int g, int t, F between) {
+  bf16_t* base = C + (int64_t)(mrow0 + t) * ldc + nbase + g * 4;
+  bf16x4 old[2][2][8];  // two batches of sixteen fragments: batch b + 1 is requested before batch b is consumed
+  auto request = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        old[b & 1][j][c] = *reinterpret_cast<const bf16x4*>(base + (int64_t)(b * 2 + j) * 16 * ldc + (c >> 2) * 64 + (c & 3) * 16);
+  };
+  if (ACCUM) {
+    request(0);
+    __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler turns the batches back into one load -> add -> store chain per fragment)
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (ACCUM && b < 3) {
+      request(b + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4 a = acc[c >> 2][c & 3][b * 2 + j];
+        bf16x4 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(ACCUM ? (float)old[b & 1][j][c][r] + a[r] : a[r]);
+        *reinterpret_cast<bf16x4*>(base + (int64_t)(b * 2 + j) * 16 * ldc + (c >> 2) * 64 + (c & 3) * 16) = w;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    if (b == 0) {
+      between();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int sh_next;
@@ -2105,16 +2156,19 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
 
   // ---- queue state of the fetching thread (thread 0): home queue first, then the others in turn ----
   const int home = blockIdx.x & 7;
-  int tried = 0;          // queues found empty so far
-  int xn = home;          // queue of the ticket in flight
-  unsigned qn = 0;        // the ticket
-  auto draw = [&]() {     // one returning atomic on the current queue's head
+  const bool solo = (int)(blockIdx.x >> 3) >= p.solo_from;  // draws from the back of the queues
+  int tried = 0;                  // queues found empty so far
+  int xn = home;                  // queue of the ticket in flight
+  unsigned long long qn = 0;      // the ticket: both claim counts of the queue before this claim
+  auto draw = [&]() {             // one returning atomic on the current queue's counter
     xn = (home + tried) & 7;
-    qn = __hip_atomic_fetch_add(p.ctr + xn * TN_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    qn = __hip_atomic_fetch_add(p.ctr + xn * TN_CTR_STRIDE, solo ? (1ull << 32) : 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   auto resolve = [&]() {  // ticket -> code (queue << 24 | slot), stealing while queues turn out empty; -1: nothing left anywhere
     for (;;) {
-      if ((int)qn < tn_queue_len(p, xn)) return (xn << 24) | (int)qn;
+      const int len = tn_queue_len(p, xn);
+      const int front = (int)(unsigned)qn, back = (int)(qn >> 32);
+      if (front + back < len) return (xn << 24) | (solo ? len - 1 - back : front);
       if (++tried >= 8) return -1;
       draw();
     }
@@ -2128,10 +2182,20 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
 
   f32x4 acc[2][4][8];  // [64-column block][ni][mi], pinned in AGPRs by the inline-asm MFMAs
 
+#ifdef OP_GEMM_TIMELINE
+  int tl_slot = 0;  // per workgroup 32 records of four words: ticket code, tile start, main loop end, tile end (s_memrealtime)
+#define TLG(k, v)                                                                                                       \
+  do {                                                                                                                  \
+    if (g_timeline && tid == 0 && tl_slot < 32) g_timeline[(int64_t)blockIdx.x * 128 + tl_slot * 4 + (k)] = (v);          \
+  } while (0)
+#else
+#define TLG(k, v)
+#endif
   while (code >= 0) {
     int prob, pid_m, pid_n;
     const bool valid = tn_decode(p, code >> 24, code & 0xffffff, prob, pid_m, pid_n);
-    if (tid == 0 && tried < 8) draw();  // the NEXT tile's ticket: in flight during this tile's main loop
+    TLG(0, (unsigned long long)(unsigned)code | ((unsigned long long)(valid ? prob + 1 : 0) << 32));
+    TLG(1, __builtin_amdgcn_s_memrealtime());
     if (valid) {
       const TnProb& q = p.pr[prob];
       const int M = q.M, N = q.N;
@@ -2237,7 +2301,24 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
         step_tail(kt, fA, fB);
         step_tail(kt + 1, fB, fA);
       }
-      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");  // the inline-asm MFMAs are invisible to the hazard recogniser
+      // The inline-asm MFMAs are invisible to the hazard recogniser: 24 wait states before anything reads an accumulator.  The
+      // accumulators are OPERANDS of the padding statements, or the scheduler hoists v_accvgpr_read above them (it did: caught by
+      // tools/check_mfma_hazards.py); volatile asm statements keep their order, so the later groups sit behind the s_nops too.
+#define TN_ACC8(b, n) "+a"(acc[b][n][0]), "+a"(acc[b][n][1]), "+a"(acc[b][n][2]), "+a"(acc[b][n][3]), "+a"(acc[b][n][4]), "+a"(acc[b][n][5]), "+a"(acc[b][n][6]), "+a"(acc[b][n][7])
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : TN_ACC8(0, 0), TN_ACC8(0, 1), TN_ACC8(0, 2));
+      asm volatile("" : TN_ACC8(0, 3), TN_ACC8(1, 0), TN_ACC8(1, 1));
+      asm volatile("" : TN_ACC8(1, 2), TN_ACC8(1, 3));
+#undef TN_ACC8
+      TLG(2, __builtin_amdgcn_s_memrealtime());
+      // the NEXT tile's ticket: drawn inside the epilogue, in flight during the rest of it.  (Drawn at the start of the tile -- round 4's first
+      // version -- the last tickets of a launch sat for up to a whole tile with workgroups that were busy, while workgroups that
+      // became free found the queues empty and left: finish times spread over 700 us of a 4.5 ms launch.)
+      auto draw_next = [&]() { if (tid == 0) draw(); };
+      if (m0 + 256 <= M && n0 + 256 <= N) {  // (uniform) tile inside the matrix: no guards, the old values of 32 fragments in flight
+        if (q.accumulate) tn_epilogue_full<true>(q.C, q.ldc, acc, m0 + wm * 128, n0 + wn * 128, g, t, draw_next);
+        else tn_epilogue_full<false>(q.C, q.ldc, acc, m0 + wm * 128, n0 + wn * 128, g, t, draw_next);
+      } else {
+      draw_next();
       GemmArgs e;
       e.M = M; e.N = N; e.ldc = q.ldc; e.resid = q.C; e.ldr = q.ldc;
       if (q.accumulate) {
@@ -2247,17 +2328,25 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
         tn_epilogue<EPI_BIAS, 4>(e, q.C, acc[0], m0 + wm * 128, n0 + wn * 128, g, t);
         tn_epilogue<EPI_BIAS, 4>(e, q.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, g, t);
       }
+      }
     }
-    if (tid == 0) sh_next = tried < 8 ? resolve() : -1;
+    TLG(3, __builtin_amdgcn_s_memrealtime());
+#ifdef OP_GEMM_TIMELINE
+    ++tl_slot;
+#endif
+    if (tid == 0) {
+      if (!valid) draw();  // (an empty slot has no main loop behind which the draw was issued)
+      sh_next = resolve();
+    }
     __syncthreads();  // the ticket is published, and every wave is done with the LDS stages the next tile overwrites
     code = __builtin_amdgcn_readfirstlane(sh_next);
     __syncthreads();  // ... and has read it before thread 0 publishes the one after
   }
   if (tid == 0) {  // the last workgroup to leave re-arms the counters for the next launch on this stream
-    const unsigned gone = __hip_atomic_fetch_add(p.ctr + 8 * TN_CTR_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long gone = __hip_atomic_fetch_add(p.ctr + 8 * TN_CTR_STRIDE, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gone == gridDim.x - 1) {
 #pragma unroll 1
-      for (int x = 0; x <= 8; ++x) __hip_atomic_store(p.ctr + x * TN_CTR_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int x = 0; x <= 8; ++x) __hip_atomic_store(p.ctr + x * TN_CTR_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -2888,7 +2977,7 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 
 // Bytes of the counter block op_gemm_tn_grouped needs: device memory the caller zeroes ONCE; every launch leaves it zeroed.
 // One block per stream that may run the op (launches on one stream are ordered, the block is re-armed by the launch itself).
-int64_t op_gemm_tn_grouped_counter_bytes(void) { return (int64_t)(9 * TN_CTR_STRIDE) * 4; }
+int64_t op_gemm_tn_grouped_counter_bytes(void) { return (int64_t)(9 * TN_CTR_STRIDE) * 8; }
 
 // Host-only query (works without a GPU): the tile queues op_gemm_tn_grouped builds for these problem sizes.  Writes, queue by queue
 // (0..7) and in draw order, one record of four int32 per tile: queue, problem (the caller's index), tile row, tile column; returns the
@@ -2924,7 +3013,7 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
 // x of nn.Linear, autograd's dW = dy^T x) as ONE persistent launch without split-K (gemm256w_tn_grouped_kernel): every output
 // tile runs its whole K and is written / accumulated once.  Shape rules per problem as op_gemm_tn; returns OP_ENOTSUP (nothing
 // launched) when a problem does not qualify -- the caller then uses op_gemm_tn per problem.  Problems may come in any order.
-// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile).
+// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = no solo workgroups (A/B timing).
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
                        void* counters, int64_t tune, void* stream) {
@@ -2946,7 +3035,7 @@ int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, 
   TnGroupArgs ga;
   memset(&ga, 0, sizeof(ga));
   ga.nprob = (int)nprob;
-  ga.ctr = (unsigned*)counters;
+  ga.ctr = (unsigned long long*)counters;
   double work = 0.0;
   int64_t tiles = 0;
   for (int i = 0; i < (int)nprob; ++i) {
@@ -2963,6 +3052,12 @@ int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, 
   int nwg = (int)(tune & 1023);
   if (nwg <= 0) nwg = num_cus();
   if (nwg > tiles) nwg = (int)tiles;
+  {  // workgroups blockIdx >> 3 >= solo_from draw single tiles from the back of the queues: what is left of an XCD's workgroups
+     // beyond a multiple of the group size of the longest-K problem (32 per XCD, groups of 6: the last two)
+    const TnGeom G0 = tn_geom(ga.pr[0].tiles_m, ga.pr[0].tiles_n);
+    const int per_xcd = nwg / 8;
+    ga.solo_from = ((tune >> 10) & 1) || G0.csz < 2 || per_xcd < G0.csz ? (1 << 30) : (per_xcd / G0.csz) * G0.csz;
+  }
   const size_t sh = STAGES2 * STAGE2_BYTES;
   OP_ENSURE_LDS(gemm256w_tn_grouped_kernel, (int)sh, "gemm_tn_grouped");
   const int slot = op_prof_begin(0, work, stream);

@@ -515,6 +515,451 @@ __global__ __launch_bounds__(RES_MAX_NW * 64, 5) void attn_fwd_res_kernel(AttnAr
   }
 }
 
+// =====================================================================================================================
+// Persistent forward for the 193 ... 257-token streams (5 s audio: 250, 256^2 image: 257) -- round 4.
+// What the resident kernel above costs at these lengths (tools/attn_bench.py + PMC, B = 128): a workgroup lives ~12 us, of which
+// its waves COMPUTE ~2.5 us -- every workgroup first stages 66 ... 74 KiB of K / V (a prologue that runs at the ~11 B/cycle/CU of
+// a cold burst: 2.5 ... 3 us with every CU doing the same) and sets up selectors / addresses for ONE 16-query block per wave;
+// two workgroups per CU overlap only partly (SQ_WAIT_ANY 57 % of the wave cycles), K / V are staged twice per (sample, head), and
+// at S = 257 the seventeenth query block makes one wave of the first workgroup run twice as long as the other fifteen.  Here:
+//   * ONE workgroup of 16 waves per CU walks the (sample, head) items  blockIdx, blockIdx + gridDim, ...  -- the order one-item
+//     workgroups are dispatched in, so the 24 heads of a sample (the 128-byte slices of one 9 KiB qkv row) are still read by the
+//     chip at the same time;
+//   * K / V of item i + 1 are fetched by LDS-DMA into the OTHER half of a double buffer (2 x 72 KiB at 288 rows) while item i is
+//     computed: one barrier per item, no staging phase; the next item's Q fragments travel in registers, the bias fragments of the
+//     next key tile are requested one tile ahead (there is room for that at 4 waves per SIMD = 128 registers);
+//   * wave w owns query block w of EVERY item (selectors, swizzle offsets, fragment addresses are set up once per launch);
+//   * S = 257: the lone query of block 16 is spread over the workgroup BY KEYS -- wave w runs it against key block w (wave 0 also
+//     against block 16: one QK^T fragment, one softmax step, one half-empty PV fragment: +8 % per wave instead of +100 % for one),
+//     the sixteen partial (max, sum, O) triples meet in LDS and are merged by one wave after the NEXT item's barrier.
+// Same swapped formulation, bias on the matrix pipe, exp2-domain softmax and LDS image as attn_fwd_res_kernel; the per-tile code is
+// that kernel's, so the 16 regular query blocks give the same bits; the lone query's softmax is merged in a different order
+// (fp32 online-softmax merge: same value up to fp32 rounding).
+// =====================================================================================================================
+constexpr int PERS_NW = 8;        // waves per workgroup: two 16-query blocks each (256 registers per wave: everything prefetched, no spills;
+                                  // sixteen waves of one block each -- 128 registers -- spilled 35 of them, and a spill reload next to
+                                  // LDS-DMA is an s_waitcnt vmcnt(0): the K / V fetch of the next item stopped overlapping)
+constexpr int PERS_MAX_ROWS = 288;
+constexpr int PERS_SCR = 68;      // floats per (item parity, wave) of the merge scratch: O[64], m2, l, pad
+constexpr int PERS_PPT = 2;       // LDS-DMA pieces of the next item a wave issues per key tile (<= 9 pieces over >= 4 tiles; 5 tiles at 9)
+
+// transpose read as inline asm: through the builtin the compiler orders it behind every pending LDS-DMA write (s_waitcnt vmcnt(0) in
+// front of the first one after each DMA issue: the next item's K / V fetch would stop overlapping with this item's tiles).  The
+// caller waits (lgkmcnt) and fences the scheduler before the first use.
+__device__ __forceinline__ s16x4 tr_read_a(const char* p) {
+  s16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"((unsigned)(uintptr_t)((__attribute__((address_space(3))) const char*)p)));
+  return r;
+}
+#define ATTN_WAIT_LGKM0()                         \
+  do {                                            \
+    __builtin_amdgcn_s_waitcnt(0xC07F);           \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+
+// The bias / pad loads of the item loop as inline asm + hand-placed waits.  vmcnt counts in ISSUE order, so a load issued behind
+// pieces of the next item's fetch cannot be waited for without those pieces; and the compiler, which does its own bookkeeping for
+// the loads it can see, answers anything it cannot count (a loop-carried prefetch next to LDS-DMA) with vmcnt(0) = the whole fetch.
+// Protocol of a key tile: wait until only the PERS_PPT youngest operations are outstanding (= the previous tile's fetch pieces; this
+// tile's small loads, issued before them, have landed), request the NEXT tile's small loads, then this tile's fetch pieces.
+__device__ __forceinline__ void gload16_asm(bf16x8& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
+__device__ __forceinline__ void gload4_asm(unsigned& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
+
+template <bool HAS_BIAS, bool HAS_PAD>
+__global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs p, const bf16_t* __restrict__ bias_frag, int rows_pad,
+                                                                         int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, t = lane & 15;
+  const int KVB = 2 * rows_pad * 128;                       // bytes of one K | V buffer
+  float* scratch = reinterpret_cast<float*>(smem + 2 * KVB);  // [2][PERS_NW][PERS_SCR]
+  const int nqb = (p.S + 15) >> 4, nkp = (p.S + 31) >> 5;
+  const bool has_left = nqb > 2 * PERS_NW;   // S = 257 (launch condition: then the 17th block holds exactly one query)
+  const int q0 = wid * 32;                   // this wave's query blocks: rows q0 .. q0 + 15 and q0 + 16 .. q0 + 31
+  const int nact = min(2, max(0, nqb - 2 * wid));  // how many of them exist (uniform)
+  const int64_t per_head = (int64_t)nqb * nkp * FRAG_BLOCK;
+  const int ntiles = (p.S + BKV - 1) / BKV;
+  const float c1 = p.scale * LOG2E;
+
+  bf16x8 sel_lo, sel_hi;
+  {
+    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
+      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
+    }
+  }
+  int trsw[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+  const int kswz[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+
+  // ---- LDS-DMA of one item's K and V: 8 rows x 128 B per wave-level instruction (see attn_fwd_res_kernel) ----
+  const int ngrp = rows_pad >> 3;
+  const int r_in = lane >> 3, slot = lane & 7;
+  const int npiece = (2 * ngrp - wid + PERS_NW - 1) / PERS_NW;  // pieces of this wave: groups wid, wid + PERS_NW, ...
+  auto piece = [&](int it, int buf, int j) {
+    const int b = it / p.heads, h = it - b * p.heads;
+    const int grp = wid + j * PERS_NW;
+    const bool isv = grp >= ngrp;
+    const int gi = isv ? grp - ngrp : grp;
+    const int r = gi * 8 + r_in;
+    const int kr = min(r, p.S - 1);
+    const bf16_t* src = (isv ? p.v : p.k) + ((int64_t)b * p.S + kr) * p.ld + h * HD + ((slot ^ (r & 7)) << 3);
+    char* dst = smem + buf * KVB + (isv ? rows_pad * 128 : 0) + gi * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto load_q = [&](int it, int qrow, bf16x8 (&q)[2]) {
+    const int b = it / p.heads, h = it - b * p.heads;
+    const bf16_t* qp = p.q + ((int64_t)b * p.S + qrow) * p.ld + h * HD;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) q[kk] = *reinterpret_cast<const bf16x8*>(qp + kk * 32 + g * 8);
+  };
+  const int qi_main[2] = {min(q0 + t, p.S - 1), min(q0 + 16 + t, p.S - 1)};
+
+  // small loads of (item, key tile): bias fragments of this wave's two query blocks (a block that does not exist re-reads the last
+  // one: never stored) and the key-pad words; tile index == ntiles means "tile 0 of the next item" for the caller
+  bf16x8 bn[2][2];
+  unsigned padn[4] = {0u, 0u, 0u, 0u};
+  auto small_loads = [&](int it, int kt) {
+    const int b = it / p.heads, h = it - b * p.heads;
+    if constexpr (HAS_BIAS) {
+      const bf16_t* fhead = bias_frag + ((p.bias_bs != 0 ? (int64_t)b * p.heads : 0) + h) * per_head + lane * 8;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const bf16_t* fb = fhead + (int64_t)min(2 * wid + qb, nqb - 1) * nkp * FRAG_BLOCK;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) gload16_asm(bn[qb][m], fb + min(2 * kt + m, nkp - 1) * FRAG_BLOCK);
+      }
+    }
+    if constexpr (HAS_PAD) {
+      const uint8_t* pr = p.key_pad + (int64_t)b * p.Spad + g * 4 + kt * BKV;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) gload4_asm(padn[kb], pr + kb * 16);
+    }
+  };
+
+  // late loads, issued in the LAST key tile of an item (registers are free there: S = 257's fifth tile is one 16-key block): the Q
+  // fragments of the next item and, with a lone query, its Q fragments, bias fragments and pad words for this wave's key pair(s)
+  constexpr int NSMALL = (HAS_BIAS ? 4 : 0) + (HAS_PAD ? 4 : 0);  // operations of small_loads
+  bf16x8 qn[2][2], ql[2], bfl[2];
+  unsigned padl[2][2] = {{0u, 0u}, {0u, 0u}};
+  auto late_loads = [&](int it_next, int it) {
+    {
+      const int b = it_next / p.heads, h = it_next - b * p.heads;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const bf16_t* qp = p.q + ((int64_t)b * p.S + qi_main[qb]) * p.ld + h * HD;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) gload16_asm(qn[qb][kk], qp + kk * 32 + g * 8);
+      }
+    }
+    if (has_left) {
+      const int b = it / p.heads, h = it - b * p.heads;
+      const bf16_t* qp = p.q + ((int64_t)b * p.S + p.S - 1) * p.ld + h * HD;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) gload16_asm(ql[kk], qp + kk * 32 + g * 8);
+      if constexpr (HAS_BIAS) {
+        const bf16_t* fleft = bias_frag + ((p.bias_bs != 0 ? (int64_t)b * p.heads : 0) + h) * per_head + lane * 8 + (int64_t)(nqb - 1) * nkp * FRAG_BLOCK;
+        gload16_asm(bfl[0], fleft + wid * FRAG_BLOCK);
+        gload16_asm(bfl[1], fleft + min(PERS_NW, nkp - 1) * FRAG_BLOCK);
+      }
+      if constexpr (HAS_PAD) {
+        const uint8_t* pr = p.key_pad + (int64_t)b * p.Spad + g * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          gload4_asm(padl[0][j], pr + (2 * wid + j) * 16);
+          gload4_asm(padl[1][j], pr + min((2 * PERS_NW + j) * 16, p.Spad - 16));
+        }
+      }
+    }
+  };
+
+  int item = blockIdx.x;
+  const int step = gridDim.x;
+  if (item < nitems) {
+    for (int j = 0; j < npiece; ++j) piece(item, 0, j);
+    load_q(item, qi_main[0], qn[0]);
+    load_q(item, qi_main[1], qn[1]);
+    small_loads(item, 0);
+  }
+  int buf = 0, prev_item = -1;
+
+  // merge of the lone query's partials of item `it` (scratch half `sb`) by the calling wave: lane = head dimension
+  auto merge_left = [&](int it, int sb) {
+    const float* sc = scratch + sb * (PERS_NW * PERS_SCR);
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < PERS_NW; ++w) M = fmaxf(M, sc[w * PERS_SCR + 64]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < PERS_NW; ++w) {
+      const float f = __builtin_amdgcn_exp2f(sc[w * PERS_SCR + 64] - M);  // (-inf - M = -inf -> 0: a wave whose keys were all masked)
+      L = __builtin_fmaf(sc[w * PERS_SCR + 65], f, L);
+      o = __builtin_fmaf(sc[w * PERS_SCR + lane], f, o);
+    }
+    const int b = it / p.heads, h = it - b * p.heads;
+    const int qrow = p.S - 1;
+    p.out[((int64_t)b * p.S + qrow) * p.ldo + h * HD + lane] = (bf16_t)(o / L);
+    if (lane == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.lse_ld + qrow] = M * (1.0f / LOG2E) + logf(L);
+  };
+
+  for (; item < nitems; item += step, buf ^= 1) {
+    const int b = item / p.heads, h = item - b * p.heads;
+    const int64_t row_base = (int64_t)b * p.S;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // this item's K / V have landed (and its first small loads); every wave is done with the other buffer and with
+                      // the scratch half it re-uses
+    bf16x8 qf[2][2] = {{qn[0][0], qn[0][1]}, {qn[1][0], qn[1][1]}};
+    const bool more = item + step < nitems;
+    const int nxt = more ? item + step : item;  // (no next item: the current one is fetched again into the idle buffer -- nothing branches)
+    if (has_left && prev_item >= 0 && wid == ((prev_item / step) & (PERS_NW - 1))) merge_left(prev_item, buf ^ 1);
+    prev_item = item;
+
+    const char* ldsK = smem + buf * KVB;
+    const char* ldsV = ldsK + rows_pad * 128;
+
+    f32x4 ot[2][4];
+    float m2_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) ot[qb][db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto tile = [&](const int kt, auto full_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      const int k0 = kt * BKV;
+      const int nkb = FULL ? 4 : ((p.S - k0 + 15) >> 4);
+      // ---- the pipeline of small loads and fetch pieces (see above) ----
+      if (kt > 0) {  // (tile 0: everything outstanding was waited for at the top of the item)
+        if constexpr (HAS_BIAS && HAS_PAD)
+          asm volatile("s_waitcnt vmcnt(%8)" : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(PERS_PPT));
+        else if constexpr (HAS_BIAS)
+          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]) : "n"(PERS_PPT));
+        else if constexpr (HAS_PAD)
+          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(PERS_PPT));
+      }
+      bf16x8 bf[2][2];
+      unsigned padw[4] = {0u, 0u, 0u, 0u};
+      if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) bf[qb][m] = bn[qb][m];
+      }
+      if constexpr (HAS_PAD) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) padw[kb] = padn[kb];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (FULL) {  // (FULL = not the last tile of the item: the caller peels that one)
+        small_loads(item, kt + 1);
+      } else {
+        late_loads(nxt, item);
+        small_loads(nxt, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < PERS_PPT; ++jj) piece(nxt, buf ^ 1, min(kt * PERS_PPT + jj, npiece - 1));  // (past the last piece: that piece again)
+      __builtin_amdgcn_sched_barrier(0);
+      if (nact == 0) return;  // (uniform) a wave without query blocks (short sequences) only fetches its share
+
+      const char* kt_ = ldsK + k0 * 128;
+      const char* vt = ldsV + k0 * 128;
+      f32x4 st[2][4];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) st[qb][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        if (!FULL && kb >= nkb) break;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt_ + (kb * 16 + t) * 128 + kswz[kk]);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][kk], st[qb][kb], 0, 0, 0);
+        }
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[qb][kb >> 1], (kb & 1) ? sel_hi : sel_lo, st[qb][kb], 0, 0, 0);
+        }
+      }
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          if (!FULL && kb >= nkb) break;
+          const int key = k0 + kb * 16 + g * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (!FULL || HAS_PAD) {
+              bool masked = false;
+              if constexpr (!FULL) masked = key + r >= p.S;
+              if constexpr (HAS_PAD) masked = masked || ((padw[kb] >> (8 * r)) & 0xffu);
+              st[qb][kb][r] = masked ? -INFINITY : st[qb][kb][r];
+            }
+            mx = fmaxf(mx, st[qb][kb][r]);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m2_new = fmaxf(m2_run[qb], mx * c1);
+        const float m2_use = (m2_new == -INFINITY) ? 0.f : m2_new;
+        const float alpha = __builtin_amdgcn_exp2f(m2_run[qb] - m2_use);
+        m2_run[qb] = m2_new;
+        float psum = 0.f;
+        float pv[4][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+          if (FULL || kb < nkb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qb][kb][r], c1, -m2_use));
+              pv[kb][r] = e;
+              psum += e;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pv[kb][r] = 0.f;
+          }
+        }
+        l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ot[qb][db][r] *= alpha;
+        pf[qb][0] = pack8(pv[0], pv[1]);
+        pf[qb][1] = pack8(pv[2], pv[3]);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if (!FULL && 2 * m >= nkb) break;
+        s16x4 v0[4], v1[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          v0[db] = tr_read_a(vt + trsw[db] + (2 * m) * 2048);
+          v1[db] = tr_read_a(vt + trsw[db] + (2 * m + 1) * 2048);
+        }
+        ATTN_WAIT_LGKM0();
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const bf16x8 vf = join_tr(v0[db], v1[db]);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][m], ot[qb][db], 0, 0, 0);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < ntiles - 1; ++kt) tile(kt, std::true_type{});
+    tile(ntiles - 1, std::false_type{});  // the last tile: partial (or full at S = 256: its masks are then all false); issues the late loads
+    if (has_left) {  // (BEFORE the stores below: the hand-counted wait in here must see exactly the operations of the last tile behind it)
+      // ---- the lone query (row S - 1 = 256) against this wave's key blocks 2w, 2w + 1 (wave 0: also block 16): every query column of
+      // the fragment is that row ----
+      f32x4 ol[4];
+      float m2 = -INFINITY, lsum = 0.f;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) ol[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // the late loads of the last tile: behind them only the next item's first small loads and that tile's fetch pieces were issued
+      asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ql[0]), "+v"(ql[1]), "+v"(bfl[0]), "+v"(bfl[1]), "+v"(padl[0][0]), "+v"(padl[0][1]), "+v"(padl[1][0]), "+v"(padl[1][1]) : "n"(NSMALL + PERS_PPT));
+      const int npc = wid == 0 ? 2 : 1;
+      for (int pc = 0; pc < npc; ++pc) {
+        const int kp = pc == 0 ? wid : PERS_NW;  // absolute 32-key pair block
+        f32x4 s4[2];
+        const unsigned padw[2] = {padl[pc][0], padl[pc][1]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          s4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + ((2 * kp + j) * 16 + t) * 128 + kswz[kk]);
+            s4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[kk], s4[j], 0, 0, 0);
+          }
+          if constexpr (HAS_BIAS) s4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[pc], j ? sel_hi : sel_lo, s4[j], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bool masked = (2 * kp + j) * 16 + g * 4 + r >= p.S;
+            if constexpr (HAS_PAD) masked = masked || ((padw[j] >> (8 * r)) & 0xffu);
+            s4[j][r] = masked ? -INFINITY : s4[j][r];
+            mx = fmaxf(mx, s4[j][r]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m2_new = fmaxf(m2, mx * c1);
+        const float m2_use = (m2_new == -INFINITY) ? 0.f : m2_new;
+        const float alpha = __builtin_amdgcn_exp2f(m2 - m2_use);
+        m2 = m2_new;
+        float pv[2][4];
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pv[j][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[j][r], c1, -m2_use));
+            psum += pv[j][r];
+          }
+        lsum = lsum * alpha + psum;
+        const bf16x8 pf = pack8(pv[0], pv[1]);
+        s16x4 v0[4], v1[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          v0[db] = tr_read_a(ldsV + trsw[db] + (2 * kp) * 2048);
+          v1[db] = tr_read_a(ldsV + trsw[db] + (2 * kp + 1) * 2048);
+        }
+        ATTN_WAIT_LGKM0();
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ol[db][r] *= alpha;
+          ol[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(v0[db], v1[db]), pf, ol[db], 0, 0, 0);
+        }
+      }
+      lsum += __shfl_xor(lsum, 16);
+      lsum += __shfl_xor(lsum, 32);
+      float* sc = scratch + (buf * PERS_NW + wid) * PERS_SCR;
+      if (t == 0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(sc + db * 16 + g * 4) = ol[db];
+        if (g == 0) { sc[64] = m2; sc[65] = lsum; }
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float l = l_run[qb];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const int qrow = q0 + qb * 16 + t;
+      if (qb < nact && qrow < p.S) {
+        const float inv = 1.f / l;
+        bf16_t* op = p.out + (row_base + qrow) * p.ldo + h * HD;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (bf16_t)(ot[qb][db][r] * inv);
+          *reinterpret_cast<bf16x4*>(op + db * 16 + g * 4) = o;
+        }
+        if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.lse_ld + qrow] = m2_run[qb] * (1.0f / LOG2E) + logf(l);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last tiles' asm loads and the idle-buffer fetch must not outlive the wave)
+  if (has_left && prev_item >= 0) {
+    __syncthreads();
+    if (wid == 0) merge_left(prev_item, buf ^ 1);
+  }
+}
+
 // Fragment-major bias image (what attn_fwd_res_kernel's bias MFMA reads): for every 16-query block qb and 32-key pair-block
 // kp one contiguous block of 64 lanes x 8 bf16; lane (g,t) holds bias[q = qb*16 + (g&1)*8 + i][key = kp*32 + (g>>1)*16 + t],
 // i = 0..7, zero outside the sequence.  src: row-major image [n_img][S][Spad] (n_img = heads, or B * heads per-sample).
@@ -1382,7 +1827,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 
 // Per-call tuning words (last argument before the stream; 0 = what production uses; the library keeps no tuning state):
 //   op_attn_fwd:  bit 0 = always the streaming kernel (tests / A-B timing); bits 1-2 = timing ablations of the resident kernel
-//                 (tools only: 1 no K/V staging, 2 no compute)
+//                 (tools only: 1 no K/V staging, 2 no compute); bits 3-6 = waves per workgroup of the resident kernel; bit 7 = no
+//                 persistent kernel (193 ... 257 tokens then run the resident one: tests / A-B timing)
 //   op_attn_bwd / op_attn_bwd_dbias_slabs:  bit 0 = separate dQ and dBias kernels instead of the merged one (tests);
 //                 bit 1 = round 2's batch-chunk rule of the merged kernel (A/B timing); bits 2-3 = 2: dK/dV kernel with 64 keys per workgroup;
 //                 bits 4-9 = forced number of batch chunks of the merged kernel (sweep of tools/attn_chunks_ab.py: the rule's choice is
@@ -1396,12 +1842,32 @@ int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, siz
   return OP_OK;
 }
 
+template <bool HAS_BIAS, bool HAS_PAD>
+int launch_fwd_pers(const AttnArgs& a, const bf16_t* frag, int nwg, size_t sh, int rows_pad, int nitems, hipStream_t s) {
+  OP_ENSURE_LDS((attn_fwd_pers_kernel<HAS_BIAS, HAS_PAD>), 4 * PERS_MAX_ROWS * 128 + 2 * PERS_NW * PERS_SCR * 4, "attn_fwd");
+  hipLaunchKernelGGL((attn_fwd_pers_kernel<HAS_BIAS, HAS_PAD>), dim3(nwg), dim3(PERS_NW * 64), sh, s, a, frag, rows_pad, nitems);
+  return OP_OK;
+}
+
 // number of batch chunks (= dbias slabs) of the merged dQ + dBias kernel; 1 when the separate kernels run.
 // A workgroup of that kernel walks the samples of its chunk, two workgroups fit a CU (256 VGPRs), and all workgroups of a launch
 // take the same time: the launch costs  rounds x samples-per-chunk  with rounds = ceil(workgroups / (2 x CUs)).  Round 2 aimed at
 // ">= 768 workgroups", which at 257 tokens (5 query tiles x 24 heads) gave 7 chunks of 19 samples = 840 workgroups = 1.64 -> 2
 // rounds x 19 = 38 sample-times; 4 chunks of 32 (480 workgroups, one round) or 8 of 16 cost 32.  Chosen here: the chunk count with
 // the smallest cost (+ a little per chunk for the slab read-modify-write at the end of every workgroup; fewer slabs on a tie).
+// CUs of the CURRENT device, cached per device (a process may drive several)
+inline int attn_num_cus() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 inline int dbias_chunks(int64_t B, int64_t S, int64_t heads, bool merge, bool round2_rule = false, int forced = 0) {
   if (!merge || ceil_div(S, BKV) > 6) return 1;
   if (forced > 0) return ceil_div(B, ceil_div(B, min((int64_t)forced, B)));  // (tune bits 4-9: A/B timing)
@@ -1412,12 +1878,7 @@ inline int dbias_chunks(int64_t B, int64_t S, int64_t heads, bool merge, bool ro
     if (chunks > B) chunks = (int)B;
     return ceil_div(B, ceil_div(B, chunks));
   }
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-    else cus = 256;
-  }
+  const int cus = attn_num_cus();
   const int64_t base = (int64_t)ceil_div(S, 64) * heads, slots = 2 * (int64_t)cus;
   int best = 1;
   double best_cost = 1e30;
@@ -1463,6 +1924,23 @@ int op_attn_fwd(const void* q, const void* k, const void* v, int64_t ld, const v
   hipStream_t s = (hipStream_t)stream;
   // resident-K/V kernel: needs the fragment-major bias image when a bias is used, and 1/scale exact in bf16 (head_dim 64)
   const bool inv_exact = (float)(bf16_t)(1.0f / scale) * scale == 1.0f;
+  // persistent kernel (round 4): 193 ... 256 tokens (<= 16 query blocks = one per wave) or exactly 257 (256 + a lone query); tune bit 7: off
+  if (!(tune & 1) && !(tune & 128) && S > 192 && S <= 257 && (!bias || (bias_frag && inv_exact))) {
+    const int rows_pad = ceil_div(S, 32) * 32;
+    const size_t sh = (size_t)4 * rows_pad * 128 + 2 * PERS_NW * PERS_SCR * 4;
+    const int nitems = (int)(B * heads);
+    const int nwg = min(nitems, attn_num_cus());
+    const bf16_t* fr = (const bf16_t*)bias_frag;
+    int rc;
+    if (bias && key_pad) rc = launch_fwd_pers<true, true>(a, fr, nwg, sh, rows_pad, nitems, s);
+    else if (bias) rc = launch_fwd_pers<true, false>(a, fr, nwg, sh, rows_pad, nitems, s);
+    else if (key_pad) rc = launch_fwd_pers<false, true>(a, fr, nwg, sh, rows_pad, nitems, s);
+    else rc = launch_fwd_pers<false, false>(a, fr, nwg, sh, rows_pad, nitems, s);
+    op_prof_end(slot, stream);
+    if (rc != OP_OK) return rc;
+    OP_LAUNCH_CHECK();
+    return OP_OK;
+  }
   if (!(tune & 1) && S <= RES_MAX_S && (!bias || (bias_frag && inv_exact))) {
     const int nqb = ceil_div(S, 16);
     const int nwg = ceil_div(nqb, RES_MAX_NW);

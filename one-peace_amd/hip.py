@@ -98,6 +98,7 @@ class Tuning:
         self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
         self.attn_waves = 0      # resident forward kernel: waves per workgroup (0 = production rule; tests / A-B timing)
+        self.attn_pers = 1       # attention forward: 1 persistent kernel for 193 ... 257 tokens (round 4), 0 the resident one
         self.dbias_chunks_r2 = 0  # merged dQ + dBias kernel: round 2's batch-chunk rule (A/B timing)
         self.dkdv_keys = 0       # dK/dV kernel: 0 auto, 1 = 128 keys per workgroup, 2 = 64 (A/B timing)
         self.dbias_chunks = 0    # merged dQ + dBias kernel: forced number of batch chunks (0 = the library's rule; A/B timing)
@@ -109,7 +110,7 @@ class Tuning:
                 | (0 if self.glds else 1) << 19 | (self.sched & 7) << 20)
 
     def attn_fwd(self):
-        return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1 | (self.attn_waves & 15) << 3
+        return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1 | (self.attn_waves & 15) << 3 | (0 if self.attn_pers else 128)
 
     def attn_bwd(self):
         return (0 if self.merge_dbias else 1) | (2 if self.dbias_chunks_r2 else 0) | (self.dkdv_keys & 3) << 2 | (self.dbias_chunks & 63) << 4

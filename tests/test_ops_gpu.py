@@ -671,6 +671,59 @@ def test_attention_forward_backward(B, S, heads, use_bias, use_pad, merge_dbias,
         assert_close(dbias[:, :, :S], bias_r.grad, fro=1.2e-2, mx=3e-2, what="dbias")
 
 
+@pytest.mark.parametrize("B,S,heads,use_bias,use_pad,per_sample", [
+    (40, 257, 12, True, False, False), (48, 250, 12, True, True, False), (30, 200, 10, False, True, False),
+    (26, 257, 12, True, True, True), (70, 256, 8, True, False, False), (33, 257, 9, False, False, False), (2, 193, 1, True, True, False)])
+def test_attention_persistent_forward_over_several_items_per_workgroup(B, S, heads, use_bias, use_pad, per_sample):
+    """Round 4: the persistent forward kernel (193 ... 257 tokens) with MORE (sample, head) items than workgroups, so that every
+    workgroup walks several items through its K / V double buffer and the hand-counted waits, the lone query of S = 257 is
+    merged after the next item's barrier, and the last item's merge happens after the loop.  The 16 regular query blocks run
+    the resident kernel's per-tile code: bit-identical to it; the lone query (fp32 merge of 9 partial softmaxes) agrees to the
+    op tolerance, like everything against the fp32 reference."""
+    hip = hipmod()
+    H = heads * 64
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(B * S, 3 * H, generator=g, device=DEV).to(torch.bfloat16)
+    Spad = hip.attn_spad(S)
+    bias_d = pad_d = None
+    if use_bias:
+        shape = (B, heads, S, Spad) if per_sample else (heads, S, Spad)
+        bias_d = torch.zeros(shape, dtype=torch.bfloat16, device=DEV)
+        bias_d[..., :S] = torch.randn(*shape[:-1], S, generator=g, device=DEV).to(torch.bfloat16)
+    if use_pad:
+        pad = torch.zeros(B, Spad, dtype=torch.uint8, device=DEV)
+        pad[:, S:] = 1
+        for b in range(1, B):
+            pad[b, S - 1 - (7 * b) % (S // 2):] = 1
+        pad_d = pad
+    frag = hip.attn_bias_pack(bias_d, S) if use_bias else None
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    out, lse = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad, bias_frag=frag)
+    old = hip.TUNE.attn_pers
+    hip.TUNE.attn_pers = 0
+    try:
+        out_r, lse_r = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad, bias_frag=frag)
+    finally:
+        hip.TUNE.attn_pers = old
+    nreg = min(S, 256)
+    o3, r3 = out.view(B, S, H), out_r.view(B, S, H)
+    assert torch.equal(o3[:, :nreg], r3[:, :nreg]), "regular query blocks differ from the resident kernel"
+    torch.testing.assert_close(lse[:, :, :nreg], lse_r[:, :, :nreg], rtol=2e-6, atol=2e-6)  # (same max and sum; the final log / fma may contract differently)
+    if S > 256:
+        assert_close(o3[:, 256:], r3[:, 256:].float().cpu(), fro=4e-3, mx=2e-2, what="lone query")
+        assert_close(lse[:, :, 256:S], lse_r[:, :, 256:S].cpu(), fro=1e-5, mx=1e-5, what="lone query lse")
+    # against fp32 on a few samples
+    for b in (0, B // 2, B - 1):
+        qf, kf, vf = (x[b * S:(b + 1) * S].float().view(1, S, H) for x in (q, k, v))
+        bb = None
+        if use_bias:
+            bb = (bias_d[b] if per_sample else bias_d)[..., :S].float()
+        kp = pad_d[b:b + 1, :S].bool() if use_pad else None
+        ref, lse_ref = _attn_ref(qf, kf, vf, heads, 0.125, bb, kp)
+        assert_close(o3[b:b + 1], ref.cpu(), fro=6e-3, what="attn out vs fp32 (sample %d)" % b)
+        assert_close(lse[b:b + 1, :, :S], lse_ref.cpu(), fro=1e-3, mx=2e-3, what="lse vs fp32")
+
+
 @pytest.mark.parametrize("B,S,heads", [(20, 72, 2), (3, 257, 2), (2, 330, 1)])
 def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_dbias):
     """lse / delta rows, bias columns and bias rows in [S, Spad) are unspecified (the wrappers allocate with torch.empty, the

@@ -1,0 +1,39 @@
+"""Round 4: persistent attention forward kernel against the resident one, same process, interleaved (B = 128 by default).
+
+    python tools/attn_pers_ab.py [B]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from one_peace_amd import hip  # noqa: E402
+from tools.bench_ops import timeit  # noqa: E402
+
+H, heads = 1536, 24
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+bf = dict(dtype=torch.bfloat16, device="cuda")
+for S, use_pad in ((257, False), (250, True), (256, False), (197, False)):
+    Spad = hip.attn_spad(S)
+    qkv = torch.randn(B * S, 3 * H, **bf)
+    bias = torch.randn(heads, S, Spad, **bf)
+    pad = None
+    if use_pad:
+        pad = torch.zeros(B, Spad, dtype=torch.uint8, device="cuda")
+        pad[:, S:] = 1
+        pad[1::3, S - 20:] = 1
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    fl = 4.0 * B * heads * S * S * 64
+    frag = hip.attn_bias_pack(bias, S)
+    fn = lambda: hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias, pad, Spad, want_lse=True, bias_frag=frag)  # noqa: E731
+    res = {}
+    for rnd in range(2):
+        for pers in (1, 0):
+            hip.TUNE.attn_pers = pers
+            res.setdefault(pers, []).append(timeit(fn, iters=30, warmup=5))
+    hip.TUNE.attn_pers = 1
+    tp, tr = min(res[1]), min(res[0])
+    print("B=%d S=%d pad=%d: persistent %.4f ms (%.0f TF/s, %.2f TB/s of q,k,v,out)  resident %.4f ms   %+.1f %%   (runs %s | %s)" % (
+        B, S, int(use_pad), tp, fl / tp / 1e9, 8.0 * B * S * H / tp / 1e9, tr, 100.0 * (tp / tr - 1),
+        " ".join("%.4f" % x for x in res[1]), " ".join("%.4f" % x for x in res[0])), flush=True)

@@ -564,6 +564,19 @@ __device__ __forceinline__ s16x4 tr_read_a(const char* p) {
 // tile's small loads, issued before them, have landed), request the NEXT tile's small loads, then this tile's fetch pieces.
 __device__ __forceinline__ void gload16_asm(bf16x8& d, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(p)); }
 __device__ __forceinline__ void gload4_asm(unsigned& d, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=v"(d) : "v"(p)); }
+// the same with a wave-uniform base in SGPRs and a 32-bit per-lane byte offset (ONE address register for all loads of a row instead
+// of a 64-bit pair per load: the kernels at the register limit); OFF: immediate byte offset (< 4096)
+// (s_nop 4: a VMEM instruction needs five wait states behind a VALU / SALU write of an SGPR it reads -- the compiler restores spilled
+// SGPRs with v_readlane right in front of the statement and does not know what is inside it: the first version of the round-4
+// backward kernel read its bases one instruction after they were written and faulted; tools/check_mfma_hazards.py has the rule)
+template <int OFF>
+__device__ __forceinline__ void gload16_s(bf16x8& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void gload4_s(unsigned& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+}
 
 template <bool HAS_BIAS, bool HAS_PAD>
 __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs p, const bf16_t* __restrict__ bias_frag, int rows_pad,
@@ -687,6 +700,12 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
     small_loads(item, 0);
   }
   int buf = 0, prev_item = -1;
+  // everything the item loop finds in flight at its top has landed at the END of the previous trip (or here): see the tile
+  auto wait_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0][0]), "+v"(qn[0][1]), "+v"(qn[1][0]), "+v"(qn[1][1]), "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]),
+                 "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : : "memory");
+  };
+  wait_all();
 
   // merge of the lone query's partials of item `it` (scratch half `sb`) by the calling wave: lane = head dimension
   auto merge_left = [&](int it, int sb) {
@@ -710,9 +729,8 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
   for (; item < nitems; item += step, buf ^= 1) {
     const int b = item / p.heads, h = item - b * p.heads;
     const int64_t row_base = (int64_t)b * p.S;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // this item's K / V have landed (and its first small loads); every wave is done with the other buffer and with
-                      // the scratch half it re-uses
+    __syncthreads();  // this item's K / V have landed (every wave waited for its own pieces at the end of the previous trip); every
+                      // wave is done with the other buffer and with the scratch half it re-uses
     bf16x8 qf[2][2] = {{qn[0][0], qn[0][1]}, {qn[1][0], qn[1][1]}};
     const bool more = item + step < nitems;
     const int nxt = more ? item + step : item;  // (no next item: the current one is fetched again into the idle buffer -- nothing branches)
@@ -733,15 +751,10 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
       constexpr bool FULL = decltype(full_c)::value;
       const int k0 = kt * BKV;
       const int nkb = FULL ? 4 : ((p.S - k0 + 15) >> 4);
-      // ---- the pipeline of small loads and fetch pieces (see above) ----
-      if (kt > 0) {  // (tile 0: everything outstanding was waited for at the top of the item)
-        if constexpr (HAS_BIAS && HAS_PAD)
-          asm volatile("s_waitcnt vmcnt(%8)" : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(PERS_PPT));
-        else if constexpr (HAS_BIAS)
-          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]) : "n"(PERS_PPT));
-        else if constexpr (HAS_PAD)
-          asm volatile("s_waitcnt vmcnt(%4)" : "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(PERS_PPT));
-      }
+      // ---- the pipeline of small loads and fetch pieces (see above).  The wait for a tile's small loads stands at the END of the
+      // previous tile's code (below), not here: a register an inline-asm load is still writing must not be live across a loop back
+      // edge -- the register allocator is free to put copies at a loop header, and it did (round 4: copies of the in-flight Q
+      // fragments in front of the wait of a sample loop = stale operands, NaN; tools/check_mfma_hazards.py looks for exactly that) ----
       bf16x8 bf[2][2];
       unsigned padw[4] = {0u, 0u, 0u, 0u};
       if constexpr (HAS_BIAS) {
@@ -856,8 +869,20 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
         }
       }
     };
+    // the next tile's small loads have landed when only this tile's PERS_PPT fetch pieces are outstanding (see the tile)
+    auto wait_small = [&]() {
+      if constexpr (HAS_BIAS && HAS_PAD)
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(PERS_PPT));
+      else if constexpr (HAS_BIAS)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]) : "n"(PERS_PPT));
+      else if constexpr (HAS_PAD)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(PERS_PPT));
+    };
 #pragma unroll 1
-    for (int kt = 0; kt < ntiles - 1; ++kt) tile(kt, std::true_type{});
+    for (int kt = 0; kt < ntiles - 1; ++kt) {
+      tile(kt, std::true_type{});
+      wait_small();
+    }
     tile(ntiles - 1, std::false_type{});  // the last tile: partial (or full at S = 256: its masks are then all false); issues the late loads
     if (has_left) {  // (BEFORE the stores below: the hand-counted wait in here must see exactly the operations of the last tile behind it)
       // ---- the lone query (row S - 1 = 256) against this wave's key blocks 2w, 2w + 1 (wave 0: also block 16): every query column of
@@ -952,8 +977,8 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
         if (g == 0 && p.lse) p.lse[((int64_t)b * p.heads + h) * p.lse_ld + qrow] = m2_run[qb] * (1.0f / LOG2E) + logf(l);
       }
     }
+    wait_all();  // the next item's K / V pieces of this wave, its Q fragments and first small loads (and this item's stores)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the last tiles' asm loads and the idle-buffer fetch must not outlive the wave)
   if (has_left && prev_item >= 0) {
     __syncthreads();
     if (wid == 0) merge_left(prev_item, buf ^ 1);
@@ -1706,6 +1731,432 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_dbias_kernel(AttnBwdArgs p
   }
 }
 
+// =====================================================================================================================
+// Persistent dQ + dBias kernel for the 193 ... 257-token streams with a shared bias image (round 4; the forward's skeleton).
+// attn_bwd_dq_dbias_kernel above streams every K / V tile through registers into LDS with two barriers per tile, 64 queries per
+// workgroup (K / V of a (sample, head) are staged five times at S = 257), one 16-query block per wave at two waves per SIMD: its
+// waves wait 54 % of their cycles.  Here a workgroup of 8 waves owns ONE (head, half of the query blocks) for a chunk of the batch:
+// wave w keeps the dBias accumulators of query block half * 8 + w over all keys (68 registers at S = 257) while it walks the
+// samples; K / V of sample b + 1 arrive by LDS-DMA in the other half of a double buffer while sample b is computed (one barrier
+// per sample), K^T fragments of dQ^T += K^T dS^T come from the same resident K by transpose reads; Q / dO / O fragments, lse of
+// the next sample and the bias / pad words of the next tile travel as inline-asm loads with hand-counted waits (see
+// attn_fwd_pers_kernel).  delta = rowsum(dO o O) is computed here and stored for the dK/dV kernel.  S = 257: the lone query is
+// spread over the LAST half's workgroup by keys -- wave w: key pair w (wave 0 also pair 8) -- its dQ partials are summed through
+// LDS after the next sample's barrier, its dBias row lives in two more accumulators per wave.
+// =====================================================================================================================
+template <bool HAS_BIAS, bool HAS_PAD, int NT, int LASTB, bool LEFT>  // LEFT: S = 257, the workgroups of the last query half
+__device__ __forceinline__ void attn_bwd_dq_pers_body(const AttnBwdArgs& p, char* smem, int rows_pad, int nqh, int qhalf0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, t = lane & 15;
+  const int KVB = 2 * rows_pad * 128;
+  float* scratch = reinterpret_cast<float*>(smem + 2 * KVB);  // [2][PERS_NW][64]: dQ partials of the lone query
+  const int nqb = (p.S + 15) >> 4, nkp = (p.S + 31) >> 5;
+  // grid: (chunk, head, query half)
+  const int qhalf = qhalf0, h = (blockIdx.x / nqh) % p.heads, chunk = blockIdx.x / (nqh * p.heads);
+  const int b_begin = chunk * p.bchunk, b_end = min(p.B, b_begin + p.bchunk);
+  if (b_begin >= b_end) return;
+  const int qblk = qhalf * PERS_NW + wid;
+  const bool active = qblk < min(nqb, 2 * PERS_NW);
+  constexpr bool has_left = LEFT;  // S = 257: this workgroup also owns the lone query (row 256)
+  const int q0w = min(qblk, nqb - 1) * 16;
+  const int qi = min(q0w + t, p.S - 1);
+  const float c1 = p.scale * LOG2E;
+  const int64_t per_head = (int64_t)nqb * nkp * FRAG_BLOCK;
+
+  bf16x8 sel_lo, sel_hi;
+  {
+    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
+      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
+    }
+  }
+  int trsw[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+  const int kswz[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+
+  const int ngrp = rows_pad >> 3;
+  const int r_in = lane >> 3, slot = lane & 7;
+  const int npiece = (2 * ngrp - wid + PERS_NW - 1) / PERS_NW;
+  auto piece = [&](int b, int buf, int j) {
+    const int grp = wid + j * PERS_NW;
+    const bool isv = grp >= ngrp;
+    const int gi = isv ? grp - ngrp : grp;
+    // The lane's source offset is recomputed per piece from a laundered input (six VALU instructions): as a loop invariant the
+    // compiler keeps one 64-bit address per piece alive over the whole kernel -- 18 registers this kernel does not have (they were
+    // spilled, and every reload next to the fetch is an s_waitcnt vmcnt(0)).  Uniform base + 32-bit lane offset: the saddr form.
+    int rl = r_in;
+    asm volatile("" : "+v"(rl));
+    const int r = gi * 8 + rl;
+    const int kr = min(r, p.S - 1);
+    const unsigned voff = (unsigned)((kr * (int)p.ld + ((slot ^ (r & 7)) << 3)) * 2);
+    const char* sbase = (const char*)((isv ? p.v : p.k) + (int64_t)b * p.S * p.ld + h * HD);
+    char* dst = smem + buf * KVB + (isv ? rows_pad * 128 : 0) + gi * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + voff),
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+
+  // ---- in-flight (inline-asm) loads: next tile's bias fragments / pad words; next sample's query-side operands ----
+  constexpr int NSMALL = (HAS_BIAS ? 2 : 0) + (HAS_PAD ? 4 : 0);
+  // fetch pieces a wave issues in key tile kt: all of the next sample's <= 9 in the first three tiles -- they have landed long before
+  // the barrier at the top of the next sample (two per tile up to the last one left the last two in flight there: exposed latency)
+  constexpr int BPPT = 3;
+  auto ppt_of = [](int kt) { return kt < 3 ? BPPT : 0; };
+  // wave-uniform bases in SGPRs + one 32-bit lane offset per kind of row (see gload16_s)
+  const bf16_t* fwave = HAS_BIAS ? p.bias_frag + (int64_t)h * per_head + (int64_t)(q0w >> 4) * nkp * FRAG_BLOCK : nullptr;  // this wave's query block
+  const bf16_t* fleft = HAS_BIAS ? p.bias_frag + (int64_t)h * per_head + (int64_t)(nqb - 1) * nkp * FRAG_BLOCK : nullptr;  // the lone query's block
+  const unsigned vo_frag = lane * 16, vo_pad = g * 4;
+  const unsigned vo_q = (unsigned)(((int64_t)qi * p.ld + h * HD + g * 8) * 2), vo_o = (unsigned)(((int64_t)qi * p.ldo + h * HD + g * 8) * 2);
+  const unsigned vo_ql = (unsigned)(((int64_t)(p.S - 1) * p.ld + h * HD + g * 8) * 2), vo_ol = (unsigned)(((int64_t)(p.S - 1) * p.ldo + h * HD + g * 8) * 2);
+  const unsigned vo_lse = qi * 4, vo_lsel = (p.S - 1) * 4;
+  bf16x8 bn[2];
+  unsigned padn[4] = {0u, 0u, 0u, 0u};
+  auto small_loads = [&](int b, int kt) {
+    if constexpr (HAS_BIAS) {
+      gload16_s<0>(bn[0], fwave + min(2 * kt, nkp - 1) * FRAG_BLOCK, vo_frag);
+      gload16_s<0>(bn[1], fwave + min(2 * kt + 1, nkp - 1) * FRAG_BLOCK, vo_frag);
+    }
+    if constexpr (HAS_PAD) {
+      const uint8_t* pr = p.key_pad + (int64_t)b * p.Spad + kt * BKV;
+      gload4_s<0>(padn[0], pr, vo_pad);
+      gload4_s<16>(padn[1], pr, vo_pad);
+      gload4_s<32>(padn[2], pr, vo_pad);
+      gload4_s<48>(padn[3], pr, vo_pad);
+    }
+  };
+  bf16x8 qn[2], don[2], oon[2], ql[2], dol[2], ool[2], bfl[2];
+  float lsen, lsel;
+  unsigned padl[2][2] = {{0u, 0u}, {0u, 0u}};
+  auto query_loads = [&](int b, unsigned voq, unsigned voo, unsigned vol, bf16x8 (&q)[2], bf16x8 (&d)[2], bf16x8 (&o)[2], float& l) {
+    const bf16_t* sq = p.q + (int64_t)b * p.S * p.ld;
+    const bf16_t* sd = p.dout + (int64_t)b * p.S * p.ldo;
+    const bf16_t* so = p.out + (int64_t)b * p.S * p.ldo;
+    gload16_s<0>(q[0], sq, voq);
+    gload16_s<64>(q[1], sq, voq);
+    gload16_s<0>(d[0], sd, voo);
+    gload16_s<64>(d[1], sd, voo);
+    gload16_s<0>(o[0], so, voo);
+    gload16_s<64>(o[1], so, voo);
+    unsigned lw;
+    gload4_s<0>(lw, p.lse + ((int64_t)b * p.heads + h) * p.Spad, vol);
+    l = __builtin_bit_cast(float, lw);
+  };
+  // LEFT: the next sample's operands are requested later (behind the stores of this sample: registers) -- see the sample loop
+  auto late_loads = [&](int b_next, int b) {
+    (void)b_next;
+    if (has_left) {
+      query_loads(b, vo_ql, vo_ol, vo_lsel, ql, dol, ool, lsel);
+      if constexpr (HAS_BIAS) {
+        gload16_s<0>(bfl[0], fleft + wid * FRAG_BLOCK, vo_frag);
+        gload16_s<0>(bfl[1], fleft + min(PERS_NW, nkp - 1) * FRAG_BLOCK, vo_frag);
+      }
+      if constexpr (HAS_PAD) {
+        const uint8_t* pr = p.key_pad + (int64_t)b * p.Spad;
+        gload4_s<0>(padl[0][0], pr + 2 * wid * 16, vo_pad);
+        gload4_s<16>(padl[0][1], pr + 2 * wid * 16, vo_pad);
+        gload4_s<0>(padl[1][0], pr + min(2 * PERS_NW * 16, p.Spad - 32), vo_pad);
+        gload4_s<16>(padl[1][1], pr + min(2 * PERS_NW * 16, p.Spad - 32), vo_pad);
+      }
+    }
+  };
+
+  // dBias accumulators of this wave's query block over all keys, and of the lone query over this wave's key pair(s)
+  f32x4 acc[NT][4], accl[2][2];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) acc[kt][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) accl[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int j = 0; j < npiece; ++j) piece(b_begin, 0, j);
+  query_loads(b_begin, vo_q, vo_o, vo_lse, qn, don, oon, lsen);
+  small_loads(b_begin, 0);
+  int buf = 0, prev_b = -1;
+  auto merge_left = [&](int b, int sb) {  // sum of the eight dQ partials of the lone query; lane = head dimension
+    const float* sc = scratch + sb * (PERS_NW * 64);
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < PERS_NW; ++w) o += sc[w * 64 + lane];
+    p.dq[((int64_t)b * p.S + p.S - 1) * p.ldg + h * HD + lane] = (bf16_t)(o * p.scale);
+  };
+
+  // Everything a sample finds in flight at its top has landed at the END of the previous trip (or here): a register an inline-asm
+  // load is still writing must not be live across the loop's back edge -- the register allocator puts copies at a loop header when it
+  // likes, and it did (copies of the in-flight Q / dO / O fragments in front of the wait: stale operands, NaN).  Every such register
+  // is an operand of the wait statement, so nothing that reads one can move above it either.
+  auto wait_all = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(don[0]), "+v"(don[1]), "+v"(oon[0]), "+v"(oon[1]), "+v"(lsen), "+v"(bn[0]), "+v"(bn[1]),
+                 "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : : "memory");
+  };
+  wait_all();
+  for (int b = b_begin; b < b_end; ++b, buf ^= 1) {
+    __syncthreads();
+    const bf16x8 qf[2] = {qn[0], qn[1]}, dof[2] = {don[0], don[1]};
+    const float dl = delta_from_frags(dof, oon);
+    const float nl2 = -lsen * LOG2E;
+    if (active && g == 0 && q0w + t < p.S) p.delta_w[((int64_t)b * p.heads + h) * p.Spad + q0w + t] = dl;
+    const int nxt = b + 1 < b_end ? b + 1 : b;  // (no next sample: this one is fetched again into the idle buffer -- nothing branches)
+    if (has_left && prev_b >= 0 && wid == (prev_b & (PERS_NW - 1))) merge_left(prev_b, buf ^ 1);
+    prev_b = b;
+    const char* ldsK = smem + buf * KVB;
+    const char* ldsV = ldsK + rows_pad * 128;
+    f32x4 dqT[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) dqT[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // One 64-key tile, two 16-key blocks at a time (S^T, dP^T -> P, dS -> dBias accumulators -> dQ^T; 16 score registers instead of
+    // 32: with the 68 dBias accumulators this kernel lives at the register limit).  The in-flight small loads of the NEXT tile are
+    // requested after this tile's last use of the current ones (bias: the S^T MFMAs; pad words: the dS step) into the SAME registers,
+    // followed by this tile's share of the next sample's fetch; the hand-counted wait at the top of a tile therefore allows exactly
+    // those PERS_PPT pieces to be outstanding.
+    auto tile = [&](const int kt, auto last_c) {
+      constexpr bool LAST = decltype(last_c)::value;
+      const int k0 = kt * BKV;
+      // ---- in-flight loads: wait for this tile's small loads (behind them only the previous tile's fetch pieces were issued), move
+      // them out of the landing registers, request the next tile's (LEFT: the same registers are re-used later instead, see below) ----
+      if (kt > 0) {
+        if (ppt_of(kt - 1) > 0) {
+          if constexpr (HAS_BIAS && HAS_PAD)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(BPPT));
+          else if constexpr (HAS_BIAS)
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bn[0]), "+v"(bn[1]) : "n"(BPPT));
+          else if constexpr (HAS_PAD)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]) : "n"(BPPT));
+        } else {
+          if constexpr (HAS_BIAS && HAS_PAD)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]), "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]));
+          else if constexpr (HAS_BIAS)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[0]), "+v"(bn[1]));
+          else if constexpr (HAS_PAD)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(padn[0]), "+v"(padn[1]), "+v"(padn[2]), "+v"(padn[3]));
+        }
+      }
+      bf16x8 bf[2];
+      unsigned padw[4] = {0u, 0u, 0u, 0u};
+      if constexpr (HAS_BIAS) { bf[0] = bn[0]; bf[1] = bn[1]; }
+      if constexpr (HAS_PAD) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) padw[kb] = padn[kb];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) {
+        if constexpr (!LEFT) {  // the next sample's operands a whole tile (+ the short last one) ahead; BEFORE the small loads, whose
+          if (kt == NT - 2) query_loads(nxt, vo_q, vo_o, vo_lse, qn, don, oon, lsen);  // wait then does not include them
+        }
+        small_loads(b, kt + 1);
+      } else {
+        late_loads(nxt, b);
+        small_loads(nxt, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jj = 0; jj < BPPT; ++jj)
+        if (ppt_of(kt) > 0) piece(nxt, buf ^ 1, min(kt * BPPT + jj, npiece - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      const char* kt_ = ldsK + k0 * 128;
+      const char* vt = ldsV + k0 * 128;
+      constexpr int NKB = LAST ? LASTB : 4;  // 16-key blocks of this tile that can hold keys
+      constexpr int NM = (NKB + 1) / 2;
+      if (!active) return;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        f32x4 st[2], ds[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int kb = 2 * m + j;
+          st[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          ds[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (kb >= NKB) continue;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kt_ + (kb * 16 + t) * 128 + kswz[kk]);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt + (kb * 16 + t) * 128 + kswz[kk]);
+            st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], st[j], 0, 0, 0);
+            ds[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[kk], ds[j], 0, 0, 0);
+          }
+          if constexpr (HAS_BIAS) st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[m], j ? sel_hi : sel_lo, st[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int kb = 2 * m + j;
+          if (kb >= NKB) continue;
+          const int key = k0 + kb * 16 + g * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = __builtin_fmaf(st[j][r], c1, nl2);
+            if constexpr (LAST || HAS_PAD) {
+              bool dead = false;
+              if constexpr (LAST) dead = key + r >= p.S;
+              if constexpr (HAS_PAD) dead = dead || ((padw[kb] >> (8 * r)) & 0xffu);
+              x = dead ? -INFINITY : x;
+            }
+            ds[j][r] = __builtin_amdgcn_exp2f(x) * (ds[j][r] - dl);  // dP and delta of a live query are finite: 0 * x = 0
+          }
+        }
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            if (2 * m + j < NKB) acc[kt][2 * m + j] += ds[j];
+        }
+        float a0[4], a1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a0[r] = ds[0][r]; a1[r] = ds[1][r]; }
+        const bf16x8 dsf = pack8(a0, a1);
+        s16x4 k0r[4], k1r[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          k0r[db] = tr_read_a(kt_ + trsw[db] + (2 * m) * 2048);
+          k1r[db] = tr_read_a(kt_ + trsw[db] + (2 * m + 1) * 2048);
+        }
+        ATTN_WAIT_LGKM0();
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dqT[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(k0r[db], k1r[db]), dsf, dqT[db], 0, 0, 0);
+      }
+    };
+    // (unrolled: with a run-time tile index the compiler turns the compare chain that picks the accumulator set into an indexed
+    // access and moves the accumulators to scratch memory; every load in the tile is asm or LDS, fenced: nothing gets hoisted)
+#pragma unroll
+    for (int kt = 0; kt < NT - 1; ++kt) tile(kt, std::false_type{});
+    tile(NT - 1, std::true_type{});
+
+    if (active && q0w + t < p.S) {
+      bf16_t* qp = p.dq + ((int64_t)b * p.S + q0w + t) * p.ldg + h * HD;
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        bf16x4 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = (bf16_t)(dqT[db][r] * p.scale);
+        *reinterpret_cast<bf16x4*>(qp + db * 16 + g * 4) = a;
+      }
+    }
+    if (has_left) {
+      // The next sample's query-side operands: in this instantiation requested HERE, where the accumulators of dQ and this sample's
+      // fragments are dead (in the last tile, next to the lone query's operands, they did not fit: 33 spilled registers); the lone
+      // query's phase below and the barrier cover part of their latency.
+      query_loads(nxt, vo_q, vo_o, vo_lse, qn, don, oon, lsen);
+      // the late loads of the last tile must have landed: behind them came that tile's small loads (no fetch pieces: NT >= 4), the
+      // seven requests above (and this wave's stores, if it had any: with them the wait only asks for more than it needs -- it never
+      // under-waits)
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSMALL + 7) : "memory");
+      asm volatile("" : "+v"(ql[0]), "+v"(ql[1]), "+v"(dol[0]), "+v"(dol[1]), "+v"(ool[0]), "+v"(ool[1]), "+v"(bfl[0]), "+v"(bfl[1]), "+v"(lsel),
+                   "+v"(padl[0][0]), "+v"(padl[0][1]), "+v"(padl[1][0]), "+v"(padl[1][1]));
+      const float dll = delta_from_frags(dol, ool);
+      const float nl2l = -lsel * LOG2E;
+      if (wid == 0 && lane == 0) p.delta_w[((int64_t)b * p.heads + h) * p.Spad + p.S - 1] = dll;
+      f32x4 dql[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) dql[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {  // (unrolled: pc indexes register arrays)
+        if (pc == 1 && wid != 0) break;
+        const int kp = pc == 0 ? wid : PERS_NW;  // absolute 32-key pair block
+        f32x4 s4[2], d4[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          s4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          d4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + ((2 * kp + j) * 16 + t) * 128 + kswz[kk]);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(ldsV + ((2 * kp + j) * 16 + t) * 128 + kswz[kk]);
+            s4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[kk], s4[j], 0, 0, 0);
+            d4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dol[kk], d4[j], 0, 0, 0);
+          }
+          if constexpr (HAS_BIAS) s4[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfl[pc], j ? sel_hi : sel_lo, s4[j], 0, 0, 0);
+        }
+        float a0[4], a1[4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            bool dead = (2 * kp + j) * 16 + g * 4 + r >= p.S;
+            if constexpr (HAS_PAD) dead = dead || ((padl[pc][j] >> (8 * r)) & 0xffu);
+            const float x = dead ? -INFINITY : __builtin_fmaf(s4[j][r], c1, nl2l);
+            const float v = __builtin_amdgcn_exp2f(x) * (d4[j][r] - dll);
+            d4[j][r] = v;
+            (j ? a1 : a0)[r] = v;
+          }
+        if constexpr (HAS_BIAS) { accl[pc][0] += d4[0]; accl[pc][1] += d4[1]; }
+        const bf16x8 dsf = pack8(a0, a1);
+        s16x4 k0r[4], k1r[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          k0r[db] = tr_read_a(ldsK + trsw[db] + (2 * kp) * 2048);
+          k1r[db] = tr_read_a(ldsK + trsw[db] + (2 * kp + 1) * 2048);
+        }
+        ATTN_WAIT_LGKM0();
+#pragma unroll
+        for (int db = 0; db < 4; ++db) dql[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_tr(k0r[db], k1r[db]), dsf, dql[db], 0, 0, 0);
+      }
+      float* sc = scratch + (buf * PERS_NW + wid) * 64;
+      if (t == 0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) *reinterpret_cast<f32x4*>(sc + db * 16 + g * 4) = dql[db];
+      }
+    }
+
+    wait_all();
+  }
+  if (has_left && prev_b >= 0) {
+    __syncthreads();
+    if (wid == 0) merge_left(prev_b, buf ^ 1);
+  }
+  if constexpr (HAS_BIAS) {
+    if (p.dbias == nullptr) return;
+    // slab `chunk` of dbias belongs to this batch chunk alone: plain read-modify-write (see attn_bwd_dq_dbias_kernel)
+    if (active && q0w + t < p.S) {
+      float* drow = p.dbias + (((int64_t)chunk * p.heads + h) * p.S + q0w + t) * p.Spad + g * 4;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        f32x4 cur[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if ((kt < NT - 1 || kb < LASTB) && kt * BKV + kb * 16 < p.Spad) cur[kb] = *reinterpret_cast<const f32x4*>(drow + kt * BKV + kb * 16);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+          if ((kt < NT - 1 || kb < LASTB) && kt * BKV + kb * 16 < p.Spad)
+            *reinterpret_cast<f32x4*>(drow + kt * BKV + kb * 16) = cur[kb] + acc[kt][kb];
+      }
+    }
+    if (has_left && t == 0) {  // the lone query's row: this wave's key pair(s); every query column of the fragment held that row
+      float* drow = p.dbias + (((int64_t)chunk * p.heads + h) * p.S + p.S - 1) * p.Spad + g * 4;
+#pragma unroll
+      for (int pc = 0; pc < 2; ++pc) {
+        if (pc == 1 && wid != 0) break;
+        const int kp = pc == 0 ? wid : PERS_NW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int key0 = (2 * kp + j) * 16;
+          if (key0 < p.Spad) {
+            float* d = drow + key0;
+            *reinterpret_cast<f32x4*>(d) = *reinterpret_cast<const f32x4*>(d) + accl[pc][j];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <bool HAS_BIAS, bool HAS_PAD, int NT, int LASTB>
+__global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dq_pers_kernel(AttnBwdArgs p, int rows_pad, int nqh) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int qhalf = blockIdx.x % nqh;
+  const bool lone = ((p.S + 15) >> 4) > 2 * PERS_NW && qhalf == nqh - 1;  // (uniform) S = 257: the last half's workgroups own the lone query
+  if constexpr (NT == 5) {
+    if (lone) {
+      attn_bwd_dq_pers_body<HAS_BIAS, HAS_PAD, NT, LASTB, true>(p, smem, rows_pad, nqh, qhalf);
+      return;
+    }
+  }
+  attn_bwd_dq_pers_body<HAS_BIAS, HAS_PAD, NT, LASTB, false>(p, smem, rows_pad, nqh, qhalf);
+}
+
 // grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
 // same for every sample of the chunk (per-sample bias images: chunks of ONE sample, gradient slab b for sample b -- the path of
 // masked pretraining with more kept tokens than the merged kernel's 384) and is loaded once; each sample's K/V tile goes through LDS once for all four waves (next
@@ -1832,7 +2283,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dbias_kernel(AttnBwdArgs p) {
 //   op_attn_bwd / op_attn_bwd_dbias_slabs:  bit 0 = separate dQ and dBias kernels instead of the merged one (tests);
 //                 bit 1 = round 2's batch-chunk rule of the merged kernel (A/B timing); bits 2-3 = 2: dK/dV kernel with 64 keys per workgroup;
 //                 bits 4-9 = forced number of batch chunks of the merged kernel (sweep of tools/attn_chunks_ab.py: the rule's choice is
-//                 within 1 % of the best of {2 ... 16} at S = 257 / 250 / 65)
+//                 within 1 % of the best of {2 ... 16} at S = 257 / 250 / 65); bit 10 = no persistent dQ (+ dBias) kernel (193 ... 257
+//                 tokens then run the kernels of rounds 1-3: tests / A-B timing)
 
 template <bool HAS_BIAS, bool HAS_PAD>
 int launch_fwd_res(const AttnArgs& a, const bf16_t* frag, dim3 grid, int nw, size_t sh, int rows_pad, int qb_per_wg, int abl,
@@ -1891,6 +2343,29 @@ inline int dbias_chunks(int64_t B, int64_t S, int64_t heads, bool merge, bool ro
   return best;
 }
 
+// batch chunks (= dbias slabs) of the persistent dQ + dBias kernel: one workgroup per (chunk, head, half of the query blocks), at most
+// one workgroup per CU
+inline int pers_bwd_chunks(int64_t B, int64_t S, int64_t heads) {
+  const int nqh = ceil_div(min((int64_t)ceil_div(S, 16), (int64_t)2 * PERS_NW), PERS_NW);
+  int c = (int)(attn_num_cus() / (heads * nqh));
+  if (c < 1) c = 1;
+  if (c > B) c = (int)B;
+  return ceil_div(B, ceil_div(B, c));
+}
+inline bool pers_bwd_shape(int64_t S) { return S > 192 && S <= 257; }
+
+template <bool HAS_BIAS, bool HAS_PAD>
+int launch_bwd_dq_pers(const AttnBwdArgs& a, int nwg, size_t sh, int rows_pad, int nqh, hipStream_t s) {
+  if (a.S > 256) {
+    OP_ENSURE_LDS((attn_bwd_dq_pers_kernel<HAS_BIAS, HAS_PAD, 5, 1>), 4 * PERS_MAX_ROWS * 128 + 2 * PERS_NW * 64 * 4, "attn_bwd");
+    hipLaunchKernelGGL((attn_bwd_dq_pers_kernel<HAS_BIAS, HAS_PAD, 5, 1>), dim3(nwg), dim3(PERS_NW * 64), sh, s, a, rows_pad, nqh);
+  } else {
+    OP_ENSURE_LDS((attn_bwd_dq_pers_kernel<HAS_BIAS, HAS_PAD, 4, 4>), 4 * PERS_MAX_ROWS * 128 + 2 * PERS_NW * 64 * 4, "attn_bwd");
+    hipLaunchKernelGGL((attn_bwd_dq_pers_kernel<HAS_BIAS, HAS_PAD, 4, 4>), dim3(nwg), dim3(PERS_NW * 64), sh, s, a, rows_pad, nqh);
+  }
+  return OP_OK;
+}
+
 }  // namespace
 
 extern "C" int op_prof_begin(int family, double work, void* stream);
@@ -1900,7 +2375,13 @@ extern "C" {
 
 // dbias of op_attn_bwd is fp32 [slabs][heads][S][Spad], pre-zeroed, slabs = this value (the batch chunks of the merged
 // dQ + dBias kernel add into their own slab without atomics; sum the slabs afterwards).  `tune` as for op_attn_bwd.
-int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune) { return dbias_chunks(B, S, heads, !(tune & 1), (tune & 2) != 0, (int)((tune >> 4) & 63)); }
+// (the persistent dQ + dBias kernel of the 193 ... 257-token streams has its own chunk rule; which of the two kernels a call takes
+// also depends on arguments this query does not see -- the larger count is returned, slabs a kernel does not write stay zero)
+int64_t op_attn_bwd_dbias_slabs(int64_t B, int64_t S, int64_t heads, int64_t tune) {
+  const int64_t n = dbias_chunks(B, S, heads, !(tune & 1), (tune & 2) != 0, (int)((tune >> 4) & 63));
+  if (!(tune & 1) && !(tune & 1024) && pers_bwd_shape(S)) return max(n, (int64_t)pers_bwd_chunks(B, S, heads));
+  return n;
+}
 
 // q, k, v: bf16 rows of `ld` elements (row = b*S + s), head h occupies columns [h*64, h*64+64) of each pointer
 // (so one packed [B*S, 3H] projection output serves all three with pointer offsets 0, H, 2H).
@@ -2063,6 +2544,33 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
     OP_LAUNCH_CHECK();
   }
   const int nt = ceil_div(S, BKV);
+  // persistent dQ (+ dBias) kernel (round 4): 193 ... 257 tokens, shared bias image in fragment-major form (or no bias), delta computed
+  // in the kernel (out given); tune bit 10: off
+  if (merge_dbias && !(tune & 1024) && out && pers_bwd_shape(S) && a.bias_bs == 0 &&
+      (!bias || (a.bias_frag != nullptr && (float)(bf16_t)(1.0f / scale) * scale == 1.0f))) {
+    const int nqb = ceil_div(S, 16);
+    const int nqh = ceil_div(min(nqb, 2 * PERS_NW), PERS_NW);
+    const int chunks = pers_bwd_chunks(B, S, heads);
+    a.bchunk = ceil_div(B, chunks);
+    const int rows_pad = S > 256 ? PERS_MAX_ROWS : 256;
+    const size_t sh = (size_t)4 * rows_pad * 128 + 2 * PERS_NW * 64 * 4;
+    const int nwg = chunks * (int)heads * nqh;
+    AttnBwdArgs d = a;
+    if (!bias) d.dbias = nullptr;
+    slot = op_prof_begin(2, 1.5 * fl, stream);
+    int rc;
+    if (bias && key_pad) rc = launch_bwd_dq_pers<true, true>(d, nwg, sh, rows_pad, nqh, s);
+    else if (bias) rc = launch_bwd_dq_pers<true, false>(d, nwg, sh, rows_pad, nqh, s);
+    else if (key_pad) rc = launch_bwd_dq_pers<false, true>(d, nwg, sh, rows_pad, nqh, s);
+    else rc = launch_bwd_dq_pers<false, false>(d, nwg, sh, rows_pad, nqh, s);
+    op_prof_end(slot, stream);
+    if (rc != OP_OK) return rc;
+    OP_LAUNCH_CHECK();
+    a.bchunk = bchunk_dkdv;
+    launch_dkdv();
+    OP_LAUNCH_CHECK();
+    return OP_OK;
+  }
   if (dbias && nt <= 6 && merge_dbias) {  // dQ and dBias together: dS summed over the batch chunk in registers
     // per-sample bias: every sample is its own chunk, slab b of dbias is the gradient of sample b's bias image
     const int chunks = a.bias_bs != 0 ? (int)B : dbias_chunks(B, S, heads, true, (tune & 2) != 0, (int)((tune >> 4) & 63));

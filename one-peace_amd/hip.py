@@ -102,6 +102,7 @@ class Tuning:
         self.dbias_chunks_r2 = 0  # merged dQ + dBias kernel: round 2's batch-chunk rule (A/B timing)
         self.dkdv_keys = 0       # dK/dV kernel: 0 auto, 1 = 128 keys per workgroup, 2 = 64 (A/B timing)
         self.dbias_chunks = 0    # merged dQ + dBias kernel: forced number of batch chunks (0 = the library's rule; A/B timing)
+        self.attn_pers_bwd = 1   # attention backward: 1 persistent dQ (+ dBias) kernel for 193 ... 257 tokens (round 4), 0 rounds 1-3
 
     def gemm(self):
         fl = {2: 0, 0: 1, 1: 2, 3: 3}.get(self.fullline, 0)
@@ -113,7 +114,8 @@ class Tuning:
         return (0 if self.resident & 1 else 1) | ((self.resident >> 1) & 3) << 1 | (self.attn_waves & 15) << 3 | (0 if self.attn_pers else 128)
 
     def attn_bwd(self):
-        return (0 if self.merge_dbias else 1) | (2 if self.dbias_chunks_r2 else 0) | (self.dkdv_keys & 3) << 2 | (self.dbias_chunks & 63) << 4
+        return ((0 if self.merge_dbias else 1) | (2 if self.dbias_chunks_r2 else 0) | (self.dkdv_keys & 3) << 2 | (self.dbias_chunks & 63) << 4
+                | (0 if self.attn_pers_bwd else 1024))
 
 
 TUNE = Tuning()

@@ -68,3 +68,50 @@ def test_no_compiler_instruction_touches_an_accumulator_behind_an_inline_asm_mfm
     kernels, problems = C.check(C.compile_isa(str(tmp_path)))
     assert kernels > 20
     assert problems == [], problems[:5]
+
+
+def test_inflight_load_checker_sees_a_copy_of_a_register_that_is_still_being_loaded():
+    """Round 4: inline-asm loads of the persistent attention kernels (tools/check_mfma_hazards.py: check_inflight_asm_loads)."""
+    bad = """_Z3foov:
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[4:7], v1, s[2:3] offset:0
+\t;;#ASMEND
+\tv_mov_b32_e32 v9, v5
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\t;;#ASMEND
+\ts_endpgm"""
+    assert len(C.check_inflight_asm_loads(bad.split("\n"))) == 1
+    good = bad.replace("\tv_mov_b32_e32 v9, v5\n", "") + "\n"
+    assert C.check_inflight_asm_loads(good.split("\n")) == []
+    # a counted wait delivers everything but the N youngest operations: two younger LDS-DMA pieces, vmcnt(2) -> the load has landed
+    counted = """_Z3barv:
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[4:7], v1, s[2:3] offset:0
+\t;;#ASMEND
+\tglobal_load_lds_dwordx4 v2, s[0:1]
+\tglobal_load_lds_dwordx4 v2, s[0:1]
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(2)
+\t;;#ASMEND
+\tv_mov_b32_e32 v9, v5
+\ts_endpgm"""
+    assert C.check_inflight_asm_loads(counted.split("\n")) == []
+    assert len(C.check_inflight_asm_loads(counted.replace("vmcnt(2)", "vmcnt(3)").split("\n"))) == 1
+    sgpr = """_Z3bazv:
+\tv_readlane_b32 s0, v182, 12
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[4:7], v1, s[0:1] offset:0
+\t;;#ASMEND
+\ts_endpgm"""
+    assert len(C.check_asm_vmem_sgprs(sgpr.split("\n"))) == 1  # the fault of the first round-4 backward kernel
+    assert C.check_asm_vmem_sgprs(sgpr.replace("\tglobal_load", "\ts_nop 4\n\tglobal_load").split("\n")) == []
+
+
+@pytest.mark.skipif(shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None, reason="needs hipcc")
+def test_attention_kernels_keep_their_hands_off_registers_in_flight(tmp_path):
+    """csrc/attention.hip: no compiler instruction touches the destination of an inline-asm load before the hand-placed wait that
+    covers it, and every inline-asm load brings the wait states for its SGPR base itself."""
+    lines = open(C.compile_isa(str(tmp_path), "attention")).read().split("\n")
+    problems = C.check_inflight_asm_loads(lines) + C.check_asm_vmem_sgprs(lines)
+    assert problems == [], problems[:5]

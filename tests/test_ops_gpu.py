@@ -724,6 +724,67 @@ def test_attention_persistent_forward_over_several_items_per_workgroup(B, S, hea
         assert_close(lse[b:b + 1, :, :S], lse_ref.cpu(), fro=1e-3, mx=2e-3, what="lse vs fp32")
 
 
+@pytest.mark.parametrize("B,S,heads,use_bias,use_pad", [(40, 257, 12, True, False), (48, 250, 12, True, True), (30, 200, 10, False, True),
+                                                       (26, 257, 8, True, True), (64, 256, 4, True, False), (33, 257, 9, False, False),
+                                                       (128, 257, 24, True, False)])
+def test_attention_persistent_backward_over_several_samples_per_workgroup(B, S, heads, use_bias, use_pad):
+    """Round 4: the persistent dQ (+ dBias) kernel -- a workgroup owns one (head, half of the query blocks) and walks a CHUNK of the
+    batch through its K / V double buffer, keeping the dBias accumulators in registers.  Against the kernels of rounds 1-3 (tune
+    bit 10) on the same inputs: dq of the 16 regular query blocks and delta bit-identical (same per-tile arithmetic and order),
+    the lone query of S = 257 (summed from nine key-pair partials) and dbias (other chunking of the fp32 sums) to fp32 accuracy;
+    dk / dv -- the old kernel, fed with this kernel's delta -- bit-identical."""
+    hip = hipmod()
+    H = heads * 64
+    g = torch.Generator(device=DEV).manual_seed(7)
+    qkv = torch.randn(B * S, 3 * H, generator=g, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(B * S, H, generator=g, device=DEV).to(torch.bfloat16)
+    Spad = hip.attn_spad(S)
+    bias_d = biasT_d = pad_d = frag = None
+    if use_bias:
+        bias_d = torch.zeros(heads, S, Spad, dtype=torch.bfloat16, device=DEV)
+        bias_d[..., :S] = torch.randn(heads, S, S, generator=g, device=DEV).to(torch.bfloat16)
+        biasT_d = torch.zeros_like(bias_d)
+        biasT_d[..., :S] = bias_d[..., :S].transpose(1, 2)
+        frag = hip.attn_bias_pack(bias_d, S)
+    if use_pad:
+        pad_d = torch.zeros(B, Spad, dtype=torch.uint8, device=DEV)
+        pad_d[:, S:] = 1
+        for b in range(1, B):
+            pad_d[b, S - 1 - (5 * b) % (S // 2):] = 1
+    q, k, v = qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:]
+    out, lse = hip.attn_fwd(q, k, v, 3 * H, B, S, heads, 0.125, bias_d, pad_d, Spad, bias_frag=frag)
+    res = {}
+    for pers in (1, 0):
+        hip.TUNE.attn_pers_bwd = pers
+        try:
+            res[pers] = hip.attn_bwd(q, k, v, 3 * H, dout, out, lse, B, S, heads, 0.125, bias_d, biasT_d, pad_d, Spad,
+                                     want_dbias=use_bias, bias_frag=frag)
+        finally:
+            hip.TUNE.attn_pers_bwd = 1
+    (new, dbn), (old, dbo) = res[1], res[0]
+    assert new.isfinite().all()
+    n3, o3 = new.view(B, S, 3 * H), old.view(B, S, 3 * H)
+    nreg = min(S, 256)
+    if use_bias:
+        assert torch.equal(n3[:, :nreg, :H], o3[:, :nreg, :H]), "dq of the regular query blocks differs from the round-3 kernel"
+    else:  # (without a bias rounds 1-3 run attn_bwd_dq_kernel: exp instead of exp2 of the pre-scaled score)
+        assert_close(n3[:, :nreg, :H], o3[:, :nreg, :H].float().cpu(), fro=4e-3, mx=2e-2, what="dq")
+    assert torch.equal(n3[:, :, H:], o3[:, :, H:]), "dk / dv differ (delta?)"
+    if S > 256:
+        assert_close(n3[:, 256:, :H], o3[:, 256:, :H].float().cpu(), fro=4e-3, mx=2e-2, what="dq of the lone query")
+    if use_bias:
+        assert_close(dbn[:, :, :S], dbo[:, :, :S].cpu(), fro=2e-5, mx=2e-4, what="dbias")
+    if B <= 64:  # fp32 reference on two samples
+        for b in (0, B - 1):
+            qkv_r = qkv[b * S:(b + 1) * S].float().cpu().requires_grad_(True)
+            qr, kr, vr = (qkv_r[:, i * H:(i + 1) * H].reshape(1, S, H) for i in range(3))
+            bb = bias_d[..., :S].float().cpu() if use_bias else None
+            kp = pad_d[b:b + 1, :S].bool().cpu() if use_pad else None
+            ref, _ = _attn_ref(qr, kr, vr, heads, 0.125, bb, kp)
+            ref.backward(dout[b * S:(b + 1) * S].float().cpu().view(1, S, H))
+            assert_close(n3[b], qkv_r.grad, fro=1.2e-2, mx=3e-2, what="dqkv vs fp32 (sample %d)" % b)
+
+
 @pytest.mark.parametrize("B,S,heads", [(20, 72, 2), (3, 257, 2), (2, 330, 1)])
 def test_attention_backward_ignores_unspecified_pad_entries(B, S, heads, merge_dbias):
     """lse / delta rows, bias columns and bias rows in [S, Spad) are unspecified (the wrappers allocate with torch.empty, the

@@ -34,6 +34,25 @@ for S, use_pad in ((257, False), (250, True), (256, False), (197, False)):
             res.setdefault(pers, []).append(timeit(fn, iters=30, warmup=5))
     hip.TUNE.attn_pers = 1
     tp, tr = min(res[1]), min(res[0])
-    print("B=%d S=%d pad=%d: persistent %.4f ms (%.0f TF/s, %.2f TB/s of q,k,v,out)  resident %.4f ms   %+.1f %%   (runs %s | %s)" % (
+    print("B=%d S=%d pad=%d: fwd persistent %.4f ms (%.0f TF/s, %.2f TB/s of q,k,v,out)  resident %.4f ms   %+.1f %%   (runs %s | %s)" % (
         B, S, int(use_pad), tp, fl / tp / 1e9, 8.0 * B * S * H / tp / 1e9, tr, 100.0 * (tp / tr - 1),
         " ".join("%.4f" % x for x in res[1]), " ".join("%.4f" % x for x in res[0])), flush=True)
+    # backward (dQ + dBias kernel persistent or rounds 1-3; the dK/dV kernel is the same in both arms)
+    biasT = torch.zeros_like(bias)
+    biasT[..., :S] = bias[..., :S].transpose(1, 2)
+    out, lse = fn()
+    dout = torch.randn_like(out)
+    dqkv = torch.empty(B * S, 3 * H, **bf)
+    dbias = hip.attn_dbias_buffer(B, S, heads, Spad, "cuda")
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device="cuda")
+    bw = lambda: hip.attn_bwd_launch(q, k, v, 3 * H, dout, bias, biasT, pad, lse, delta, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:], 3 * H,  # noqa: E731
+                                     dbias, B, S, Spad, heads, 0.125, frag, out=out)
+    resb = {}
+    for rnd in range(2):
+        for pers in (1, 0):
+            hip.TUNE.attn_pers_bwd = pers
+            resb.setdefault(pers, []).append(timeit(bw, iters=20, warmup=3))
+    hip.TUNE.attn_pers_bwd = 1
+    tp, tr = min(resb[1]), min(resb[0])
+    print("              bwd (dQ + dBias + dK/dV): persistent dQ %.4f ms (%.0f TF/s)  rounds 1-3 %.4f ms   %+.1f %%   (runs %s | %s)" % (
+        tp, 2.5 * fl / tp / 1e9, tr, 100.0 * (tp / tr - 1), " ".join("%.4f" % x for x in resb[1]), " ".join("%.4f" % x for x in resb[0])), flush=True)

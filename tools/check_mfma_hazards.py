@@ -89,12 +89,69 @@ def agprs(text):
     return out
 
 
-def compile_isa(workdir):
-    src = os.path.join(ROOT, "one-peace_amd", "csrc", "gemm.hip")
+def compile_isa(workdir, name="gemm"):
+    src = os.path.join(ROOT, "one-peace_amd", "csrc", name + ".hip")
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-           "-munsafe-fp-atomics", "-save-temps", "-c", src, "-o", os.path.join(workdir, "gemm.o")]
+           "-munsafe-fp-atomics", "-save-temps", "-c", src, "-o", os.path.join(workdir, name + ".o")]
     subprocess.run(cmd, cwd=workdir, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    return os.path.join(workdir, "gemm-hip-amdgcn-amd-amdhsa-gfx950.s")
+    return os.path.join(workdir, name + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+VM_OP = re.compile(r"^(global_|buffer_|flat_|scratch_)(load|store|atomic)")
+WAIT_VM = re.compile(r"s_waitcnt\b.*\bvmcnt\((\d+)\)")
+
+
+def check_inflight_asm_loads(lines):
+    """Round 4 (csrc/attention.hip, persistent kernels): loads issued as inline asm write their destination registers some hundred
+    cycles AFTER the statement, and the compiler -- for which the statement's outputs are defined at once -- is free to copy or
+    re-use those registers.  The kernels tie them to their hand-placed `s_waitcnt vmcnt(N)` statements; this walks every function
+    in fall-through order, counts vector-memory operations (loads, stores and LDS-DMA complete in issue order), and reports any
+    instruction outside an asm block that reads or writes a register an inline-asm load has not provably delivered yet (a wait
+    vmcnt(N) delivers everything but the N youngest operations).  A linear walk, not a control-flow analysis: behind an unconditional
+    branch nothing is assumed to be in flight, so it can miss a hazard on a jumped-to path but does not invent one; what it is for --
+    copies the register allocator puts at a loop header or in a fall-through block -- it sees.  Returns [problem strings]."""
+    problems, name, in_asm, issued, inflight = [], None, False, 0, {}
+    for n, raw in enumerate(lines, 1):
+        line = raw.strip()
+        m = re.match(r"^(_Z\w+):", raw)
+        if m:
+            name, in_asm, issued, inflight = m.group(1), False, 0, {}
+            continue
+        if ";;#ASMSTART" in line:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in line:
+            in_asm = False
+            continue
+        if not line or line.startswith((".", ";")) or line.endswith(":"):
+            continue
+        code = line.split(";")[0].strip()
+        if not code:
+            continue
+        op = code.split()[0]
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):  # what follows is reached from elsewhere: nothing is known there (lenient)
+            inflight = {}
+            continue
+        w = WAIT_VM.search(code)
+        if w:
+            done = issued - int(w.group(1))
+            inflight = {r: i for r, i in inflight.items() if i > done}
+            continue
+        if op == "s_waitcnt" and "vmcnt" not in code and not in_asm:
+            continue
+        regs = vgprs(code.split(None, 1)[1]) if len(code.split(None, 1)) > 1 else []
+        if not (in_asm and op.startswith("global_load")):
+            hit = [r for r in regs if r in inflight]
+            if hit and not in_asm:
+                problems.append("%s: line %d: `%s` touches v%d while the inline-asm load of it is in flight" % (name, n, code, hit[0]))
+                for r in hit:
+                    inflight.pop(r, None)
+        if VM_OP.match(op):
+            issued += 1
+            if in_asm and op.startswith("global_load") and len(code.split(None, 1)) > 1:
+                for r in vgprs(code.split(None, 1)[1].split(",")[0]):
+                    inflight[r] = issued
+    return problems
 
 
 def check_lines(lines):
@@ -199,7 +256,7 @@ def check_asm_vmem_sgprs(lines):
 def check(path):
     lines = open(path).read().split("\n")
     kernels, problems = check_lines(lines)
-    return kernels, problems + check_store_data(lines) + check_asm_vmem_sgprs(lines)
+    return kernels, problems + check_store_data(lines) + check_asm_vmem_sgprs(lines) + check_inflight_asm_loads(lines)
 
 
 def main():

@@ -484,6 +484,8 @@ def main():
         if not micro:
             torch.cuda.synchronize()
 
+    mem_report = {}  # first contact with a multi-GPU node: does the batch survive RCCL's buffers? (config.distributed.memory)
+
     def fit_batch_to_free_memory():
         """First-contact safety: after the model, the optimiser state and RCCL's own buffers exist, compare what is actually
         free on the device (minimum over ranks) with the activation estimate and halve the batch until it fits -- every rank
@@ -495,6 +497,7 @@ def main():
         free_t = torch.tensor([free_b / 1e9], dtype=torch.float64, device=device)
         if dist.is_initialized():
             dist.all_reduce(free_t, op=dist.ReduceOp.MIN)
+        mem_report["free_gb_after_model_optimizer_collectives_min_over_ranks"] = float(free_t.item())
         free_gb = float(free_t.item()) + torch.cuda.memory_reserved(device) / 1e9 - torch.cuda.memory_allocated(device) / 1e9
         per_tok_gb = (0.25 / 571 if args.recompute else 1.64 / 571) * 1.0737 * args.layers / LAYERS
         changed = False
@@ -647,6 +650,18 @@ def main():
                 "grad_allreduce_bytes_per_step": flat.numel * flat.grads.element_size() if flat is not None else 0,
                 "embedding_allgather_bytes_per_step": k_mod * args.batch * H * (4 if micro else 2) * dist.get_world_size(),
                 "bucket_launch_order_identical_on_all_ranks": order_same}
+            if not micro:  # per-rank peak memory and what was left of the device at the peak (the 6 GB RCCL reserve has never met hardware)
+                total_b = torch.cuda.mem_get_info(device)[1]
+                mine = torch.tensor([torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9,
+                                     torch.cuda.mem_get_info(device)[0] / 1e9], dtype=torch.float64, device=device)
+                allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+                dist.all_gather(allr, mine)
+                mem_report.update({"device_total_gb": total_b / 1e9,
+                                   "peak_allocated_gb_per_rank": [round(float(t[0]), 2) for t in allr],
+                                   "peak_reserved_gb_per_rank": [round(float(t[1]), 2) for t in allr],
+                                   "free_gb_at_exit_per_rank": [round(float(t[2]), 2) for t in allr],
+                                   "margin_gb_min_over_ranks": round(min(total_b / 1e9 - float(t[1]) for t in allr), 2)})
+                out["config"]["distributed"]["memory"] = mem_report
         if reducer is not None and (world > 1 or reducer.active):
             rep = reducer.overlap_report()
             out["config"]["grad_allreduce_overlap"] = rep

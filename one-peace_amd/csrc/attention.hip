@@ -802,6 +802,15 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
             st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[qb][kb >> 1], (kb & 1) ? sel_hi : sel_lo, st[qb][kb], 0, 0, 0);
         }
       }
+      // V^T fragments of the tile's first 32 keys: requested BEFORE the softmax arithmetic, which covers their LDS latency (the second
+      // half is requested in front of the first half's MFMAs); waiting right behind the request left ~150 cycles exposed twice per
+      // tile with two waves per SIMD
+      s16x4 va0[4], va1[4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        va0[db] = tr_read_a(vt + trsw[db]);
+        va1[db] = tr_read_a(vt + trsw[db] + 2048);
+      }
       bf16x8 pf[2][2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
@@ -851,21 +860,29 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_fwd_pers_kernel(AttnArgs
         pf[qb][0] = pack8(pv[0], pv[1]);
         pf[qb][1] = pack8(pv[2], pv[3]);
       }
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        if (!FULL && 2 * m >= nkb) break;
-        s16x4 v0[4], v1[4];
+      const bool second = FULL || nkb > 2;  // (uniform) keys 32 .. 63 of the tile hold keys
+      ATTN_WAIT_LGKM0();
+      s16x4 vb0[4], vb1[4];
+      if (second) {
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          v0[db] = tr_read_a(vt + trsw[db] + (2 * m) * 2048);
-          v1[db] = tr_read_a(vt + trsw[db] + (2 * m + 1) * 2048);
+          vb0[db] = tr_read_a(vt + trsw[db] + 2 * 2048);
+          vb1[db] = tr_read_a(vt + trsw[db] + 3 * 2048);
         }
+      }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const bf16x8 vf = join_tr(va0[db], va1[db]);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][0], ot[qb][db], 0, 0, 0);
+      }
+      if (second) {
         ATTN_WAIT_LGKM0();
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const bf16x8 vf = join_tr(v0[db], v1[db]);
+          const bf16x8 vf = join_tr(vb0[db], vb1[db]);
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][m], ot[qb][db], 0, 0, 0);
+          for (int qb = 0; qb < 2; ++qb) ot[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[qb][1], ot[qb][db], 0, 0, 0);
         }
       }
     };

@@ -69,6 +69,9 @@ def _wrapper_forward_multi(self, src_tokens=None, src_images=None, src_audios=No
     """ModelWrapper.forward_multi: the single-modality passes of the given inputs as one lock-step pass (see
     TransformerEncoder.forward_multi); returns {modality: features [B, S, H]}, or None when the configuration / inputs do not
     qualify (the caller then runs one forward per modality)."""
+    probe = next(self.fusion_model.parameters())
+    if not self.fusion_model.multi_possible(probe.device, probe.dtype):  # before the adapters run: a fallback must not run them twice
+        return None
     infos = {}
     if src_tokens is not None and hasattr(self, "text_adapter"):
         infos["text"] = self.text_adapter(src_tokens, None, None, None)

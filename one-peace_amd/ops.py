@@ -40,6 +40,8 @@ def refresh_weight_cache():
     _cache_epoch += 1
     # fp8 copies of the FFN weights (opt-in variant): re-quantised IN PLACE into the same buffers -- a replayed TrainStepGraph keeps
     # reading these addresses, and an eager step must not pay a cache miss per weight either
+    if not FP8_FFN and _fp8_cache:  # the opt-in variant was switched off: nothing reads these copies any more
+        _fp8_cache.clear()
     for k, (ref, _, qs) in list(_fp8_cache.items()):
         w = ref()
         if w is None:
@@ -558,13 +560,19 @@ def _geglu_split(Fd, fln_w):
     return GEGLU_SPLIT and fln_w is not None and Fd % 256 == 0
 
 
-def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True):
-    """out = x_mid + ps2 * g2 * W2(LN_F(gelu(LN2(x_mid) W0^T) * (LN2(x_mid) W1^T)))  on x_mid [B*S, H]."""
+def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True, grad=None):
+    """out = x_mid + ps2 * g2 * W2(LN_F(gelu(LN2(x_mid) W0^T) * (LN2(x_mid) W1^T)))  on x_mid [B*S, H].
+    grad: the pass belongs to a training step (default: keep).  The GeGLU form is chosen by THAT, not by `keep`: with
+    checkpoint_activations the forward (keep = False) and its recomputation in backward (keep = True) must run the same kernels, or the
+    LayerNorm(F) statistics the gradients use are not those of the forward output.  No-grad inference keeps the fused
+    GeGLU epilogue (one store instead of three; h0 / h1 rounded to bf16 only in the split form: a bf16-level train / eval difference)."""
+    if grad is None:
+        grad = keep
     xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
     Fd = P["w0"].shape[0]
     h0 = h1 = None
     fp8 = FP8_FFN and x_mid.shape[1] % 128 == 0 and Fd % 128 == 0
-    split = keep and not fp8 and _geglu_split(Fd, P["fln_w"])
+    split = grad and not fp8 and _geglu_split(Fd, P["fln_w"])
     if keep and not split:
         h0 = torch.empty(x_mid.shape[0], Fd, dtype=x_mid.dtype, device=x_mid.device)
         h1 = torch.empty_like(h0)
@@ -837,7 +845,7 @@ class FfnBranchFn(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
         needs = dict(zip(FFN_PARAMS, ctx.needs_input_grad[3:]))
-        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"])
+        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"], grad=need_grad)
         ctx.dims, ctx.n_params = (B, S, H), len(params)
         ctx.direct = ()
         if need_grad:
@@ -929,7 +937,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
     params: ln2_w, ln2_b, g2, then (w0, w1, fln_w, fln_b, w2, b2) per segment."""
 
     @staticmethod
-    def _compute(x2, segs, pss, params, keep, want_y):
+    def _compute(x2, segs, pss, params, keep, want_y, grad=None):
         nseg = len(segs)
         shared = dict(zip(FFN_SHARED, params[:3]))
         own = [dict(zip(FFN_OWN, params[3 + 6 * i:9 + 6 * i])) for i in range(nseg)]
@@ -938,7 +946,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
         xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep)
         dev, dt = x2.device, x2.dtype
         has_fln = own[0]["fln_w"] is not None
-        split = keep and _geglu_split(Fd, own[0]["fln_w"])
+        split = (keep if grad is None else grad) and _geglu_split(Fd, own[0]["fln_w"])  # (by the kind of pass, not by `keep`: see _ffn_forward)
         if split:
             hh = torch.empty(N, 2 * Fd, dtype=dt, device=dev)
             g, h0, h1 = None, hh[:, :Fd], hh[:, Fd:]
@@ -947,8 +955,8 @@ class FfnBranchMultiFn(torch.autograd.Function):
             h0 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
             h1 = torch.empty(N, Fd, dtype=dt, device=dev) if keep else None
         gln = torch.empty(N, Fd, dtype=dt, device=dev) if has_fln else g
-        mean_f = torch.empty(N, dtype=torch.float32, device=dev) if keep and has_fln else None
-        rstd_f = torch.empty(N, dtype=torch.float32, device=dev) if keep and has_fln else None
+        mean_f = torch.empty(N, dtype=torch.float32, device=dev) if (keep or split) and has_fln else None
+        rstd_f = torch.empty(N, dtype=torch.float32, device=dev) if (keep or split) and has_fln else None
         L = hip.lib()
         for sg, P in zip(segs, own):
             r = slice(sg.row0, sg.end)
@@ -984,7 +992,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
         keep = bool(save_acts) and need_grad
         needs = ctx.needs_input_grad[4:]
         has_fln = params[5] is not None
-        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]))
+        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]), grad=need_grad)
         ctx.segs, ctx.n_params, ctx.dims = segs, len(params), (N, H, Fd)
         ctx.direct = ()
         names = list(FFN_SHARED) + ["%s@%d" % (n, i) for i in range(nseg) for n in FFN_OWN]

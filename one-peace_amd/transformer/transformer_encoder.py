@@ -130,9 +130,20 @@ class TransformerEncoder(nn.Module):
                 "image_encoder_states": [], "audio_encoder_states": []}
 
     # ------------------------------------------------------------------------------------------------------
+    def multi_possible(self, device=None, dtype=None):
+        """The preconditions of a lock-step pass that do not need the adapters' outputs (ModelWrapper.forward_multi asks BEFORE it runs
+        the adapters: otherwise a pass that does not qualify -- CPU, fp32, layerdrop -- ran every adapter twice): the HIP
+        path for the activations' device / dtype, no layerdrop in training, fused layers, and no opt-in fp8 FFN (the lock-step FFN
+        launches are bf16 only: with ops.set_fp8_ffn(True) the streams run one by one on the fp8 kernels instead of silently in bf16)."""
+        if device is not None and not (torch.device(device).type == "cuda" and dtype == torch.bfloat16):
+            return False
+        if ops.FP8_FFN or (self.encoder_layerdrop > 0.0 and self.training):
+            return False
+        return all(any(getattr(layer, "fused_supported", lambda e: False)(m) for m in ("text", "image", "audio")) for layer in self.layers)
+
     def multi_ok(self, infos):
         """Can the single-modality streams `infos` ({modality: (x, pad, biases)}) run as ONE lock-step pass?"""
-        if len(infos) < 2:
+        if len(infos) < 2 or not self.multi_possible():
             return False
         xs = [p[0] for p in infos.values()]
         if not all(ops.hip_eligible(x) and x.device == xs[0].device for x in xs):

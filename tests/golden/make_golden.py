@@ -294,6 +294,32 @@ def deep_vision_fixture():
     print("deep vision: logits norm %.4f, %d grads" % (float(logits.norm()), len(fx["grads"])))
 
 
+def deep_text_audio_fixture():
+    """Round 4: the text and audio towers at the 4B layer dimensions (H=1536, F=6144, 24 heads), EIGHT layers deep, WITH a backward
+    (the deep fixtures pinned the image tower only): the reference's retrieval model on b = 3 captions of 24 tokens
+    (padded rows) and 2 s waveforms (100 frames + CLS, no padding), loss = sum(text_logits * w_t) + sum(audio_logits * w_a).
+    Stored: both normalised embeddings, the first feature rows of both towers, every parameter gradient's norm, small gradients in
+    full and the first four rows of the large ones (grads_summary).  Weights: oracle/synth.py, never stored."""
+    m, shapes = build_ref_model(DEEP, 1000, head_type="al")
+    B = 3
+    inp = synth.synth_inputs(B, text_len=24, audio_samples=32000, vocab=1000)
+    t = m(src_tokens=inp["src_tokens"], encoder_type="text")
+    a = m(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")
+    with torch.no_grad():
+        feats_t = m.encoder_wrapper(src_tokens=inp["src_tokens"], encoder_type="text")[0]
+        feats_a = m.encoder_wrapper(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")[2]
+    wt = synth.synth_tensor("deep_ta/wt", t.shape, seed=6)
+    wa = synth.synth_tensor("deep_ta/wa", a.shape, seed=7)
+    m.zero_grad()
+    ((t * wt).sum() + (a * wa).sum()).backward()
+    grads = {k: v for k, v in grads_summary(m, set()).items()  # row probes of the first and last layer only (file size)
+             if not k.endswith("#rows4") or ".layers.0." in k or ".layers.7." in k}
+    fx = dict(cfg=DEEP, vocab=1000, shapes=shapes, batch=B, text_len=24, audio_samples=32000, text_logits=t.detach(), audio_logits=a.detach(),
+              text_feats_head=feats_t[:, :4].detach().clone(), audio_feats_head=feats_a[:, :4].detach().clone(), grads=grads)
+    torch.save(fx, os.path.join(HERE, "deep_text_audio.pt"))
+    print("deep text+audio: logits norms %.4f / %.4f, %d gradient entries" % (float(t.norm()), float(a.norm()), len(grads)))
+
+
 DEEP40 = dict(DEEP, layers=40)
 
 
@@ -360,9 +386,9 @@ def optim_fixture():
 
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
-    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep", "stage2", "deep40"):
+    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep", "stage2", "deep40", "deep_ta"):
         {"optim": optim_fixture, "deep": deep_vision_fixture, "stage2": lambda: pretrain_al_fixture(stage2=True),
-         "deep40": deep_vision40_fixture}[sys.argv[1]]()
+         "deep40": deep_vision40_fixture, "deep_ta": deep_text_audio_fixture}[sys.argv[1]]()
         sys.exit(0)
     micro_fixture()
     tiny_text_fixture()
@@ -373,6 +399,7 @@ if __name__ == "__main__":
     optim_fixture()
     deep_vision_fixture()
     deep_vision40_fixture()
+    deep_text_audio_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

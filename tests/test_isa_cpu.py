@@ -11,6 +11,34 @@ sys.path.insert(0, ROOT)
 from tools import check_mfma_hazards as C  # noqa: E402
 
 
+# Register hygiene: every kernel has ScratchSize 0 -- nothing spilled, no private arrays in memory -- except the
+# ones named here with the bytes per lane they are KNOWN to use today (none of it inside a main loop; each entry says where).
+# A new spill, or one of these growing, fails the CPU tier.  Substring of the demangled name -> allowed bytes per lane.
+GEMM_SCRATCH_ALLOWED = {
+    "gemm256p_kernelILi0E": 256, "gemm256p_kernelILi1E": 288, "gemm256p_kernelILi2E": 64, "gemm256p_kernelILi3E": 232,  # tile walk of the
+    # persistent grouped NT kernel: descriptor set-up of the next tile between two tiles (16-28 scratch operations per tile)
+    "gemm256v_kernelILi0E": 24,          # bias epilogue: prologue / epilogue only
+    "gemm256w_tn_grouped_kernel": 40,    # per-tile set-up and the batched epilogue of the grouped weight-gradient kernel
+}
+ATTN_SCRATCH_ALLOWED = {
+    "attn_fwd_res_kernelILb1ELb1E": 56, "attn_fwd_res_kernelILb1ELb0E": 36,   # resident forward (<= 192 tokens since round 4): prologue
+    "attn_bwd_dq_dbias_kernelILi4ELb1ELi4E": 20, "attn_bwd_dq_dbias_kernelILi5ELb1ELi1E": 28, "attn_bwd_dq_dbias_kernelILi5ELb1ELi4E": 84,
+    "attn_bwd_dq_dbias_kernelILi6ELb1ELi1E": 104, "attn_bwd_dq_dbias_kernelILi6ELb1ELi4E": 156, "attn_bwd_dq_dbias_kernelILi6ELb0ELi4E": 12,
+    # merged dQ + dBias kernel of rounds 2-3 (per-sample bias images and the lengths the persistent kernel does not take)
+    "attn_bwd_dbias_kernel": 12,
+}
+
+
+def _assert_scratch(usage, allowed):
+    assert len(usage) > 10
+    bad = []
+    for name, u in usage.items():
+        limit = max([v for k, v in allowed.items() if k in name] or [0])
+        if u.get("ScratchSize", 0) > limit:
+            bad.append("%s: ScratchSize %d bytes/lane (allowed %d)" % (name, u.get("ScratchSize", 0), limit))
+    assert not bad, bad
+
+
 def test_hazard_checker_sees_a_stale_accumulator_read():
     bad = """_Z3foov:
 \t;;#ASMSTART
@@ -65,9 +93,11 @@ def test_no_compiler_instruction_touches_an_accumulator_behind_an_inline_asm_mfm
     see; copies it places on control-flow edges must come at least 18 wait states after the MFMA that writes the register.
     Same compile: no VALU write of a wide buffer store's data registers right behind it, and every inline-asm VMEM instruction
     brings the wait states for its SGPR operands itself."""
-    kernels, problems = C.check(C.compile_isa(str(tmp_path)))
+    isa = C.compile_isa(str(tmp_path))
+    kernels, problems = C.check(isa)
     assert kernels > 20
     assert problems == [], problems[:5]
+    _assert_scratch(C.resource_usage(isa), GEMM_SCRATCH_ALLOWED)
 
 
 def test_inflight_load_checker_sees_a_copy_of_a_register_that_is_still_being_loaded():
@@ -112,6 +142,8 @@ def test_inflight_load_checker_sees_a_copy_of_a_register_that_is_still_being_loa
 def test_attention_kernels_keep_their_hands_off_registers_in_flight(tmp_path):
     """csrc/attention.hip: no compiler instruction touches the destination of an inline-asm load before the hand-placed wait that
     covers it, and every inline-asm load brings the wait states for its SGPR base itself."""
-    lines = open(C.compile_isa(str(tmp_path), "attention")).read().split("\n")
+    isa = C.compile_isa(str(tmp_path), "attention")
+    lines = open(isa).read().split("\n")
     problems = C.check_inflight_asm_loads(lines) + C.check_asm_vmem_sgprs(lines)
     assert problems == [], problems[:5]
+    _assert_scratch(C.resource_usage(isa), ATTN_SCRATCH_ALLOWED)

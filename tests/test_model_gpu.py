@@ -29,9 +29,14 @@ def _fx(golden_dir, name):
 
 
 # name fragment -> bound that replaces the default one (measured value in brackets; torch-bf16 lands at the same error)
+# EXACT tensor names (as _check reports them).  The audio relative-position table: a tiny (|g| = 8.6e-3) gradient that is a sum of
+# strongly cancelling dS entries over buckets that each cover a large share of the keys.  dS = P o (dP - delta) sums to zero along a
+# row only if delta is exactly sum_k P dP; the kernels take delta = dO . O from the bf16-rounded forward output (no second pass
+# over the keys), the reference algorithm in bf16 takes it from a bf16-rounded dP: both break the cancellation at the bf16 level,
+# in different places (ours 1.0e-1, torch-bf16 0.65e-1 ... 0.98e-1 on the micro fixture; 2.9e-2 ... 3.8e-2 on the others).
 BOUND_EXCEPTIONS = {
-    "audio_adapter.rel_pos_table_list.0.weight": 1.3e-1,  # [1.02e-1; torch-bf16 0.98e-1] tiny table gradient: sums of strongly cancelling bf16 dS entries
-    "al_audio": 2.5e-2,                                    # [1.86e-2; torch-bf16 2.0e-2] audio CLS embedding of the joint pretraining step
+    "grad encoder_wrapper.audio_adapter.rel_pos_table_list.0.weight": 1.2e-1,  # [1.02e-1 micro fixture]
+    "al_audio": 2.3e-2,                                                         # [1.86e-2; torch-bf16 2.0e-2] audio CLS embedding of the joint step
 }
 
 
@@ -39,9 +44,7 @@ def _check(name, hip_val, torch_val, ref, bound, report, abs_err=0.0):
     """Absolute gate:  |hip - ref|_F <= bound * |ref|_F + abs_err  (abs_err: Frobenius slack for small-norm gradients whose bf16
     error does not scale with their norm).  The torch-bf16 error is reported, not gated on."""
     e_hip, e_t = rel_fro(hip_val.float(), ref), rel_fro(torch_val.float(), ref)
-    for frag, b in BOUND_EXCEPTIONS.items():
-        if frag in name:
-            bound = b
+    bound = BOUND_EXCEPTIONS.get(name, bound)
     report.append("%-60s hip %.3e  torch-bf16 %.3e  (bound %.1e)" % (name, e_hip, e_t, bound))
     nref = float(ref.double().norm())
     assert e_hip * nref <= bound * nref + abs_err, "%s: hip %.3e > bound %.1e (torch-bf16 %.3e, abs %.1e, |ref| %.3e)" % (
@@ -413,6 +416,92 @@ def test_full_size_layer_4b_dimensions():
         "\n".join(report) + "\n")
 
 
+def test_lock_step_layer_4b_dimensions_against_the_fp32_oracle():
+    """Round 4: ONE encoder layer at the 4B dimensions in its LOCK-STEP form -- text, image and audio rows packed
+    in one matrix, the modality-shared attention branch launched once over all of them, each segment through its own FFN, every
+    weight gradient of the layer in the grouped launch -- against the fp32 CPU oracle run once per modality on the same weights:
+    per-modality outputs and input gradients, the bias-table gradients, and EVERY parameter gradient (those of the shared
+    parameters are the oracle's sum over the three passes)."""
+    from one_peace_amd import hip, ops
+    from one_peace_amd.relpos import RelPosSpec, add_cls_buckets, make_image_bucket_position, make_token_bucket_position
+    from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    cfg = one_peace_encoder_config(embed_dim=1536, ffn_embed_dim=6144, layers=1, attention_heads=24, drop_path_rate=0.0)
+    torch.manual_seed(0)
+    layer = TransformerEncoderLayer(cfg, drop_path_rate=0.0)
+    for n, q in layer.named_parameters():
+        if q.dim() == 1:
+            q.data.add_(0.1 * torch.randn_like(q))
+    H, heads = 1536, 24
+    g = torch.Generator().manual_seed(2)
+    shapes = {"text": (3, 64), "image": (3, 257), "audio": (3, 250)}
+    nrel_img = (2 * 16 - 1) ** 2 + 3
+    buckets = {"image": make_image_bucket_position(16, nrel_img),
+               "text": add_cls_buckets(make_token_bucket_position(256)[:64, :64].clone(), 2 * 256 - 1),
+               "audio": add_cls_buckets(make_token_bucket_position(512)[:250, :250].clone(), 2 * 512 - 1)}
+    tables = {m: 0.5 * torch.randn(int(buckets[m].max()) + 1, heads, generator=g) for m in shapes}
+    xs = {m: torch.randn(b, s, H, generator=g) for m, (b, s) in shapes.items()}
+    dys = {m: torch.randn(b, s, H, generator=g) for m, (b, s) in shapes.items()}
+    pads = {"audio": torch.zeros(3, 250, dtype=torch.bool)}
+    pads["audio"][1, 230:] = True
+    pads["audio"][2, 190:] = True
+
+    # ---- fp32 oracle, one pass per modality on shared leaves ----
+    sdo = {"L." + k: v.detach().clone().float().requires_grad_(True) for k, v in layer.state_dict().items()}
+    ref_out, ref_dx, ref_dt = {}, {}, {}
+    for m, (b, s) in shapes.items():
+        xo, tabo = xs[m].clone().requires_grad_(True), tables[m].clone().requires_grad_(True)
+        bias_o = O.rel_pos_bias(tabo, buckets[m]).unsqueeze(0).expand(b, -1, -1, -1)
+        if m in pads:
+            bias_o = bias_o.masked_fill(pads[m][:, None, None, :], float("-inf"))
+        yo = O.encoder_layer(xo.transpose(0, 1), sdo, "L", heads, m, bias_o).transpose(0, 1)
+        live = (~pads[m]).unsqueeze(-1).float() if m in pads else 1.0
+        (yo * dys[m] * live).sum().backward()
+        ref_out[m], ref_dx[m], ref_dt[m] = yo.detach(), xo.grad, tabo.grad
+    g32 = {k[2:]: v.grad for k, v in sdo.items() if v.grad is not None}
+
+    # ---- HIP lock-step pass ----
+    mdev = layer.to(DEV).to(torch.bfloat16)
+    mdev.zero_grad()
+    segs, x2, tabs, row0 = [], [], {}, 0
+    for m, (b, s) in shapes.items():
+        tabs[m] = tables[m].to(DEV).to(torch.bfloat16).requires_grad_(True)
+        key_pad = None
+        if m in pads:
+            key_pad = torch.ones(b, hip.attn_spad(s), dtype=torch.uint8, device=DEV)
+            key_pad[:, :s] = pads[m].to(torch.uint8).to(DEV)
+        segs.append(ops.StreamSeg(m, b, s, row0, RelPosSpec(tabs[m], buckets[m].to(DEV)).handle(), key_pad))
+        x2.append(xs[m].reshape(b * s, H))
+        row0 += b * s
+    x2d = torch.cat(x2).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    y2 = mdev.forward_fused_multi(x2d, segs, None, [None] * 3)
+    dy2 = torch.cat([(dys[m] * ((~pads[m]).unsqueeze(-1).float() if m in pads else 1.0)).reshape(-1, H) for m in shapes]).to(DEV)
+    (y2.float() * dy2).sum().backward()
+    torch.cuda.synchronize()
+    report = []
+
+    def check(name, got, ref, bound):
+        e = rel_fro(got.float().cpu(), ref)
+        report.append("%-60s hip %.3e (bound %.1e)" % (name, e, bound))
+        assert e <= bound, "%s: %.3e > %.1e" % (name, e, bound)
+    for sg in segs:
+        m, (b, s) = sg.name, shapes[sg.name]
+        rows = slice(sg.row0, sg.end)
+        live = (~pads[m]) if m in pads else torch.ones(b, s, dtype=torch.bool)
+        check("lock-step 4B layer out " + m, y2[rows].view(b, s, H)[live.to(DEV)], ref_out[m][live], 1.5e-2)
+        check("lock-step 4B layer dx " + m, x2d.grad[rows].view(b, s, H), ref_dx[m], 5e-2)
+        check("lock-step 4B layer dtable " + m, tabs[m].grad, ref_dt[m], 5e-2 if m != "audio" else 1.2e-1)
+    n = 0
+    for name, q in mdev.named_parameters():
+        if name in g32 and float(g32[name].norm()) > 1e-7:
+            assert q.grad is not None, name
+            check("lock-step 4B layer grad " + name, q.grad, g32[name], 5e-2)
+            n += 1
+    assert n >= 40  # attention branch + three FFN sets + norms / layer-scale vectors
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "lock_step_layer_4b_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")
+
+
 def test_sample_prefetcher_matches_prepare_sample():
     """staging.SamplePrefetcher == trainer.py:1297-1336 (_prepare_sample: move_to_cuda + fp32->bf16 of floating tensors,
     integer / bool tensors untouched, nested dict structure kept), for a stream of different samples and slot reuse."""
@@ -742,6 +831,67 @@ def test_deep_vision_branch_8_layers_4b_dimensions(golden_dir):
             assert e_f <= 2e-2, report[-1]
             assert worst_n <= 2e-2 and worst_s <= 5e-2, report[-1]
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "deep_vision_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")
+
+
+def test_deep_text_and_audio_towers_8_layers_4b_dimensions_with_backward(golden_dir):
+    """tests/golden/deep_text_audio.pt (round 4): the reference's text and audio towers at the 4B layer dimensions, EIGHT layers
+    deep, three captions (padded rows) and three two-second clips, WITH the backward of loss = sum(text_logits * w_t) +
+    sum(audio_logits * w_a).  The HIP path in bf16 must reproduce both normalised embeddings, the first feature rows, every
+    parameter-gradient norm, the small gradients and the row probes of the large ones.  Same absolute tolerances as the 8-layer
+    image fixture: embeddings rel-Frobenius <= 2e-2 and cosine >= 0.9998, features <= 2e-2, gradient norms within 2 % (3 % below a
+    norm of 1e-3), element-wise probes rel-Frobenius <= 5e-2 + 1.5e-3 absolute (the audio relative-position table: 1.2e-1, see
+    BOUND_EXCEPTIONS)."""
+    fx = _fx(golden_dir, "deep_text_audio.pt")
+    inp = _to_dev(synth.synth_inputs(fx["batch"], text_len=fx["text_len"], audio_samples=fx["audio_samples"], vocab=fx["vocab"]))
+    wt = synth.synth_tensor("deep_ta/wt", fx["text_logits"].shape, seed=6).to(DEV)
+    wa = synth.synth_tensor("deep_ta/wa", fx["audio_logits"].shape, seed=7).to(DEV)
+    out = {}
+    for mode in ("hip", "torch"):
+        m = load_synth(build_retrieval(dict(fx["cfg"]), fx["vocab"], head_type="al"), fx["shapes"]).to(DEV).to(torch.bfloat16).eval()
+        _force_torch_path(m, mode == "torch")
+        t = m(src_tokens=inp["src_tokens"], encoder_type="text")
+        a = m(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")
+        with torch.no_grad():
+            ft = m.encoder_wrapper(src_tokens=inp["src_tokens"], encoder_type="text")[0]
+            fa = m.encoder_wrapper(src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"], encoder_type="audio")[2]
+        m.zero_grad()
+        ((t.float() * wt).sum() + (a.float() * wa).sum()).backward()
+        torch.cuda.synchronize()
+        out[mode] = (t.detach().float().cpu(), a.detach().float().cpu(), ft[:, :4].float().cpu(), fa[:, :4].float().cpu(),
+                     {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+        del m
+        torch.cuda.empty_cache()
+    report = []
+    for mode in ("hip", "torch"):
+        t, a, ft, fa, gr = out[mode]
+        e_t, e_a = rel_fro(t, fx["text_logits"]), rel_fro(a, fx["audio_logits"])
+        cos = min(float(torch.nn.functional.cosine_similarity(t, fx["text_logits"], dim=1).min()),
+                  float(torch.nn.functional.cosine_similarity(a, fx["audio_logits"], dim=1).min()))
+        e_f = max(rel_fro(ft, fx["text_feats_head"]), rel_fro(fa, fx["audio_feats_head"]))
+        worst_n, worst_s, worst_name = 0.0, 0.0, ""
+        for k, ref in fx["grads"].items():
+            if k.endswith("#norm"):
+                n = k[:-5]
+                r = float(ref)
+                if r > 1e-6:
+                    dev = abs(float(gr[n].double().norm()) - r) / r / (1.5 if r < 1e-3 else 1.0)
+                    worst_n = max(worst_n, dev)
+            else:
+                n = k[:-6] if k.endswith("#rows4") else k
+                got = gr[n][:4] if k.endswith("#rows4") else gr[n]
+                if float(ref.norm()) > 1e-6:
+                    bound_scale = 5e-2 / 1.2e-1 if n.endswith("audio_adapter.rel_pos_table_list.0.weight") else 1.0
+                    e = (float((got - ref).double().norm()) - 1.5e-3) / float(ref.double().norm()) * bound_scale
+                    if e > worst_s:
+                        worst_s, worst_name = e, k
+        report.append("%-6s logits rel-fro %.3e / %.3e cos %.6f | feats %.3e | worst grad-norm dev %.3e | worst probe rel-fro (after abs slack) %.3e %s"
+                      % (mode, e_t, e_a, cos, e_f, worst_n, worst_s, worst_name))
+        if mode == "hip":
+            assert max(e_t, e_a) <= 2e-2 and cos >= 0.9998, report[-1]
+            assert e_f <= 2e-2, report[-1]
+            assert worst_n <= 2e-2 and worst_s <= 5e-2, report[-1]
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "deep_text_audio_parity_report.txt"), "w").write(
         "\n".join(report) + "\n")
 
 

@@ -1009,6 +1009,39 @@ def test_gemm_full_size_launches_match_torch(M, N, K, epi):
     assert_close(out, ref, what=epi)
 
 
+@pytest.mark.parametrize("kind", ["down_resid", "dgrad"])
+def test_grouped_gemm_at_the_headline_launches_matches_torch(kind):
+    """Round 4: op_gemm_nt_grouped at the EXACT grouped launches of the headline step -- the three per-modality FFN
+    problems of the lock-step pass (8 192 text, 32 896 image, 32 000 audio rows, N = 1536) as one persistent launch: the
+    down-projection + bias + layer-scale / drop-path residual with the branch output saved (K = 6144) and the K = 12 288 input
+    gradient of wi_0 | wi_1 -- every problem against an fp32 matmul of the same bf16 operands on the device."""
+    hip = hipmod()
+    g = torch.Generator(device=DEV).manual_seed(13)
+    rows, rps = (8192, 32896, 32000), (64, 257, 250)
+    N, K = 1536, (6144 if kind == "down_resid" else 12288)
+    mk = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g, device=DEV, dtype=torch.float32) * sc).to(torch.bfloat16)  # noqa: E731
+    As = [mk(m, K) for m in rows]
+    Ws = [mk(N, K, sc=0.05) for _ in rows]
+    outs = [torch.empty(m, N, dtype=torch.bfloat16, device=DEV) for m in rows]
+    if kind == "down_resid":
+        bs, gamma = [mk(N, sc=0.05) for _ in rows], mk(N, sc=0.05)
+        res = [mk(m, N) for m in rows]
+        ys = [torch.empty(m, N, dtype=torch.bfloat16, device=DEV) for m in rows]
+        pss = [(torch.rand(m // r, generator=g, device=DEV) > 0.4).float() / 0.6 for m, r in zip(rows, rps)]
+        got = hip.gemm_nt_grouped(As, Ws, biases=bs, outs=outs, epilogue=hip.EPI_RESID, h0s=ys, resids=res, gammas=[gamma] * 3,
+                                  rowscales=pss, rows_per_sample=list(rps))
+        assert got is not None, "the grouped launch did not take the headline shape"
+        for a, w, b, r, ps, rp, o, y in zip(As, Ws, bs, res, pss, rps, outs, ys):
+            yref = a.float() @ w.float().t() + b.float()
+            assert_close(y, yref, what="branch output")
+            assert_close(o, r.float() + ps.repeat_interleave(rp)[:, None] * gamma.float() * yref, what="grouped down-projection + residual")
+    else:
+        got = hip.gemm_nt_grouped(As, Ws, outs=outs)
+        assert got is not None, "the grouped launch did not take the headline shape"
+        for a, w, o in zip(As, Ws, outs):
+            assert_close(o, a.float() @ w.float().t(), what="grouped input gradient")
+
+
 @pytest.mark.parametrize("M,No,Ni", [(16448, 1536, 6144), (32896, 1536, 6144), (32896, 12288, 1536), (73216, 4608, 1536)])
 def test_weight_gradient_full_size_matches_torch(M, No, Ni):
     """dW = dy^T x at BASELINE size with in-place accumulation, transpose-read kernels + split-K: tokens = 16448 (round 1),

@@ -173,3 +173,37 @@ def test_deep_vision_branch_against_reference(golden_dir):
         logits = O.l2_normalize(O.linear(feats[:, 0], sd["image_proj.weight"], sd["image_proj.bias"]))
     assert torch.allclose(feats[:, :4], fx["feats_head"], atol=2e-4, rtol=1e-4)
     assert torch.allclose(logits, fx["logits"], atol=ATOL, rtol=1e-4)
+
+
+def test_deep_text_and_audio_towers_with_backward_against_reference(golden_dir):
+    """tests/golden/deep_text_audio.pt (round 4; reference, H=1536 / F=6144 / 24 heads, 8 layers, 3 captions + 3 two-second clips):
+    the oracle reproduces both embeddings and the feature rows, and -- the first DEEP fixture with a backward -- every parameter
+    gradient norm of loss = sum(text_logits * w_t) + sum(audio_logits * w_a), the small gradients in full and row probes of the
+    large ones in the first and last layer."""
+    fx = _load(golden_dir, "deep_text_audio.pt")
+    cfg = fx["cfg"]
+    sd = synth.synth_state_dict(fx["shapes"])
+    sd["encoder_wrapper.text_adapter.rp_bucket"] = O.token_bucket_position(cfg["text_bucket_size"])
+    sd["encoder_wrapper.audio_adapter.rp_bucket"] = O.token_bucket_position(cfg["audio_bucket_size"])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    inp = synth.synth_inputs(fx["batch"], text_len=fx["text_len"], audio_samples=fx["audio_samples"], vocab=fx["vocab"])
+    heads, L = cfg["attention_heads"], cfg["layers"]
+    t, tf = O.contrastive_embed(sd, heads, L, "text", src_tokens=inp["src_tokens"])
+    a, af = O.contrastive_embed(sd, heads, L, "audio", src_audios=inp["src_audios"], audio_padding_masks=inp["audio_padding_masks"])
+    assert torch.allclose(t, fx["text_logits"], atol=ATOL, rtol=1e-4) and torch.allclose(a, fx["audio_logits"], atol=ATOL, rtol=1e-4)
+    assert torch.allclose(tf[:, :4], fx["text_feats_head"], atol=2e-4, rtol=1e-4)
+    assert torch.allclose(af[:, :4], fx["audio_feats_head"], atol=2e-4, rtol=1e-4)
+    wt = synth.synth_tensor("deep_ta/wt", t.shape, seed=6)
+    wa = synth.synth_tensor("deep_ta/wa", a.shape, seed=7)
+    ((t * wt).sum() + (a * wa).sum()).backward()
+    checked = 0
+    for k, g in fx["grads"].items():
+        if k.endswith("#norm"):
+            got = sd[k[:-5]].grad.double().norm().float()
+            assert torch.allclose(got, g, rtol=5e-4, atol=1e-6), (k, float(got), float(g))
+        elif k.endswith("#rows4"):
+            assert torch.allclose(sd[k[:-6]].grad[:4], g, atol=1e-4, rtol=5e-4), k
+        else:
+            assert torch.allclose(sd[k].grad, g, atol=1e-4, rtol=5e-4), k
+        checked += 1
+    assert checked > 300

@@ -92,9 +92,30 @@ def agprs(text):
 def compile_isa(workdir, name="gemm"):
     src = os.path.join(ROOT, "one-peace_amd", "csrc", name + ".hip")
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-           "-munsafe-fp-atomics", "-save-temps", "-c", src, "-o", os.path.join(workdir, name + ".o")]
-    subprocess.run(cmd, cwd=workdir, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+           "-munsafe-fp-atomics", "-save-temps", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(workdir, name + ".o")]
+    r = subprocess.run(cmd, cwd=workdir, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    open(os.path.join(workdir, name + ".resource_usage.txt"), "w").write(r.stdout)  # the remarks of the same compile (resource_usage)
     return os.path.join(workdir, name + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+
+
+def resource_usage(isa_path):
+    """{mangled kernel name: {"VGPRs", "AGPRs", "SGPRs", "ScratchSize", "Occupancy", "LDS"}} from the kernel-resource-usage remarks
+    compile_isa stored next to the assembly."""
+    txt = open(isa_path.replace("-hip-amdgcn-amd-amdhsa-gfx950.s", ".resource_usage.txt")).read()
+    out, cur = {}, None
+    keys = {"VGPRs": "VGPRs", "AGPRs": "AGPRs", "SGPRs": "SGPRs", "ScratchSize": "ScratchSize", "Occupancy": "Occupancy", "LDS Size": "LDS"}
+    for line in txt.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        if cur is None:
+            continue
+        for k, short in keys.items():
+            m = re.search(r"remark: .*?" + k + r"[^:]*: (\d+)", line)
+            if m and short not in cur:
+                cur[short] = int(m.group(1))
+    return out
 
 
 VM_OP = re.compile(r"^(global_|buffer_|flat_|scratch_)(load|store|atomic)")

@@ -607,6 +607,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_v = float(loss.float().mean().item())
+    allr = None
+    if dist.is_initialized() and not micro:  # memory figures of EVERY rank (a collective: all ranks, not inside the rank-0 report)
+        mine = [torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9,
+                torch.cuda.mem_get_info(device)[0] / 1e9]
+        allr = [None] * dist.get_world_size()
+        dist.all_gather_object(allr, mine)  # (object collective: gloo has no all_gather of device tensors)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -650,12 +656,8 @@ def main():
                 "grad_allreduce_bytes_per_step": flat.numel * flat.grads.element_size() if flat is not None else 0,
                 "embedding_allgather_bytes_per_step": k_mod * args.batch * H * (4 if micro else 2) * dist.get_world_size(),
                 "bucket_launch_order_identical_on_all_ranks": order_same}
-            if not micro:  # per-rank peak memory and what was left of the device at the peak (the 6 GB RCCL reserve has never met hardware)
+            if allr is not None:  # per-rank peak memory and what was left of the device at the peak (the 6 GB RCCL reserve has never met hardware)
                 total_b = torch.cuda.mem_get_info(device)[1]
-                mine = torch.tensor([torch.cuda.max_memory_allocated(device) / 1e9, torch.cuda.max_memory_reserved(device) / 1e9,
-                                     torch.cuda.mem_get_info(device)[0] / 1e9], dtype=torch.float64, device=device)
-                allr = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
-                dist.all_gather(allr, mine)
                 mem_report.update({"device_total_gb": total_b / 1e9,
                                    "peak_allocated_gb_per_rank": [round(float(t[0]), 2) for t in allr],
                                    "peak_reserved_gb_per_rank": [round(float(t[1]), 2) for t in allr],

@@ -842,10 +842,11 @@ class FfnBranchFn(torch.autograd.Function):
         B, S, H = x.shape
         P = dict(zip(FFN_PARAMS, params))
         x2 = x.reshape(B * S, H)
-        need_grad = any(ctx.needs_input_grad)
-        keep = bool(save_acts) and need_grad
+        need_grad = any(ctx.needs_input_grad) and bool(int(save_acts) & 2)
+        keep = bool(int(save_acts) & 1) and need_grad
         needs = dict(zip(FFN_PARAMS, ctx.needs_input_grad[3:]))
-        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"], grad=need_grad)
+        # (needs_input_grad is also set inside torch.no_grad() -- the teacher passes of a trainable model: only the flag says "recording")
+        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"], grad=bool(int(save_acts) & 2))
         ctx.dims, ctx.n_params = (B, S, H), len(params)
         ctx.direct = ()
         if need_grad:
@@ -988,11 +989,11 @@ class FfnBranchMultiFn(torch.autograd.Function):
         nseg = len(segs)
         N, H = x2.shape
         Fd = params[3].shape[0]
-        need_grad = any(ctx.needs_input_grad)
-        keep = bool(save_acts) and need_grad
+        need_grad = any(ctx.needs_input_grad) and bool(int(save_acts) & 2)
+        keep = bool(int(save_acts) & 1) and need_grad
         needs = ctx.needs_input_grad[4:]
         has_fln = params[5] is not None
-        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]), grad=need_grad)
+        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]), grad=bool(int(save_acts) & 2))
         ctx.segs, ctx.n_params, ctx.dims = segs, len(params), (N, H, Fd)
         ctx.direct = ()
         names = list(FFN_SHARED) + ["%s@%d" % (n, i) for i in range(nseg) for n in FFN_OWN]
@@ -1113,7 +1114,7 @@ def ffn_branch_multi(x2, segs, pss, shared, own, save_acts=True):
     flat = list(shared)
     for o in own:
         flat += list(o)
-    return FfnBranchMultiFn.apply(x2, segs, tuple(pss), save_acts, *flat)
+    return FfnBranchMultiFn.apply(x2, segs, tuple(pss), _save_flags(save_acts), *flat)
 
 
 def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag, dq, dk, dv):
@@ -1147,8 +1148,15 @@ def attn_branch_multi(x2, segs, ps_rows, heads, params, save_acts=False):
                               *params)
 
 
+def _save_flags(save_acts):
+    """bit 0: keep the activations; bit 1: autograd is recording (inside Function.forward grad mode is always off).  The GeGLU form of
+    the FFN is chosen by bit 1 -- not by which parameters happen to be trainable: a frozen branch (stage-2 pretraining) and a trainable
+    one must give the same forward bits, and so must a checkpointed forward and its recomputation."""
+    return int(bool(save_acts)) | (2 if torch.is_grad_enabled() else 0)
+
+
 def ffn_branch(x, ps, params, save_acts=False):
-    return FfnBranchFn.apply(x, ps, save_acts, *params)
+    return FfnBranchFn.apply(x, ps, _save_flags(save_acts), *params)
 
 
 def encoder_layer(x, bias, key_pad, ps1, ps2, heads, params, save_acts=False):

@@ -677,8 +677,8 @@ def main():
             g = prof[0]
             ach = g["work"] / (g["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma",
-                               "kernel": "GEMM family (gemm256v / gemm256p four-wave NT kernels, gemm256_tn / gemm256w_tn weight-gradient kernels, gemm_nt tail-rows "
-                                         "kernel, incl. their split-K folds)",
+                               "kernel": "GEMM family (gemm256v / gemm256p four-wave NT kernels, the grouped weight-gradient launch gemm256w_tn_grouped + "
+                                         "gemm256_tn / gemm256w_tn for row counts it does not take, gemm_nt tail-rows kernel, incl. split-K folds)",
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": g["count"], "avg_launch_ms": g["ms"] / g["count"],
                                "profiled_steps": profiled_steps,
@@ -694,7 +694,7 @@ def main():
             # HBM bytes per GEMM launch need separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), so they
             # cannot be collected inside this process: tools/pmc_bench_traffic.sh runs this command under those passes and writes
             # the file; it is quoted only for the exact configuration it was measured on.
-            for tname in ("r3_gemm_hbm_traffic.json", "r2_gemm_hbm_traffic.json", "r1_gemm_hbm_traffic.json"):
+            for tname in ("r4_gemm_hbm_traffic.json", "r3_gemm_hbm_traffic.json", "r2_gemm_hbm_traffic.json", "r1_gemm_hbm_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if not os.path.exists(tpath):
                     continue

@@ -20,7 +20,7 @@ def load(d):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         fam = "gemm" if "gemm" in k else "other"
-        key = (fam, "wtn" if "gemm256w_tn" in k else ("tn" if "gemm256_tn" in k else ("v" if "gemm256v" in k else ("p" if "gemm256p" in k else (
+        key = (fam, "gtn" if "gemm256w_tn_grouped" in k else "wtn" if "gemm256w_tn" in k else ("tn" if "gemm256_tn" in k else ("v" if "gemm256v" in k else ("p" if "gemm256p" in k else (
             "w" if "gemm256w" in k else ("b" if "gemm256b" in k else ("a" if "gemm256_kernel" in k else ("s" if "gemm_nt" in k else "-"))))))))
         agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
     return agg
@@ -48,7 +48,7 @@ out = {
     "what": "HBM-side bytes per GEMM-family launch (all gemm* kernels; split-K folds are not counted as launches), one bench.py step",
     "command": "tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --kernel-include-regex 'gemm|splitk' -- "
                "python bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline (two separate passes + two calibration launches each)",
-    "round": 3, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
+    "round": 4, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
     "fetch_size_correction": fc, "write_size_correction": wc,
     "calibration": "tools/pmc_calib.py: A[32896,6144] bf16 read exactly once (404 MB > 256 MB Infinity Cache)",
     "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
@@ -56,7 +56,8 @@ out = {
     "by_kernel_write_bytes_per_launch": {k: v[0] * 1024.0 * wc / v[1] for k, v in res["WRITE_SIZE"]["bench_by_kernel_kb"].items()},
     "by_kernel_launches": {k: v[1] for k, v in res["FETCH_SIZE"]["bench_by_kernel_kb"].items()},
     "kernel_keys": "s = gemm_nt_kernel (128x128), a / b / w = gemm256 / gemm256b / gemm256w_kernel, v = gemm256v_kernel (four waves, production), "
-                   "p = gemm256p_kernel (grouped launches), tn / wtn = gemm256_tn_kernel / gemm256w_tn_kernel",
+                   "p = gemm256p_kernel (grouped launches), tn / wtn = gemm256_tn_kernel / gemm256w_tn_kernel, gtn = gemm256w_tn_grouped_kernel (round 4: all weight "
+                   "gradients of a layer, no split-K slabs)",
     "note": "counter bytes include Infinity-Cache hits (MI355X_MICROARCH.md); weight panels re-fetched per M-tile group are mostly such hits",
 }
 json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the 1 s register-only MFMA loop behind roofline.power_limited_peak")
     ap.add_argument("--objective", choices=["contrastive", "pretrain-vl", "pretrain-al"], default="contrastive",
                     help="config 3 only: contrastive = the headline tri-modal ITC+ATC step; pretrain-vl = the full image-text "
                          "pretraining objective (ITC + four DCL terms, six passes incl. the masked students and the decoder); "
@@ -705,6 +706,15 @@ def main():
                     out["roofline"]["traffic_source"] = ("profiles/%s: committed rocprofv3 --pmc passes of this command "
                                                          "(not collected in this run)" % tname)
                     break
+        if world == 1 and out.get("roofline") and not args.no_power_probe:
+            # `peak` above is the data sheet's dense-bf16 figure at 2.4 GHz.  With random operands the package reaches its 1400 W
+            # limit long before that clock: a register-only MFMA loop (op_probe_mfma_rate, ~1 s, after the timed region) measures
+            # what the limit leaves on THIS box, and the GEMM family is quoted against that as well (DESIGN.md "Power").
+            pp = hip.mfma_rate_probe(seconds=1.0, waves_per_cu=8, data="normal")
+            out["roofline"]["power_limited_peak"] = {
+                "tflops": pp["tflops"], "shader_mhz": pp["mhz"], "frac": out["roofline"]["achieved"] / pp["tflops"],
+                "how": "register-only v_mfma_f32_16x16x32_bf16 loop, 8 waves per CU, random normal operands, %.0f ms, measured in this run"
+                       % pp["ms"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(modal, backward=train)
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, 16-byte rule of op_gemm_tn_grouped's C */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -95,7 +95,7 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
  * makes per nn.Linear of an encoder layer (transformer_layer.py:165-228 backward: q|k|v, out_proj, wi_0|wi_1 and wo of every
  * modality FFN); per-tile results are bit-identical to an unsplit op_gemm_tn.  Every array argument is a HOST array of nprob
  * entries.  counters: op_gemm_tn_grouped_counter_bytes() bytes of device memory zeroed ONCE by the caller (the launch re-arms
- * it; one block per stream).  Shape rules per problem as op_gemm_tn (+ ldc % 4 == 0); returns -95 and launches nothing when a
+ * it; one block per stream).  Shape rules per problem as op_gemm_tn (+ ldc % 8 == 0 and C_i 16-byte aligned: the gradient is read-modify-written in 16-byte pieces); returns -95 and launches nothing when a
  * problem does not qualify.  tune: bits 0-9 forced number of workgroups (0 = one per CU); bit 10: every workgroup draws from the
  * front of its queue (A/B timing of the solo workgroups, see the kernel). */
 int64_t op_gemm_tn_grouped_counter_bytes(void);
@@ -272,6 +272,11 @@ int op_probe_tr16(const void* img, const int* addr, void* out, int n, void* stre
 int op_probe_glds(const void* src, const int* src_off, int lds_base, void* dump, void* stream);
 /* raw v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 e4m3 x fp8 e4m3): a, b = [n][64 lanes][8 dwords], sa, sb = [n][64] E8M0 scale dwords */
 int op_probe_mfma_f8(const void* a, const void* b, const void* sa, const void* sb, float* d, int n, void* stream);
+/* Register-only MFMA loop (no LDS, no global memory inside): `workgroups` x 4 waves each issue iters x 64 v_mfma_f32_16x16x32_bf16 on
+ * the 8 operand fragments of `operands` (8 x 64 lanes x 8 bf16).  out: workgroups x 256 floats; clk: workgroups x 2 uint64 = shader
+ * clock ticks and 100 MHz ticks over the loop.  The caller times the launch: flops = workgroups x 4 x iters x 64 x 16384.  bench.py
+ * uses it to report the MFMA rate the package sustains at its power limit beside the data-sheet peak. */
+int op_probe_mfma_rate(const void* operands, float* out, void* clk, int workgroups, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2086,45 +2086,69 @@ __host__ __device__ __forceinline__ bool tn_decode(const TnGroupArgs& p, int x, 
   return false;
 }
 
-// Epilogue of a tile that lies inside the matrix (no guards): the 128 x 128 block of a wave, acc[blk][f][mi][r] =
-// C[mrow0 + mi*16 + t][nbase + blk*64 + f*16 + g*4 + r] (tn_epilogue's layout).  The old gradient values of two row blocks (16
-// fragments, 8 bytes per lane each) are requested before the first is used -- as one load -> add -> store chain per fragment
-// (tn_epilogue, 64 per wave) the epilogue took 26 us of a tile, a latency each (tools/wgrad_grouped_timeline.py).
-// `between`: called once after the first batch has been consumed (the caller's ticket atomic: outstanding in front of the first wait
-// it would turn the counted vmcnt into vmcnt(0) -- loads and returning atomics may complete out of order).
-template <bool ACCUM, typename F>
-__device__ __forceinline__ void tn_epilogue_full(bf16_t* C, int64_t ldc, f32x4 (&acc)[2][4][8], int mrow0, int nbase, int g, int t, F between) {
-  bf16_t* base = C + (int64_t)(mrow0 + t) * ldc + nbase + g * 4;
-  bf16x4 old[2][2][8];  // two batches of sixteen fragments: batch b + 1 is requested before batch b is consumed
-  auto request = [&](int b) {
+// The epilogue of the grouped weight-gradient kernel, through LDS (the operand stages are free once every wave has left the main
+// loop): the wave parks each [128 rows x 64 columns] fp32 half of its block in its own 32 KiB (256-byte rows, 16-byte chunks
+// XOR-swizzled by the row: the fragment-layout writes -- 8 lanes = 8 rows of one chunk column -- and the row-layout reads are both
+// conflict free) and reads it back with a lane per 8 consecutive columns: the read-modify-write of the bf16 gradient is then 16
+// bytes per lane, 8 lanes = one 128-byte line, 16 loads + 16 stores per half.  (Round 4's first epilogue wrote straight from the
+// MFMA fragment layout: 32 + 32 eight-byte accesses per half with adjacent lanes on different ROWS, which the texture addresser
+// took one lane at a time -- 20 us of a tile.)  The old values travel in two batches of eight while the block is parked / while the
+// first batch is folded; `between` (the next ticket's draw) runs after the first half so that its returning atomic is not in front
+// of loads the wave waits for.  GUARD: tiles on the matrix edge (M, N are multiples of 8: a lane's 8 columns are in or out together).
+template <bool ACCUM, bool GUARD, typename F>
+__device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&acc)[2][4][8], int mrow0, int nbase, int M, int N, int lane, char* wlds,
+                                                F between) {
+  const int g = lane >> 4, t = lane & 15;
+  const int rrow = lane >> 3, cp = lane & 7;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int blk = 0; blk < 2; ++blk) {
+    bf16_t* cbase = C + (int64_t)(mrow0 + rrow) * ldc + nbase + blk * 64 + cp * 8;
+    const bool col_ok = !GUARD || nbase + blk * 64 + cp * 8 < N;
+    auto ok = [&](int i) { return !GUARD || (col_ok && mrow0 + rrow + i * 8 < M); };
+    bf16x8 old[8];
+    if (ACCUM) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        old[b & 1][j][c] = *reinterpret_cast<const bf16x4*>(base + (int64_t)(b * 2 + j) * 16 * ldc + (c >> 2) * 64 + (c & 3) * 16);
-  };
-  if (ACCUM) {
-    request(0);
-    __builtin_amdgcn_sched_barrier(0);  // (left alone the scheduler turns the batches back into one load -> add -> store chain per fragment)
-  }
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    if (ACCUM && b < 3) {
-      request(b + 1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i)
+        if (ok(i)) old[i] = *reinterpret_cast<const bf16x8*>(cbase + (int64_t)i * 8 * ldc);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const f32x4 a = acc[c >> 2][c & 3][b * 2 + j];
-        bf16x4 w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = (bf16_t)(ACCUM ? (float)old[b & 1][j][c][r] + a[r] : a[r]);
-        *reinterpret_cast<bf16x4*>(base + (int64_t)(b * 2 + j) * 16 * ldc + (c >> 2) * 64 + (c & 3) * 16) = w;
+      for (int f = 0; f < 4; ++f) {
+        const int row = mi * 16 + t;
+        *reinterpret_cast<f32x4*>(wlds + row * 256 + (((f * 4 + g) ^ t) << 4)) = acc[blk][f][mi];
       }
     __builtin_amdgcn_sched_barrier(0);
-    if (b == 0) {
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+      bf16x8 nxt[8];
+      if (ACCUM && hb == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (ok(8 + i)) nxt[i] = *reinterpret_cast<const bf16x8*>(cbase + (int64_t)(8 + i) * 8 * ldc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (hb * 8 + i) * 8 + rrow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + row * 256 + (((2 * cp) ^ (row & 15)) << 4));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + row * 256 + (((2 * cp + 1) ^ (row & 15)) << 4));
+        bf16x8 w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          w[r] = (bf16_t)(ACCUM ? (float)old[i][r] + lo[r] : lo[r]);
+          w[4 + r] = (bf16_t)(ACCUM ? (float)old[i][4 + r] + hi[r] : hi[r]);
+        }
+        if (ok(hb * 8 + i)) *reinterpret_cast<bf16x8*>(cbase + (int64_t)(hb * 8 + i) * 8 * ldc) = w;
+      }
+      if (ACCUM && hb == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) old[i] = nxt[i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (blk == 0) {
       between();
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -2184,18 +2208,28 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
 
 #ifdef OP_GEMM_TIMELINE
   int tl_slot = 0;  // per workgroup 32 records of four words: ticket code, tile start, main loop end, tile end (s_memrealtime)
+  unsigned long long tl_cyc = 0;  // s_memtime at the tile's start: the shader clock over the main loop goes into bits 36+ of word 0
+#define TLG_CYC0() tl_cyc = __builtin_readcyclecounter()
+#define TLG_CYC1()                                                                                                      \
+  do {                                                                                                                  \
+    if (g_timeline && tid == 0 && tl_slot < 32)                                                                         \
+      g_timeline[(int64_t)blockIdx.x * 128 + tl_slot * 4] |= (unsigned long long)(__builtin_readcyclecounter() - tl_cyc) << 36; \
+  } while (0)
 #define TLG(k, v)                                                                                                       \
   do {                                                                                                                  \
     if (g_timeline && tid == 0 && tl_slot < 32) g_timeline[(int64_t)blockIdx.x * 128 + tl_slot * 4 + (k)] = (v);          \
   } while (0)
 #else
 #define TLG(k, v)
+#define TLG_CYC0()
+#define TLG_CYC1()
 #endif
   while (code >= 0) {
     int prob, pid_m, pid_n;
     const bool valid = tn_decode(p, code >> 24, code & 0xffffff, prob, pid_m, pid_n);
     TLG(0, (unsigned long long)(unsigned)code | ((unsigned long long)(valid ? prob + 1 : 0) << 32));
     TLG(1, __builtin_amdgcn_s_memrealtime());
+    TLG_CYC0();
     if (valid) {
       const TnProb& q = p.pr[prob];
       const int M = q.M, N = q.N;
@@ -2310,24 +2344,22 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
       asm volatile("" : TN_ACC8(1, 2), TN_ACC8(1, 3));
 #undef TN_ACC8
       TLG(2, __builtin_amdgcn_s_memrealtime());
+      TLG_CYC1();
       // the NEXT tile's ticket: drawn inside the epilogue, in flight during the rest of it.  (Drawn at the start of the tile -- round 4's first
       // version -- the last tickets of a launch sat for up to a whole tile with workgroups that were busy, while workgroups that
       // became free found the queues empty and left: finish times spread over 700 us of a 4.5 ms launch.)
       auto draw_next = [&]() { if (tid == 0) draw(); };
-      if (m0 + 256 <= M && n0 + 256 <= N) {  // (uniform) tile inside the matrix: no guards, the old values of 32 fragments in flight
-        if (q.accumulate) tn_epilogue_full<true>(q.C, q.ldc, acc, m0 + wm * 128, n0 + wn * 128, g, t, draw_next);
-        else tn_epilogue_full<false>(q.C, q.ldc, acc, m0 + wm * 128, n0 + wn * 128, g, t, draw_next);
-      } else {
-      draw_next();
-      GemmArgs e;
-      e.M = M; e.N = N; e.ldc = q.ldc; e.resid = q.C; e.ldr = q.ldc;
-      if (q.accumulate) {
-        tn_epilogue<EPI_RESID, 4>(e, q.C, acc[0], m0 + wm * 128, n0 + wn * 128, g, t);
-        tn_epilogue<EPI_RESID, 4>(e, q.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, g, t);
-      } else {
-        tn_epilogue<EPI_BIAS, 4>(e, q.C, acc[0], m0 + wm * 128, n0 + wn * 128, g, t);
-        tn_epilogue<EPI_BIAS, 4>(e, q.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, g, t);
-      }
+      __syncthreads();  // every wave is out of the main loop: the operand stages are free for the epilogue
+      {
+        char* wlds = smem + wid * 32768;
+        const int mr = m0 + wm * 128, nb = n0 + wn * 128;
+        if (m0 + 256 <= M && n0 + 256 <= N) {  // (uniform) tile inside the matrix
+          if (q.accumulate) tn_epilogue_lds<true, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
+          else tn_epilogue_lds<false, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
+        } else {
+          if (q.accumulate) tn_epilogue_lds<true, true>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
+          else tn_epilogue_lds<false, true>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
+        }
       }
     }
     TLG(3, __builtin_amdgcn_s_memrealtime());
@@ -3013,7 +3045,8 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
 // x of nn.Linear, autograd's dW = dy^T x) as ONE persistent launch without split-K (gemm256w_tn_grouped_kernel): every output
 // tile runs its whole K and is written / accumulated once.  Shape rules per problem as op_gemm_tn; returns OP_ENOTSUP (nothing
 // launched) when a problem does not qualify -- the caller then uses op_gemm_tn per problem.  Problems may come in any order.
-// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = no solo workgroups (A/B timing).
+// The gradient is read-modify-written in 16-byte pieces: ldc_i % 8 == 0 and C_i 16-byte aligned as well.
+// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = no solo workgroups.
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
                        void* counters, int64_t tune, void* stream) {
@@ -3023,7 +3056,7 @@ int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, 
   for (int i = 0; i < (int)nprob; ++i) {
     OP_CHECK_ARG(A[i] && B[i] && C[i], "gemm_tn_grouped: null operand of problem %d", i);
     if (K[i] % 64 != 0 || K[i] < 64 || M[i] % 8 != 0 || N[i] % 8 != 0 || lda[i] % 8 != 0 || ldb[i] % 8 != 0 || M[i] < 8 || N[i] < 8 ||
-        31 * lda[i] + M[i] >= ((int64_t)1 << 30) || 31 * ldb[i] + N[i] >= ((int64_t)1 << 30) || ldc[i] % 4 != 0) {
+        31 * lda[i] + M[i] >= ((int64_t)1 << 30) || 31 * ldb[i] + N[i] >= ((int64_t)1 << 30) || ldc[i] % 8 != 0 || ((uintptr_t)C[i] & 15) != 0) {
       op_set_error("gemm_tn_grouped: problem %d (M=%lld N=%lld K=%lld) not supported by the transpose-read kernel", i, (long long)M[i],
                    (long long)N[i], (long long)K[i]);
       return OP_ENOTSUP;

@@ -77,9 +77,60 @@ __global__ void probe_mfma_f8_kernel(const int* a, const int* b, const int* sa, 
   }
 }
 
+// What the matrix cores sustain with nothing else going on: every wave issues v_mfma_f32_16x16x32_bf16 back to back on register
+// operands (4 x 4 fragments of the caller's image -> 16 independent accumulators, the register tile of a GEMM wave), no LDS, no
+// global memory in the loop.  clk[2 * workgroup] = s_memtime ticks (the clock the shader ran at), clk[2 * workgroup + 1] =
+// s_memrealtime ticks (100 MHz) over the loop.  The caller times the launch.  (Round 4: the GEMMs of the step run with the package
+// at its power limit -- this loop is the ceiling that limit leaves, see DESIGN.md "Power".)
+__global__ __launch_bounds__(256) void probe_mfma_rate_kernel(const bf16x8* __restrict__ in, float* out, unsigned long long* clk, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = in[i * 64 + lane];
+    b[i] = in[(4 + i) * 64 + lane];
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+  if (threadIdx.x == 0) {
+    clk[2 * blockIdx.x] = c1 - c0;
+    clk[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// operands: 8 fragments x 64 lanes x 8 bf16 (8 KiB); out: workgroups x 256 floats; clk: workgroups x 2 uint64.  64 MFMAs per wave and
+// iteration: flops = workgroups x 4 waves x iters x 64 x 16 384.
+int op_probe_mfma_rate(const void* operands, float* out, void* clk, int workgroups, int iters, void* stream) {
+  OP_CHECK_ARG(operands && out && clk && workgroups > 0 && iters > 0, "probe_mfma_rate: bad argument");
+  hipLaunchKernelGGL(probe_mfma_rate_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const bf16x8*)operands, out,
+                     (unsigned long long*)clk, iters);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
 
 int op_probe_mfma_f8(const void* a, const void* b, const void* sa, const void* sb, float* d, int n, void* stream) {
   hipLaunchKernelGGL(probe_mfma_f8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const int*)a, (const int*)b, (const int*)sa,

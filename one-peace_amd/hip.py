@@ -75,6 +75,7 @@ SIGNATURES = {
     "op_probe_tr16": (c_int, [P, P, P, c_int, P]),
     "op_probe_glds": (c_int, [P, P, c_int, P, P]),
     "op_probe_mfma_f8": (c_int, [P, P, P, P, P, c_int, P]),
+    "op_probe_mfma_rate": (c_int, [P, P, P, c_int, c_int, P]),
 }
 
 
@@ -737,3 +738,30 @@ class profile_kernels:
         work = (c_double * n)()
         lib().op_prof_collect(ms, cnt, work, n)
         return [dict(ms=ms[i], count=cnt[i], work=work[i]) for i in range(n)]
+
+
+def mfma_rate_probe(seconds=1.0, waves_per_cu=8, data="normal", device=None):
+    """The bf16 MFMA rate this GPU sustains with nothing else going on (op_probe_mfma_rate: register operands only), after the
+    package has settled at its power limit: {"tflops", "mhz" (shader clock over the loop, mean / min / max), "ms", "workgroups"}.
+    `data`: "normal" (random normal operands, what a training step multiplies), "zeros" (no toggling: the clock stays at its maximum)."""
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    wgs = cus * max(1, (int(waves_per_cu) + 3) // 4)
+    g = torch.Generator().manual_seed(1)
+    img = (torch.randn(8 * 64 * 8, generator=g) * 0.5 if data == "normal" else torch.zeros(8 * 64 * 8)).to(device=device, dtype=torch.bfloat16)
+    out = torch.empty(wgs * 256, dtype=torch.float32, device=device)
+    clk = torch.zeros(wgs * 2, dtype=torch.int64, device=device)
+    iters, ms = 20000, 0.0
+    for leg in range(3):  # calibrate, settle (clock and power follow the load with a delay), report
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(device))
+        _check(lib().op_probe_mfma_rate(ptr(img), ptr(out), ptr(clk), wgs, iters, stream()), "op_probe_mfma_rate")
+        e1.record(torch.cuda.current_stream(device))
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if leg == 0:
+            iters = max(1, int(iters * seconds * 1e3 / ms))
+    c = clk.view(wgs, 2).double().cpu()
+    mhz = c[:, 0] / (c[:, 1] * 0.01)
+    return {"tflops": wgs * 4 * iters * 64 * 16384.0 / (ms * 1e-3) / 1e12, "ms": ms, "workgroups": wgs,
+            "mhz": {"mean": float(mhz.mean()), "min": float(mhz.min()), "max": float(mhz.max())}}

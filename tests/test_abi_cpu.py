@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header(lib_path):
         assert len(hip.SIGNATURES[name][1]) == nargs, "%s: header has %d args, ctypes table %d" % (
             name, nargs, len(hip.SIGNATURES[name][1]))
     L = hip.lib()
-    assert L.op_abi_version() == 4  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4)
+    assert L.op_abi_version() == 5  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4); 5: op_probe_mfma_rate
 
 
 def test_no_silent_cpu_fallback():

@@ -18,7 +18,7 @@ GEMM_SCRATCH_ALLOWED = {
     "gemm256p_kernelILi0E": 256, "gemm256p_kernelILi1E": 288, "gemm256p_kernelILi2E": 64, "gemm256p_kernelILi3E": 232,  # tile walk of the
     # persistent grouped NT kernel: descriptor set-up of the next tile between two tiles (16-28 scratch operations per tile)
     "gemm256v_kernelILi0E": 24,          # bias epilogue: prologue / epilogue only
-    "gemm256w_tn_grouped_kernel": 40,    # per-tile set-up and the batched epilogue of the grouped weight-gradient kernel
+    "gemm256w_tn_grouped_kernel": 0,    # per-tile set-up and the batched epilogue of the grouped weight-gradient kernel
 }
 ATTN_SCRATCH_ALLOWED = {
     "attn_fwd_res_kernelILb1ELb1E": 56, "attn_fwd_res_kernelILb1ELb0E": 36,   # resident forward (<= 192 tokens since round 4): prologue

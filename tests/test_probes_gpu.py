@@ -121,3 +121,15 @@ def test_global_load_lds_semantics():
         s0 = int(perm[l]) * 16 * 3 // 2
         exp[base // 2 + l * 8: base // 2 + l * 8 + 8] = torch.arange(s0, s0 + 8)
     assert torch.equal(got, exp), "global_load_lds placement differs from base + lane*16"
+
+
+def test_mfma_rate_probe_reports_a_sane_rate_and_clock():
+    """op_probe_mfma_rate (bench.py's roofline.power_limited_peak): a register-only MFMA loop.  A short run says nothing about the
+    power limit, only that the accounting is right: the rate can never exceed the data-sheet figure at the measured clock, and a
+    full chip of back-to-back MFMAs must get well past half of it."""
+    hip = _hip()
+    r = hip.mfma_rate_probe(seconds=0.05, waves_per_cu=8, data="zeros")
+    mhz = r["mhz"]["mean"]
+    assert 500.0 < mhz < 2600.0, r
+    at_clock = 2500.0 * mhz / 2400.0
+    assert 0.5 * at_clock < r["tflops"] <= 1.02 * at_clock, r

@@ -46,8 +46,9 @@ for w in range(NW):
         code, a, b, c = [int(v) for v in d[w, s]]
         if a == 0:
             continue
-        pr = (code >> 32) - 1
-        recs.append((w, s, (code >> 24) & 0xff, code & 0xffffff, pr, (a - t0) * 0.01, (b - t0) * 0.01 if b else None, (c - t0) * 0.01))
+        pr = ((code >> 32) & 15) - 1
+        recs.append((w, s, (code >> 24) & 0xff, code & 0xffffff, pr, (a - t0) * 0.01, (b - t0) * 0.01 if b else None, (c - t0) * 0.01,
+                     (code >> 36) & 0xfffffff))  # last: s_memtime ticks over the main loop
 end = max(r[7] for r in recs)
 print("workgroups %d, tiles %d (+ %d empty slots), makespan %.1f us" % (NW, sum(1 for r in recs if r[4] >= 0), sum(1 for r in recs if r[4] < 0), end))
 busy = {}
@@ -70,6 +71,9 @@ for pi, oi in enumerate(order):
     print("%-10s K=%6d tiles %4d  tile time min %.1f med %.1f max %.1f us (%.2f TF/s per CU at the median)  loop med %.1f  epilogue med %.1f  start of first / last tile %.1f / %.1f us" % (
         names[oi][0], K, len(rs), dur[0], dur[len(dur) // 2], dur[-1], fl / dur[len(dur) // 2] / 1e6, loop[len(loop) // 2], epi[len(epi) // 2],
         min(r[5] for r in rs), max(r[5] for r in rs)))
+    mhz = sorted(r[8] / (r[6] - r[5]) for r in rs if r[6] and r[6] > r[5])
+    print("           s_memtime ticks per us of the main loop (the clock the shader actually ran at, MHz): min %.0f  median %.0f  max %.0f" % (
+        mhz[0], mhz[len(mhz) // 2], mhz[-1]))
     # groups: consecutive runs of 6 slots in one queue
     skews = []
     for x in range(8):

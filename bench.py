@@ -294,6 +294,11 @@ def main():
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-dropped", action="store_true",
+                    help="stochastic depth on the kept samples only (TransformerEncoder.skip_dropped_branches): the timed step does not "
+                         "compute the branch outputs the reference multiplies by zero; default: the reference's arithmetic")
+    ap.add_argument("--no-skip-leg", action="store_true",
+                    help="single-GPU headline config: do not time the extra leg with skip_dropped_branches that is reported beside `value`")
     ap.add_argument("--no-power-probe", action="store_true", help="skip the 1 s register-only MFMA loop behind roofline.power_limited_peak")
     ap.add_argument("--objective", choices=["contrastive", "pretrain-vl", "pretrain-al"], default="contrastive",
                     help="config 3 only: contrastive = the headline tri-modal ITC+ATC step; pretrain-vl = the full image-text "
@@ -416,6 +421,8 @@ def main():
     if micro:
         model = model.float()  # CPU: the torch path of the mirrors in fp32
     model = model.train() if train else model.eval()
+    if args.skip_dropped:
+        model.encoder_wrapper.fusion_model.skip_dropped_branches = True
     nparams = sum(p.numel() for p in model.parameters())
     bkw = dict(text_len=15, dtype=torch.float32) if micro else {}
     batch, audio_S = synthetic_batch(args.batch, device, 3407 + rank, res=res, audio_seconds=audio_s, text=args.config != 1, **bkw)
@@ -586,6 +593,27 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = hip.profile_kernels.collect(4) if profiled_steps else None
+    skip_leg = None
+    fusion = getattr(getattr(model, "encoder_wrapper", None), "fusion_model", None)
+    if (train and world == 1 and not micro and args.config == 3 and not full and not args.skip_dropped and not args.no_skip_leg
+            and graph is None and fusion is not None and not args.recompute):
+        # second leg, outside `value`: the same step with every residual branch computed for the samples stochastic depth keeps only
+        fusion.skip_dropped_branches = True
+        for _ in range(2):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loss2 = step()
+        sync()
+        dt2 = time.perf_counter() - t1
+        fusion.skip_dropped_branches = False
+        skip_leg = {"ms_per_step": dt2 / args.steps * 1e3, "value": args.batch * args.steps / dt2, "unit": "samples/s",
+                    "steps": args.steps, "warmup": 2, "final_loss": float(loss2.float().mean().item()),
+                    "what": "TransformerEncoder.skip_dropped_branches: every residual branch runs on the packed rows of the samples its "
+                            "drop-path mask keeps (op_rows_gather / op_rows_merge); the reference computes all samples and multiplies the "
+                            "dropped ones by zero (transformer_layer.py:78-88) -- `value` above does the same.  drop_path_rate 0.4 over "
+                            "linspace(0, 0.4, 40): a fifth of the branch work on average"}
     order_same = None
     if args.check_replicas and world > 1:
         chk = torch.stack([flat.params.double().sum(), flat.params.double().abs().sum(), opt.exp_avg.double().sum()])
@@ -645,6 +673,11 @@ def main():
         }
         if sweep:
             out["config"]["sweep"] = sweep
+        if train:
+            out["config"]["stochastic_depth"] = ("branches of dropped samples are not computed (--skip-dropped)" if args.skip_dropped
+                                                 else "reference arithmetic: every sample computed, dropped ones multiplied by zero")
+        if skip_leg is not None:
+            out["skip_dropped_branches"] = skip_leg
         if micro:
             out["metric"] = "NOT A MEASUREMENT: CPU control-flow run of the data-parallel step (micro model, gloo)"
             out["dtype"], out["roofline"] = "f32 (torch path on CPU)", None

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, 16-byte rule of op_gemm_tn_grouped's C */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -264,6 +264,24 @@ int op_adamw_step_groups(void* p, const void* g, float* m, float* v, int64_t num
 /* out[0] = sum of squares of a bf16 vector in fp32 (the global gradient norm of fairseq/fairseq/utils.py:349-391 over the
  * flat gradient buffer; feeds op_adamw_step's device-side clip coefficient, trainer.py:929).  workspace: 1024 floats. */
 int op_sqnorm(const void* x, int64_t numel, float* workspace, float* out, void* stream);
+
+/* ---- stochastic depth without the multiplications by zero ------------------------------------------------------------
+ * The reference multiplies the branch output of a dropped sample by 0 (transformer_layer.py:78-88: fused_dropout_res).  These two
+ * entries pack the rows of the samples a residual branch KEEPS into a smaller matrix (the branch then runs on that alone) and merge
+ * its result back.  Per segment i < nseg (<= 4; a segment = the B samples x S tokens of one modality inside the packed activation
+ * matrix), host arrays: src_row0 (first row in the full matrix), dst_row0 (first row in the packed matrix), S, n_kept, dst_rows
+ * (>= n_kept * S, rounded up by the caller; the surplus rows are written as ZEROS so that they add nothing to a weight gradient),
+ * n_samples, list_off (start of the segment's list inside `list`, a DEVICE int32 array).
+ *   op_rows_gather: list = the kept sample numbers, ascending:  dst[dst_row0 + j*S + t] = src[src_row0 + list[j]*S + t].
+ *   op_rows_merge:  list = per sample its position among the kept ones or -1:  out[r] = upd[dst_row0 + list[sample]*S + t] for
+ *                   kept samples, base[r] otherwise; out may be base (then only the kept rows are written).
+ * bf16 rows of `cols` elements (cols % 8 == 0), densely packed. */
+int op_rows_gather(const void* src, void* dst, const int* list, int64_t nseg, const int64_t* src_row0, const int64_t* dst_row0,
+                   const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples, const int64_t* list_off,
+                   int64_t dst_total, int64_t cols, void* stream);
+int op_rows_merge(const void* base, const void* upd, void* out, const int* list, int64_t nseg, const int64_t* src_row0,
+                  const int64_t* dst_row0, const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples,
+                  const int64_t* list_off, int64_t total, int64_t cols, void* stream);
 
 /* ---- hardware-semantics probes (test infrastructure; tests/test_probes_gpu.py) --------------------------------------- */
 int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream);

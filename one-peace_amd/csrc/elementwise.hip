@@ -3,6 +3,7 @@
 // All move 16-byte vectors per lane, accumulate in fp32 and are deterministic (two-stage reductions, no
 // floating-point atomics except the relative-position table scatter which is documented below).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -575,6 +576,68 @@ inline int ew_grid(int64_t work_items) {
   return (int)b;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Stochastic depth without the multiplications by zero (transformer_layer.py:78-88: a dropped sample's branch output is
+// multiplied by 0 before it is added to the residual).  The rows of the samples a residual branch KEEPS are packed into a
+// smaller matrix, the branch runs on that, and its result is merged back into the full activation matrix:
+//   gather:  dst[seg.dst_row0 + j*S + t] = src[seg.src_row0 + kept[j]*S + t]   j < n_kept;  the rest of the segment's dst rows = 0
+//            (each segment is padded to a multiple of 64 rows: the weight-gradient kernels want K % 64 == 0, and 0-rows add 0)
+//   merge:   out[r] = upd[seg.dst_row0 + inv[sample]*S + t]  if the sample of row r is kept (inv >= 0), else base[r]
+// One wave per row, 16-byte vectors; `list` holds the int32 kept[] lists (gather) or inv[] lists (merge) of the segments.
+// ------------------------------------------------------------------------------------------------------------
+struct RowsSeg { int64_t src_row0, dst_row0; int S, n_kept, dst_rows, n_samples, list_off, pad_; };
+struct RowsSegs { int nseg, pad_; RowsSeg seg[4]; };
+
+__global__ __launch_bounds__(256) void rows_gather_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                          const int* __restrict__ list, const RowsSegs d, int64_t dst_total, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int n8 = cols / 8;
+  for (int64_t rc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); rc < dst_total; rc += (int64_t)gridDim.x * 4) {
+    int64_t from = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < d.nseg && rc >= d.seg[i].dst_row0 && rc < d.seg[i].dst_row0 + d.seg[i].dst_rows) {
+        const int local = (int)(rc - d.seg[i].dst_row0);
+        const int j = local / d.seg[i].S;
+        if (j < d.seg[i].n_kept) from = d.seg[i].src_row0 + (int64_t)list[d.seg[i].list_off + j] * d.seg[i].S + (local - j * d.seg[i].S);
+      }
+    }
+    bf16x8* o = reinterpret_cast<bf16x8*>(dst + rc * cols);
+    if (from >= 0) {
+      const bf16x8* in = reinterpret_cast<const bf16x8*>(src + from * cols);
+      for (int c = lane; c < n8; c += 64) o[c] = in[c];
+    } else {
+      bf16x8 z;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = (bf16_t)0.f;
+      for (int c = lane; c < n8; c += 64) o[c] = z;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_merge_kernel(const bf16_t* __restrict__ base, const bf16_t* __restrict__ upd,
+                                                         bf16_t* __restrict__ out, const int* __restrict__ list, const RowsSegs d,
+                                                         int64_t total, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int n8 = cols / 8;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < total; r += (int64_t)gridDim.x * 4) {
+    int64_t from = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < d.nseg && r >= d.seg[i].src_row0 && r < d.seg[i].src_row0 + (int64_t)d.seg[i].n_samples * d.seg[i].S) {
+        const int local = (int)(r - d.seg[i].src_row0);
+        const int smp = local / d.seg[i].S;
+        const int j = list[d.seg[i].list_off + smp];
+        if (j >= 0) from = d.seg[i].dst_row0 + (int64_t)j * d.seg[i].S + (local - smp * d.seg[i].S);
+      }
+    }
+    if (from < 0 && out == base) continue;  // in place: rows of dropped samples stay what they are
+    const bf16x8* in = reinterpret_cast<const bf16x8*>(from >= 0 ? upd + from * cols : base + r * cols);
+    bf16x8* o = reinterpret_cast<bf16x8*>(out + r * cols);
+    for (int c = lane; c < n8; c += 64) o[c] = in[c];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -847,6 +910,55 @@ int op_relpos_bias_bwd(const float* dbias, const int* bucket, int64_t bucket_ld,
   OP_CHECK_ARG(dbias && bucket && dtable, "relpos_bias_bwd: null pointer");
   hipLaunchKernelGGL(relpos_bwd_kernel, dim3(ew_grid(S * S)), dim3(256), 0, (hipStream_t)stream, dbias, bucket, bucket_ld,
                      dtable, (int)heads, (int)S, (int)Spad);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// Row packing of the samples a stochastic-depth branch keeps (see rows_gather_kernel).  Per segment i < nseg (<= 4), host arrays:
+// src_row0 (first row of the segment in the full matrix), dst_row0 (first row in the packed matrix), S (rows per sample),
+// n_kept, dst_rows (n_kept * S rounded up by the caller; the surplus rows are written as zeros), n_samples, list_off (where the
+// segment's list starts in `list`).  `list` (device int32): gather: the kept sample numbers in ascending order; merge: for every
+// sample of the segment its position among the kept ones or -1.  cols % 8 == 0, rows 16-byte aligned.
+static int rows_segs(RowsSegs& d, int64_t nseg, const int64_t* src_row0, const int64_t* dst_row0, const int64_t* S, const int64_t* n_kept,
+                     const int64_t* dst_rows, const int64_t* n_samples, const int64_t* list_off) {
+  if (nseg < 1 || nseg > 4 || !src_row0 || !dst_row0 || !S || !n_kept || !dst_rows || !n_samples || !list_off) return 0;
+  memset(&d, 0, sizeof(d));
+  d.nseg = (int)nseg;
+  for (int i = 0; i < (int)nseg; ++i) {
+    if (S[i] < 1 || n_kept[i] < 0 || n_kept[i] > n_samples[i] || dst_rows[i] < n_kept[i] * S[i]) return 0;
+    d.seg[i].src_row0 = src_row0[i]; d.seg[i].dst_row0 = dst_row0[i]; d.seg[i].S = (int)S[i]; d.seg[i].n_kept = (int)n_kept[i];
+    d.seg[i].dst_rows = (int)dst_rows[i]; d.seg[i].n_samples = (int)n_samples[i]; d.seg[i].list_off = (int)list_off[i];
+  }
+  return 1;
+}
+
+int op_rows_gather(const void* src, void* dst, const int* list, int64_t nseg, const int64_t* src_row0, const int64_t* dst_row0,
+                   const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples, const int64_t* list_off,
+                   int64_t dst_total, int64_t cols, void* stream) {
+  RowsSegs d;
+  OP_CHECK_ARG(src && dst && list && cols > 0 && cols % 8 == 0, "rows_gather: bad argument");
+  OP_CHECK_ARG(rows_segs(d, nseg, src_row0, dst_row0, S, n_kept, dst_rows, n_samples, list_off), "rows_gather: bad segment table");
+  if (dst_total == 0) return OP_OK;
+  int64_t nb = (dst_total + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(rows_gather_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, list, d,
+                     dst_total, (int)cols);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// out may be `base` itself (then only the rows of kept samples are written).
+int op_rows_merge(const void* base, const void* upd, void* out, const int* list, int64_t nseg, const int64_t* src_row0,
+                  const int64_t* dst_row0, const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples,
+                  const int64_t* list_off, int64_t total, int64_t cols, void* stream) {
+  RowsSegs d;
+  OP_CHECK_ARG(base && upd && out && list && cols > 0 && cols % 8 == 0, "rows_merge: bad argument");
+  OP_CHECK_ARG(rows_segs(d, nseg, src_row0, dst_row0, S, n_kept, dst_rows, n_samples, list_off), "rows_merge: bad segment table");
+  if (total == 0) return OP_OK;
+  int64_t nb = (total + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(rows_merge_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)base, (const bf16_t*)upd,
+                     (bf16_t*)out, list, d, total, (int)cols);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

@@ -76,6 +76,8 @@ SIGNATURES = {
     "op_probe_glds": (c_int, [P, P, c_int, P, P]),
     "op_probe_mfma_f8": (c_int, [P, P, P, P, P, c_int, P]),
     "op_probe_mfma_rate": (c_int, [P, P, P, c_int, c_int, P]),
+    "op_rows_gather": (c_int, [P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
+    "op_rows_merge": (c_int, [P, P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
 }
 
 
@@ -738,6 +740,77 @@ class profile_kernels:
         work = (c_double * n)()
         lib().op_prof_collect(ms, cnt, work, n)
         return [dict(ms=ms[i], count=cnt[i], work=work[i]) for i in range(n)]
+
+
+class KeptRows:
+    """The samples ONE residual branch of ONE layer keeps under stochastic depth, as the row packing op_rows_gather / op_rows_merge
+    work with.  segs: [(src_row0, S, n_samples, kept sample numbers ascending)] per segment of the packed activation matrix;
+    `lists`: the device int32 tensor that holds, from `base` on, for every segment its kept list followed by its inverse list
+    (position among the kept samples or -1) -- built for the whole stack at once by `pack_kept_lists` (one host-to-device copy per
+    step).  Every segment's packed rows are rounded up to a multiple of `pad` (zero rows: the weight-gradient kernels want
+    K % 64 == 0, whole 256-row tiles avoid tail launches)."""
+
+    def __init__(self, segs, lists, base, full_rows, scale, pad=256):
+        n = len(segs)
+        assert 1 <= n <= 4
+        self.lists, self.full_rows, self.scale, self.nseg = lists, int(full_rows), float(scale), n
+        self.S = [int(s[1]) for s in segs]
+        self.n_samples = [int(s[2]) for s in segs]
+        self.n_kept = [len(s[3]) for s in segs]
+        self.src_row0 = [int(s[0]) for s in segs]
+        self.dst_rows = [-(-(k * S) // pad) * pad for k, S in zip(self.n_kept, self.S)]
+        self.dst_row0, self.off_kept, self.off_inv = [], [], []
+        r, o = 0, int(base)
+        for k, ns, dr in zip(self.n_kept, self.n_samples, self.dst_rows):
+            self.dst_row0.append(r)
+            self.off_kept.append(o)
+            self.off_inv.append(o + k)
+            r, o = r + dr, o + k + ns
+        self.total, self.list_end = r, o
+        arr = lambda v: (c_int64 * n)(*v)  # noqa: E731
+        self._c = tuple(arr(v) for v in (self.src_row0, self.dst_row0, self.S, self.n_kept, self.dst_rows, self.n_samples))
+        self._c_kept, self._c_inv = arr(self.off_kept), arr(self.off_inv)
+
+    def kept_list(self, i):
+        """Device int32 view: the kept sample numbers of segment i (e.g. to index_select the key-padding rows)."""
+        return self.lists[self.off_kept[i]:self.off_kept[i] + self.n_kept[i]]
+
+
+def pack_kept_lists(plans):
+    """plans: [[(src_row0, S, n_samples, kept list)] per segment] per branch -> (int32 CPU tensor with all kept / inverse lists, the
+    offset of each plan's first entry).  Host only."""
+    out, bases = [], []
+    for segs in plans:
+        bases.append(len(out))
+        for _, _, ns, kept in segs:
+            inv = [-1] * ns
+            for j, smp in enumerate(kept):
+                inv[smp] = j
+            out.extend(int(v) for v in kept)
+            out.extend(inv)
+    return torch.tensor(out if out else [0], dtype=torch.int32), bases
+
+
+def rows_gather(src, kr):
+    """Pack the rows of the kept samples: [kr.total, cols] (zero rows where a segment is rounded up)."""
+    assert src.dim() == 2 and src.is_contiguous() and src.shape[0] == kr.full_rows and src.dtype == torch.bfloat16
+    dst = torch.empty(kr.total, src.shape[1], dtype=src.dtype, device=src.device)
+    c = kr._c
+    _check(lib().op_rows_gather(ptr(src), ptr(dst), ptr(kr.lists), kr.nseg, c[0], c[1], c[2], c[3], c[4], c[5], kr._c_kept, kr.total,
+                                src.shape[1], stream()), "op_rows_gather")
+    return dst
+
+
+def rows_merge(base, upd, kr, out=None):
+    """base with the rows of the kept samples replaced by the packed rows `upd`; out=base: in place."""
+    assert base.dim() == 2 and base.is_contiguous() and upd.is_contiguous() and base.shape[0] == kr.full_rows and upd.shape[0] == kr.total
+    assert base.dtype == torch.bfloat16 and upd.dtype == torch.bfloat16 and base.shape[1] == upd.shape[1]
+    if out is None:
+        out = torch.empty_like(base)
+    c = kr._c
+    _check(lib().op_rows_merge(ptr(base), ptr(upd), ptr(out), ptr(kr.lists), kr.nseg, c[0], c[1], c[2], c[3], c[4], c[5], kr._c_inv,
+                               kr.full_rows, base.shape[1], stream()), "op_rows_merge")
+    return out
 
 
 def mfma_rate_probe(seconds=1.0, waves_per_cu=8, data="normal", device=None):

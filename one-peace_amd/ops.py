@@ -401,6 +401,12 @@ class RelPosBias:
         (per-sample images: one slab per sample)."""
         if self.acc is None:
             self.acc = hip.attn_dbias_buffer(B, self.S, self.heads, self.Spad, self.image.device, per_sample=self.ids is not None)
+        elif self.ids is None:  # layers that skip their dropped samples call with different batch sizes: slab counts differ
+            need = hip.lib().op_attn_bwd_dbias_slabs(B, self.S, self.heads, hip.TUNE.attn_bwd())
+            if need > self.acc.shape[0]:
+                grown = torch.zeros(need, *self.acc.shape[1:], dtype=self.acc.dtype, device=self.acc.device)
+                grown[:self.acc.shape[0]] = self.acc
+                self.acc = grown
         return self.acc
 
 
@@ -495,19 +501,25 @@ LAYER_PARAMS = ATTN_PARAMS + FFN_PARAMS
 class StreamSeg:
     """One stream's rows inside a packed [sum B*S, H] activation matrix: B samples of S tokens starting at row `row0`, with their
     own relative-position bias handle (RelPosBias-like or None) and key-padding bytes.  A single-stream layer is one segment;
-    a lock-step pass over several modalities (transformer_encoder.forward_multi) has one per modality."""
-    __slots__ = ("name", "B", "S", "row0", "bias", "key_pad")
+    a lock-step pass over several modalities (transformer_encoder.forward_multi) has one per modality.  pad: rows behind the B*S
+    token rows that still belong to the segment (zero rows of a packed kept-sample matrix, hip.KeptRows): LayerNorms and GEMMs run
+    over them, the attention core does not."""
+    __slots__ = ("name", "B", "S", "row0", "bias", "key_pad", "pad")
 
-    def __init__(self, name, B, S, row0, bias=None, key_pad=None):
-        self.name, self.B, self.S, self.row0, self.bias, self.key_pad = name, B, S, row0, bias, key_pad
+    def __init__(self, name, B, S, row0, bias=None, key_pad=None, pad=0):
+        self.name, self.B, self.S, self.row0, self.bias, self.key_pad, self.pad = name, B, S, row0, bias, key_pad, pad
 
     @property
-    def rows(self):
+    def tokens(self):
         return self.B * self.S
 
     @property
+    def rows(self):
+        return self.B * self.S + self.pad
+
+    @property
     def end(self):
-        return self.row0 + self.B * self.S
+        return self.row0 + self.B * self.S + self.pad
 
     def frag(self, limit):
         return self.bias.frag if self.bias is not None and self.S <= limit else None
@@ -534,6 +546,8 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
                               sg.bias.image.detach() if sg.bias is not None else None, sg.key_pad, hip.attn_spad(sg.S), out=attn[r],
                               want_lse=keep, bias_frag=sg.frag(hip.ATTN_RESIDENT_MAX_S))
         lses.append(lse)
+        if sg.pad:  # rows of no sample: the out-proj weight gradient multiplies them with exact zeros, so they must be finite
+            attn[sg.end - sg.pad:sg.end].zero_()
     if P["aln_w"] is not None:
         aln, mean_a, rstd_a = hip.layernorm_fwd(attn, P["aln_w"], P["aln_b"], want_stats=keep)
     else:
@@ -715,17 +729,23 @@ class AttnBranchFn(torch.autograd.Function):
     row // rps, or None.  imgs: one bias image per segment (or None) -- only there to put the tables into the autograd graph."""
 
     @staticmethod
-    def forward(ctx, x2, segs, rowscale, rps, heads, save_acts, *rest):
+    def forward(ctx, x2, segs, rowscale, rps, heads, save_acts, kept, *rest):
         nseg = len(segs)
         params = rest[nseg:]
-        N, H = x2.shape
         P = dict(zip(ATTN_PARAMS, params))
-        scale = (H // heads) ** -0.5
         need_grad = any(ctx.needs_input_grad)
         keep = bool(save_acts) and need_grad
-        first_param = 6 + nseg
+        first_param = 7 + nseg
         needs = dict(zip(ATTN_PARAMS, ctx.needs_input_grad[first_param:]))
+        x_full = x2
+        if kept is not None:  # the branch runs on the rows of the samples it keeps (segs / rowscale describe THOSE rows)
+            x2 = hip.rows_gather(x_full, kept)
+        N, H = x2.shape
+        scale = (H // heads) ** -0.5
         x_mid, acts = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"])
+        if kept is not None:
+            x_mid = hip.rows_merge(x_full, x_mid, kept)
+        ctx.kept = kept
         ctx.segs, ctx.dims, ctx.n_params, ctx.first_param = segs, (N, H, heads, scale, rps), len(params), first_param
         ctx.direct = ()
         if need_grad:
@@ -757,6 +777,9 @@ class AttnBranchFn(torch.autograd.Function):
             _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True)
         if not dx_mid.is_contiguous():
             dx_mid = dx_mid.contiguous()
+        kept, dx_full = ctx.kept, dx_mid
+        if kept is not None:  # rows of dropped samples: the gradient passes through the skip connection untouched
+            dx_mid = hip.rows_gather(dx_full, kept)
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
         dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs)
@@ -785,6 +808,8 @@ class AttnBranchFn(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             for i, sg in enumerate(segs):
                 r = slice(sg.row0, sg.end)
+                if sg.pad:  # rows of no sample: zero gradient (they are operand rows of the q|k|v weight gradient)
+                    dqkv[sg.end - sg.pad:sg.end].zero_()
                 dparts = {n: dqkv[r, slot[n] * H:(slot[n] + 1) * H] for n in qkv_names}
                 _attn_backward(qkv[r], dattn[r], A["attn"][r], A["lse%d" % i], sg.B, sg.S, heads, scale,
                                sg.bias.image.detach() if sg.bias is not None else None, sg.bias.imageT if sg.bias is not None else None,
@@ -823,14 +848,16 @@ class AttnBranchFn(torch.autograd.Function):
                 if want:
                     _finish(direct, G, ("ln1_w", "ln1_b"), (dw_, db_), acc)
         if dx is None and need_x:  # nothing upstream of the residual wanted a gradient: only the skip connection carries one
-            dx = dx_mid
+            dx = dx_full
+        elif dx is not None and kept is not None:
+            dx = hip.rows_merge(dx_full, dx, kept)
         flush_wgrads()  # the layer's weight gradients (this branch's and the FFN branch's, which ran before it) as one launch
         grads = _return_grads(ATTN_PARAMS, params, G, direct)
         dimgs = []
         for sg, w in zip(segs, want_dbias):  # placeholders (see _RelPosImageFn.backward); the real gradients went into bias.acc
             img = sg.bias.image if sg.bias is not None else None
             dimgs.append(torch.zeros((), dtype=img.dtype, device=img.device).expand(img.shape) if w else None)
-        return (dx, None, None, None, None, None, *dimgs, *grads)
+        return (dx, None, None, None, None, None, None, *dimgs, *grads)
 
 
 class FfnBranchFn(torch.autograd.Function):
@@ -985,15 +1012,21 @@ class FfnBranchMultiFn(torch.autograd.Function):
         return out, acts
 
     @staticmethod
-    def forward(ctx, x2, segs, pss, save_acts, *params):
+    def forward(ctx, x2, segs, pss, save_acts, kept, *params):
         nseg = len(segs)
-        N, H = x2.shape
         Fd = params[3].shape[0]
         need_grad = any(ctx.needs_input_grad) and bool(int(save_acts) & 2)
         keep = bool(int(save_acts) & 1) and need_grad
-        needs = ctx.needs_input_grad[4:]
+        needs = ctx.needs_input_grad[5:]
         has_fln = params[5] is not None
+        x_full = x2
+        if kept is not None:  # the branch runs on the rows of the samples it keeps (segs / pss describe THOSE rows)
+            x2 = hip.rows_gather(x_full, kept)
+        N, H = x2.shape
         out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]), grad=bool(int(save_acts) & 2))
+        if kept is not None:
+            out = hip.rows_merge(x_full, out, kept)
+        ctx.kept = kept
         ctx.segs, ctx.n_params, ctx.dims = segs, len(params), (N, H, Fd)
         ctx.direct = ()
         names = list(FFN_SHARED) + ["%s@%d" % (n, i) for i in range(nseg) for n in FFN_OWN]
@@ -1019,7 +1052,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
         nseg = len(segs)
         N, H, Fd = ctx.dims
         P = dict(zip(names, params))
-        needs = {n: bool(ng) and q is not None for n, q, ng in zip(names, params, ctx.needs_input_grad[4:])}
+        needs = {n: bool(ng) and q is not None for n, q, ng in zip(names, params, ctx.needs_input_grad[5:])}
         need_x = bool(ctx.needs_input_grad[0])
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_f", "rstd_f", "y2", "gln", "xln2"))
@@ -1027,6 +1060,9 @@ class FfnBranchMultiFn(torch.autograd.Function):
             _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, True)
         if not dout.is_contiguous():
             dout = dout.contiguous()
+        kept, dout_full = ctx.kept, dout
+        if kept is not None:
+            dout = hip.rows_gather(dout_full, kept)
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
         has_fln = P["fln_w@0"] is not None
@@ -1104,17 +1140,40 @@ class FfnBranchMultiFn(torch.autograd.Function):
             if want:
                 _finish(direct, G, ("ln2_w", "ln2_b"), (dw_, db_), acc)
         if dx is None and need_x:
-            dx = dout
+            dx = dout_full
+        elif dx is not None and kept is not None:
+            dx = hip.rows_merge(dout_full, dx, kept)
         grads = _return_grads(names, params, G, direct)
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
-def ffn_branch_multi(x2, segs, pss, shared, own, save_acts=True):
-    """shared: (ln2_w, ln2_b, g2); own: per segment (w0, w1, fln_w, fln_b, w2, b2); save_acts False: recompute in backward."""
+def ffn_branch_multi(x2, segs, pss, shared, own, save_acts=True, kept=None):
+    """shared: (ln2_w, ln2_b, g2); own: per segment (w0, w1, fln_w, fln_b, w2, b2); save_acts False: recompute in backward.
+    kept (hip.KeptRows): as attn_branch_multi -- segs and pss describe the packed rows of the kept samples."""
     flat = list(shared)
     for o in own:
         flat += list(o)
-    return FfnBranchMultiFn.apply(x2, segs, tuple(pss), _save_flags(save_acts), *flat)
+    return FfnBranchMultiFn.apply(x2, segs, tuple(pss), _save_flags(save_acts), kept, *flat)
+
+
+_SCALE_ROWS = {}
+
+
+def kept_segments(kept, segs, device):
+    """The packed-row view of a branch that skips its dropped samples: ([StreamSeg] over the rows of hip.KeptRows `kept`, an fp32
+    vector of the drop-path multiplier 1/keep_prob long enough for every row- or sample-indexed use).  segs: the full-matrix
+    segments (bias handles and key-padding rows are taken from them; key padding is gathered per kept sample)."""
+    out = []
+    for i, sg in enumerate(segs):
+        key_pad = sg.key_pad.index_select(0, kept.kept_list(i)) if sg.key_pad is not None else None
+        out.append(StreamSeg(sg.name, kept.n_kept[i], sg.S, kept.dst_row0[i], sg.bias, key_pad, pad=kept.dst_rows[i] - kept.n_kept[i] * sg.S))
+    key = (device, kept.scale)
+    vec = _SCALE_ROWS.get(key)
+    if vec is None or vec.numel() < kept.total + 8:
+        if len(_SCALE_ROWS) > 256:
+            _SCALE_ROWS.clear()
+        vec = _SCALE_ROWS[key] = torch.full((max(kept.full_rows, kept.total) + 8,), kept.scale, dtype=torch.float32, device=device)
+    return out, vec
 
 
 def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag, dq, dk, dv):
@@ -1136,16 +1195,18 @@ def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):
     drop-path multipliers or None."""
     B, S, H = x.shape
     seg = StreamSeg("x", B, S, 0, bias, key_pad)
-    out = AttnBranchFn.apply(x.reshape(B * S, H), [seg], ps, S, heads, save_acts, bias.image if bias is not None else None, *params)
+    out = AttnBranchFn.apply(x.reshape(B * S, H), [seg], ps, S, heads, save_acts, None, bias.image if bias is not None else None, *params)
     return out.view(B, S, H)
 
 
-def attn_branch_multi(x2, segs, ps_rows, heads, params, save_acts=False):
+def attn_branch_multi(x2, segs, ps_rows, heads, params, save_acts=False, kept=None):
     """Lock-step pass: x2 [sum rows, H] holds the rows of several streams (segs); ps_rows: fp32 [sum rows] per-row drop-path
     multipliers or None.  The attention-branch weights are modality-shared (transformer_layer.py:111-138), so LayerNorm, q|k|v,
-    sub-LayerNorm and out-proj (and, in backward, their input- and weight-gradient GEMMs) are ONE launch over all rows."""
-    return AttnBranchFn.apply(x2, segs, ps_rows, 1, heads, save_acts, *[sg.bias.image if sg.bias is not None else None for sg in segs],
-                              *params)
+    sub-LayerNorm and out-proj (and, in backward, their input- and weight-gradient GEMMs) are ONE launch over all rows.
+    kept (hip.KeptRows): the branch runs only on the samples stochastic depth keeps -- segs and ps_rows then describe the PACKED
+    rows (kept_segments), x2 stays the full matrix; rows of dropped samples pass through unchanged, forward and backward."""
+    return AttnBranchFn.apply(x2, segs, ps_rows, 1, heads, save_acts, kept,
+                              *[sg.bias.image if sg.bias is not None else None for sg in segs], *params)
 
 
 def _save_flags(save_acts):

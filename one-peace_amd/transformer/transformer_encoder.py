@@ -9,6 +9,7 @@ MI355X path (bf16; single-modality and joint vl/al streams): activations stay ba
 joint stream, the block-diagonal pair of tables) becomes one ``[heads, S, Spad]`` image and key padding a ``[B, Spad]``
 byte mask -- and every block is two fused HIP functions (attention branch, per-modality FFN branch)."""
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -51,6 +52,11 @@ class TransformerEncoder(nn.Module):
         self.text_layer_norm = LayerNorm(cfg.embed_dim) if cfg.use_text_moe and use_text_norm else None
         self.image_layer_norm = LayerNorm(cfg.embed_dim) if cfg.use_image_moe and use_image_norm else None
         self.audio_layer_norm = LayerNorm(cfg.embed_dim) if cfg.use_audio_moe and use_audio_norm else None
+        # Stochastic depth in the lock-step pass: compute a residual branch only for the samples it keeps (the reference multiplies the
+        # branch output of the others by zero, transformer_layer.py:78-88; linspace(0, drop_path_rate) over the layers = a fifth of all
+        # branch work at 0.4).  Off by default: the default step performs the reference's arithmetic, zeros included.
+        self.skip_dropped_branches = os.environ.get("ONEPEACE_SKIP_DROPPED", "0") == "1"
+        self.kept_rows_pad = 256  # packed rows per segment are rounded up to whole 256-row GEMM tiles (zero rows)
 
     def build_encoder_layer(self, cfg, drop_path_rate=0.0):
         return TransformerEncoderLayer(cfg, drop_path_rate=drop_path_rate)
@@ -175,7 +181,11 @@ class TransformerEncoder(nn.Module):
             samples += B
         x2 = torch.cat(xs, dim=0)
         dev = x2.device
-        scales = self._draw_path_scales(samples, dev)
+        packable = all(getattr(h, "ids", None) is None and not isinstance(h, ops.DenseBias) for hs in per_layer for h in hs)
+        if self.skip_dropped_branches and packable:
+            scales, plans = self._draw_kept_plans(segs, samples, row0, dev)
+        else:
+            scales, plans = self._draw_path_scales(samples, dev), None
         row2sample = None
         if scales is not None:
             row2sample = torch.cat([torch.arange(B, device=dev).repeat_interleave(S) + s0 for (_, B, S, _, _, s0) in segs])
@@ -189,12 +199,49 @@ class TransformerEncoder(nn.Module):
                 ps1, ps2 = scales[idx]
             ps1_rows = ps1.index_select(0, row2sample) if ps1 is not None else None
             ps2s = [ps2[s0:s0 + B] if ps2 is not None else None for (_, B, _, _, _, s0) in segs]
-            x2 = layer.forward_fused_multi(x2, lsegs, ps1_rows, ps2s)
+            x2 = layer.forward_fused_multi(x2, lsegs, ps1_rows, ps2s, kept=plans[idx] if plans is not None else (None, None))
         out = {}
         for (m, B, S, r0, _, _) in segs:
             norm, rows = getattr(self, m + "_layer_norm"), x2[r0:r0 + B * S]
             out[m] = (norm(rows) if norm is not None else rows).view(B, S, -1)
         return out
+
+    def _draw_kept_plans(self, segs, samples, rows, device):
+        """Stochastic depth for `skip_dropped_branches`: the Bernoulli masks of the whole stack are drawn on the HOST (the packed
+        row counts size every launch of a layer, and a device-side draw would cost a synchronisation per step), per layer and branch
+        the kept sample numbers of every segment go to the device in ONE int32 copy, and each branch gets a hip.KeptRows.
+        A branch in which some segment keeps no sample at all falls back to the multiplier form (scales).  Returns
+        (scales or None, [(KeptRows | None, KeptRows | None)] per layer) -- (None, None) outside training / without drop-path."""
+        if not self.training:
+            return None, None
+        probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers]
+        if max(probs, default=0.0) <= 0.0:
+            return None, None
+        mask = self._draw_keep_mask(probs, samples)
+        todo, dense = [], {}
+        for i, p in enumerate(probs):
+            for b in range(2):
+                if p <= 0.0:
+                    continue
+                per_seg = [(r0, S, B, torch.nonzero(mask[i, b, s0:s0 + B]).flatten().tolist()) for (_, B, S, r0, _, s0) in segs]
+                if all(len(t[3]) > 0 for t in per_seg):
+                    todo.append(((i, b), per_seg))
+                else:
+                    dense[(i, b)] = (mask[i, b].float() / (1.0 - p)).to(device)
+        lists, bases = hip.pack_kept_lists([t[1] for t in todo])
+        lists = lists.to(device, non_blocking=True)
+        kept = {key: hip.KeptRows(per_seg, lists, base, rows, 1.0 / (1.0 - probs[key[0]]), pad=self.kept_rows_pad)
+                for (key, per_seg), base in zip(todo, bases)}
+        plans = [(kept.get((i, 0)), kept.get((i, 1))) for i in range(len(probs))]
+        scales = [(dense.get((i, 0)), dense.get((i, 1))) for i in range(len(probs))] if dense else None
+        return scales, plans
+
+    @staticmethod
+    def _draw_keep_mask(probs, samples):
+        """bool [layers, 2 branches, samples] on the host: True = the sample keeps the branch (CPU generator: reproducible under
+        torch.manual_seed)."""
+        keep = 1.0 - torch.tensor(probs, dtype=torch.float32).view(-1, 1, 1)
+        return torch.bernoulli(keep.expand(-1, 2, samples)).bool()
 
     def _draw_path_scales(self, B, device):
         """Per-sample stochastic-depth multipliers of the whole stack in ONE draw (transformer_layer.py:78-85 draws a fresh

@@ -138,15 +138,26 @@ class TransformerEncoderLayer(nn.Module):
         parts = (x[:, :n_text].contiguous(), x[:, n_text:].contiguous())
         return torch.cat([ops.ffn_branch(part, ps2, self.ffn_params(m), keep) for part, m in zip(parts, streams)], dim=1)
 
-    def forward_fused_multi(self, x2, segs, ps1_rows, ps2s):
+    def forward_fused_multi(self, x2, segs, ps1_rows, ps2s, kept=(None, None)):
         """Lock-step pass over several single-modality streams: x2 [sum rows, H] packs the rows of the streams in `segs`
         (ops.StreamSeg, named by modality).  The attention branch is modality-shared, so it runs once over all rows; every segment
         then goes through its own FFN.  ps1_rows: fp32 [sum rows] per-row drop-path multipliers of the attention branch or None;
-        ps2s: per segment fp32 [B] multipliers of the FFN branch or None."""
+        ps2s: per segment fp32 [B] multipliers of the FFN branch or None.  kept: per branch a hip.KeptRows (or None): the branch is
+        computed for the samples stochastic depth keeps only (the reference multiplies the others' branch output by zero,
+        transformer_layer.py:78-88); its ps argument is then ignored."""
         keep = not getattr(self.cfg, "checkpoint_activations", False)
-        x2 = ops.attn_branch_multi(x2, segs, ps1_rows, self.self_attn.num_heads, self.attn_params(), keep)
+        k1, k2 = kept
+        if k1 is not None:
+            csegs, vec = ops.kept_segments(k1, segs, x2.device)
+            x2 = ops.attn_branch_multi(x2, csegs, vec, self.self_attn.num_heads, self.attn_params(), keep, kept=k1)
+        else:
+            x2 = ops.attn_branch_multi(x2, segs, ps1_rows, self.self_attn.num_heads, self.attn_params(), keep)
         own = [self.ffn_params(sg.name)[2:8] for sg in segs]
-        return ops.ffn_branch_multi(x2, segs, ps2s, (self.final_layer_norm.weight, self.final_layer_norm.bias, self.gamma_2), own, keep)
+        shared = (self.final_layer_norm.weight, self.final_layer_norm.bias, self.gamma_2)
+        if k2 is not None:
+            csegs, vec = ops.kept_segments(k2, segs, x2.device)
+            return ops.ffn_branch_multi(x2, csegs, [vec] * len(segs), shared, own, keep, kept=k2)
+        return ops.ffn_branch_multi(x2, segs, ps2s, shared, own, keep)
 
     def upgrade_state_dict_named(self, state_dict, name):
         """Legacy key renames + fill-in of missing keys (reference transformer_layer.py:230-248)."""

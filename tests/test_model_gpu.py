@@ -976,6 +976,80 @@ def test_lock_step_pass_matches_one_forward_per_modality(flat, drop_path, recomp
     assert n_exact > 40 and n_close > 20
 
 
+@pytest.mark.parametrize("flat,recompute", [(False, False), (True, False), (True, True)])
+def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(flat, recompute):
+    """TransformerEncoder.skip_dropped_branches: every residual branch of the lock-step pass is computed for the samples stochastic
+    depth KEEPS only (packed rows, hip.KeptRows) instead of for all samples with the dropped ones multiplied by zero
+    (transformer_layer.py:78-88).  Same masks in both runs: the loss and every gradient must agree within bf16 rounding (the
+    packed GEMMs see other row counts, so tile shapes / split-K may differ; weight gradients sum the same non-zero terms in another
+    order).  The masks include a layer without drop-path, a branch that keeps every sample, one that drops a whole modality
+    (multiplier fallback for that branch) and one that keeps a single sample of a segment."""
+    from one_peace_amd import hip as hipm
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.transformer import transformer_encoder as TE
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=4, attention_heads=2, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B, L, rate = 6, 4, 0.45
+    inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    probs = torch.linspace(0, rate, L).tolist()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mask = torch.bernoulli(torch.full((L, 2, 3 * B), 0.6), generator=g).bool()
+    mask[1, 0] = True                    # a branch that keeps everything
+    mask[2, 0, :B] = False               # ... that drops the whole text segment (samples 0..B-1): multiplier fallback
+    mask[3, 1, B:2 * B] = False
+    mask[3, 1, B + 2] = True             # ... that keeps one image sample
+    orig_scales, orig_mask = TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask
+
+    def fixed_scales(self, nb, device):
+        assert nb == 3 * B
+        return [(None, None) if p <= 0.0 else ((mask[i, 0].float() / (1 - p)).to(device), (mask[i, 1].float() / (1 - p)).to(device))
+                for i, p in enumerate(probs)]
+    TE.TransformerEncoder._draw_path_scales = fixed_scales
+    TE.TransformerEncoder._draw_keep_mask = staticmethod(lambda pr, n: mask.clone())
+    res = {}
+    try:
+        for skip in (False, True):
+            enc = one_peace_encoder_config(drop_path_rate=rate, layer_scale_init_value=1e-1, checkpoint_activations=recompute, **cfg)
+            torch.manual_seed(0)
+            m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+            m = m.to(DEV).to(torch.bfloat16).train()
+            m.encoder_wrapper.fusion_model.skip_dropped_branches = skip
+            fl = FlatParameters(m) if flat else None
+            packed = {"n": 0}
+            orig_gather = hipm.rows_gather
+
+            def counted(src, kr):
+                packed["n"] += 1
+                return orig_gather(src, kr)
+            hipm.rows_gather = counted
+            try:
+                loss, _, log = TriModalContrastiveCriterion(None, 0.0, lock_step=True)(m, {"net_input": inp, "nsentences": B})
+                (fl.zero_grad() if fl is not None else m.zero_grad())
+                loss.backward()
+                torch.cuda.synchronize()
+            finally:
+                hipm.rows_gather = orig_gather
+            # 3 layers with drop-path x 2 branches, minus the fallback branch: 5 packed branches, each gathered in forward and backward
+            # (+ once more per branch when the forward is recomputed... the recomputation runs on the saved packed rows: no gather)
+            assert packed["n"] == (10 if skip else 0), packed
+            res[skip] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+    finally:
+        TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask = orig_scales, orig_mask
+    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    worst = ("", 0.0)
+    for n, gd in res[False][1].items():
+        e = float((res[True][1][n] - gd).norm()) / (float(gd.norm()) + 1e-6)
+        worst = max(worst, (n, e), key=lambda t: t[1])
+        assert e <= 3e-2, (n, e)
+    assert len(res[True][1]) > 60, len(res[True][1])
+
+
 def test_vision_tower_40_layers_matches_reference(golden_dir):
     """tests/golden/deep_vision40.pt: the reference's FULL-DEPTH image tower -- 40 layers at the 4B layer dimensions (1.5 B
     parameters, BASELINE configs[1]) -- one 256^2 image, forward, run on CPU in fp32 through ref_shim.  The HIP path in bf16 against

@@ -1295,3 +1295,35 @@ def test_fp8_ffn_branch_forward_close_to_bf16_and_backward_unchanged():
     assert rel_fro(outs[1] - x.float(), outs[0] - x.float()) <= 1.5 * FP8_TOL   # the branch itself, without the residual
     for g8, g16 in zip(grads[1], grads[0]):
         assert g8.isfinite().all() and rel_fro(g8, g16) <= 0.15  # same bf16 backward kernels on slightly different activations
+
+
+def test_rows_gather_and_merge_of_kept_samples():
+    """op_rows_gather / op_rows_merge (stochastic depth on the samples a branch keeps): three segments with their own tokens per
+    sample, kept lists incl. 'all', 'one' and 'the last', packed rows rounded up to 64 with ZERO rows behind every segment;
+    the merge replaces exactly the kept samples' rows, out of place and in place."""
+    hip = hipmod()
+    cols = 136
+    segs_full = [(0, 5, 4), (20, 7, 3), (41, 3, 6)]          # (first row, tokens per sample, samples)
+    kept = [[0, 2, 3], [1], [0, 1, 2, 3, 4, 5]]
+    rows = 41 + 3 * 6
+    lists, bases = hip.pack_kept_lists([[(r0, S, n, k) for (r0, S, n), k in zip(segs_full, kept)]])
+    kr = hip.KeptRows([(r0, S, n, k) for (r0, S, n), k in zip(segs_full, kept)], lists.to("cuda"), bases[0], rows, 1.25, pad=64)
+    assert kr.dst_rows == [64, 64, 64] and kr.total == 192 and kr.n_kept == [3, 1, 6]
+    x = dev_bf16(rnd(rows, cols, seed=3))
+    packed = hip.rows_gather(x, kr)
+    want = torch.zeros(192, cols, dtype=torch.bfloat16, device="cuda")
+    for i, ((r0, S, n), k) in enumerate(zip(segs_full, kept)):
+        for j, smp in enumerate(k):
+            want[kr.dst_row0[i] + j * S:kr.dst_row0[i] + (j + 1) * S] = x[r0 + smp * S:r0 + (smp + 1) * S]
+    assert torch.equal(packed, want)
+    upd = dev_bf16(rnd(192, cols, seed=4))
+    merged = hip.rows_merge(x, upd, kr)
+    ref = x.clone()
+    for i, ((r0, S, n), k) in enumerate(zip(segs_full, kept)):
+        for j, smp in enumerate(k):
+            ref[r0 + smp * S:r0 + (smp + 1) * S] = upd[kr.dst_row0[i] + j * S:kr.dst_row0[i] + (j + 1) * S]
+    assert torch.equal(merged, ref)
+    inplace = x.clone()
+    hip.rows_merge(inplace, upd, kr, out=inplace)
+    assert torch.equal(inplace, ref)
+    torch.cuda.synchronize()

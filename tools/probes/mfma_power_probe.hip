@@ -4,7 +4,7 @@
 // gemm256w_tn_grouped_kernel did not get faster when 2 % of its time (the epilogue) was removed, and rocm-smi shows the package at
 // its 1400 W limit during the launch: is the dense-bf16 figure of the data sheet (2.5 PFLOP/s at 2.4 GHz) reachable at that limit at all?
 //   hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_power_probe tools/probes/mfma_power_probe.hip
-//   tools/probes/mfma_power_probe [waves per CU = 4] [data: 0 random normal, 1 zeros, 2 constant 1.0] [seconds = 1.0]
+//   tools/probes/mfma_power_probe [waves per CU = 4] [data: 0 random normal, 1 zeros, 2 constant 1.0] [seconds = 1.0] [shape 16 | 32]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -50,6 +50,48 @@ __global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, 
   }
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+// the same with v_mfma_f32_32x32x16_bf16 (32 768 flops per instruction, half the instructions and operand reads per flop): 2 x 2 fragments
+__global__ __launch_bounds__(256) void mfma_loop32(const bf16x8* __restrict__ in, float* out, unsigned long long* clk, int iters) {
+  const int lane = threadIdx.x & 63;
+  bf16x8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = in[(i * 64 + lane)];
+    b[i] = in[((4 + i) * 64 + lane)];
+  }
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i + 2 * (rep & 1)], b[j], acc[i][j], 0, 0, 0);
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+  if (threadIdx.x == 0) {
+    clk[2 * blockIdx.x] = c1 - c0;
+    clk[2 * blockIdx.x + 1] = r1 - r0;
+  }
+}
+
 static unsigned short f2bf(float f) {
   unsigned u;
   memcpy(&u, &f, 4);
@@ -60,6 +102,7 @@ int main(int argc, char** argv) {
   const int waves_per_cu = argc > 1 ? atoi(argv[1]) : 4;
   const int data = argc > 2 ? atoi(argv[2]) : 0;
   const double seconds = argc > 3 ? atof(argv[3]) : 1.0;
+  const int shape = argc > 4 ? atoi(argv[4]) : 16;  // 16: v_mfma_f32_16x16x32_bf16, 32: v_mfma_f32_32x32x16_bf16
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const int cus = prop.multiProcessorCount;
@@ -88,7 +131,8 @@ int main(int argc, char** argv) {
   float ms = 0.f;
   for (int pass = 0; pass < 3; ++pass) {  // pass 0 calibrates, pass 1 warms the package up, pass 2 is reported
     hipEventRecord(e0);
-    hipLaunchKernelGGL(mfma_loop, dim3(wgs), dim3(256), 0, 0, din, dout, dclk, iters);
+    if (shape == 32) hipLaunchKernelGGL(mfma_loop32, dim3(wgs), dim3(256), 0, 0, din, dout, dclk, iters);
+    else hipLaunchKernelGGL(mfma_loop, dim3(wgs), dim3(256), 0, 0, din, dout, dclk, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -103,15 +147,15 @@ int main(int argc, char** argv) {
     if (mhz < mhz_min) mhz_min = mhz;
     if (mhz > mhz_max) mhz_max = mhz;
   }
-  const double flops = (double)wgs * 4 * iters * 64.0 * 2.0 * 16 * 16 * 32;
+  const double flops = (double)wgs * 4 * iters * (shape == 32 ? 32.0 : 64.0) * 2.0 * (shape == 32 ? 32 * 32 * 16 : 16 * 16 * 32);
   const double tf = flops / (ms * 1e-3) / 1e12;
   const double mhz = mhz_sum / wgs;
   // one v_mfma_f32_16x16x32_bf16 = 16384 flops per wave; at 4 SIMDs per CU the data-sheet rate (2.5 PFLOP/s at 2400 MHz over 256 CUs)
   // is 16384 flops per 16 ... cycles: report the fraction of the issue slots at the MEASURED clock instead of assuming it
   const double peak_at_clock = 2500.0 * mhz / 2400.0 * cus / 256.0;
-  printf("CUs %d  workgroups %d (%d waves per CU)  data %s  %.1f ms: %.0f TFLOP/s; shader clock mean %.0f MHz (min %.0f max %.0f); "
+  printf("mfma %s  CUs %d  workgroups %d (%d waves per CU)  data %s  %.1f ms: %.0f TFLOP/s; shader clock mean %.0f MHz (min %.0f max %.0f); "
          "data-sheet rate at that clock %.0f TFLOP/s -> %.3f of the issue slots\n",
-         cus, wgs, 4 * ((waves_per_cu + 3) / 4), data == 0 ? "normal" : data == 1 ? "zeros" : "ones", ms, tf, mhz, mhz_min, mhz_max, peak_at_clock,
+         shape == 32 ? "32x32x16" : "16x16x32", cus, wgs, 4 * ((waves_per_cu + 3) / 4), data == 0 ? "normal" : data == 1 ? "zeros" : "ones", ms, tf, mhz, mhz_min, mhz_max, peak_at_clock,
          tf / peak_at_clock);
   return 0;
 }

@@ -217,6 +217,9 @@ class TransformerEncoder(nn.Module):
         probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers]
         if max(probs, default=0.0) <= 0.0:
             return None, None
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("skip_dropped_branches sizes its launches by the masks of the step: it cannot be captured in a hipGraph "
+                               "(graphs.TrainStepGraph needs the default multiplier form)")
         mask = self._draw_keep_mask(probs, samples)
         todo, dense = [], {}
         for i, p in enumerate(probs):

@@ -490,7 +490,7 @@ def test_lock_step_layer_4b_dimensions_against_the_fp32_oracle():
         live = (~pads[m]) if m in pads else torch.ones(b, s, dtype=torch.bool)
         check("lock-step 4B layer out " + m, y2[rows].view(b, s, H)[live.to(DEV)], ref_out[m][live], 1.5e-2)
         check("lock-step 4B layer dx " + m, x2d.grad[rows].view(b, s, H), ref_dx[m], 5e-2)
-        check("lock-step 4B layer dtable " + m, tabs[m].grad, ref_dt[m], 5e-2 if m != "audio" else 1.2e-1)
+        check("lock-step 4B layer dtable " + m, tabs[m].grad, ref_dt[m], 5e-2)  # (audio: 8.3e-3 measured at this size)
     n = 0
     for name, q in mdev.named_parameters():
         if name in g32 and float(g32[name].norm()) > 1e-7:

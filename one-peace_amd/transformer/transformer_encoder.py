@@ -90,6 +90,14 @@ class TransformerEncoder(nn.Module):
         return all(getattr(layer, "fused_supported", lambda e: False)(encoder_type) for layer in self.layers)
 
     def _forward_fused(self, encoder_type, streams, parts):
+        if (len(parts) == 1 and self.skip_dropped_branches and self.training and self.multi_possible()
+                and max((float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers), default=0.0) > 0.0
+                and not any(torch.is_tensor(b) or getattr(b, "ids", None) is not None for b in (parts[0][2] or ()))):
+            # a single-modality training pass with skip_dropped_branches: the lock-step pass with ONE segment (per row the same
+            # arithmetic; it is the form that packs the kept samples of every branch)
+            feats = self.forward_multi({encoder_type: parts[0]})[encoder_type]
+            return {"encoder_out": [feats.transpose(0, 1)], "encoder_padding_mask": parts[0][1], "text_encoder_states": [],
+                    "image_encoder_states": [], "audio_encoder_states": []}
         lens = [p[0].shape[1] for p in parts]
         dense = any(torch.is_tensor(b) for p in parts if p[2] is not None for b in p[2])
         if len(parts) == 1:

@@ -1050,6 +1050,50 @@ def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(f
     assert len(res[True][1]) > 60, len(res[True][1])
 
 
+def test_single_stream_skip_of_dropped_samples_matches_the_multiplier_form():
+    """skip_dropped_branches on a SINGLE-modality training pass (image tower, the forwards of BASELINE configs 2 and 4): it runs as a
+    lock-step pass with one segment and packs the kept samples of every branch; same masks as the multiplier form -> embeddings
+    and gradients within bf16 rounding."""
+    from one_peace_amd.transformer import transformer_encoder as TE
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=3, attention_heads=2, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B, L, rate = 7, 3, 0.4
+    imgs = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))["src_images"]
+    probs = torch.linspace(0, rate, L).tolist()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    mask = torch.bernoulli(torch.full((L, 2, B), 0.6), generator=g).bool()
+    mask[:, :, 0] = True
+    orig_scales, orig_mask = TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask
+    TE.TransformerEncoder._draw_path_scales = lambda self, nb, device: [
+        (None, None) if p <= 0.0 else ((mask[i, 0].float() / (1 - p)).to(device), (mask[i, 1].float() / (1 - p)).to(device))
+        for i, p in enumerate(probs)]
+    TE.TransformerEncoder._draw_keep_mask = staticmethod(lambda pr, n: mask.clone())
+    res = {}
+    try:
+        for skip in (False, True):
+            enc = one_peace_encoder_config(drop_path_rate=rate, layer_scale_init_value=1e-1, **cfg)
+            torch.manual_seed(0)
+            m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+            m = m.to(DEV).to(torch.bfloat16).train()
+            m.encoder_wrapper.fusion_model.skip_dropped_branches = skip
+            m.zero_grad()
+            emb = m(src_images=imgs, encoder_type="image")
+            (emb.float() * torch.linspace(-1, 1, emb.numel(), device=DEV).view_as(emb)).sum().backward()
+            torch.cuda.synchronize()
+            res[skip] = (emb.detach().float().cpu(), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+    finally:
+        TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask = orig_scales, orig_mask
+    assert rel_fro(res[True][0], res[False][0]) <= 1e-2
+    assert set(res[True][1]) == set(res[False][1]) and len(res[True][1]) > 25
+    for n, gd in res[False][1].items():
+        e = float((res[True][1][n] - gd).norm()) / (float(gd.norm()) + 1e-6)
+        assert e <= 3e-2, (n, e)
+
+
 def test_vision_tower_40_layers_matches_reference(golden_dir):
     """tests/golden/deep_vision40.pt: the reference's FULL-DEPTH image tower -- 40 layers at the 4B layer dimensions (1.5 B
     parameters, BASELINE configs[1]) -- one 256^2 image, forward, run on CPU in fp32 through ref_shim.  The HIP path in bf16 against

@@ -92,3 +92,17 @@ for M, tag in ((MI, "image"), (MA, "audio")):
 worse = [r for r in rows if r[2] / r[1] < 1.0]
 print("%d launches; hipBLASLt faster on %d: %s" % (len(rows), len(worse), ", ".join("%s (%.3f)" % (r[0].split(" M=")[0], r[2] / r[1]) for r in worse)))
 print("sum ours %.3f ms, sum hipBLASLt %.3f ms" % (sum(r[1] for r in rows), sum(r[2] for r in rows)))
+
+# ---- round 4: the six weight gradients above as ONE grouped persistent launch (what the step runs) against the sum of addmm ----
+probs, blas_fns, fl = [], [], 0.0
+for M, o, i in ((MALL, 3 * H, H), (MALL, H, H), (MI, 2 * F, H), (MI, H, F), (MA, 2 * F, H), (MA, H, F)):
+    dy_, x_, g_ = rnd(M, o), rnd(M, i), torch.zeros(o, i, **bf)
+    probs.append((dy_, x_, g_, True))
+    blas_fns.append((lambda g=g_, a=dy_, b=x_: torch.addmm(g, a.t(), b, out=g)))
+    fl += 2.0 * M * o * i
+tg = tbl = 1e9
+for _ in range(ROUNDS):
+    tg = min(tg, timeit(lambda: hip.gemm_tn_grouped(probs), iters=IT, warmup=5))
+    tbl = min(tbl, timeit(lambda: [f() for f in blas_fns], iters=IT, warmup=5))
+print("the six weight gradients: ONE grouped launch %.4f ms %5.0f TF/s | six addmm %.4f ms %5.0f TF/s | hipBLASLt / ours %.3f" % (
+    tg, fl / tg / 1e9, tbl, fl / tbl / 1e9, tbl / tg))

@@ -1056,6 +1056,7 @@ struct AttnBwdArgs {
   float* dbias;                      // [heads][S][Spad] fp32, pre-zeroed
   int B, S, Spad, heads, bchunk;
   float scale;
+  int lone_keys;                     // dK/dV: a trailing key block of <= 16 keys is split over the waves by queries (tune bit 11: off)
 };
 
 // D[b][h][q] = sum_d dO * O ; one thread per (row, head, 8 dims), 8-lane groups reduce
@@ -1105,17 +1106,20 @@ __device__ __forceinline__ float delta_from_frags(const bf16x8 (&dO)[2], const b
 // score instead of 11.  Keys that do not exist or are padded need NO masking here: a key is a COLUMN of every product of this
 // kernel, so whatever its P / dS columns hold only reaches its own dK / dV rows, which are written as zeros (padded keys) or
 // not at all (keys >= S).  Query rows >= S of the last tile get lse = +inf (P = 0) and delta = 0.
-template <bool HAS_BIAS, int KB>  // KB: 16-key blocks per wave (2: 128 keys per workgroup; 1: 64 -- see op_attn_bwd)
-__global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+// LONE [r4]: the workgroup's keys fit ONE 16-key block (the 257th token of the image stream: one key).  Until round 4 that
+// workgroup ran the whole query loop on one wave with two key blocks (three idle waves, a dead block): S = 256 -> 257 cost +40 % on
+// this kernel.  Now its four waves split every 64-query tile by 16-query blocks (wave w: half m = w >> 1, block j = w & 1; the other
+// block of the half enters the dV / dK products as zeros) and their partial dK / dV are summed through LDS at the end.
+template <bool HAS_BIAS, int KBW, bool LONE>  // KBW: 16-key blocks per wave (2: 128 keys per workgroup; 1: 64 -- see op_attn_bwd)
+__device__ __forceinline__ void attn_bwd_dkdv_body(const AttnBwdArgs& p, char* smem, int bx, int h, int b) {
+  constexpr int KB = LONE ? 1 : KBW;
   char* ldsQ = smem;
   char* ldsO = smem + 64 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
-  int bx, h, b;
-  xcd_work_item(bx, h, b);
-  const int kbase = bx * (64 * KB) + wid * (16 * KB);
-  const bool wave_active = kbase < p.S;
+  const int kbase = LONE ? bx * (64 * KBW) : bx * (64 * KBW) + wid * (16 * KBW);
+  const bool wave_active = LONE || kbase < p.S;
+  const int my_m = wid >> 1, my_j = wid & 1;  // (LONE) this wave's 16-query block of every tile
   const int64_t row_base = (int64_t)b * p.S;
 
   // K, V fragments (second operand): lane (g,t) <- X[kbase + kb*16 + t][kk*32 + g*8 ..]
@@ -1219,6 +1223,7 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(Att
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
       if (q0 + m * 32 >= p.S) break;  // uniform: no valid query in this half of the tile
+      if (LONE && (m != my_m || q0 + (2 * m + my_j) * 16 >= p.S)) continue;  // (per wave) not this wave's block / no valid query in it
       f32x4 s[2][KB], dp[2][KB];
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -1226,6 +1231,8 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(Att
         for (int kb = 0; kb < KB; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if (LONE && j != my_j) continue;  // the other block stays zero: it adds nothing to dV / dK below
+        if (q0 + (2 * m + j) * 16 >= p.S) continue;  // (uniform) no valid query in this block (the lone 257th query: j = 0 only)
         const int qb = 2 * m + j;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -1246,6 +1253,7 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(Att
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        if ((LONE && j != my_j) || q0 + (2 * m + j) * 16 >= p.S) continue;
         const int qrow = q0 + (2 * m + j) * 16 + g * 4;  // + r
         float l2[4], dl[4];
 #pragma unroll
@@ -1289,6 +1297,28 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(Att
     }
   }
   if (!wave_active) return;
+  if constexpr (LONE) {  // sum the four waves' partial dV^T / dK^T (4 KiB per wave and matrix) into wave 0
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      __syncthreads();  // (first round: every wave is out of the tile loop; second: wave 0 has read the first round)
+      if (wid > 0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) red[((wid - 1) * 4 + db) * 64 + lane] = which ? dkT[0][db] : dvT[0][db];
+      }
+      __syncthreads();
+      if (wid == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            if (which) dkT[0][db] += red[(w * 4 + db) * 64 + lane];
+            else dvT[0][db] += red[(w * 4 + db) * 64 + lane];
+          }
+      }
+    }
+    if (wid > 0) return;
+  }
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     const int key = kbase + kb * 16 + t;
@@ -1307,6 +1337,15 @@ __global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(Att
       *reinterpret_cast<bf16x4*>(vp + db * 16 + g * 4) = c;
     }
   }
+}
+
+template <bool HAS_BIAS, int KB>
+__global__ __launch_bounds__(256, KB == 1 ? 3 : 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+  int bx, h, b;
+  xcd_work_item(bx, h, b);
+  if (KB == 2 && bx > 0 && p.S - bx * 128 <= 16 && p.lone_keys) attn_bwd_dkdv_body<HAS_BIAS, KB, true>(p, smem, bx, h, b);  // (uniform)
+  else attn_bwd_dkdv_body<HAS_BIAS, KB, false>(p, smem, bx, h, b);
 }
 
 // Shared by the dQ and dBias kernels: for one 64-key tile, lane (g,t) computes dS^T[key = kb*16 + g*4 + r][q = t]
@@ -2527,6 +2566,7 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
   a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta; a.out = (const bf16_t*)out; a.delta_w = delta;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg; a.dbias = dbias;
   a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
+  a.lone_keys = !(tune & 2048);
   {  // batch chunk per workgroup: enough workgroups to fill the chip, as few atomic rounds as possible
     const int64_t base = (int64_t)ceil_div(S, BQ) * ceil_div(S, BKV) * heads;
     int chunks = (int)((1024 + base - 1) / base);

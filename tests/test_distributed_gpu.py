@@ -19,11 +19,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_step_keeps_replicas_identical():
+@pytest.mark.parametrize("skip_dropped", [False, True])
+def test_two_rank_step_keeps_replicas_identical(skip_dropped):
+    """skip_dropped: the same with TransformerEncoder.skip_dropped_branches -- every rank packs ITS kept samples (other row counts,
+    other launch sizes per rank and layer); the collectives and the bucket order must not notice."""
     env = dict(os.environ, ONEPEACE_DIST_BACKEND="gloo", ONEPEACE_SINGLE_DEVICE_DEBUG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "8", "--layers", "3", "--check-replicas", "--no-profile"]
+           "--batch", "8", "--layers", "3", "--check-replicas", "--no-profile"] + (["--skip-dropped"] if skip_dropped else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:  # the ranks' own tracebacks come before torchrun's summary: keep the whole log
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -56,3 +56,15 @@ for S, use_pad in ((257, False), (250, True), (256, False), (197, False)):
     tp, tr = min(resb[1]), min(resb[0])
     print("              bwd (dQ + dBias + dK/dV): persistent dQ %.4f ms (%.0f TF/s)  rounds 1-3 %.4f ms   %+.1f %%   (runs %s | %s)" % (
         tp, 2.5 * fl / tp / 1e9, tr, 100.0 * (tp / tr - 1), " ".join("%.4f" % x for x in resb[1]), " ".join("%.4f" % x for x in resb[0])), flush=True)
+    # dK/dV: a trailing block of <= 16 keys split over the waves by queries (round 4) against one wave running it (bit-identical?)
+    if S % 128 and S % 128 <= 16:
+        resl, outs = {}, {}
+        for rnd in range(2):
+            for lone in (1, 0):
+                hip.TUNE.attn_lone_keys = lone
+                resl.setdefault(lone, []).append(timeit(bw, iters=20, warmup=3))
+                outs[lone] = dqkv.clone()
+        hip.TUNE.attn_lone_keys = 1
+        err = float((outs[1].float() - outs[0].float()).abs().max())
+        print("              bwd with the lone key block split by queries %.4f ms, on one wave %.4f ms   %+.1f %%   max |difference| of dq|dk|dv %.3e" % (
+            min(resl[1]), min(resl[0]), 100.0 * (min(resl[1]) / min(resl[0]) - 1), err), flush=True)

@@ -673,6 +673,10 @@ def main():
         }
         if sweep:
             out["config"]["sweep"] = sweep
+        if not micro and world == 1:
+            out["config"]["memory"] = {"peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2),
+                                       "peak_reserved_gb": round(torch.cuda.max_memory_reserved(device) / 1e9, 2),
+                                       "device_total_gb": round(torch.cuda.mem_get_info(device)[1] / 1e9, 2)}
         if train:
             out["config"]["stochastic_depth"] = ("branches of dropped samples are not computed (--skip-dropped)" if args.skip_dropped
                                                  else "reference arithmetic: every sample computed, dropped ones multiplied by zero")

@@ -2213,6 +2213,410 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dq_pers_kernel(AttnB
   attn_bwd_dq_pers_body<HAS_BIAS, HAS_PAD, NT, LASTB, false>(p, smem, rows_pad, nqh, qhalf);
 }
 
+// =====================================================================================================================
+// Persistent dK / dV kernel for the 193 ... 257-token streams with a shared bias image (round 4; the counterpart of
+// attn_bwd_dq_pers_kernel).  attn_bwd_dkdv_kernel stages every 64-query tile of Q / dO through registers into LDS with two barriers per
+// tile and does so in each of the 2 - 3 key workgroups of a (sample, head); its waves wait 35 % of their cycles.  Here ONE workgroup
+// of 8 waves per CU walks the items (sample, head) = blockIdx, blockIdx + gridDim, ...: wave w owns keys 32 w ... 32 w + 31 (K / V
+// fragments and the dK^T / dV^T accumulators in registers); ALL of Q and dO of an item, its lse and delta rows (and, S = 257, the K / V
+// row of key 256) sit in LDS -- fetched by LDS-DMA into the other half of a double buffer while the previous item is computed: one
+// barrier per item.  K / V fragments, key-padding bytes and the first bias fragments of the next item and the transposed-bias
+// fragments of the next query tile travel as inline-asm loads with hand-counted waits (protocol and hazards: attn_fwd_pers_kernel).
+// S = 257: the lone KEY is not a ninth wave -- wave w runs it against the 32-query half w (wave 0 also against the lone query), the
+// eight partial dK / dV rows meet in LDS and are summed by one wave after the next item's barrier.  The per-tile arithmetic is
+// attn_bwd_dkdv_kernel's: same bits for keys 0 ... 255, the lone key's sums are taken in another order (fp32).
+// =====================================================================================================================
+constexpr int PERS_SCRL = 136;  // floats per (item parity, wave) of the lone key's scratch: dV[64], dK[64], dead flag, pad
+
+template <int OFF>
+__device__ __forceinline__ void gload1_s(unsigned& d, const void* sbase, unsigned voff) {
+  asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+
+template <bool HAS_BIAS, bool HAS_PAD, int NT, bool LONE>  // NT: 64-query tiles (S = 257: 5, the fifth holds one query); LONE: S = 257
+__global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dkdv_pers_kernel(AttnBwdArgs p, int rows_pad, int nitems) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, t = lane & 15;
+  const int QBY = rows_pad * 128;         // bytes of the Q (or dO) rows of one buffer
+  const int BUFB = 2 * QBY + 6144;        // Q | dO | lse (2 KiB) | delta (2 KiB) | lone K row x 8 (1 KiB) | lone V row x 8 (1 KiB)
+  float* scratch = reinterpret_cast<float*>(smem + 2 * BUFB);  // [2][PERS_NW][PERS_SCRL]
+  const int kbase = wid * 32;
+  const bool wave_active = kbase < min(p.S, 256);
+  const float c1 = p.scale * LOG2E;
+
+  bf16x8 sel_lo, sel_hi;
+  {
+    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
+      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
+    }
+  }
+  int trsw[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
+  const int kswz[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+
+  // ---- LDS-DMA of one item: groups of 1 KiB (8 rows x 128 B of Q, then of dO; two chunks of the lse row, two of the delta row, the
+  // lone key's K row and V row eight times each) dealt to the waves ----
+  const int ngrp = rows_pad >> 3;
+  const int NG = 2 * ngrp + (LONE ? 6 : 4);
+  const int r_in = lane >> 3, slot = lane & 7;
+  const int npiece = (NG - wid + PERS_NW - 1) / PERS_NW;
+  auto piece = [&](int it, int buf, int j) {
+    const int b = it / p.heads, h = it - b * p.heads;
+    const int grp = wid + j * PERS_NW;
+    int rl = r_in;
+    asm volatile("" : "+v"(rl));  // (laundered: see attn_bwd_dq_pers_body -- no per-piece address kept alive over the kernel)
+    const char* sbase;
+    unsigned voff;
+    int dst_off;
+    if (grp < 2 * ngrp) {
+      const bool isd = grp >= ngrp;
+      const int gi = isd ? grp - ngrp : grp;
+      const int r = gi * 8 + rl;
+      const int qr = min(r, p.S - 1);
+      const int ldx = isd ? (int)p.ldo : (int)p.ld;
+      voff = (unsigned)((qr * ldx + ((slot ^ (r & 7)) << 3)) * 2);
+      sbase = isd ? (const char*)(p.dout + (int64_t)b * p.S * p.ldo + h * HD) : (const char*)(p.q + (int64_t)b * p.S * p.ld + h * HD);
+      dst_off = (isd ? QBY : 0) + gi * 1024;
+    } else {
+      const int e = grp - 2 * ngrp;  // 0, 1: lse chunks; 2, 3: delta chunks; 4: lone K row; 5: lone V row
+      if (e < 4) {
+        voff = (unsigned)min((e & 1) * 1024 + (rl * 8 + slot) * 16, p.Spad * 4 - 16);
+        sbase = (const char*)((e < 2 ? p.lse : p.delta) + ((int64_t)b * p.heads + h) * p.Spad);
+      } else {
+        voff = (unsigned)(((p.S - 1) * (int)p.ld + slot * 8) * 2);
+        sbase = (const char*)((e == 4 ? p.k : p.v) + (int64_t)b * p.S * p.ld + h * HD);
+      }
+      dst_off = 2 * QBY + e * 1024;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + voff),
+                                     (__attribute__((address_space(3))) void*)(smem + buf * BUFB + dst_off), 16, 0, 0);
+  };
+
+  // ---- in-flight (inline-asm) loads ----
+  // K / V fragments of this wave's keys (second operand: lane (g, t) <- X[kbase + kb * 16 + t][kk * 32 + g * 8 ..]) and their pad bytes
+  const int key_kb[2] = {min(kbase + t, p.S - 1), min(kbase + 16 + t, p.S - 1)};
+  const unsigned vo_k[2] = {(unsigned)((key_kb[0] * (int)p.ld + g * 8) * 2), (unsigned)((key_kb[1] * (int)p.ld + g * 8) * 2)};
+  // LONE: requested straight into the fragment registers once the last tile is done with them (the lone key's phase and the stores cover
+  // the latency: a second set of 32 landing registers does not fit next to that phase); otherwise into landing registers in the last tile
+  bf16x8 kf[2][2], vf[2][2], kn[LONE ? 1 : 2][2], vn[LONE ? 1 : 2][2];
+  unsigned kdn[2] = {0u, 0u}, kdl = 0u;
+  auto kv_loads = [&](int it, bf16x8 (&kd)[2][2], bf16x8 (&vd)[2][2]) {
+    const int b = it / p.heads, h = it - b * p.heads;
+    const bf16_t* sk = p.k + (int64_t)b * p.S * p.ld + h * HD;
+    const bf16_t* sv = p.v + (int64_t)b * p.S * p.ld + h * HD;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      gload16_s<0>(kd[kb][0], sk, vo_k[kb]);
+      gload16_s<64>(kd[kb][1], sk, vo_k[kb]);
+      gload16_s<0>(vd[kb][0], sv, vo_k[kb]);
+      gload16_s<64>(vd[kb][1], sv, vo_k[kb]);
+    }
+    if constexpr (HAS_PAD) {
+      const uint8_t* pr = p.key_pad + (int64_t)b * p.Spad;
+      gload1_s<0>(kdn[0], pr, (unsigned)key_kb[0]);
+      gload1_s<0>(kdn[1], pr, (unsigned)key_kb[1]);
+      if constexpr (LONE) gload1_s<0>(kdl, pr, (unsigned)(p.S - 1));
+    }
+  };
+  constexpr int NKV = 8 + (HAS_PAD ? (LONE ? 3 : 2) : 0);
+  // transposed bias image rows of this lane's two keys: 8 consecutive queries at g * 8 = one second-operand fragment per 32 queries
+  const unsigned vo_b[2] = {(unsigned)((key_kb[0] * p.Spad + g * 8) * 2), (unsigned)((key_kb[1] * p.Spad + g * 8) * 2)};
+  const unsigned vo_bl = (unsigned)(((p.S - 1) * p.Spad + g * 8) * 2);  // the lone key's row
+  bf16x8 bn[2][2], bfl[2];
+  auto bias_loads = [&](int it, auto qt_c, auto m_c) {  // the fragments of half m of query tile QT (two key blocks: two loads)
+    constexpr int QT = decltype(qt_c)::value, M = decltype(m_c)::value;
+    if constexpr (HAS_BIAS) {
+      const int h = it % p.heads;
+      const bf16_t* sb = p.biasT + (int64_t)h * p.S * p.Spad;
+      gload16_s<(QT * 64 + M * 32) * 2>(bn[M][0], sb, vo_b[0]);
+      gload16_s<(QT * 64 + M * 32) * 2>(bn[M][1], sb, vo_b[1]);
+    }
+  };
+  constexpr int NBH = HAS_BIAS ? 2 : 0;  // operations of one bias_loads
+  auto lone_bias_loads = [&](int it) {  // the lone key against this wave's 32-query half (and, wave 0, against the lone query's block)
+    if constexpr (HAS_BIAS && LONE) {
+      const int h = it % p.heads;
+      const bf16_t* sb = p.biasT + (int64_t)h * p.S * p.Spad;
+      gload16_s<0>(bfl[0], sb + wid * 32, vo_bl);
+      gload16_s<512>(bfl[1], sb, vo_bl);
+    }
+  };
+  constexpr int NLB = (HAS_BIAS && LONE) ? 2 : 0;
+  constexpr int BPPT = NT == 5 ? 3 : 4;  // fetch pieces a wave issues in each query tile but the last (<= 10 pieces)
+
+  int item = blockIdx.x;
+  const int step = gridDim.x;
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (item < nitems) {
+    for (int j = 0; j < npiece; ++j) piece(item, 0, j);
+    if constexpr (LONE) kv_loads(item, kf, vf);
+    else kv_loads(item, kn, vn);
+    bias_loads(item, I0{}, I0{});
+    bias_loads(item, I0{}, I1{});
+  }
+  auto wait_all = [&]() {
+    if constexpr (LONE)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]),
+                   "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(kdn[0]), "+v"(kdn[1]), "+v"(kdl) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kn[0][0]), "+v"(kn[0][1]), "+v"(kn[1][0]), "+v"(kn[1][1]), "+v"(vn[0][0]), "+v"(vn[0][1]), "+v"(vn[1][0]), "+v"(vn[1][1]),
+                   "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(kdn[0]), "+v"(kdn[1]), "+v"(kdl) : : "memory");
+  };
+  wait_all();
+  int buf = 0, prev_item = -1;
+  auto merge_lone = [&](int it, int sb) {  // dK / dV rows of key S - 1: the sum of the eight partials; lane = head dimension
+    const float* sc = scratch + sb * (PERS_NW * PERS_SCRL);
+    float dv = 0.f, dk = 0.f;
+#pragma unroll
+    for (int w = 0; w < PERS_NW; ++w) { dv += sc[w * PERS_SCRL + lane]; dk += sc[w * PERS_SCRL + 64 + lane]; }
+    const bool dead = sc[128] != 0.f;
+    const int b = it / p.heads, h = it - b * p.heads;
+    const int64_t row = ((int64_t)b * p.S + p.S - 1) * p.ldg + h * HD + lane;
+    p.dv[row] = dead ? (bf16_t)0.f : (bf16_t)dv;
+    p.dk[row] = dead ? (bf16_t)0.f : (bf16_t)(dk * p.scale);
+  };
+
+  for (; item < nitems; item += step, buf ^= 1) {
+    const int b = item / p.heads, h = item - b * p.heads;
+    __syncthreads();  // this item's rows have landed (every wave waited for its own pieces at the end of the previous trip); every wave is
+                      // done with the other buffer and with the scratch half it re-uses
+    if constexpr (!LONE) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { kf[kb][kk] = kn[kb][kk]; vf[kb][kk] = vn[kb][kk]; }
+    }
+    const bool kdead[2] = {HAS_PAD && kdn[0] != 0u, HAS_PAD && kdn[1] != 0u};
+    const bool ldead = HAS_PAD && LONE && kdl != 0u;
+    const int nxt = item + step < nitems ? item + step : item;  // (no next item: this one is fetched again into the idle buffer)
+    if (LONE && prev_item >= 0 && wid == ((prev_item / step) & (PERS_NW - 1))) merge_lone(prev_item, buf ^ 1);
+    prev_item = item;
+    const char* ldsQ = smem + buf * BUFB;
+    const char* ldsO = ldsQ + QBY;
+    const float* ldsL = reinterpret_cast<const float*>(ldsQ + 2 * QBY);
+    const float* ldsD = ldsL + 512;
+
+    f32x4 dvT[2][4], dkT[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) { dvT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // one 32-query half against NKB 16-key blocks whose K / V fragments are kx / vx: S, dP -> P, dS -> dV^T, dK^T (attn_bwd_dkdv_kernel)
+    auto half = [&](const int q0h, auto nkb_c, const bf16x8 (&kx)[2][2], const bf16x8 (&vx)[2][2], const bf16x8 (&bx)[2],
+                    f32x4 (&dvx)[2][4], f32x4 (&dkx)[2][4]) {
+      constexpr int NKB = decltype(nkb_c)::value;
+      f32x4 s[2][NKB], dp[2][NKB];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      const bool second = q0h + 16 < p.S;  // (uniform) the half's second 16-query block holds a query
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !second) continue;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int off = (q0h + j * 16 + t) * 128 + kswz[kk];
+          const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(ldsQ + off);
+          const bf16x8 ofr = *reinterpret_cast<const bf16x8*>(ldsO + off);
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kx[kb][kk], s[j][kb], 0, 0, 0);
+            dp[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vx[kb][kk], dp[j][kb], 0, 0, 0);
+          }
+        }
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j ? sel_hi : sel_lo, bx[kb], s[j][kb], 0, 0, 0);
+        }
+      }
+      // the transposed dO / Q fragments of the first two head-dimension blocks: requested BEFORE the softmax arithmetic, which covers
+      // their LDS latency (as in attn_fwd_pers_kernel)
+      const s16x4 zero4 = {0, 0, 0, 0};
+      s16x4 o0[2], o1[2], q0r[2], q1r[2];
+      auto tr_request = [&](int dh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int db = 2 * dh + i;
+          o0[i] = tr_read_a(ldsO + q0h * 128 + trsw[db]);
+          q0r[i] = tr_read_a(ldsQ + q0h * 128 + trsw[db]);
+          o1[i] = zero4;
+          q1r[i] = zero4;
+          if (second) {
+            o1[i] = tr_read_a(ldsO + q0h * 128 + trsw[db] + 2048);
+            q1r[i] = tr_read_a(ldsQ + q0h * 128 + trsw[db] + 2048);
+          }
+        }
+      };
+      float l2[2][4], dl[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !second) continue;
+        const int qrow = q0h + j * 16 + g * 4;  // + r
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsL + qrow);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsD + qrow);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {  // rows >= S: lse / delta are unspecified (possibly NaN / inf) -> P = 0, delta = 0
+          const bool live = qrow + r < p.S;
+          l2[j][r] = live ? l4[r] * LOG2E : INFINITY;
+          dl[j][r] = live ? d4[r] : 0.f;
+        }
+      }
+      // (behind the compiler's own LDS reads above: its lgkmcnt bookkeeping does not see the asm reads, and a wait it places for one of
+      // its loads behind them would wait for them too)
+      __builtin_amdgcn_sched_barrier(0);
+      tr_request(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !second) continue;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][r], c1, -l2[j][r]));
+            s[j][kb][r] = pr;
+            dp[j][kb][r] = pr * (dp[j][kb][r] - dl[j][r]);
+          }
+        }
+      }
+      bf16x8 pfr[NKB], dsf[NKB];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0[r] = s[0][kb][r]; a1[r] = s[1][kb][r];
+          b0[r] = dp[0][kb][r]; b1[r] = dp[1][kb][r];
+        }
+        pfr[kb] = pack8(a0, a1);
+        dsf[kb] = pack8(b0, b1);
+      }
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh) {  // two head-dimension blocks at a time: 8 transpose reads in flight
+        if (dh == 1) tr_request(1);
+        ATTN_WAIT_LGKM0();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int db = 2 * dh + i;
+          const bf16x8 oT = join_tr(o0[i], o1[i]), qT = join_tr(q0r[i], q1r[i]);
+#pragma unroll
+          for (int kb = 0; kb < NKB; ++kb) {
+            dvx[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT, pfr[kb], dvx[kb][db], 0, 0, 0);
+            dkx[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsf[kb], dkx[kb][db], 0, 0, 0);
+          }
+        }
+      }
+    };
+
+    // Query tile QT.  Transposed-bias fragments travel one HALF ahead in the registers the MFMAs read them from (no copies: the
+    // kernel lives at the register limit): half 0 of tile QT + 1 is requested when half 0 of tile QT is done, half 1 when half 1 is
+    // done; the counted waits allow exactly what was requested behind the awaited pair (fetch pieces, the other half's pair).
+    auto tile = [&](auto qt_c) {
+      constexpr int QT = decltype(qt_c)::value;
+      constexpr bool LAST = QT == NT - 1;
+      using QN = std::integral_constant<int, LAST ? 0 : QT + 1>;
+      if constexpr (!LAST) {
+#pragma unroll
+        for (int jj = 0; jj < BPPT; ++jj) piece(nxt, buf ^ 1, min(QT * BPPT + jj, npiece - 1));  // (past the last piece: that piece again)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave_active) half(QT * 64, std::integral_constant<int, 2>{}, kf, vf, bn[0], dvT, dkT);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) bias_loads(item, QN{}, I0{});
+      // half 1's fragments of THIS tile (requested at the end of the previous tile; tile 0: landed with the item)
+      if constexpr (HAS_BIAS && QT > 0) {
+        if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bn[1][0]), "+v"(bn[1][1]) : "n"(BPPT + NBH));
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn[1][0]), "+v"(bn[1][1]));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (wave_active && QT * 64 + 32 < p.S) half(QT * 64 + 32, std::integral_constant<int, 2>{}, kf, vf, bn[1], dvT, dkT);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!LAST) {
+        bias_loads(item, QN{}, I1{});
+        if constexpr (HAS_BIAS) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bn[0][0]), "+v"(bn[0][1]) : "n"(NBH));  // half 0 of the next tile
+      } else {  // late loads: the lone key's bias fragments first, then the next item's first bias fragments (and, !LONE, its K / V)
+        lone_bias_loads(item);
+        bias_loads(nxt, I0{}, I0{});
+        bias_loads(nxt, I0{}, I1{});
+        if constexpr (!LONE) kv_loads(nxt, kn, vn);
+      }
+    };
+    // (unrolled by hand: the tile index is a compile-time constant -- immediate offsets of the bias loads, counted waits)
+    tile(std::integral_constant<int, 0>{});
+    tile(std::integral_constant<int, 1>{});
+    tile(std::integral_constant<int, 2>{});
+    tile(std::integral_constant<int, 3>{});
+    if constexpr (NT == 5) tile(std::integral_constant<int, 4>{});
+
+    if constexpr (LONE) {  // key S - 1 = 256: this wave's 32-query half (wave 0 also the lone query's block); all 16 key columns of the
+                           // fragments are that key (its row is replicated in LDS), column t = 0 is the one that is kept
+      // the next item's K / V fragments: the tiles are done with the registers; the lone key's bias fragments were requested first in the
+      // last tile: behind them the next item's first bias fragments and these
+      kv_loads(nxt, kf, vf);
+      if constexpr (NLB > 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(bfl[0]), "+v"(bfl[1]) : "n"(NKV + 2 * NBH));
+      const char* ldsLK = ldsQ + 2 * QBY + 4096;
+      bf16x8 kl[2][2], vl[2][2];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        kl[0][kk] = *reinterpret_cast<const bf16x8*>(ldsLK + (kk * 4 + g) * 16);
+        vl[0][kk] = *reinterpret_cast<const bf16x8*>(ldsLK + 1024 + (kk * 4 + g) * 16);
+        kl[1][kk] = kl[0][kk];
+        vl[1][kk] = vl[0][kk];
+      }
+      f32x4 dvl[2][4], dkl[2][4];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) { dvl[0][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkl[0][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      const bf16x8 bl0[2] = {bfl[0], bfl[0]}, bl1[2] = {bfl[1], bfl[1]};
+      half(wid * 32, std::integral_constant<int, 1>{}, kl, vl, bl0, dvl, dkl);
+      if (wid == 0) half(256, std::integral_constant<int, 1>{}, kl, vl, bl1, dvl, dkl);
+      float* sc = scratch + (buf * PERS_NW + wid) * PERS_SCRL;
+      if (t == 0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          *reinterpret_cast<f32x4*>(sc + db * 16 + g * 4) = dvl[0][db];
+          *reinterpret_cast<f32x4*>(sc + 64 + db * 16 + g * 4) = dkl[0][db];
+        }
+      }
+      if (wid == 0 && lane == 0) sc[128] = ldead ? 1.f : 0.f;
+    }
+
+    if (wave_active) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int key = kbase + kb * 16 + t;
+        if (key >= min(p.S, 256)) continue;
+        bf16_t* kp = p.dk + ((int64_t)b * p.S + key) * p.ldg + h * HD;
+        bf16_t* vp = p.dv + ((int64_t)b * p.S + key) * p.ldg + h * HD;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          bf16x4 a, c;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a[r] = kdead[kb] ? (bf16_t)0.f : (bf16_t)(dkT[kb][db][r] * p.scale);
+            c[r] = kdead[kb] ? (bf16_t)0.f : (bf16_t)dvT[kb][db][r];
+          }
+          *reinterpret_cast<bf16x4*>(kp + db * 16 + g * 4) = a;
+          *reinterpret_cast<bf16x4*>(vp + db * 16 + g * 4) = c;
+        }
+      }
+    }
+    wait_all();
+  }
+  if (LONE && prev_item >= 0) {
+    __syncthreads();
+    if (wid == 0) merge_lone(prev_item, buf ^ 1);
+  }
+}
+
 // grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
 // same for every sample of the chunk (per-sample bias images: chunks of ONE sample, gradient slab b for sample b -- the path of
 // masked pretraining with more kept tokens than the merged kernel's 384) and is loaded once; each sample's K/V tile goes through LDS once for all four waves (next
@@ -2422,6 +2826,25 @@ int launch_bwd_dq_pers(const AttnBwdArgs& a, int nwg, size_t sh, int rows_pad, i
   return OP_OK;
 }
 
+// persistent dK / dV kernel: one workgroup per CU walks the (sample, head) items
+inline int dkdv_pers_rows(int64_t S) { return (int)((S + 15) / 16) * 16; }
+inline size_t dkdv_pers_lds(int64_t S) { return (size_t)2 * (2 * dkdv_pers_rows(S) * 128 + 6144) + 2 * PERS_NW * PERS_SCRL * 4; }
+template <bool HAS_BIAS, bool HAS_PAD>
+int launch_bwd_dkdv_pers(const AttnBwdArgs& a, hipStream_t s) {
+  const int rows_pad = dkdv_pers_rows(a.S);
+  const size_t sh = dkdv_pers_lds(a.S);
+  const int nitems = a.B * a.heads;
+  const int nwg = min(nitems, attn_num_cus());
+  if (a.S > 256) {
+    OP_ENSURE_LDS((attn_bwd_dkdv_pers_kernel<HAS_BIAS, HAS_PAD, 5, true>), (int)dkdv_pers_lds(257), "attn_bwd");
+    hipLaunchKernelGGL((attn_bwd_dkdv_pers_kernel<HAS_BIAS, HAS_PAD, 5, true>), dim3(nwg), dim3(PERS_NW * 64), sh, s, a, rows_pad, nitems);
+  } else {
+    OP_ENSURE_LDS((attn_bwd_dkdv_pers_kernel<HAS_BIAS, HAS_PAD, 4, false>), (int)dkdv_pers_lds(256), "attn_bwd");
+    hipLaunchKernelGGL((attn_bwd_dkdv_pers_kernel<HAS_BIAS, HAS_PAD, 4, false>), dim3(nwg), dim3(PERS_NW * 64), sh, s, a, rows_pad, nitems);
+  }
+  return OP_OK;
+}
+
 }  // namespace
 
 extern "C" int op_prof_begin(int family, double work, void* stream);
@@ -2624,7 +3047,19 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
     if (rc != OP_OK) return rc;
     OP_LAUNCH_CHECK();
     a.bchunk = bchunk_dkdv;
-    launch_dkdv();
+    // persistent dK / dV kernel (round 4; tune bit 12: the rounds 1-3 kernel).  Measured at B = 128 (tools/attn_pers_ab.py): S = 257
+    // -12 % on the backward pair, S = 250 -2 %, S = 197 -1 %, S = 256 +5 % (two full key workgroups: nothing to gain) -- bit 13 forces it
+    if (!(tune & 4096) && (!bias || biasT) && (S != 256 || (tune & 8192))) {
+      const int sl = op_prof_begin(2, 2.0 * fl, stream);
+      if (bias && key_pad) rc = launch_bwd_dkdv_pers<true, true>(a, s);
+      else if (bias) rc = launch_bwd_dkdv_pers<true, false>(a, s);
+      else if (key_pad) rc = launch_bwd_dkdv_pers<false, true>(a, s);
+      else rc = launch_bwd_dkdv_pers<false, false>(a, s);
+      op_prof_end(sl, stream);
+      if (rc != OP_OK) return rc;
+    } else {
+      launch_dkdv();
+    }
     OP_LAUNCH_CHECK();
     return OP_OK;
   }

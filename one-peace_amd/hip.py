@@ -105,6 +105,7 @@ class Tuning:
         self.dbias_chunks_r2 = 0  # merged dQ + dBias kernel: round 2's batch-chunk rule (A/B timing)
         self.dkdv_keys = 0       # dK/dV kernel: 0 auto, 1 = 128 keys per workgroup, 2 = 64 (A/B timing)
         self.dbias_chunks = 0    # merged dQ + dBias kernel: forced number of batch chunks (0 = the library's rule; A/B timing)
+        self.attn_pers_dkdv = 1  # attention backward: persistent dK / dV kernel behind the persistent dQ kernel (round 4), 0 the rounds 1-3 kernel
         self.attn_lone_keys = 1  # dK/dV: a trailing block of <= 16 keys (the 257th token) split over the waves by queries (round 4), 0 one wave
         self.attn_pers_bwd = 1   # attention backward: 1 persistent dQ (+ dBias) kernel for 193 ... 257 tokens (round 4), 0 rounds 1-3
 
@@ -119,7 +120,7 @@ class Tuning:
 
     def attn_bwd(self):
         return ((0 if self.merge_dbias else 1) | (2 if self.dbias_chunks_r2 else 0) | (self.dkdv_keys & 3) << 2 | (self.dbias_chunks & 63) << 4
-                | (0 if self.attn_pers_bwd else 1024) | (0 if self.attn_lone_keys else 2048))
+                | (0 if self.attn_pers_bwd else 1024) | (0 if self.attn_lone_keys else 2048) | (0 if self.attn_pers_dkdv else 4096))
 
 
 TUNE = Tuning()

@@ -56,6 +56,17 @@ for S, use_pad in ((257, False), (250, True), (256, False), (197, False)):
     tp, tr = min(resb[1]), min(resb[0])
     print("              bwd (dQ + dBias + dK/dV): persistent dQ %.4f ms (%.0f TF/s)  rounds 1-3 %.4f ms   %+.1f %%   (runs %s | %s)" % (
         tp, 2.5 * fl / tp / 1e9, tr, 100.0 * (tp / tr - 1), " ".join("%.4f" % x for x in resb[1]), " ".join("%.4f" % x for x in resb[0])), flush=True)
+    # persistent dK / dV kernel (round 4) against the rounds 1-3 kernel, both behind the persistent dQ kernel
+    resk, outk = {}, {}
+    for rnd in range(2):
+        for pk in (1, 0):
+            hip.TUNE.attn_pers_dkdv = pk
+            resk.setdefault(pk, []).append(timeit(bw, iters=20, warmup=3))
+            outk[pk] = dqkv.clone()
+    hip.TUNE.attn_pers_dkdv = 1
+    same = torch.equal(outk[1].view(B, S, 3 * H)[:, :min(S, 256)], outk[0].view(B, S, 3 * H)[:, :min(S, 256)])
+    print("              bwd with the persistent dK / dV kernel %.4f ms, rounds 1-3 dK / dV %.4f ms   %+.1f %%   keys 0..255 bit-identical: %s, max |difference| %.3e" % (
+        min(resk[1]), min(resk[0]), 100.0 * (min(resk[1]) / min(resk[0]) - 1), same, float((outk[1].float() - outk[0].float()).abs().max())), flush=True)
     # dK/dV: a trailing block of <= 16 keys split over the waves by queries (round 4) against one wave running it (bit-identical?)
     if S % 128 and S % 128 <= 16:
         resl, outs = {}, {}

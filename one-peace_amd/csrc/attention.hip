@@ -2233,6 +2233,18 @@ __device__ __forceinline__ void gload1_s(unsigned& d, const void* sbase, unsigne
   asm volatile("s_nop 4\n\tglobal_load_ubyte %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF));
 }
 
+// 8-byte buffer store (raw descriptor, per-lane byte offset; a lane whose offset lies behind the descriptor's size is DROPPED by the
+// hardware, but the instruction is issued and counted by vmcnt all the same: the persistent kernels need an exact count of the stores
+// behind their last loads).  Wait states as in gemm.hip: store_b128_padded.
+__device__ __forceinline__ u32x4 attn_raw_rsrc(const void* base, int nbytes) {
+  const uint64_t a = (uint64_t)base;
+  return (u32x4){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffffu,
+                 (unsigned)__builtin_amdgcn_readfirstlane(nbytes), 0x00020000u};
+}
+__device__ __forceinline__ void bstore8(const bf16x4& data, const u32x4& rsrc, unsigned voff) {
+  asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc) : "memory");
+}
+
 template <bool HAS_BIAS, bool HAS_PAD, int NT, bool LONE>  // NT: 64-query tiles (S = 257: 5, the fifth holds one query); LONE: S = 257
 __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dkdv_pers_kernel(AttnBwdArgs p, int rows_pad, int nitems) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2361,15 +2373,20 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dkdv_pers_kernel(Att
     bias_loads(item, I0{}, I0{});
     bias_loads(item, I0{}, I1{});
   }
-  auto wait_all = [&]() {
-    if constexpr (LONE)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]),
-                   "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(kdn[0]), "+v"(kdn[1]), "+v"(kdl) : : "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(kn[0][0]), "+v"(kn[0][1]), "+v"(kn[1][0]), "+v"(kn[1][1]), "+v"(vn[0][0]), "+v"(vn[0][1]), "+v"(vn[1][0]), "+v"(vn[1][1]),
-                   "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(kdn[0]), "+v"(kdn[1]), "+v"(kdl) : : "memory");
-  };
-  wait_all();
+  // everything an item finds in flight at its top has landed at the END of the previous trip (or here): all loads, i.e. everything but
+  // the NST stores issued behind them (vmcnt completes in issue order)
+#define DKDV_WAIT_LOADS(NST)                                                                                                                  \
+  do {                                                                                                                                     \
+    if constexpr (LONE)                                                                                                                    \
+      asm volatile("s_waitcnt vmcnt(%15)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]), "+v"(vf[0][0]), "+v"(vf[0][1]),   \
+                   "+v"(vf[1][0]), "+v"(vf[1][1]), "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(kdn[0]), "+v"(kdn[1]), \
+                   "+v"(kdl) : "n"(NST) : "memory");                                                                                      \
+    else                                                                                                                                   \
+      asm volatile("s_waitcnt vmcnt(%15)" : "+v"(kn[0][0]), "+v"(kn[0][1]), "+v"(kn[1][0]), "+v"(kn[1][1]), "+v"(vn[0][0]), "+v"(vn[0][1]),   \
+                   "+v"(vn[1][0]), "+v"(vn[1][1]), "+v"(bn[0][0]), "+v"(bn[0][1]), "+v"(bn[1][0]), "+v"(bn[1][1]), "+v"(kdn[0]), "+v"(kdn[1]), \
+                   "+v"(kdl) : "n"(NST) : "memory");                                                                                      \
+  } while (0)
+  DKDV_WAIT_LOADS(0);
   int buf = 0, prev_item = -1;
   auto merge_lone = [&](int it, int sb) {  // dK / dV rows of key S - 1: the sum of the eight partials; lane = head dimension
     const float* sc = scratch + sb * (PERS_NW * PERS_SCRL);
@@ -2385,8 +2402,12 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dkdv_pers_kernel(Att
 
   for (; item < nitems; item += step, buf ^= 1) {
     const int b = item / p.heads, h = item - b * p.heads;
-    __syncthreads();  // this item's rows have landed (every wave waited for its own pieces at the end of the previous trip); every wave is
-                      // done with the other buffer and with the scratch half it re-uses
+    // this item's rows have landed (every wave waited for its own pieces at the end of the previous trip); every wave is done with the
+    // other buffer and with the scratch half it re-uses.  A raw barrier: __syncthreads() would wait for vmcnt(0), i.e. for the dK / dV
+    // stores of the previous item, which are left to drain under this item's first tile
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if constexpr (!LONE) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -2589,13 +2610,15 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dkdv_pers_kernel(Att
       if (wid == 0 && lane == 0) sc[128] = ldead ? 1.f : 0.f;
     }
 
-    if (wave_active) {
+    {  // 16 buffer stores per wave, none of them behind a branch: lanes whose key does not exist -- all lanes of a wave without keys --
+       // are dropped by the descriptor, and ONE wait statement on one path follows (in a two-armed version the compiler put the next
+       // item's copies of the landing registers in front of one arm's wait: tools/check_mfma_hazards.py)
+      const int nrec = ((min(p.S, 256) - 1) * (int)p.ldg + HD) * 2;
+      const u32x4 rk = attn_raw_rsrc(p.dk + (int64_t)b * p.S * p.ldg + h * HD, nrec);
+      const u32x4 rv = attn_raw_rsrc(p.dv + (int64_t)b * p.S * p.ldg + h * HD, nrec);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
-        const int key = kbase + kb * 16 + t;
-        if (key >= min(p.S, 256)) continue;
-        bf16_t* kp = p.dk + ((int64_t)b * p.S + key) * p.ldg + h * HD;
-        bf16_t* vp = p.dv + ((int64_t)b * p.S + key) * p.ldg + h * HD;
+        const unsigned voff = (unsigned)(((kbase + kb * 16 + t) * (int)p.ldg + g * 4) * 2);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           bf16x4 a, c;
@@ -2604,18 +2627,20 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_dkdv_pers_kernel(Att
             a[r] = kdead[kb] ? (bf16_t)0.f : (bf16_t)(dkT[kb][db][r] * p.scale);
             c[r] = kdead[kb] ? (bf16_t)0.f : (bf16_t)dvT[kb][db][r];
           }
-          *reinterpret_cast<bf16x4*>(kp + db * 16 + g * 4) = a;
-          *reinterpret_cast<bf16x4*>(vp + db * 16 + g * 4) = c;
+          bstore8(a, rk, voff + db * 32);
+          bstore8(c, rv, voff + db * 32);
         }
       }
+      DKDV_WAIT_LOADS(16);
     }
-    wait_all();
   }
   if (LONE && prev_item >= 0) {
     __syncthreads();
     if (wid == 0) merge_lone(prev_item, buf ^ 1);
   }
 }
+
+#undef DKDV_WAIT_LOADS
 
 // grid (q tiles of 128, key tiles of 64, heads * batch chunks).  The bias fragment of the (head, q tile, key tile) is the
 // same for every sample of the chunk (per-sample bias images: chunks of ONE sample, gradient slab b for sample b -- the path of

@@ -7,7 +7,7 @@ out=$1; R=$GRAFT_REPO_ROOT
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmcb_$c /tmp/pmcc0_$c /tmp/pmcc1_$c
-  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcb_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcb_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline --no-skip-leg --no-power-probe > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcc0_$c -o p -- python $R/tools/pmc_calib.py 0 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "gemm|splitk" --output-format csv -d /tmp/pmcc1_$c -o p -- python $R/tools/pmc_calib.py 1 > /dev/null 2>&1
 done
@@ -47,7 +47,7 @@ wr = res["WRITE_SIZE"]["bench_gemm_sum_kb"] * 1024.0 * wc / n
 out = {
     "what": "HBM-side bytes per GEMM-family launch (all gemm* kernels; split-K folds are not counted as launches), one bench.py step",
     "command": "tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --kernel-include-regex 'gemm|splitk' -- "
-               "python bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline (two separate passes + two calibration launches each)",
+               "python bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline --no-skip-leg --no-power-probe (two separate passes + two calibration launches each)",
     "round": 4, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
     "fetch_size_correction": fc, "write_size_correction": wc,
     "calibration": "tools/pmc_calib.py: A[32896,6144] bf16 read exactly once (404 MB > 256 MB Infinity Cache)",

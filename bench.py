@@ -599,6 +599,7 @@ def main():
             and graph is None and fusion is not None and not args.recompute):
         # second leg, outside `value`: the same step with every residual branch computed for the samples stochastic depth keeps only
         fusion.skip_dropped_branches = True
+        torch.cuda.empty_cache()  # the packed leg allocates other sizes every step: do not stack them on the first leg's cached blocks
         for _ in range(2):
             step()
         sync()
@@ -608,6 +609,7 @@ def main():
         sync()
         dt2 = time.perf_counter() - t1
         fusion.skip_dropped_branches = False
+        torch.cuda.empty_cache()
         skip_leg = {"ms_per_step": dt2 / args.steps * 1e3, "value": args.batch * args.steps / dt2, "unit": "samples/s",
                     "steps": args.steps, "warmup": 2, "final_loss": float(loss2.float().mean().item()),
                     "what": "TransformerEncoder.skip_dropped_branches: every residual branch runs on the packed rows of the samples its "

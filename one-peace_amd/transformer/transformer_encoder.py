@@ -57,6 +57,9 @@ class TransformerEncoder(nn.Module):
         # branch work at 0.4).  Off by default: the default step performs the reference's arithmetic, zeros included.
         self.skip_dropped_branches = os.environ.get("ONEPEACE_SKIP_DROPPED", "0") == "1"
         self.kept_rows_pad = 256  # packed rows per segment are rounded up to whole 256-row GEMM tiles (zero rows)
+        # below these drop rates a branch (attention, FFN) keeps the multiplier form: the two packing passes + the zero rows cost more than
+        # the dropped samples' share of the branch (headline step: 0.3 ms against 5.7 ms resp. 12 ms per branch, forward + backward)
+        self.pack_min_drop = (0.055, 0.03)
 
     def build_encoder_layer(self, cfg, drop_path_rate=0.0):
         return TransformerEncoderLayer(cfg, drop_path_rate=drop_path_rate)
@@ -235,7 +238,7 @@ class TransformerEncoder(nn.Module):
                 if p <= 0.0:
                     continue
                 per_seg = [(r0, S, B, torch.nonzero(mask[i, b, s0:s0 + B]).flatten().tolist()) for (_, B, S, r0, _, s0) in segs]
-                if all(len(t[3]) > 0 for t in per_seg):
+                if p >= self.pack_min_drop[b] and all(len(t[3]) > 0 for t in per_seg):
                     todo.append(((i, b), per_seg))
                 else:
                     dense[(i, b)] = (mask[i, b].float() / (1.0 - p)).to(device)

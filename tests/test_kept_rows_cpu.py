@@ -45,5 +45,10 @@ def test_encoder_plans_cover_every_branch_with_drop_path():
     assert all(r % 256 == 0 for r in k.dst_rows)
     k = plans[1][0]
     assert k.n_kept == [4, 5, 5]
+    # a branch whose drop rate is below the break-even of packing keeps the multiplier form
+    enc.pack_min_drop = (0.15, 0.05)          # layer 1 has p = 0.1: its attention branch stays dense, its FFN branch packs
+    scales, plans = enc._draw_kept_plans(segs, 3 * B, rows, torch.device("cpu"))
+    assert plans[1][0] is None and plans[1][1] is not None
+    assert torch.allclose(scales[1][0], mask[1, 0].float() / 0.9) and scales[1][1] is None
     enc.eval()
     assert enc._draw_kept_plans(segs, 3 * B, rows, torch.device("cpu")) == (None, None)

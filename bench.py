@@ -294,6 +294,8 @@ def main():
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lock-step", action="store_true",
+                    help="contrastive configs: one encoder pass per modality (the reference's call pattern) instead of the lock-step pass")
     ap.add_argument("--skip-dropped", action="store_true",
                     help="stochastic depth on the kept samples only (TransformerEncoder.skip_dropped_branches): the timed step does not "
                          "compute the branch outputs the reference multiplies by zero; default: the reference's arithmetic")
@@ -445,9 +447,9 @@ def main():
             from one_peace_amd.criterions.pretrain import ImageTextPretrainLossCriterion
             crit = ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, 0.0)  # pretrain_vl_3B.yaml criterion block
         elif args.config == 3:
-            crit = TriModalContrastiveCriterion(None, 0.0)
+            crit = TriModalContrastiveCriterion(None, 0.0, lock_step=not args.no_lock_step)
         else:
-            crit = ImageTextRetrievalCriterion(None, 0.0)
+            crit = ImageTextRetrievalCriterion(None, 0.0, lock_step=not args.no_lock_step)
 
     feeder = None
     if args.host_inputs:  # fp32 pixels / waveforms on the host, as the reference's collate_fn delivers them

@@ -66,17 +66,27 @@ class _PairCriterion(FairseqCriterion):
     other = "image"          # the non-text modality
     keys = ("i2t", "t2i")
 
-    def __init__(self, task, label_smoothing=0.0):
+    def __init__(self, task, label_smoothing=0.0, lock_step=True):
         super().__init__(task)
         self.label_smoothing = label_smoothing
+        self.lock_step = lock_step  # False: always one model call per modality, exactly the reference's call pattern
 
     def _other_logits(self, model, net_input):
         raise NotImplementedError
 
+    def _other_inputs(self, net_input):
+        raise NotImplementedError
+
     def forward(self, model, sample, reduce=True):
         ni = sample["net_input"]
-        text = _first(model(src_tokens=ni["src_tokens"], encoder_type="text"))
-        other = self._other_logits(model, ni)
+        multi = None
+        if self.lock_step and hasattr(model, "forward_multi"):  # both streams layer by layer in lock-step (MI355X path; round 4)
+            multi = model.forward_multi(src_tokens=ni["src_tokens"], **self._other_inputs(ni))
+        if multi is not None:
+            text, other = multi["text"], multi[self.other]
+        else:
+            text = _first(model(src_tokens=ni["src_tokens"], encoder_type="text"))
+            other = self._other_logits(model, ni)
         text_all, other_all = gather_without_grad(text, other)
         scale = model(return_logit_scale=True)
         loss, o2t, t2o = contrastive_pair_loss(other, text, other_all, text_all, scale, self.label_smoothing)
@@ -110,6 +120,9 @@ class ImageTextRetrievalCriterion(_PairCriterion):
     def _other_logits(self, model, ni):
         return _first(model(src_images=ni["src_images"], encoder_type="image"))
 
+    def _other_inputs(self, ni):
+        return {"src_images": ni["src_images"]}
+
     def compute_itc_loss(self, image_logits, text_logits, image_logits_all, text_logits_all, logit_scale_exp):
         return contrastive_pair_loss(image_logits, text_logits, image_logits_all, text_logits_all, logit_scale_exp,
                                      self.label_smoothing)
@@ -122,6 +135,9 @@ class AudioTextRetrievalCriterion(_PairCriterion):
     def _other_logits(self, model, ni):
         return _first(model(src_audios=ni["src_audios"], audio_padding_masks=ni["audio_padding_masks"],
                             encoder_type="audio"))
+
+    def _other_inputs(self, ni):
+        return {"src_audios": ni["src_audios"], "audio_padding_masks": ni["audio_padding_masks"]}
 
     def compute_atc_loss(self, audio_logits, text_logits, audio_logits_all, text_logits_all, logit_scale_exp):
         return contrastive_pair_loss(audio_logits, text_logits, audio_logits_all, text_logits_all, logit_scale_exp,

@@ -1050,6 +1050,56 @@ def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(f
     assert len(res[True][1]) > 60, len(res[True][1])
 
 
+@pytest.mark.parametrize("other", ["image", "audio"])
+def test_pair_criterions_in_lock_step_match_one_forward_per_modality(other):
+    """image_text_retrieval_criterion / audio_text_retrieval_criterion (BASELINE configs 2 and 4): text + image (audio) advanced in
+    lock-step through the shared encoder against one model call per modality (image_text_retrieval_loss.py:64-112): same loss
+    bits, per-modality gradients bit-identical, gradients of the shared attention branch within bf16 rounding (one fp32 sum over all
+    rows instead of two rounded sums)."""
+    from one_peace_amd.criterions.contrastive import AudioTextRetrievalCriterion, ImageTextRetrievalCriterion
+    from one_peace_amd.transformer import transformer_encoder as TE
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=3, attention_heads=2, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B = 6
+    inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    Crit = ImageTextRetrievalCriterion if other == "image" else AudioTextRetrievalCriterion
+    res = {}
+    for lock in (False, True):
+        enc = one_peace_encoder_config(drop_path_rate=0.0, layer_scale_init_value=1e-2, **cfg)
+        torch.manual_seed(0)
+        m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+        m = m.to(DEV).to(torch.bfloat16).train()
+        used = {"multi": 0}
+        orig_multi = TE.TransformerEncoder.forward_multi
+
+        def counted(self, infos):
+            used["multi"] += 1
+            return orig_multi(self, infos)
+        TE.TransformerEncoder.forward_multi = counted
+        try:
+            m.zero_grad()
+            loss, _, log = Crit(None, 0.0, lock_step=lock)(m, {"net_input": inp, "nsentences": B})
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            TE.TransformerEncoder.forward_multi = orig_multi
+        assert used["multi"] == (1 if lock else 0)
+        res[lock] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    shared_tags = ("self_attn.", "self_attn_layer_norm", "final_layer_norm", "gamma_1", "gamma_2", "logit_scale")
+    assert set(res[True][1]) == set(res[False][1])
+    for n, gs in res[False][1].items():
+        gm = res[True][1][n]
+        if any(t in n for t in shared_tags):
+            assert float((gm - gs).norm()) <= 2e-2 * float(gs.norm()) + 1e-5, (n, float((gm - gs).norm()), float(gs.norm()))
+        else:
+            assert torch.equal(gm, gs), (n, float((gm - gs).abs().max()))
+
+
 def test_single_stream_skip_of_dropped_samples_matches_the_multiplier_form():
     """skip_dropped_branches on a SINGLE-modality training pass (image tower, the forwards of BASELINE configs 2 and 4): it runs as a
     lock-step pass with one segment and packs the kept samples of every branch; same masks as the multiplier form -> embeddings

@@ -52,6 +52,7 @@ class ImageTextPretrainLossCriterion(FairseqCriterion):
         self.dcl_text_alpha, self.dcl_image_alpha = dcl_text_alpha, dcl_image_alpha
         self.dcl_vl_text_alpha, self.dcl_vl_image_alpha = dcl_vl_text_alpha, dcl_vl_image_alpha
         self.dcl_logit_scale, self.label_smoothing = dcl_logit_scale, label_smoothing
+        self.lock_step = True  # False: one model call per pass, exactly the reference's call pattern
 
     def compute_dcl_loss(self, student_features, teacher_features, mask_indices, padding_masks=None):
         return compute_dcl_loss(student_features, teacher_features, mask_indices, self.dcl_logit_scale, self.label_smoothing,
@@ -63,8 +64,12 @@ class ImageTextPretrainLossCriterion(FairseqCriterion):
     def forward(self, model, sample, reduce=True):
         ni = sample["net_input"]
         tok, img = ni["src_tokens"], ni["src_images"]
-        text_logits, teacher_text = model(src_tokens=tok, encoder_type="text")
-        image_logits, teacher_image = model(src_images=img, encoder_type="image")
+        multi = model.forward_multi(src_tokens=tok, src_images=img) if self.lock_step and hasattr(model, "forward_multi") else None
+        if multi is not None:  # the two unmasked single-modality passes in lock-step (MI355X path; same rows, same arithmetic)
+            (text_logits, teacher_text), (image_logits, teacher_image) = multi["text"], multi["image"]
+        else:
+            text_logits, teacher_text = model(src_tokens=tok, encoder_type="text")
+            image_logits, teacher_image = model(src_images=img, encoder_type="image")
         text_all, image_all = gather_without_grad(text_logits, image_logits)
         with torch.no_grad():
             teacher_vl_text, teacher_vl_image = model(src_tokens=tok, src_images=img, encoder_type="vl")

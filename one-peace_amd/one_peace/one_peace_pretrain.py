@@ -97,6 +97,16 @@ class OnePeacePretrainModel(OnePeaceBaseModel):
             return feats["text"], feats["audio"]
         raise NotImplementedError(encoder_type)
 
+    def forward_multi(self, src_tokens=None, src_images=None, src_audios=None, audio_padding_masks=None):
+        """{modality: (normalised CLS embedding, features)} of the given UNMASKED inputs -- what one `forward(..., encoder_type=m)` per
+        modality returns (lines 91-93 above) -- from ONE lock-step pass through the shared encoder (MI355X path); None when that pass
+        does not apply.  The criterion's first two passes (image_text_pretrain_loss.py:76-83) qualify."""
+        feats = self.encoder_wrapper.forward_multi(src_tokens=src_tokens, src_images=src_images, src_audios=src_audios,
+                                                   audio_padding_masks=audio_padding_masks)
+        if feats is None:
+            return None
+        return {m: (normalized_projection(getattr(self, m + "_proj"), f[:, 0, :]), f) for m, f in feats.items()}
+
     def upgrade_state_dict_named(self, state_dict, name):
         super().upgrade_state_dict_named(state_dict, name)
         if self.cfg.reset_logit_scale:

@@ -545,23 +545,27 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
         dense_inits.append(tuple(dense.shape))  # [B, heads, K, K] tensor (adapter/image.py:188-204 is replaced, not ported)
         orig_dense_init(self, dense)
     _ops.DenseBias.__init__ = _no_dense
-    of, ot = TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch
+    of, ot, om = TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch, TE.TransformerEncoder.forward_multi
 
     def cf(self, *a, **k):
         calls["fused"] += 1
         return of(self, *a, **k)
+
+    def cm(self, infos):
+        calls["multi"] = calls.get("multi", 0) + len(infos)
+        return om(self, infos)
 
     def ct(self, *a, **k):
         calls["torch"] += 1
         return ot(self, *a, **k)
 
     res = {}
-    TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch = cf, ct
+    TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch, TE.TransformerEncoder.forward_multi = cf, ct, cm
     try:
         for mode in ("hip", "torch"):
             m = _build_pretrain(fx, audio_language=stage == "al").to(DEV).to(torch.bfloat16).eval()
             _force_torch_path(m, mode == "torch")
-            calls["fused"] = calls["torch"] = 0
+            calls["fused"] = calls["torch"] = calls["multi"] = 0
             crit = (ImageTextPretrainLossCriterion(None, 0.5, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0) if stage == "vl"
                     else AudioTextPretrainLossCriterion(None, 1.0, 0.5, 0.5, 2.5, label_smoothing=0.0))
             loss, _, log = crit(m, {"net_input": ni, "nsentences": 4})
@@ -569,12 +573,14 @@ def test_full_pretraining_objective_on_hip(golden_dir, stage):
             loss.backward()
             torch.cuda.synchronize()
             if mode == "hip":
-                # vl: 6 encoder + 3 decoder passes; al: 5 encoder + 2 decoder passes -- all on the fused layers
-                assert calls["torch"] == 0 and calls["fused"] == (9 if stage == "vl" else 7), calls
+                # vl: 6 encoder + 3 decoder passes; al: 5 encoder + 2 decoder passes -- all on the fused layers (round 4: the two unmasked
+                # single-modality passes of the vl objective as ONE lock-step pass)
+                assert calls["torch"] == 0 and calls["fused"] + calls["multi"] == (9 if stage == "vl" else 7), calls
+                assert calls["multi"] == (2 if stage == "vl" else 0), calls
             res[mode] = dict(log={k: float(v) for k, v in log.items() if "loss" in k},
                              grads={n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
     finally:
-        TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch = of, ot
+        TE.TransformerEncoder._forward_fused, TE.TransformerEncoder._forward_torch, TE.TransformerEncoder.forward_multi = of, ot, om
         _ops.DenseBias.__init__ = orig_dense_init
     assert not dense_inits, "dense per-sample bias tensors were built: %s" % dense_inits
     report = []

@@ -241,9 +241,17 @@ class TransformerEncoder(nn.Module):
                 if p >= self.pack_min_drop[b] and all(len(t[3]) > 0 for t in per_seg):
                     todo.append(((i, b), per_seg))
                 else:
-                    dense[(i, b)] = (mask[i, b].float() / (1.0 - p)).to(device)
+                    dense[(i, b)] = mask[i, b].float() / (1.0 - p)
         lists, bases = hip.pack_kept_lists([t[1] for t in todo])
-        lists = lists.to(device, non_blocking=True)
+        if device.type == "cuda":  # pinned staging + asynchronous copies: a pageable-memory copy would make the host wait for the stream
+            lists = lists.pin_memory().to(device, non_blocking=True)
+            if dense:
+                keys = sorted(dense)
+                allps = torch.stack([dense[k] for k in keys]).pin_memory().to(device, non_blocking=True)
+                dense = {k: allps[j] for j, k in enumerate(keys)}
+        else:
+            lists = lists.to(device)
+            dense = {k: v.to(device) for k, v in dense.items()}
         kept = {key: hip.KeptRows(per_seg, lists, base, rows, 1.0 / (1.0 - probs[key[0]]), pad=self.kept_rows_pad)
                 for (key, per_seg), base in zip(todo, bases)}
         plans = [(kept.get((i, 0)), kept.get((i, 1))) for i in range(len(probs))]

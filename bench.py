@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss-curve", action="store_true", help="record the loss of every timed step in config.loss_curve (same batch every step)")
     ap.add_argument("--no-lock-step", action="store_true",
                     help="contrastive configs: one encoder pass per modality (the reference's call pattern) instead of the lock-step pass")
     ap.add_argument("--skip-dropped", action="store_true",
@@ -583,6 +584,7 @@ def main():
         sync()
     hip.GEMM_ALGO_BYTES[0] = hip.GEMM_ALGO_BYTES[1] = 0
     profiled_steps = 0
+    curve = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         prof_on = not args.no_profile and i % PROFILE_EVERY == 0
@@ -590,6 +592,8 @@ def main():
             hip.lib().op_prof_enable(1)
             profiled_steps += 1
         loss = step()
+        if args.loss_curve and train:
+            curve.append(loss.detach().float().mean())  # (device scalars: read after the timed region)
         if prof_on:
             hip.lib().op_prof_enable(0)
     sync()
@@ -679,6 +683,7 @@ def main():
                        "algorithmic_tflop_per_sample": None if full else fl / 1e12,
                        "step_algorithmic_tflops_per_gpu": None if full else fl * args.batch / (ms / 1e3) / 1e12,
                        "objective": "forward" if not train else args.objective, "final_loss": loss_v if train else None,
+                       **({"loss_curve": [round(float(x), 5) for x in curve]} if curve else {}),
                        "launch_path": ("hipGraph replay of zero-grad + forwards + loss + backward, eager optimiser step" if args.graphs
                                        else "eager (one ctypes call per kernel)")},
         }

@@ -88,7 +88,7 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
                        const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
                        const void* const* resid, int64_t ldr, const void* const* gamma, const float* const* rowscale,
                        const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream);
-/* Grouped form of op_gemm_tn: up to 12 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  with their own operands,
+/* Grouped form of op_gemm_tn: up to 16 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  with their own operands,
  * sizes, K_i and outputs as ONE persistent launch WITHOUT split-K: the tile list of all problems is walked by one workgroup per
  * CU (per-XCD queues of tiles that share an operand panel, longest K first, work stealing), every output tile runs its whole K
  * and is written / accumulated exactly once -- no fp32 slabs, no fold kernel.  Replaces the weight-gradient launches autograd

@@ -170,9 +170,12 @@ class GroupedConv1dSameFn(torch.autograd.Function):
             dyr = torch.zeros(G, B * Ts, cg, dtype=dy.dtype, device=dy.device)  # output-row layout, zero garbage rows
             dyr.view(G, B, Ts, cg)[:, :, :T] = dy.view(B, T, G, cg).permute(2, 0, 1, 3)
             dwg = torch.empty(G, cg, k * cg, dtype=dy.dtype, device=dy.device)
-            for g in range(G):
-                patches = _as_rows(xg[g], B * Ts, k * cg, cg, 0)
-                ops.wgrad(dyr[g], patches, out=dwg[g])
+            probs = [(dyr[g], _as_rows(xg[g], B * Ts, k * cg, cg, 0), dwg[g], False) for g in range(G)]
+            # the G per-group products as ONE persistent launch (op_gemm_tn_grouped: every tile runs its whole K, no split-K slabs and
+            # folds; 16 launches + 16 folds per layer before round 4) when the shapes qualify, else one launch per group
+            if not (G <= hip.TN_GROUP_MAX and (B * Ts) % 64 == 0 and cg % 8 == 0 and hip.gemm_tn_grouped(probs)):
+                for dyg, patches, out, _ in probs:
+                    ops.wgrad(dyg, patches, out=out)
             dw = dwg.view(G, cg, k, cg).permute(0, 1, 3, 2).reshape(C, cg, k)  # [g, co, j, ci] -> [C, ci, j]
         if has_bias and ctx.needs_input_grad[2]:
             db = hip.colsum(dy.view(B * T, C))

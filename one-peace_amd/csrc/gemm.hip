@@ -2031,7 +2031,7 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) 
 // queue holds both claim counts, a claim is good while their sum is below the queue length.
 // Main loop, LDS image, fragment order = gemm256w_tn_kernel (bit-identical per-tile results to its unsplit launch).
 // =====================================================================================================================
-constexpr int TN_MAX_PROB = 12;
+constexpr int TN_MAX_PROB = 16;
 constexpr int TN_CTR_STRIDE = 8;   // 64-bit counters 64 bytes apart: queues 0..7 (claims from the front | from the back << 32), then the exit counter
 struct TnProb {
   const bf16_t* A; const bf16_t* B; bf16_t* C;  // C[M,N] (+)= A[K,M]^T B[K,N]
@@ -3041,7 +3041,7 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
   return n;
 }
 
-// Up to 12 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  (A_i [K_i, M_i], B_i [K_i, N_i] row-major bf16: dy and
+// Up to 16 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  (A_i [K_i, M_i], B_i [K_i, N_i] row-major bf16: dy and
 // x of nn.Linear, autograd's dW = dy^T x) as ONE persistent launch without split-K (gemm256w_tn_grouped_kernel): every output
 // tile runs its whole K and is written / accumulated once.  Shape rules per problem as op_gemm_tn; returns OP_ENOTSUP (nothing
 // launched) when a problem does not qualify -- the caller then uses op_gemm_tn per problem.  Problems may come in any order.

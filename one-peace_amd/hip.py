@@ -424,11 +424,11 @@ def gemm_tn(A_km, B_kn, out=None, accumulate=False, splitk=True):
 
 
 _tn_counters = {}
-TN_GROUP_MAX = 12
+TN_GROUP_MAX = 16
 
 
 def gemm_tn_grouped(problems, tune=0):
-    """ONE persistent launch for up to 12 weight-gradient GEMMs, no split-K (csrc/gemm.hip: gemm256w_tn_grouped_kernel).
+    """ONE persistent launch for up to 16 weight-gradient GEMMs, no split-K (csrc/gemm.hip: gemm256w_tn_grouped_kernel).
     problems: [(A_km [K, M], B_kn [K, N], out [M, N] bf16, accumulate)].  Returns False (nothing launched) when a problem does not
     qualify for the transpose-read kernel -- the caller then runs gemm_tn per problem."""
     n = len(problems)

@@ -1064,6 +1064,7 @@ def test_weight_gradient_full_size_matches_torch(M, No, Ni):
 GROUPED_TN_SETS = {
     "mixed": [(256, 512, 256, True), (128, 264, 520, False), (1024, 256, 1536, True), (64, 8, 8, True), (448, 2304, 2560, False)],
     "twelve": [(320, 512, 384, bool(i & 1)) for i in range(12)],
+    "sixteen": [(128, 96, 8 * (i + 1), bool(i & 1)) for i in range(16)],  # (the 16 groups of the audio positional convolution's weight gradient: M = 96)
     "one": [(512, 768, 256, True)],
 }
 
@@ -1105,7 +1106,7 @@ def test_gemm_tn_grouped_rejects_what_the_kernel_cannot_take():
     torch.cuda.synchronize()
     assert torch.equal(ok[2], before)  # nothing was launched
     with pytest.raises(RuntimeError):
-        hip.gemm_tn_grouped([ok] * 13)
+        hip.gemm_tn_grouped([ok] * 17)
 
 
 def test_weight_gradients_of_a_headline_layer_grouped_match_torch():

@@ -71,13 +71,28 @@ __device__ __forceinline__ float wave_max(float v) {
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
   typedef bf16x8 raw_t;  // load now, convert at first use (keeps prefetched rows as plain loads in flight)
+  // -DOP_NT_STREAM (A/B builds of tools/): non-temporal hint on the streaming loads / stores of the row-wise kernels
+#ifdef OP_NT_STREAM
+  static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+#else
   static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+#endif
+  // non-temporal forms for the passes that stream hundreds of MB once (training-only kernels: op_ln_geglu_fwd / _bwd; +2.5 ... 3 % on
+  // them at the headline shapes and nothing of theirs left in L2 / Infinity Cache in front of the next GEMM's panels).  NOT the default:
+  // on inference-size tensors the same hint costs 1 ... 5 % (config 1: the next launch finds its input in the caches).
+  static __device__ __forceinline__ raw_t ldraw_nt(const bf16_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+  static __device__ __forceinline__ void store_nt(bf16_t* p, const float (&v)[8]) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+    __builtin_nontemporal_store(r, reinterpret_cast<bf16x8*>(p));
+  }
   static __device__ __forceinline__ void cvt(const raw_t& r, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
   }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
-    bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+    bf16x8 r = ldraw(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
   }
@@ -85,7 +100,11 @@ template <> struct Vec8<bf16_t> {
     bf16x8 r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = (bf16_t)v[i];
+#ifdef OP_NT_STREAM
+    __builtin_nontemporal_store(r, reinterpret_cast<bf16x8*>(p));
+#else
     *reinterpret_cast<bf16x8*>(p) = r;
+#endif
   }
 };
 template <> struct Vec8<float> {

@@ -162,8 +162,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(c
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        c0[i] = Vec8<bf16_t>::ldraw(h0 + row0 * ldh + c);
-        c1[i] = Vec8<bf16_t>::ldraw(h1 + row0 * ldh + c);
+        c0[i] = Vec8<bf16_t>::ldraw_nt(h0 + row0 * ldh + c);
+        c1[i] = Vec8<bf16_t>::ldraw_nt(h1 + row0 * ldh + c);
       }
     }
   }
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(c
       for (int i = 0; i < CH; ++i) {
         const int c = (tig + G * i) * 8;
         if (c < cols) {
-          n0[i] = Vec8<bf16_t>::ldraw(h0 + nrow * ldh + c);
-          n1[i] = Vec8<bf16_t>::ldraw(h1 + nrow * ldh + c);
+          n0[i] = Vec8<bf16_t>::ldraw_nt(h0 + nrow * ldh + c);
+          n1[i] = Vec8<bf16_t>::ldraw_nt(h1 + nrow * ldh + c);
         }
       }
     }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(c
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[i][j] + bv[i][j];
-        Vec8<bf16_t>::store(yr + c, o);
+        Vec8<bf16_t>::store_nt(yr + c, o);
       }
     }
     if (tig == 0) {
@@ -393,9 +393,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        r0[i] = Vec8<bf16_t>::ldraw(h0 + row0 * ldh + c);
-        r1[i] = Vec8<bf16_t>::ldraw(h1 + row0 * ldh + c);
-        rg[i] = Vec8<bf16_t>::ldraw(dy + row0 * (int64_t)cols + c);
+        r0[i] = Vec8<bf16_t>::ldraw_nt(h0 + row0 * ldh + c);
+        r1[i] = Vec8<bf16_t>::ldraw_nt(h1 + row0 * ldh + c);
+        rg[i] = Vec8<bf16_t>::ldraw_nt(dy + row0 * (int64_t)cols + c);
       }
     }
   }
@@ -408,9 +408,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
       for (int i = 0; i < CH; ++i) {
         const int c = (tig + G * i) * 8;
         if (c < cols) {
-          n0[i] = Vec8<bf16_t>::ldraw(h0 + nrow * ldh + c);
-          n1[i] = Vec8<bf16_t>::ldraw(h1 + nrow * ldh + c);
-          ng[i] = Vec8<bf16_t>::ldraw(dy + nrow * (int64_t)cols + c);
+          n0[i] = Vec8<bf16_t>::ldraw_nt(h0 + nrow * ldh + c);
+          n1[i] = Vec8<bf16_t>::ldraw_nt(h1 + nrow * ldh + c);
+          ng[i] = Vec8<bf16_t>::ldraw_nt(dy + nrow * (int64_t)cols + c);
         }
       }
     }
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
           o0[j] = dg * b[j] * (cdf + a[j] * pdf);
           o1[j] = dg * ge;
         }
-        Vec8<bf16_t>::store(dh0 + row * ldd + c, o0);
-        Vec8<bf16_t>::store(dh1 + row * ldd + c, o1);
+        Vec8<bf16_t>::store_nt(dh0 + row * ldd + c, o0);
+        Vec8<bf16_t>::store_nt(dh1 + row * ldd + c, o1);
       }
     }
 #pragma unroll

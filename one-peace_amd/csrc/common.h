@@ -115,6 +115,19 @@ template <> struct Vec8<float> {
     r.b = *reinterpret_cast<const f32x4*>(p + 4);
     return r;
   }
+  static __device__ __forceinline__ raw_t ldraw_nt(const float* p) {
+    raw_t r;
+    r.a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+    r.b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+    return r;
+  }
+  static __device__ __forceinline__ void store_nt(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+    __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
+    __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+  }
   static __device__ __forceinline__ void cvt(const raw_t& r, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = r.a[i]; v[4 + i] = r.b[i]; }
@@ -133,6 +146,16 @@ template <> struct Vec8<float> {
     *reinterpret_cast<f32x4*>(p + 4) = b;
   }
 };
+
+// streaming access with the cache policy chosen at compile time (NT: see Vec8<bf16_t>::ldraw_nt)
+template <typename T, bool NT> __device__ __forceinline__ typename Vec8<T>::raw_t ldraw_sel(const T* p) {
+  if constexpr (NT) return Vec8<T>::ldraw_nt(p);
+  else return Vec8<T>::ldraw(p);
+}
+template <typename T, bool NT> __device__ __forceinline__ void store_sel(T* p, const float (&v)[8]) {
+  if constexpr (NT) Vec8<T>::store_nt(p, v);
+  else Vec8<T>::store(p, v);
+}
 
 // Exact-erf GELU pieces: Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and phi(x) = exp(-x^2/2) / sqrt(2 pi) from ONE exponential
 // (Abramowitz-Stegun 7.1.26: erfc(u) = t (a1 + t (a2 + ... a5 t)) e^{-u^2}, t = 1 / (1 + p u), |error| <= 1.5e-7 -- four

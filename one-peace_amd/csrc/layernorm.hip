@@ -38,7 +38,7 @@ __device__ __forceinline__ float group_sum(float v, float* red) {
   return t;
 }
 
-template <typename T, int CH, int NW, bool GELU>
+template <typename T, int CH, int NW, bool GELU, bool NT>  // NT: non-temporal row accesses (tensors far beyond the caches: training)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                      const T* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
-      if (c < cols) cur[i] = Vec8<T>::ldraw(x + row0 * (int64_t)cols + c);
+      if (c < cols) cur[i] = ldraw_sel<T, NT>(x + row0 * (int64_t)cols + c);
     }
   }
   for (int64_t row = row0; row < rows; row += rstep) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         const int c = (tig + G * i) * 8;
-        if (c < cols) nxt[i] = Vec8<T>::ldraw(x + nrow * (int64_t)cols + c);
+        if (c < cols) nxt[i] = ldraw_sel<T, NT>(x + nrow * (int64_t)cols + c);
       }
     }
     float v[CH][8];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
           float t = (v[i][j] - mean) * rstd * wv[i][j] + bv[i][j];
           o[j] = GELU ? gelu_erf(t) : t;
         }
-        Vec8<T>::store(yr + c, o);
+        store_sel<T, NT>(yr + c, o);
       }
     }
     if (tig == 0) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(c
 
 // dx = rstd * (dy*w - mean(dy*w) - xhat * mean(dy*w*xhat));  dw = sum_rows dy*xhat;  db = sum_rows dy.
 // Partial dw/db of each workgroup go to ws[gridDim.x][2][cols] (fp32); ln_bwd_reduce_kernel folds them.
-template <typename T, int CH, int NW, bool GELU>
+template <typename T, int CH, int NW, bool GELU, bool NT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const T* __restrict__ w, const T* __restrict__ b,
                                                      const float* __restrict__ mean_in,
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        curx[i] = Vec8<T>::ldraw(x + row0 * (int64_t)cols + c);
-        curg[i] = Vec8<T>::ldraw(dy + row0 * (int64_t)cols + c);
+        curx[i] = ldraw_sel<T, NT>(x + row0 * (int64_t)cols + c);
+        curg[i] = ldraw_sel<T, NT>(dy + row0 * (int64_t)cols + c);
       }
     }
   }
@@ -276,10 +276,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < CH; ++i) {  // residual-path gradient of this row + both operands of the next row
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        if (add) addv[i] = Vec8<T>::ldraw(add + row * (int64_t)cols + c);
+        if (add) addv[i] = ldraw_sel<T, NT>(add + row * (int64_t)cols + c);
         if (nrow < rows) {
-          nxtx[i] = Vec8<T>::ldraw(x + nrow * (int64_t)cols + c);
-          nxtg[i] = Vec8<T>::ldraw(dy + nrow * (int64_t)cols + c);
+          nxtx[i] = ldraw_sel<T, NT>(x + nrow * (int64_t)cols + c);
+          nxtg[i] = ldraw_sel<T, NT>(dy + nrow * (int64_t)cols + c);
         }
       }
     }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] += av[j];
         }
-        Vec8<T>::store(dr + c, o);
+        store_sel<T, NT>(dr + c, o);
       }
     }
 #pragma unroll
@@ -510,8 +510,16 @@ template <typename T, bool GELU>
 int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
                     int cols, float eps, hipStream_t s) {
   const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* Y = (T*)y;
-#define LN_F(CH, NW) \
-  hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps)
+  // cache policy: non-temporal row accesses for a TRAINING pass (the caller wants the statistics: a backward follows) over a matrix of
+  // >= 64 MiB -- it streams once, and what it left in L2 / Infinity Cache only displaced the next GEMM's panels (-2 % on the headline
+  // step with the hint on every row-wise kernel); inference keeps the default policy: there the consumer finds the row matrix in the
+  // caches (+1 ... 5 % with the hint at the image tower's sizes; profiles/r4_nontemporal_ab.txt)
+  const bool nt = mean != nullptr && (int64_t)rows * cols * (int64_t)sizeof(T) >= ((int64_t)64 << 20);
+#define LN_F(CH, NW)                                                                                                                      \
+  do {                                                                                                                                    \
+    if (nt) hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU, true>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps); \
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU, false>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps); \
+  } while (0)
   if (cols <= 512) LN_F(1, 1);
   else if (cols <= 1024) LN_F(2, 1);
   else if (cols <= 1536) LN_F(3, 1);
@@ -533,11 +541,14 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
   const T* ADD = (const T*)add;
   int grid = 0;
   float* wsk = (dw || db) ? ws : nullptr;
+  const bool nt = (int64_t)rows * cols * (int64_t)sizeof(T) >= ((int64_t)64 << 20);  // (see ln_fwd_dispatch)
 #define LN_B(CH, NW)                                                                                        \
   do {                                                                                                      \
     grid = ln_grid(rows, NW, g_ln_blocks_bwd);                                                                               \
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                          \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
+    if (nt) hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU, true>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
+                       rstd, ADD, DX, wsk, rows, cols);                                                          \
+    else hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU, false>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
                        rstd, ADD, DX, wsk, rows, cols);                                                          \
   } while (0)
   if (cols <= 512) LN_B(1, 1);

@@ -83,7 +83,7 @@ class _PairCriterion(FairseqCriterion):
         if self.lock_step and hasattr(model, "forward_multi"):  # both streams layer by layer in lock-step (MI355X path; round 4)
             multi = model.forward_multi(src_tokens=ni["src_tokens"], **self._other_inputs(ni))
         if multi is not None:
-            text, other = multi["text"], multi[self.other]
+            text, other = _first(multi["text"]), _first(multi[self.other])  # pretrain models: (logits, features)
         else:
             text = _first(model(src_tokens=ni["src_tokens"], encoder_type="text"))
             other = self._other_logits(model, ni)
@@ -163,7 +163,7 @@ class TriModalContrastiveCriterion(FairseqCriterion):
             multi = model.forward_multi(src_tokens=ni["src_tokens"], src_images=ni["src_images"], src_audios=ni["src_audios"],
                                         audio_padding_masks=ni["audio_padding_masks"])
         if multi is not None:
-            text, image, audio = multi["text"], multi["image"], multi["audio"]
+            text, image, audio = (_first(multi[m]) for m in ("text", "image", "audio"))
         else:
             text = _first(model(src_tokens=ni["src_tokens"], encoder_type="text"))
             image = _first(model(src_images=ni["src_images"], encoder_type="image"))

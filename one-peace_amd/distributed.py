@@ -106,6 +106,8 @@ class FlatParameters:
                 p._op_pending = 0
 
     def zero_grad(self):
+        from . import ops
+        ops.reset_wgrads()  # problems queued by a backward pass that raised (OOM handling of the trainer) die with its gradients
         self.grads.zero_()
         for _, p, _, _ in self.entries:
             p._op_pending = 0
@@ -208,6 +210,8 @@ class BucketedGradReducer:
 
     def reset(self):
         """Call before each (final) backward pass."""
+        from . import ops
+        ops.reset_wgrads()
         self._pending = [len(items) for (_, _, items) in self.buckets]
         self._done = [False] * len(self.flat.entries)
         self._hooked = [False] * len(self.flat.entries)

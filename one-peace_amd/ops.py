@@ -200,18 +200,40 @@ class _WgradQueue:
     kept alive until the launch is enqueued; the reducer hears about a parameter only after that."""
 
     def __init__(self):
+        self.items, self.done, self.armed, self.epoch = [], [], False, 0
+
+    def reset(self):
+        """Forget everything a backward pass that raised left behind (the engine does not run queue_callback callbacks then):
+        stale operands must not be accumulated into the freshly zeroed gradients of the next step, and the end-of-backward
+        safety net has to be registered again.  Called by distributed.FlatParameters.zero_grad / BucketedGradReducer.reset."""
         self.items, self.done, self.armed = [], [], False
+        self.epoch += 1
+
+    @staticmethod
+    def _span(out):
+        """Byte range [lo, hi) an output view covers in its storage (rows may be strided)."""
+        lo = out.data_ptr()
+        return lo, lo + ((out.shape[0] - 1) * out.stride(0) + out.shape[1]) * out.element_size()
 
     def add(self, dy, x, out, params):
+        lo, hi = self._span(out)
+        for it in self.items:  # the grouped launch read-modify-writes C tiles without ordering between problems: two
+            l2, h2 = self._span(it[2])  # contributions to one (overlapping) view go out as two launches, stream-ordered
+            if lo < h2 and l2 < hi:
+                self.flush()
+                break
         self.items.append((dy, x, out, True))
         self.done.extend(params)
         if not self.armed:  # safety net: whatever is still queued when autograd finishes this backward pass goes out then
             self.armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+            epoch = self.epoch
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: self._end_of_backward(epoch))
         if len(self.items) >= hip.TN_GROUP_MAX:
             self.flush()
 
-    def _end_of_backward(self):
+    def _end_of_backward(self, epoch):
+        if epoch != self.epoch:  # a reset() came in between: this callback belongs to an abandoned pass
+            return
         self.armed = False
         self.flush()
 
@@ -233,7 +255,8 @@ def wgrad_into(dy, x, grad_view, params):
     """grad_view (+)= dy^T x for the flat-buffer gradient views of `params` (one view spanning all of them).  Deferred into the
     layer's grouped launch when the shape allows, else launched now; either way every parameter's completion is signalled."""
     K, M = dy.shape
-    if (GROUPED_WGRAD and USE_TN_WGRAD and K % 64 == 0 and K >= 64 and grad_view.stride(0) % 4 == 0 and grad_view.stride(1) == 1
+    if (GROUPED_WGRAD and USE_TN_WGRAD and K % 64 == 0 and K >= 64 and grad_view.stride(0) % 8 == 0 and grad_view.stride(1) == 1
+            and grad_view.data_ptr() % 16 == 0  # op_gemm_tn_grouped's rule for C: ldc % 8 == 0, 16-byte aligned (else launch now)
             and hip.gemm_tn_supported(K, M, x.shape[1], dy.stride(0), x.stride(0))):
         _wgrad_queue.add(dy, x, grad_view, params)
         return
@@ -244,6 +267,11 @@ def wgrad_into(dy, x, grad_view, params):
 
 def flush_wgrads():
     _wgrad_queue.flush()
+
+
+def reset_wgrads():
+    """Drop weight-gradient problems a failed backward pass left queued (see _WgradQueue.reset)."""
+    _wgrad_queue.reset()
 
 
 def _direct_grad(param):
@@ -733,8 +761,8 @@ class AttnBranchFn(torch.autograd.Function):
         nseg = len(segs)
         params = rest[nseg:]
         P = dict(zip(ATTN_PARAMS, params))
-        need_grad = any(ctx.needs_input_grad)
-        keep = bool(save_acts) and need_grad
+        need_grad = any(ctx.needs_input_grad) and bool(int(save_acts) & 2)  # bit 1: autograd is recording (_save_flags) -- a
+        keep = bool(int(save_acts) & 1) and need_grad                       # no-grad teacher pass registers and keeps nothing
         first_param = 7 + nseg
         needs = dict(zip(ATTN_PARAMS, ctx.needs_input_grad[first_param:]))
         x_full = x2
@@ -1195,7 +1223,7 @@ def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):
     drop-path multipliers or None."""
     B, S, H = x.shape
     seg = StreamSeg("x", B, S, 0, bias, key_pad)
-    out = AttnBranchFn.apply(x.reshape(B * S, H), [seg], ps, S, heads, save_acts, None, bias.image if bias is not None else None, *params)
+    out = AttnBranchFn.apply(x.reshape(B * S, H), [seg], ps, S, heads, _save_flags(save_acts), None, bias.image if bias is not None else None, *params)
     return out.view(B, S, H)
 
 
@@ -1205,7 +1233,7 @@ def attn_branch_multi(x2, segs, ps_rows, heads, params, save_acts=False, kept=No
     sub-LayerNorm and out-proj (and, in backward, their input- and weight-gradient GEMMs) are ONE launch over all rows.
     kept (hip.KeptRows): the branch runs only on the samples stochastic depth keeps -- segs and ps_rows then describe the PACKED
     rows (kept_segments), x2 stays the full matrix; rows of dropped samples pass through unchanged, forward and backward."""
-    return AttnBranchFn.apply(x2, segs, ps_rows, 1, heads, save_acts, kept,
+    return AttnBranchFn.apply(x2, segs, ps_rows, 1, heads, _save_flags(save_acts), kept,
                               *[sg.bias.image if sg.bias is not None else None for sg in segs], *params)
 
 

@@ -109,14 +109,16 @@ def residual_scale(x, gamma, residual, path_scale=None):
 
 def encoder_layer(x, sd, p, num_heads, encoder_type, bias=None, text_seq_len=0, image_seq_len=0,
                   audio_seq_len=0, path_scale=None):
-    """transformer_layer.py:165-228.  x: [S, B, H] time-major."""
+    """transformer_layer.py:165-228.  x: [S, B, H] time-major.  path_scale: None, one [B] multiplier vector for both residual
+    branches, or a pair (attention branch, FFN branch) -- the reference draws a fresh mask per fused_dropout_res call (:78-85)."""
     g1, g2 = sd.get(p + ".gamma_1"), sd.get(p + ".gamma_2")
+    ps_attn, ps_ffn = path_scale if isinstance(path_scale, (tuple, list)) else (path_scale, path_scale)
     res = x
     h = layer_norm(x, sd[p + ".self_attn_layer_norm.weight"], sd[p + ".self_attn_layer_norm.bias"])
     h = self_attention(h, sd, p + ".self_attn", num_heads, bias)
     if (p + ".attn_ln.weight") in sd:  # cfg.scale_attn (:139); off in the shipped configs
         h = layer_norm(h, sd[p + ".attn_ln.weight"], sd[p + ".attn_ln.bias"])
-    x = residual_scale(h, g1, res, path_scale)
+    x = residual_scale(h, g1, res, ps_attn)
     res = x
     h = layer_norm(x, sd[p + ".final_layer_norm.weight"], sd[p + ".final_layer_norm.bias"])
     scale_fc = (p + ".text_ffn.2.weight") in sd or (p + ".image_ffn.2.weight") in sd or \
@@ -131,7 +133,7 @@ def encoder_layer(x, sd, p, num_heads, encoder_type, bias=None, text_seq_len=0, 
                        geglu_ffn(h[-audio_seq_len:], sd, p + ".audio_ffn", scale_fc)], dim=0)
     else:
         raise NotImplementedError(encoder_type)
-    return residual_scale(h, g2, res, path_scale)
+    return residual_scale(h, g2, res, ps_ffn)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -28,15 +28,16 @@ def _fx(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
 
-# name fragment -> bound that replaces the default one (measured value in brackets; torch-bf16 lands at the same error)
-# EXACT tensor names (as _check reports them).  The audio relative-position table: a tiny (|g| = 8.6e-3) gradient that is a sum of
-# strongly cancelling dS entries over buckets that each cover a large share of the keys.  dS = P o (dP - delta) sums to zero along a
-# row only if delta is exactly sum_k P dP; the kernels take delta = dO . O from the bf16-rounded forward output (no second pass
-# over the keys), the reference algorithm in bf16 takes it from a bf16-rounded dP: both break the cancellation at the bf16 level,
-# in different places (ours 1.0e-1, torch-bf16 0.65e-1 ... 0.98e-1 on the micro fixture; 2.9e-2 ... 3.8e-2 on the others).
+# name -> bound that replaces the default one (measured value in brackets; torch-bf16 lands at the same error).  EXACT tensor
+# names (as _check reports them).  Round 5: the audio relative-position table's gradient lost its 1.2e-1 relative exemption.  It is a
+# tiny (|g| = 8.6e-3 on the micro fixture) gradient that sums strongly cancelling dS entries over buckets that each cover a large
+# share of the keys; its bf16 error does not scale with its norm, which is what the 1.5e-3 ABSOLUTE Frobenius slack every small
+# gradient gets (abs_err below, the same slack smoke() uses) is for: under the common 5e-2 + 1.5e-3 it measures 4.8e-2 on the micro
+# fixture, 3.6e-2 joint, 2.1e-2 in the audio-text pretraining objective and 8.3e-3 at the 4B layer dimensions
+# (profiles/r4_*parity_report*.txt, test_lock_step_layer_4b_dimensions_against_the_fp32_oracle) -- a dBias regression can no
+# longer hide behind a 12 % relative bound.
 BOUND_EXCEPTIONS = {
-    "grad encoder_wrapper.audio_adapter.rel_pos_table_list.0.weight": 1.2e-1,  # [1.02e-1 micro fixture]
-    "al_audio": 2.3e-2,                                                         # [1.86e-2; torch-bf16 2.0e-2] audio CLS embedding of the joint step
+    "al_audio": 2.3e-2,  # [1.86e-2; torch-bf16 2.0e-2] audio CLS embedding of the joint step
 }
 
 
@@ -846,8 +847,7 @@ def test_deep_text_and_audio_towers_8_layers_4b_dimensions_with_backward(golden_
     sum(audio_logits * w_a).  The HIP path in bf16 must reproduce both normalised embeddings, the first feature rows, every
     parameter-gradient norm, the small gradients and the row probes of the large ones.  Same absolute tolerances as the 8-layer
     image fixture: embeddings rel-Frobenius <= 2e-2 and cosine >= 0.9998, features <= 2e-2, gradient norms within 2 % (3 % below a
-    norm of 1e-3), element-wise probes rel-Frobenius <= 5e-2 + 1.5e-3 absolute (the audio relative-position table: 1.2e-1, see
-    BOUND_EXCEPTIONS)."""
+    norm of 1e-3), element-wise probes rel-Frobenius <= 5e-2 + 1.5e-3 absolute (no exemptions)."""
     fx = _fx(golden_dir, "deep_text_audio.pt")
     inp = _to_dev(synth.synth_inputs(fx["batch"], text_len=fx["text_len"], audio_samples=fx["audio_samples"], vocab=fx["vocab"]))
     wt = synth.synth_tensor("deep_ta/wt", fx["text_logits"].shape, seed=6).to(DEV)
@@ -887,8 +887,7 @@ def test_deep_text_and_audio_towers_8_layers_4b_dimensions_with_backward(golden_
                 n = k[:-6] if k.endswith("#rows4") else k
                 got = gr[n][:4] if k.endswith("#rows4") else gr[n]
                 if float(ref.norm()) > 1e-6:
-                    bound_scale = 5e-2 / 1.2e-1 if n.endswith("audio_adapter.rel_pos_table_list.0.weight") else 1.0
-                    e = (float((got - ref).double().norm()) - 1.5e-3) / float(ref.double().norm()) * bound_scale
+                    e = (float((got - ref).double().norm()) - 1.5e-3) / float(ref.double().norm())
                     if e > worst_s:
                         worst_s, worst_name = e, k
         report.append("%-6s logits rel-fro %.3e / %.3e cos %.6f | feats %.3e | worst grad-norm dev %.3e | worst probe rel-fro (after abs slack) %.3e %s"
@@ -1054,6 +1053,156 @@ def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(f
         worst = max(worst, (n, e), key=lambda t: t[1])
         assert e <= 3e-2, (n, e)
     assert len(res[True][1]) > 60, len(res[True][1])
+
+
+def test_skipped_branches_against_the_fp32_oracle_under_the_same_masks():
+    """skip_dropped_branches against the ORACLE (round-4 verdict: it had only been compared with the multiplier form of the same
+    HIP code): the fp32 CPU oracle runs the three towers with the SAME host-drawn drop-path masks (transformer_layer.py:78-88,
+    `path_scales` = per layer one [B] multiplier vector per residual branch) -- loss, per-modality features and every parameter
+    gradient of BOTH forms are held to it at the common bounds (features 1.5e-2, gradients 5e-2 + 1.5e-3 absolute).
+
+    And the two HIP forms against each other: per row the packed form performs the multiplier form's arithmetic (a kept sample's
+    branch rows go through the same LayerNorm / GEMM K-loops / attention items / residual epilogue, a dropped sample's rows are
+    passed through where the multiplier form adds 0 * branch), so the FORWARD features of all samples must be bit-identical and with
+    them the loss.  Parameter gradients are not bit-identical: a weight gradient is a sum over rows, the packed launch sums the
+    kept rows only (other K extents, other tile / split-K partitions) while the multiplier form sums all rows with exact zeros in
+    between -- the same terms in another order, rounded to bf16 once; both are gated against the oracle at the common bound."""
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.transformer import transformer_encoder as TE
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=128, ffn_embed_dim=256, layers=4, attention_heads=2, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B, L, rate = 6, 4, 0.45
+    raw = synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000)
+    inp = _to_dev(raw)
+    probs = torch.linspace(0, rate, L).tolist()
+    g = torch.Generator(device="cpu").manual_seed(23)
+    mask = torch.bernoulli(torch.full((L, 2, 3 * B), 0.6), generator=g).bool()
+    mask[1, 1] = True                    # a branch that keeps everything
+    mask[2, 1, 2 * B:] = False
+    mask[2, 1, 2 * B + 1] = True         # ... that keeps one audio sample
+    for i in range(L):                   # every segment keeps a sample in every branch: all branches with drop-path are PACKED
+        for b in range(2):
+            for s0 in (0, B, 2 * B):
+                if not bool(mask[i, b, s0:s0 + B].any()):
+                    mask[i, b, s0] = True
+    orig_scales, orig_mask = TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask
+
+    def fixed_scales(self, nb, device):
+        assert nb == 3 * B
+        return [(None, None) if p <= 0.0 else ((mask[i, 0].float() / (1 - p)).to(device), (mask[i, 1].float() / (1 - p)).to(device))
+                for i, p in enumerate(probs)]
+    TE.TransformerEncoder._draw_path_scales = fixed_scales
+    TE.TransformerEncoder._draw_keep_mask = staticmethod(lambda pr, n: mask.clone())
+    orig_multi = TE.TransformerEncoder.forward_multi
+    res, sd_fp32 = {}, None
+    try:
+        for skip in (False, True):
+            enc = one_peace_encoder_config(drop_path_rate=rate, layer_scale_init_value=1e-1, **cfg)
+            torch.manual_seed(0)
+            m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+            m = m.to(DEV).to(torch.bfloat16).train()
+            enc_m = m.encoder_wrapper.fusion_model
+            enc_m.skip_dropped_branches = skip
+            enc_m.pack_min_drop = (0.0, 0.0)
+            feats = {}
+
+            def capture(self, infos):
+                out = orig_multi(self, infos)
+                feats.update({k: v.detach().clone() for k, v in out.items()})
+                return out
+            TE.TransformerEncoder.forward_multi = capture
+            try:
+                loss, _, log = TriModalContrastiveCriterion(None, 0.0, lock_step=True)(m, {"net_input": inp, "nsentences": B})
+                m.zero_grad()
+                loss.backward()
+                torch.cuda.synchronize()
+            finally:
+                TE.TransformerEncoder.forward_multi = orig_multi
+            assert set(feats) == {"text", "image", "audio"}
+            if sd_fp32 is None:
+                sd_fp32 = {k: (v.detach().float().cpu().requires_grad_(True) if v.is_floating_point() else v.detach().cpu())
+                           for k, v in m.state_dict().items()}
+            res[skip] = (loss.detach().float().cpu(), {k: v.float().cpu() for k, v in feats.items()},
+                         {n: q.grad.detach().float().cpu() for n, q in m.named_parameters() if q.grad is not None})
+    finally:
+        TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask = orig_scales, orig_mask
+        TE.TransformerEncoder.forward_multi = orig_multi
+    # ---- fp32 oracle with the same masks: segment order text, image, audio = sample ranges [0,B), [B,2B), [2B,3B) ----
+    heads = cfg["attention_heads"]
+
+    def scales(s0):
+        return [None if p <= 0.0 else (mask[i, 0, s0:s0 + B].float() / (1 - p), mask[i, 1, s0:s0 + B].float() / (1 - p))
+                for i, p in enumerate(probs)]
+    t, ft = O.contrastive_embed(sd_fp32, heads, L, "text", path_scales=scales(0), src_tokens=raw["src_tokens"])
+    i_, fi = O.contrastive_embed(sd_fp32, heads, L, "image", path_scales=scales(B), src_images=raw["src_images"].to(torch.bfloat16).float())
+    a, fa = O.contrastive_embed(sd_fp32, heads, L, "audio", path_scales=scales(2 * B),
+                                src_audios=raw["src_audios"].to(torch.bfloat16).float(), audio_padding_masks=raw["audio_padding_masks"])
+    sc = O.logit_scale_exp(sd_fp32["logit_scale"])
+    ref = O.itc_loss(i_, t, i_, t, sc)[0] + O.itc_loss(a, t, a, t, sc)[0]
+    ref.backward()
+    want_feats = {"text": ft.detach(), "image": fi.detach(), "audio": fa.detach()}
+    report = []
+    for skip in (False, True):
+        loss, feats, grads = res[skip]
+        tag = "packed" if skip else "multiplier"
+        assert abs(float(loss) - float(ref)) <= 2.5e-2, (tag, float(loss), float(ref))
+        for mname, want in want_feats.items():
+            e = rel_fro(feats[mname], want)
+            report.append("%-10s features %-6s %.3e" % (tag, mname, e))
+            assert e <= 1.5e-2, (tag, mname, e)
+        n = 0
+        for name, got in grads.items():
+            want = sd_fp32[name].grad
+            assert want is not None, name
+            err, nw = float((got - want).norm()), float(want.norm())
+            report.append("%-10s grad %-70s %.3e (|ref| %.3e)" % (tag, name, err / (nw + 1e-30), nw))
+            assert err <= 5e-2 * nw + 1.5e-3, (tag, name, err, nw)
+            n += 1
+        assert n > 60, n
+    # ---- packed form against multiplier form: forward bit-identical (all samples, kept or dropped), so is the loss ----
+    for mname in want_feats:
+        assert torch.equal(res[True][1][mname], res[False][1][mname]), (mname, float((res[True][1][mname] - res[False][1][mname]).abs().max()))
+    assert float(res[True][0]) == float(res[False][0])
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "skip_dropped_oracle_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")
+
+
+@pytest.mark.parametrize("stage", ["vl", "al"])
+def test_pair_criterions_take_a_pretrain_model_in_lock_step(golden_dir, stage):
+    """Round-4 advisor finding: OnePeacePretrainModel.forward_multi returns {modality: (logits, features)} tuples where the
+    retrieval model returns bare embeddings; the pair criterions (lock-step is their default on the HIP path) must unwrap them as
+    the one-call-per-modality branch does: same loss bits either way."""
+    from tests.test_model_cpu import _build_pretrain
+    from one_peace_amd.criterions.contrastive import AudioTextRetrievalCriterion, ImageTextRetrievalCriterion
+    from one_peace_amd.transformer import transformer_encoder as TE
+    fx = _fx(golden_dir, "micro_pretrain.pt" if stage == "vl" else "micro_pretrain_al.pt")
+    ni = {k: (v.to(DEV).to(torch.bfloat16) if v.is_floating_point() else v.to(DEV)) for k, v in fx["net_input"].items()}
+    Crit = ImageTextRetrievalCriterion if stage == "vl" else AudioTextRetrievalCriterion
+    m = _build_pretrain(fx, audio_language=stage == "al").to(DEV).to(torch.bfloat16).train()
+    used = {"multi": 0}
+    orig_multi = TE.TransformerEncoder.forward_multi
+
+    def counted(self, infos):
+        used["multi"] += 1
+        return orig_multi(self, infos)
+    TE.TransformerEncoder.forward_multi = counted
+    losses = {}
+    try:
+        for lock in (True, False):
+            m.zero_grad()
+            loss, _, log = Crit(None, 0.0, lock_step=lock)(m, {"net_input": ni, "nsentences": ni["src_tokens"].shape[0]})
+            loss.backward()
+            torch.cuda.synchronize()
+            losses[lock] = float(loss.detach())
+            assert all(torch.isfinite(q.grad).all() for q in m.parameters() if q.grad is not None)
+    finally:
+        TE.TransformerEncoder.forward_multi = orig_multi
+    assert used["multi"] == 1, used
+    assert losses[True] == losses[False], losses
 
 
 @pytest.mark.parametrize("other", ["image", "audio"])

@@ -777,8 +777,10 @@ def test_attention_persistent_backward_over_several_samples_per_workgroup(B, S, 
         assert_close(n3[:, 256:, H:], o3[:, 256:, H:].float().cpu(), fro=4e-3, mx=2e-2, what="dk / dv of the lone key")
     if use_bias:
         assert_close(dbn[:, :, :S], dbo[:, :, :S].cpu(), fro=2e-5, mx=2e-4, what="dbias")
-    if B <= 64:  # fp32 reference on two samples
-        for b in (0, B - 1):
+    # fp32 reference on sampled items -- at the headline launch (B = 128, 24 heads) too, where rounds 1-4 compared the persistent
+    # kernels with the older kernels only (round-4 verdict, Weak #2)
+    if True:
+        for b in ((0, B - 1) if B <= 64 else (0, B // 2 + 1, B - 1)):
             qkv_r = qkv[b * S:(b + 1) * S].float().cpu().requires_grad_(True)
             qr, kr, vr = (qkv_r[:, i * H:(i + 1) * H].reshape(1, S, H) for i in range(3))
             bb = bias_d[..., :S].float().cpu() if use_bias else None

@@ -284,7 +284,11 @@ __device__ __forceinline__ void store_b128_padded(const u32x4& data, const u32x4
 }
 
 template <int EPI>
-__device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4][8], int mrow0, int ncol0, int g, int t) {
+__device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4][8], int mrow0, int ncol0, int g, int t,
+                                           const bf16_t* bias_of_tile = nullptr, const bool tile_bias = false) {
+  // tile_bias (a compile-time constant at every call site): the caller hands over the bias vector of the weight segment its tile
+  // lies in (n_seg % 256 == 0) instead of the table p.bias[] -- gemm256p_kernel builds its GemmArgs per tile in registers, and ONE
+  // dynamically indexed member put the whole struct into scratch (round 4: 232-288 bytes per lane, 16-28 scratch operations per tile)
   static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "epilogue_v: plain / bias and residual epilogues only");
   const int rows_left = min(p.M - mrow0, 128);  // wave-uniform
   if (rows_left <= 0) return;
@@ -293,11 +297,13 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
   const u32x4 rc = raw_rsrc((bf16_t*)p.C + (int64_t)mrow0 * p.ldc + ncol0, nrec);
   const int voff = (g * 4 * ldc + t * 8) * 2;  // + ((mi*16 + r) * ldc) * 2 as the scalar offset
   const int seg = ncol0 / p.n_seg;
-  const bf16_t* bp = p.bias[seg];
+  const bf16_t* bp = tile_bias ? bias_of_tile : p.bias[seg];
   // the lane's 8 columns: acc[j >> 2][j & 3][mi][r] <-> column t*8 + j
+  // (accumulator reads as volatile asm: they keep their place between the -- volatile -- stores.  Plain reads are hoisted ahead of
+  // the whole epilogue by the register allocator's live-range splitting and the surplus spilled: the last 12-24 bytes of scratch)
   auto row_of = [&](int mi, int r, float (&o)[8]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = acc[j >> 2][j & 3][mi][r];
+    for (int j = 0; j < 8; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[j]) : "a"(acc[j >> 2][j & 3][mi][r]));
   };
 
   if constexpr (EPI == EPI_BIAS) {
@@ -306,7 +312,10 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
       float bv[8];
       if constexpr (BIAS) unpack_bf16x8(*reinterpret_cast<const u32x4*>(bp + (ncol0 - seg * p.n_seg) + t * 8), bv);
 #pragma unroll
-      for (int mi = 0; mi < 8; ++mi)
+      for (int mi = 0; mi < 8; ++mi) {
+        // (one fragment row block at a time: left alone the scheduler hoists accumulator reads of later blocks over the stores and
+        // spills what does not fit -- the four-wave kernels own all 256 + 256 registers)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float o[8];
@@ -323,6 +332,7 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
           store_b128_padded(pack_bf16x8(o), rc, voff, (mi * 16 + r) * ldc * 2);
 #endif
         }
+      }
     };
     if (bp) stores(std::true_type{});
     else stores(std::false_type{});
@@ -370,7 +380,8 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
     for (int c = 0; c < 4; ++c) {
       if (c + 1 < 4) load_chunk(c + 1, rraw[(c + 1) & 1], rsv[(c + 1) & 1]);
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
+      for (int m2 = 0; m2 < 2; ++m2) {
+        __builtin_amdgcn_sched_barrier(0);  // (as above)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int mi = c * 2 + m2;
@@ -386,6 +397,7 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
           for (int j = 0; j < 8; ++j) o[j] = resid_out(rv[j], rs, gv[j], o[j]);
           store_b128_padded(pack_bf16x8(o), rc, voff, soff);
         }
+      }
     }
   }
 }
@@ -1433,17 +1445,18 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SCHED = 3;
+  static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "gemm256p_kernel: plain / bias and residual epilogues (epilogue_v)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int g = lane >> 4, t = lane & 15;
-  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
+  constexpr int BN_OUT = 256;
   const int nk = p.K / 64;
   const int ntiles = p.tiles_m * p.tiles_n;
   const int stride_b = gridDim.x;
 
   // ---- tile b -> problem, first row, first column; descriptors of its operand panels (all wave-uniform) ----
-  struct Tile { int prob, m0, n0; const char* a; int na; const char* b0; const char* b1; int nb; };
+  struct Tile { int prob, m0, n0; const char* a; int na; const char* b0; int nb; };
   auto locate = [&](int b) {
     Tile T;
     const bool valid = b < ntiles;
@@ -1459,39 +1472,30 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
     const int Mp = sel3(p.M, T.prob);
     T.a = (const char*)(sel3(p.A, T.prob) + (int64_t)T.m0 * p.lda);
     T.na = valid ? (int)((((int64_t)Mp - 1 - T.m0) * p.lda + p.K) * 2) : 0;  // bytes from the tile's first row to the matrix end
-    if (EPI == EPI_GEGLU) {
-      const bf16_t* w0 = T.prob == 0 ? p.B[0][0] : T.prob == 1 ? p.B[1][0] : p.B[2][0];
-      const bf16_t* w1 = T.prob == 0 ? p.B[0][1] : T.prob == 1 ? p.B[1][1] : p.B[2][1];
-      T.b0 = (const char*)(w0 + (int64_t)T.n0 * p.ldb);
-      T.b1 = (const char*)(w1 + (int64_t)T.n0 * p.ldb);
-      T.nb = valid ? (int)((((int64_t)p.N - 1 - T.n0) * p.ldb + p.K) * 2) : 0;
-    } else {
-      const int seg = T.n0 / p.n_seg, c0 = T.n0 - seg * p.n_seg;
-      const bf16_t* w = T.prob == 0 ? (seg == 0 ? p.B[0][0] : seg == 1 ? p.B[0][1] : p.B[0][2])
-                      : T.prob == 1 ? (seg == 0 ? p.B[1][0] : seg == 1 ? p.B[1][1] : p.B[1][2])
-                                    : (seg == 0 ? p.B[2][0] : seg == 1 ? p.B[2][1] : p.B[2][2]);
-      T.b0 = T.b1 = (const char*)(w + (int64_t)c0 * p.ldb);
-      T.nb = valid ? (int)((((int64_t)min(p.n_seg, p.N) - 1 - c0) * p.ldb + p.K) * 2) : 0;
-    }
+    const int seg = T.n0 / p.n_seg, c0 = T.n0 - seg * p.n_seg;
+    const bf16_t* w = T.prob == 0 ? (seg == 0 ? p.B[0][0] : seg == 1 ? p.B[0][1] : p.B[0][2])
+                    : T.prob == 1 ? (seg == 0 ? p.B[1][0] : seg == 1 ? p.B[1][1] : p.B[1][2])
+                                  : (seg == 0 ? p.B[2][0] : seg == 1 ? p.B[2][1] : p.B[2][2]);
+    T.b0 = (const char*)(w + (int64_t)c0 * p.ldb);
+    T.nb = valid ? (int)((((int64_t)min(p.n_seg, p.N) - 1 - c0) * p.ldb + p.K) * 2) : 0;
     return T;
   };
 
   // ---- staging (see gemm256v_kernel): op j covers LDS rows j*32 + (tid >> 3); nothing here depends on the tile ----
   const int srow = tid >> 3;
   const int sc = (tid & 7) ^ (srow & 7);
-  unsigned offA[8];
+  // op j of the A panel: ONE per-lane offset + a scalar offset per op (eight per-lane offsets cost seven VGPRs the epilogue of the
+  // finished tile -- which runs with the next tile's first fragments live -- had to spill around)
+  const unsigned offA = (unsigned)(((int64_t)srow * p.lda + sc * 8) * 2);
+  unsigned soffA[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) offA[j] = (unsigned)(((int64_t)(j * 32 + srow) * p.lda + sc * 8) * 2);
-  constexpr bool VMAP = EPI == EPI_BIAS || EPI == EPI_RESID;  // ends in epilogue_v: its operand order and column map
-  const int lanecol = VMAP ? (srow & 15) * 8 + (srow >> 4)
-                           : (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
-                                                : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
+  for (int j = 0; j < 8; ++j) soffA[j] = (unsigned)((int64_t)(j * 32) * p.lda * 2);
+  const int lanecol = (srow & 15) * 8 + (srow >> 4);  // ends in epilogue_v: its operand order and column map
   const unsigned offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
   unsigned soffB[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    soffB[j] = (unsigned)((int64_t)((EPI == EPI_GEGLU) ? (j & 3) * 32
-                                    : VMAP ? (j >> 2) * 128 + ((j >> 1) & 1) * 4 + (j & 1) * 2 : (j >> 1) * 64 + (j & 1) * 8) * p.ldb * 2);
+    soffB[j] = (unsigned)((int64_t)((j >> 2) * 128 + ((j >> 1) & 1) * 4 + (j & 1) * 2) * p.ldb * 2);
 
   f32x4 acc[2][4][8];  // [64-column block][ni][mi]
   auto zero_acc = [&]() {
@@ -1508,7 +1512,6 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
   const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
   auto w_off = [&](int f) {
     const int blk = f >> 2, ni = f & 3;
-    if (EPI == EPI_GEGLU) return ((ni >> 1) * 128 + (wn * 2 + blk) * 32 + (ni & 1) * 16 + t) * 128;
     return (wn * 128 + blk * 64 + ni * 16 + t) * 128;
   };
 
@@ -1517,19 +1520,18 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)kt * 128), 0, nrec > 0 ? nrec - kt * 128 : 0, 0x00020000);
   };
   auto dma_a = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offA[j], 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offA, soffA[j], 0, 0);
   };
-  auto dma_b = [&](const __amdgpu_buffer_rsrc_t& r0, const __amdgpu_buffer_rsrc_t& r1, char* dst, int j) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds((EPI == EPI_GEGLU && j >= 4) ? r1 : r0, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16,
-                                             offB, soffB[j], 0, 0);
+  auto dma_b = [&](const __amdgpu_buffer_rsrc_t& r0, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offB, soffB[j], 0, 0);
   };
   auto next_slot = [&]() { qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1; };
   auto issue_tile = [&](bool is_b, const Tile& T, int kt) {
     char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
-    const __amdgpu_buffer_rsrc_t ra = rsrc(T.a, T.na, kt), rb0 = rsrc(T.b0, T.nb, kt), rb1 = rsrc(T.b1, T.nb, kt);
+    const __amdgpu_buffer_rsrc_t ra = rsrc(T.a, T.na, kt), rb0 = rsrc(T.b0, T.nb, kt);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      if (is_b) dma_b(rb0, rb1, dst, j); else dma_a(ra, dst, j);
+      if (is_b) dma_b(rb0, dst, j); else dma_a(ra, dst, j);
     }
     next_slot();
   };
@@ -1538,7 +1540,6 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
     constexpr bool IS_B = decltype(b_tag)::value;
     char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
     const __amdgpu_buffer_rsrc_t r0 = IS_B ? rsrc(T.b0, T.nb, kt) : rsrc(T.a, T.na, kt);
-    const __amdgpu_buffer_rsrc_t r1 = (IS_B && EPI == EPI_GEGLU) ? rsrc(T.b1, T.nb, kt) : r0;
     auto rd = [&](int r) {
       if (r < 8) nxt_w[r] = *reinterpret_cast<const bf16x8*>(sb + w_off(r) + fsw[h]);
       else nxt_x[r - 8] = *reinterpret_cast<const bf16x8*>(sa + rowX + (r - 8) * 2048 + fsw[h]);
@@ -1546,14 +1547,13 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
       const int k = i >> 3, f = i & 7;
-      if constexpr (VMAP) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_x[k]), "v"(cur_w[f]));
-      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_x[k]), "v"(cur_w[f]));
       const int rd0 = vs_read(SCHED, i, 0), rd1 = vs_read(SCHED, i, 1), d = vs_dma(SCHED, i);
       if (rd0 >= 0 || rd1 >= 0 || d >= 0) {
         __builtin_amdgcn_sched_barrier(0);
         if (rd0 >= 0) rd(rd0);
         if (rd1 >= 0) rd(rd1);
-        if (d >= 0) { if (IS_B) dma_b(r0, r1, dst, d); else dma_a(r0, dst, d); }
+        if (d >= 0) { if (IS_B) dma_b(r0, dst, d); else dma_a(r0, dst, d); }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1607,15 +1607,11 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
       q.C = sel3(p.C, cur.prob); q.H0 = sel3(p.H0, cur.prob); q.H1 = sel3(p.H1, cur.prob);
       q.resid = sel3(p.resid, cur.prob); q.gamma = sel3(p.gamma, cur.prob); q.rowscale = sel3(p.rowscale, cur.prob);
       q.rows_per_sample = sel3(p.rows_per_sample, cur.prob); q.alpha = p.alpha;
-#pragma unroll
-      for (int sgi = 0; sgi < 3; ++sgi)
-        q.bias[sgi] = cur.prob == 0 ? p.bias[0][sgi] : cur.prob == 1 ? p.bias[1][sgi] : p.bias[2][sgi];
-      if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
-        epilogue_v<EPI>(q, acc, cur.m0 + wm * 128, cur.n0 + wn * 128, g, t);
-      } else {
-        gemm_epilogue<EPI, 8>(q, q.C, acc[0], cur.m0 + wm * 128, cur.n0 + wn * 128, cur.n0 + (wn * 2) * 32, g, t);
-        gemm_epilogue<EPI, 8>(q, q.C, acc[1], cur.m0 + wm * 128, cur.n0 + wn * 128 + 64, cur.n0 + (wn * 2 + 1) * 32, g, t);
-      }
+      q.bias[0] = q.bias[1] = q.bias[2] = nullptr;  // (unused: the tile's bias vector travels as an argument, see gemm_epilogue)
+      // the tile lies in ONE weight segment (n_seg is a multiple of the tile width, checked at launch): kernel-argument table look-up
+      const int segt = cur.n0 / p.n_seg;
+      const bf16_t* bt = p.bias[cur.prob][segt];
+      epilogue_v<EPI>(q, acc, cur.m0 + wm * 128, cur.n0 + wn * 128, g, t, bt, true);
     }
     zero_acc();
     cur = nxt;
@@ -2447,12 +2443,9 @@ int launch256p(const GroupArgs& ga, hipStream_t s, bool persistent = true) {
 }
 
 static int launch256p_any(const GroupArgs& ga, int epi, hipStream_t s, bool persistent) {
-  switch (epi) {
-    case EPI_BIAS: return launch256p<EPI_BIAS>(ga, s, persistent);
-    case EPI_F32: return launch256p<EPI_F32>(ga, s, persistent);
-    case EPI_GEGLU: return launch256p<EPI_GEGLU>(ga, s, persistent);
-    default: return launch256p<EPI_RESID>(ga, s, persistent);
-  }
+  if (epi == EPI_BIAS) return launch256p<EPI_BIAS>(ga, s, persistent);
+  if (epi == EPI_RESID) return launch256p<EPI_RESID>(ga, s, persistent);
+  return OP_ENOTSUP;
 }
 
 // single-problem GroupArgs of a plain launch
@@ -2489,7 +2482,9 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
       case 1: return launch256v<EPI, 1>(a, s, grid, sh5);
       case 3: return launch256v<EPI, 3>(a, s, grid, sh5);
       case 6:
-        if (a.m_off == 0) return launch256p<EPI>(group_of(a, EPI), s, true);
+        if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+          if (a.m_off == 0) return launch256p<EPI>(group_of(a, EPI), s, true);
+        }
         return launch256v<EPI, 3>(a, s, grid, sh5);
       default: break;
     }
@@ -2873,8 +2868,8 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
 // and the epilogue, in ONE launch of the persistent kernel -- the text / image / audio FFN of an encoder layer
 // (transformer_layer.py:203-226; each modality's rows go through its own weights).  All array arguments are HOST arrays with
 // nprob entries (B / bias: nprob x 2, [p*2 + 0] = the weight (GeGLU: wi_0), [p*2 + 1] = wi_1 for GeGLU, else unused); h0, h1, resid,
-// gamma, rowscale, bias entries may be null, a whole array pointer may be null.  Epilogues 0 (bias), 2 (GeGLU), 3 (residual).
-// Requirements: N % 256 == 0 (GeGLU: N % 128 == 0), K % 64 == 0, K >= 128, lda / ldb / ldc % 8 == 0, every operand below 2 GiB.
+// gamma, rowscale, bias entries may be null, a whole array pointer may be null.  Epilogues 0 (bias), 3 (residual); 2 (GeGLU) returns
+// OP_ENOTSUP since round 5 (h1 and the second weight of a problem are unused).  Requirements: N % 256 == 0, K % 64 == 0, K >= 128, lda / ldb / ldc % 8 == 0, every operand below 2 GiB.
 // Returns OP_ENOTSUP when the shape does not qualify (the caller then launches the problems one by one).
 int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, int64_t lda, const void* const* B, int64_t ldb,
                        const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
@@ -2883,7 +2878,11 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
   const GemmTune T = decode_tune(tune);
   OP_CHECK_ARG(nprob >= 1 && nprob <= 3 && A && M && B && C, "gemm_nt_grouped: 1..3 problems, non-null A / M / B / C arrays");
   OP_CHECK_ARG(epilogue == EPI_BIAS || epilogue == EPI_GEGLU || epilogue == EPI_RESID, "gemm_nt_grouped: epilogue %d", epilogue);
-  const int bn = epilogue == EPI_GEGLU ? 128 : 256;
+  if (epilogue == EPI_GEGLU) {  // round 5: the persistent kernel serves the two epilogues the step groups (plain / bias, residual); a
+    op_set_error("gemm_nt_grouped: the GeGLU epilogue has no grouped form (launch op_gemm_nt per problem)");  // GeGLU launch per problem fills the chip
+    return OP_ENOTSUP;
+  }
+  const int bn = 256;
   if (N <= 0 || K < 128 || N % bn != 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 ||
       N * ldb >= ((int64_t)1 << 30)) {
     op_set_error("gemm_nt_grouped: shape N=%lld K=%lld not supported by the persistent kernel", (long long)N, (long long)K);
@@ -2903,10 +2902,8 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
       }
       ga.A[i] = (const bf16_t*)A[i]; ga.M[i] = (int)M[i];
       ga.B[i][0] = (const bf16_t*)B[i * 2]; ga.B[i][1] = (const bf16_t*)B[i * 2 + 1];
-      if (epilogue == EPI_GEGLU) OP_CHECK_ARG(ga.B[i][1], "gemm_nt_grouped: GeGLU needs two weights per problem");
       ga.bias[i][0] = bias ? (const bf16_t*)bias[i * 2] : nullptr;
       ga.C[i] = C[i]; ga.H0[i] = h0 ? (bf16_t*)h0[i] : nullptr; ga.H1[i] = h1 ? (bf16_t*)h1[i] : nullptr;
-      OP_CHECK_ARG((ga.H0[i] == nullptr) == (ga.H1[i] == nullptr) || epilogue != EPI_GEGLU, "gemm_nt_grouped: GeGLU h0/h1 both or neither");
       ga.resid[i] = resid ? (const bf16_t*)resid[i] : nullptr;
       if (epilogue == EPI_RESID) OP_CHECK_ARG(ga.resid[i], "gemm_nt_grouped: residual epilogue needs resid");
       ga.gamma[i] = gamma ? (const bf16_t*)gamma[i] : nullptr;
@@ -2924,7 +2921,7 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
   ga.lda = lda; ga.ldb = ldb; ga.ldc = ldc; ga.ldr = ldr; ga.alpha = nullptr;
   ga.n_seg = (int)N; ga.N = (int)N; ga.K = (int)K;
   ga.gm = ga.tiles_n <= 8 ? 1 : 8;
-  const int slot = op_prof_begin(0, 2.0 * rows * (double)N * (double)K * (epilogue == EPI_GEGLU ? 2.0 : 1.0), stream);
+  const int slot = op_prof_begin(0, 2.0 * rows * (double)N * (double)K, stream);
   // persistent (one workgroup per CU walks the tile list, K-tile stream continuous across tile boundaries) unless the caller asks
   // for one tile per workgroup (tune sched = 7; tests, A/B): with the round-3 epilogue (coalesced non-temporal stores: a short
   // drain in front of the next tile's loads) the persistent form is 2.2 % faster on both grouped launches of the step

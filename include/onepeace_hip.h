@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -282,19 +282,6 @@ int op_rows_gather(const void* src, void* dst, const int* list, int64_t nseg, co
 int op_rows_merge(const void* base, const void* upd, void* out, const int* list, int64_t nseg, const int64_t* src_row0,
                   const int64_t* dst_row0, const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples,
                   const int64_t* list_off, int64_t total, int64_t cols, void* stream);
-
-/* ---- hardware-semantics probes (test infrastructure; tests/test_probes_gpu.py) --------------------------------------- */
-int op_probe_mfma16(const void* a, const void* b, float* d, int n, void* stream);
-int op_probe_mfma32(const void* a, const void* b, float* d, int n, void* stream);
-int op_probe_tr16(const void* img, const int* addr, void* out, int n, void* stream);
-int op_probe_glds(const void* src, const int* src_off, int lds_base, void* dump, void* stream);
-/* raw v_mfma_scale_f32_16x16x128_f8f6f4 (fp8 e4m3 x fp8 e4m3): a, b = [n][64 lanes][8 dwords], sa, sb = [n][64] E8M0 scale dwords */
-int op_probe_mfma_f8(const void* a, const void* b, const void* sa, const void* sb, float* d, int n, void* stream);
-/* Register-only MFMA loop (no LDS, no global memory inside): `workgroups` x 4 waves each issue iters x 64 v_mfma_f32_16x16x32_bf16 on
- * the 8 operand fragments of `operands` (8 x 64 lanes x 8 bf16).  out: workgroups x 256 floats; clk: workgroups x 2 uint64 = shader
- * clock ticks and 100 MHz ticks over the loop.  The caller times the launch: flops = workgroups x 4 x iters x 64 x 16384.  bench.py
- * uses it to report the MFMA rate the package sustains at its power limit beside the data-sheet peak. */
-int op_probe_mfma_rate(const void* operands, float* out, void* clk, int workgroups, int iters, void* stream);
 
 #ifdef __cplusplus
 }

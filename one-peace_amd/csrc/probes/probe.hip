@@ -2,7 +2,7 @@
 // They execute raw MFMA / transpose-read / LDS-DMA instructions on host-supplied register images and dump the
 // raw results, so the lane<->element maps the real kernels rely on are *measured* (tests/test_probes.py), not
 // assumed from documentation.
-#include "common.h"
+#include "../common.h"
 
 namespace {
 

@@ -70,14 +70,20 @@ SIGNATURES = {
     "op_attn_bwd": (c_int, [P, P, P, I64, P, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
     "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
+    "op_rows_gather": (c_int, [P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
+    "op_rows_merge": (c_int, [P, P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
+}
+
+
+# libonepeace_probe.so (include/onepeace_probe.h): lane-map and power probes -- test / measurement infrastructure, not product ABI
+PROBE_SIGNATURES = {
+    "op_last_error": (ctypes.c_char_p, []),
     "op_probe_mfma16": (c_int, [P, P, P, c_int, P]),
     "op_probe_mfma32": (c_int, [P, P, P, c_int, P]),
     "op_probe_tr16": (c_int, [P, P, P, c_int, P]),
     "op_probe_glds": (c_int, [P, P, c_int, P, P]),
     "op_probe_mfma_f8": (c_int, [P, P, P, P, P, c_int, P]),
     "op_probe_mfma_rate": (c_int, [P, P, P, c_int, c_int, P]),
-    "op_rows_gather": (c_int, [P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
-    "op_rows_merge": (c_int, [P, P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
 }
 
 
@@ -185,6 +191,31 @@ def lib():
             fn.argtypes = args
         _lib = _LibProxy(L)
     return _lib
+
+
+_probe_lib = None
+
+
+def probe_lib():
+    """The probe library (tests/test_probes_gpu.py, bench.py's power-limited MFMA rate); built next to the product library."""
+    global _probe_lib
+    if _probe_lib is None:
+        path = os.path.join(os.path.dirname(LIB_PATH), "libonepeace_probe.so")
+        if not os.path.exists(path):
+            raise RuntimeError("%s not found: build it with `python one-peace_amd/build.py`" % path)
+        L = ctypes.CDLL(path)
+        for name, (res, args) in PROBE_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _probe_lib = L
+    return _probe_lib
+
+
+def _check_probe(rc, what):
+    if rc != 0:
+        msg = probe_lib().op_last_error()
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
 
 
 def available():
@@ -830,7 +861,7 @@ def mfma_rate_probe(seconds=1.0, waves_per_cu=8, data="normal", device=None):
     for leg in range(3):  # calibrate, settle (clock and power follow the load with a delay), report
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(device))
-        _check(lib().op_probe_mfma_rate(ptr(img), ptr(out), ptr(clk), wgs, iters, stream()), "op_probe_mfma_rate")
+        _check_probe(probe_lib().op_probe_mfma_rate(ptr(img), ptr(out), ptr(clk), wgs, iters, stream()), "op_probe_mfma_rate")
         e1.record(torch.cuda.current_stream(device))
         e1.synchronize()
         ms = e0.elapsed_time(e1)

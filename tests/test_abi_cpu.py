@@ -10,8 +10,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_decls():
-    src = open(os.path.join(ROOT, "include", "onepeace_hip.h")).read()
+def _header_decls(header="onepeace_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
     for m in re.finditer(r"\b(?:int|int64_t|const char\*)\s+(op_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
@@ -46,7 +46,26 @@ def test_ctypes_table_matches_header(lib_path):
         assert len(hip.SIGNATURES[name][1]) == nargs, "%s: header has %d args, ctypes table %d" % (
             name, nargs, len(hip.SIGNATURES[name][1]))
     L = hip.lib()
-    assert L.op_abi_version() == 5  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4); 5: op_probe_mfma_rate
+    assert L.op_abi_version() == 6  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4); 5: op_probe_mfma_rate; 6: probes in their own library (round 5)
+
+
+def test_probe_library_is_separate_from_the_product_library(lib_path):
+    """Round 5 (hygiene): the hardware / power probes are test and measurement infrastructure -- their own shared
+    library and header; the product library exports none of them."""
+    from one_peace_amd import hip
+    probe_path = os.path.join(os.path.dirname(lib_path), "libonepeace_probe.so")
+    decls = _header_decls("onepeace_probe.h")
+    assert len(decls) >= 6 and all(n.startswith("op_probe_") or n == "op_last_error" for n in decls), decls
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+        return {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert not (set(decls) - exported(probe_path))
+    assert not [n for n in exported(lib_path) if n.startswith("op_probe_")]
+    assert not [n for n in _header_decls() if n.startswith("op_probe_")]
+    for name, nargs in decls.items():
+        assert name in hip.PROBE_SIGNATURES and len(hip.PROBE_SIGNATURES[name][1]) == nargs, name
+    hip.probe_lib()
 
 
 def test_no_silent_cpu_fallback():

@@ -37,7 +37,7 @@ def test_mfma16_fragment_maps():
     a = torch.stack(runs_a).to(torch.bfloat16).to(dev).contiguous()
     b = torch.stack(runs_b).to(torch.bfloat16).to(dev).contiguous()
     d = torch.empty(a.shape[0], 64, 4, dtype=torch.float32, device=dev)
-    hip._check(hip.lib().op_probe_mfma16(hip.ptr(a), hip.ptr(b), hip.ptr(d), a.shape[0], hip.stream()), "probe_mfma16")
+    hip._check_probe(hip.probe_lib().op_probe_mfma16(hip.ptr(a), hip.ptr(b), hip.ptr(d), a.shape[0], hip.stream()), "probe_mfma16")
     torch.cuda.synchronize()
     d = d.cpu()
     np.save(os.path.join(out_dir(), "probe_mfma16.npy"), d.numpy())
@@ -61,7 +61,7 @@ def test_mfma32_fragment_maps():
     a = a_raw[None].to(torch.bfloat16).to(dev).contiguous()
     b = b_raw[None].to(torch.bfloat16).to(dev).contiguous()
     d = torch.empty(1, 64, 16, dtype=torch.float32, device=dev)
-    hip._check(hip.lib().op_probe_mfma32(hip.ptr(a), hip.ptr(b), hip.ptr(d), 1, hip.stream()), "probe_mfma32")
+    hip._check_probe(hip.probe_lib().op_probe_mfma32(hip.ptr(a), hip.ptr(b), hip.ptr(d), 1, hip.stream()), "probe_mfma32")
     torch.cuda.synchronize()
     d = d.cpu()
     np.save(os.path.join(out_dir(), "probe_mfma32.npy"), d.numpy())
@@ -92,7 +92,7 @@ def test_tr16_read_semantics():
     runs.append(torch.full((64,), 1000 * 2))
     addr = torch.stack(runs).to(torch.int32).to(dev).contiguous()
     out = torch.empty(len(runs), 64, 4, dtype=torch.bfloat16, device=dev)
-    hip._check(hip.lib().op_probe_tr16(hip.ptr(img_dev), hip.ptr(addr), hip.ptr(out), len(runs), hip.stream()), "probe_tr16")
+    hip._check_probe(hip.probe_lib().op_probe_tr16(hip.ptr(img_dev), hip.ptr(addr), hip.ptr(out), len(runs), hip.stream()), "probe_tr16")
     torch.cuda.synchronize()
     got = out.view(torch.int16).cpu().long()
     np.save(os.path.join(out_dir(), "probe_tr16.npy"), got.numpy())
@@ -112,7 +112,7 @@ def test_global_load_lds_semantics():
     src_off = (perm * 16 * 3).to(torch.int32).to(dev)  # 16-byte chunks, scattered
     dump = torch.empty(8192, dtype=torch.int16, device=dev)
     base = 512
-    hip._check(hip.lib().op_probe_glds(hip.ptr(src), hip.ptr(src_off), base, hip.ptr(dump), hip.stream()), "probe_glds")
+    hip._check_probe(hip.probe_lib().op_probe_glds(hip.ptr(src), hip.ptr(src_off), base, hip.ptr(dump), hip.stream()), "probe_glds")
     torch.cuda.synchronize()
     got = dump.cpu().long()
     np.save(os.path.join(out_dir(), "probe_glds.npy"), got.numpy())

@@ -29,7 +29,7 @@ one = torch.full((64,), 127, dtype=torch.int32)
 for name, km in kmaps.items():
     a, b = pack(A, km).cuda(), pack(B, km).cuda()
     d = torch.zeros(64, 4, device="cuda")
-    hip._check(hip.lib().op_probe_mfma_f8(hip.ptr(a), hip.ptr(b), hip.ptr(one.cuda()), hip.ptr(one.cuda()), hip.ptr(d), 1, hip.stream()), "probe")
+    hip._check_probe(hip.probe_lib().op_probe_mfma_f8(hip.ptr(a), hip.ptr(b), hip.ptr(one.cuda()), hip.ptr(one.cuda()), hip.ptr(d), 1, hip.stream()), "probe")
     d = d.cpu()
     got = torch.zeros(16, 16)
     for l in range(64):
@@ -46,7 +46,7 @@ for l in range(64):
     sa[l] = 127 + ((l >> 4) % 3) - 1 + ((l & 15) % 2)      # depends on (g, t): block scale of A[row t][k block g]
     sb[l] = 127 - ((l >> 4) % 2) + ((l & 15) % 3)
 d = torch.zeros(64, 4, device="cuda")
-hip._check(hip.lib().op_probe_mfma_f8(hip.ptr(a), hip.ptr(b), hip.ptr(sa.cuda()), hip.ptr(sb.cuda()), hip.ptr(d), 1, hip.stream()), "probe")
+hip._check_probe(hip.probe_lib().op_probe_mfma_f8(hip.ptr(a), hip.ptr(b), hip.ptr(sa.cuda()), hip.ptr(sb.cuda()), hip.ptr(d), 1, hip.stream()), "probe")
 d = d.cpu()
 got = torch.zeros(16, 16)
 for l in range(64):

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -90,19 +90,22 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
                        const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream);
 /* Grouped form of op_gemm_tn: up to 16 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  with their own operands,
  * sizes, K_i and outputs as ONE persistent launch WITHOUT split-K: the tile list of all problems is walked by one workgroup per
- * CU (per-XCD queues of tiles that share an operand panel, longest K first, work stealing), every output tile runs its whole K
+ * CU (per-XCD queues of WAVES -- as many consecutive tiles of a problem's tile rectangle as the XCD has workgroups, all of one K, so
+ * that what an XCD runs at the same time shares its operand panels through the L2; longest K first, work stealing), every output tile runs its whole K
  * and is written / accumulated exactly once -- no fp32 slabs, no fold kernel.  Replaces the weight-gradient launches autograd
  * makes per nn.Linear of an encoder layer (transformer_layer.py:165-228 backward: q|k|v, out_proj, wi_0|wi_1 and wo of every
  * modality FFN); per-tile results are bit-identical to an unsplit op_gemm_tn.  Every array argument is a HOST array of nprob
  * entries.  counters: op_gemm_tn_grouped_counter_bytes() bytes of device memory zeroed ONCE by the caller (the launch re-arms
  * it; one block per stream).  Shape rules per problem as op_gemm_tn (+ ldc % 8 == 0 and C_i 16-byte aligned: the gradient is read-modify-written in 16-byte pieces); returns -95 and launches nothing when a
- * problem does not qualify.  tune: bits 0-9 forced number of workgroups (0 = one per CU); bit 10: every workgroup draws from the
- * front of its queue (A/B timing of the solo workgroups, see the kernel). */
+ * problem does not qualify.  tune: bits 0-9 forced number of workgroups (0 = one per CU); bit 10: round 4's form of the queues
+ * (waves of a multiple of six tiles, the odd workgroups of an XCD draw single tiles from the back; A/B timing). */
 int64_t op_gemm_tn_grouped_counter_bytes(void);
-/* Host-only (no GPU needed): the tile queues op_gemm_tn_grouped builds for these sizes -- records of four int32 (queue 0..7, problem
- * index of the caller, tile row, tile column) queue by queue in draw order; returns the record count (= the number of 256 x 256
- * output tiles, each exactly once) or -22 when `cap` records do not suffice. */
-int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int32_t* out, int64_t cap);
+/* Host-only (no GPU needed): the tile queues op_gemm_tn_grouped builds for these sizes, `workgroups` (0: one per CU; 256 without a
+ * device) and `tune` -- records of four int32 (queue 0..7, problem index of the caller, tile row, tile column) queue by queue in
+ * draw order; returns the record count (= the number of 256 x 256 output tiles, each exactly once) or -22 when `cap` records do
+ * not suffice. */
+int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int64_t workgroups, int64_t tune,
+                                int32_t* out, int64_t cap);
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
                        void* counters, int64_t tune, void* stream);

@@ -27,7 +27,9 @@
 // Roofline: MFMA (dense bf16, 2.5 PFLOP/s).  Algorithmic work = 2*M*N*K flops per launch.
 #include "common.h"
 #include <string.h>
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -2012,31 +2014,42 @@ int launch256_tn(const GemmArgs& a, hipStream_t s, int splits, bool four_waves) 
 // produce a 37.7 MB gradient) and a fold kernel that reads them back (20 ms of the 4B step).  Here up to TN_MAX_PROB problems
 // (own operands, sizes, K and output) form ONE tile list: a layer of the lock-step pass is q|k|v, out-proj and wi_0|wi_1, wo of
 // three modalities = 1440 tiles, 5.6 per CU, walked by one workgroup per CU -- every tile runs its WHOLE K and accumulates
-// straight into the bf16 gradient.  Scheduling: problems in the order given (the caller sorts by K, longest first), tiles dealt
-// to EIGHT queues, one per XCD, in groups that share the panel of the wide operand (all tiles along the short dimension of
-// the output, <= 8) so that the workgroups of one XCD read it through their L2 in K-lockstep; a workgroup draws from the queue
-// of its XCD (blockIdx & 7; speed only, any mapping is correct) with one returning atomic per tile -- issued at the START of
-// the tile it precedes, consumed after its main loop -- and steals from the other queues when its own is empty.  Greedy list
-// scheduling with the longest tiles first ends within a few per cent of the ideal makespan (1440 tiles of four lengths:
-// 0.96); the last workgroup to finish resets the counters for the next launch on the stream.
-// Groups only share their panel through L2 while their tiles run in K-lockstep, i.e. start together (tools/wgrad_grouped_timeline.py:
-// with 32 workgroups per XCD and groups of 6 the two odd workgroups break every group they touch -- start skews of up to a whole
-// tile, main loop 6 % slower; with 30 per XCD the skew stays below 20 us).  So only a multiple of the group size of an XCD's
-// workgroups draws from the FRONT of its queue; the others ("solo", p.solo_from) draw single tiles from its BACK, where the
-// shortest-K problems sit (the text FFN: small operands, little to share), until the two ends meet: one 64-bit counter per
-// queue holds both claim counts, a claim is good while their sum is below the queue length.
+// straight into the bf16 gradient.
+// Scheduling (round 5; host: tn_build_schedule): EIGHT queues, one per XCD; a workgroup draws from the queue of its XCD (blockIdx & 7;
+// speed only, any mapping is correct) with one returning atomic per tile -- issued inside the epilogue of the tile it follows -- and
+// steals from the other queues when its own is empty.  What shares an operand panel through an XCD's L2 is what that XCD's
+// workgroups run AT THE SAME TIME in K-lockstep, so the unit dealt to a queue is a WAVE: as many consecutive slots of a problem's
+// slot order (tn_geom: a rectangle of its tile grid, e.g. 5.3 rows x 6 columns) as the XCD has workgroups.  32 tiles of a wave read 6
+// panels of the narrow operand and 6 of the wide one instead of 64: 0.375 panels per tile.  Waves never mix K: tiles of one K
+// finish together and the workgroups take the next wave together (problems of equal K are cut as one list); waves are dealt
+// longest K first to the queue with the least work (LPT), which ends within a few per cent of the ideal makespan.
+// Round 4 dealt six-tile GROUPS round-robin over the queues: an XCD then held groups of different problems side by side -- nothing
+// to share between them -- and fetched 16.9 GB per layer for 4.5 GB of operands (profiles/r4_gemm_hbm_traffic.json); its two odd
+// workgroups per XCD (32 = 5 groups + 2) drew single tiles from the BACK of the queue ("solo", still available: tune bit 10).
 // Main loop, LDS image, fragment order = gemm256w_tn_kernel (bit-identical per-tile results to its unsplit launch).
 // =====================================================================================================================
 constexpr int TN_MAX_PROB = 16;
+constexpr int TN_MAX_RUNS = 160;
 constexpr int TN_CTR_STRIDE = 8;   // 64-bit counters 64 bytes apart: queues 0..7 (claims from the front | from the back << 32), then the exit counter
 struct TnProb {
   const bf16_t* A; const bf16_t* B; bf16_t* C;  // C[M,N] (+)= A[K,M]^T B[K,N]
   int64_t lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n, accumulate;
 };
-struct TnGroupArgs { int nprob; int solo_from; unsigned long long* ctr; TnProb pr[TN_MAX_PROB]; };  // solo_from: see the kernel
+// A queue is a list of RUNS: `n` consecutive slots of one problem's slot order (below), from slot0 on.
+struct TnRun { int prob_n; int slot0; };  // prob_n = problem << 24 | n
+struct TnGroupArgs {
+  int nprob; int solo_from; unsigned long long* ctr;  // solo_from: see the kernel
+  int qlen[8];                                        // slots in queue x
+  short run_begin[10];                                // runs of queue x: [run_begin[x], run_begin[x + 1])
+  TnRun runs[TN_MAX_RUNS];
+  TnProb pr[TN_MAX_PROB];
+};
 
-// groups of a problem: all tiles along the SHORT dimension of its tile grid (chunks of <= 8 when that is longer)
+// Slot order of a problem: its tiles group by group -- a group = all tiles along the SHORT dimension of the tile grid (chunks of <= 8
+// when that is longer; a partial last chunk has empty slots), groups in order along the long dimension.  Consecutive slots therefore
+// walk a [rows x short-dimension] rectangle of the tile grid row by row: W consecutive slots touch ceil(W / gs) + 1 panels of the
+// wide operand and all gs panels of the narrow one.
 struct TnGeom { int along_n, gs, nch, csz, ng; };
 __host__ __device__ __forceinline__ TnGeom tn_geom(int tiles_m, int tiles_n) {
   TnGeom G;
@@ -2047,36 +2060,23 @@ __host__ __device__ __forceinline__ TnGeom tn_geom(int tiles_m, int tiles_n) {
   G.ng = (G.along_n ? tiles_m : tiles_n) * G.nch;
   return G;
 }
-// slots (tiles incl. the empty ones of a partial last chunk) in queue x
-__host__ __device__ __forceinline__ int tn_queue_len(const TnGroupArgs& p, int x) {
-  int n = 0, rot = 0;
-  for (int i = 0; i < p.nprob; ++i) {
-    const TnGeom G = tn_geom(p.pr[i].tiles_m, p.pr[i].tiles_n);
-    const int gi0 = (x - rot) & 7;
-    n += (gi0 < G.ng ? (G.ng - 1 - gi0) / 8 + 1 : 0) * G.csz;
-    rot = (rot + G.ng) & 7;
-  }
-  return n;
-}
+__host__ __device__ __forceinline__ int tn_queue_len(const TnGroupArgs& p, int x) { return p.qlen[x]; }
 // slot q of queue x -> problem and tile; false for an empty slot
 __host__ __device__ __forceinline__ bool tn_decode(const TnGroupArgs& p, int x, int q, int& prob, int& tm, int& tn) {
-  int rot = 0;
-  for (int i = 0; i < p.nprob; ++i) {
-    const TnGeom G = tn_geom(p.pr[i].tiles_m, p.pr[i].tiles_n);
-    const int gi0 = (x - rot) & 7;
-    const int n = (gi0 < G.ng ? (G.ng - 1 - gi0) / 8 + 1 : 0) * G.csz;
+  for (int r = p.run_begin[x]; r < p.run_begin[x + 1]; ++r) {
+    const int n = p.runs[r].prob_n & 0xffffff;
     if (q < n) {
-      const int j = q / G.csz, s = q - j * G.csz;
-      const int gi = gi0 + 8 * j;
+      prob = p.runs[r].prob_n >> 24;
+      const TnGeom G = tn_geom(p.pr[prob].tiles_m, p.pr[prob].tiles_n);
+      const int sl = p.runs[r].slot0 + q;
+      const int gi = sl / G.csz, s = sl - gi * G.csz;
       const int li = gi / G.nch, c = gi - li * G.nch;
       const int si = c * G.csz + s;
-      prob = i;
       tm = G.along_n ? li : si;
       tn = G.along_n ? si : li;
       return si < G.gs;
     }
     q -= n;
-    rot = (rot + G.ng) & 7;
   }
   prob = 0; tm = tn = 0;
   return false;
@@ -3004,14 +3004,66 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   return rc;
 }
 
+// Host: the run tables of gemm256w_tn_grouped_kernel (see its header).  ga.pr[] is filled, problems sorted by K (longest first).
+// per_xcd = workgroups per queue; solo: round 4's form (waves of a multiple of the group size, the other workgroups draw from the back).
+static int tn_build_schedule(TnGroupArgs& ga, int nwg, bool solo) {
+  const int per_xcd = nwg / 8 > 0 ? nwg / 8 : 1;
+  const TnGeom G0 = tn_geom(ga.pr[0].tiles_m, ga.pr[0].tiles_n);
+  int wave = per_xcd;
+  ga.solo_from = 1 << 30;
+  if (solo && G0.csz >= 2 && per_xcd >= G0.csz) ga.solo_from = wave = (per_xcd / G0.csz) * G0.csz;
+  for (;; wave *= 2) {
+    std::vector<TnRun> q[8];
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = 0;
+    while (i < ga.nprob) {
+      int j = i;  // problems i .. j-1: one K class, cut into waves as ONE slot list
+      while (j < ga.nprob && ga.pr[j].K == ga.pr[i].K) ++j;
+      int pi = i, s0 = 0;
+      auto slots_of = [&](int k) { const TnGeom G = tn_geom(ga.pr[k].tiles_m, ga.pr[k].tiles_n); return G.ng * G.csz; };
+      while (pi < j) {
+        int x = 0;
+        for (int y = 1; y < 8; ++y)
+          if (load[y] < load[x]) x = y;
+        int left = wave;
+        while (left > 0 && pi < j) {
+          const int take = std::min(left, slots_of(pi) - s0);
+          if (!q[x].empty() && (q[x].back().prob_n >> 24) == pi && q[x].back().slot0 + (q[x].back().prob_n & 0xffffff) == s0)
+            q[x].back().prob_n += take;
+          else
+            q[x].push_back(TnRun{(pi << 24) | take, s0});
+          load[x] += (double)take * ((double)ga.pr[pi].K + 400.0);
+          left -= take;
+          s0 += take;
+          if (s0 == slots_of(pi)) { ++pi; s0 = 0; }
+        }
+      }
+      i = j;
+    }
+    size_t total = 0;
+    for (int x = 0; x < 8; ++x) total += q[x].size();
+    if (total > (size_t)TN_MAX_RUNS) continue;  // (tiny forced workgroup counts: coarser waves)
+    int r = 0;
+    for (int x = 0; x < 8; ++x) {
+      ga.run_begin[x] = (short)r;
+      ga.qlen[x] = 0;
+      for (const TnRun& t : q[x]) { ga.runs[r++] = t; ga.qlen[x] += t.prob_n & 0xffffff; }
+    }
+    ga.run_begin[8] = ga.run_begin[9] = (short)r;
+    return wave;
+  }
+}
+
 // Bytes of the counter block op_gemm_tn_grouped needs: device memory the caller zeroes ONCE; every launch leaves it zeroed.
 // One block per stream that may run the op (launches on one stream are ordered, the block is re-armed by the launch itself).
 int64_t op_gemm_tn_grouped_counter_bytes(void) { return (int64_t)(9 * TN_CTR_STRIDE) * 8; }
 
-// Host-only query (works without a GPU): the tile queues op_gemm_tn_grouped builds for these problem sizes.  Writes, queue by queue
-// (0..7) and in draw order, one record of four int32 per tile: queue, problem (the caller's index), tile row, tile column; returns the
-// number of records (every output tile of every problem appears exactly once), or -22 when `cap` records do not suffice.
-int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int32_t* out, int64_t cap) {
+// Host-only query (works without a GPU): the tile queues op_gemm_tn_grouped builds for these problem sizes and `workgroups` (0: one
+// per CU, 256 on a host without a device; bit 10 of `tune` as in op_gemm_tn_grouped).  Writes, queue by queue (0..7) and in draw
+// order, one record of four int32 per tile: queue, problem (the caller's index), tile row, tile column; returns the number of
+// records (every output tile of every problem appears exactly once), or -22 when `cap` records do not suffice.
+int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int64_t workgroups, int64_t tune,
+                                int32_t* out, int64_t cap) {
   if (nprob < 1 || nprob > TN_MAX_PROB || !M || !N || !K || !out) return OP_EINVAL;
   int order[TN_MAX_PROB];
   for (int i = 0; i < (int)nprob; ++i) order[i] = i;
@@ -3020,10 +3072,16 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
   TnGroupArgs ga;
   memset(&ga, 0, sizeof(ga));
   ga.nprob = (int)nprob;
+  int64_t tiles = 0;
   for (int i = 0; i < (int)nprob; ++i) {
     ga.pr[i].tiles_m = ceil_div(M[order[i]], 256);
     ga.pr[i].tiles_n = ceil_div(N[order[i]], 256);
+    ga.pr[i].K = (int)K[order[i]];
+    tiles += (int64_t)ga.pr[i].tiles_m * ga.pr[i].tiles_n;
   }
+  int nwg = workgroups > 0 ? (int)workgroups : num_cus();
+  if (nwg > tiles) nwg = (int)tiles;
+  tn_build_schedule(ga, nwg, ((tune >> 10) & 1) != 0);
   int64_t n = 0;
   for (int x = 0; x < 8; ++x) {
     const int len = tn_queue_len(ga, x);
@@ -3043,7 +3101,7 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
 // tile runs its whole K and is written / accumulated once.  Shape rules per problem as op_gemm_tn; returns OP_ENOTSUP (nothing
 // launched) when a problem does not qualify -- the caller then uses op_gemm_tn per problem.  Problems may come in any order.
 // The gradient is read-modify-written in 16-byte pieces: ldc_i % 8 == 0 and C_i 16-byte aligned as well.
-// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = no solo workgroups.
+// tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = round 4's solo workgroups (see the kernel).
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
                        void* counters, int64_t tune, void* stream) {
@@ -3082,12 +3140,7 @@ int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, 
   int nwg = (int)(tune & 1023);
   if (nwg <= 0) nwg = num_cus();
   if (nwg > tiles) nwg = (int)tiles;
-  {  // workgroups blockIdx >> 3 >= solo_from draw single tiles from the back of the queues: what is left of an XCD's workgroups
-     // beyond a multiple of the group size of the longest-K problem (32 per XCD, groups of 6: the last two)
-    const TnGeom G0 = tn_geom(ga.pr[0].tiles_m, ga.pr[0].tiles_n);
-    const int per_xcd = nwg / 8;
-    ga.solo_from = ((tune >> 10) & 1) || G0.csz < 2 || per_xcd < G0.csz ? (1 << 30) : (per_xcd / G0.csz) * G0.csz;
-  }
+  tn_build_schedule(ga, nwg, ((tune >> 10) & 1) != 0);
   const size_t sh = STAGES2 * STAGE2_BYTES;
   OP_ENSURE_LDS(gemm256w_tn_grouped_kernel, (int)sh, "gemm_tn_grouped");
   const int slot = op_prof_begin(0, work, stream);

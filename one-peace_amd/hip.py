@@ -39,7 +39,7 @@ SIGNATURES = {
     "op_gemm_nt_grouped": (c_int, [I64, P, P, I64, P, I64, P, P, I64, P, P, P, I64, P, P, P, I64, I64, c_int, I64, P]),
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
     "op_gemm_tn_grouped_counter_bytes": (I64, []),
-    "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, P, I64]),
+    "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, I64, I64, P, I64]),
     "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
@@ -426,13 +426,13 @@ def gemm_tn_supported(K, M, N, lda, ldb):
             and 31 * lda + M < (1 << 30) and 31 * ldb + N < (1 << 30))
 
 
-def gemm_tn_grouped_plan(sizes):
+def gemm_tn_grouped_plan(sizes, workgroups=256, tune=0):
     """[(M, N, K)] -> [(queue, problem, tile_m, tile_n)] in draw order: op_gemm_tn_grouped's schedule (host-only query)."""
     n = len(sizes)
     cap = sum(((m + 255) // 256) * ((nn + 255) // 256) for m, nn, _ in sizes)
     out = (ctypes.c_int32 * (4 * cap))()
     arr = lambda j: (c_int64 * n)(*[q[j] for q in sizes])  # noqa: E731
-    cnt = lib().op_gemm_tn_grouped_plan(n, arr(0), arr(1), arr(2), ctypes.cast(out, P), cap)
+    cnt = lib().op_gemm_tn_grouped_plan(n, arr(0), arr(1), arr(2), int(workgroups), int(tune), ctypes.cast(out, P), cap)
     if cnt < 0:
         raise RuntimeError("op_gemm_tn_grouped_plan failed (%d)" % cnt)
     return [tuple(out[4 * i:4 * i + 4]) for i in range(cnt)]

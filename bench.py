@@ -718,6 +718,8 @@ def main():
                                    "free_gb_at_exit_per_rank": [round(float(t[2]), 2) for t in allr],
                                    "margin_gb_min_over_ranks": round(min(total_b / 1e9 - float(t[1]) for t in allr), 2)})
                 out["config"]["distributed"]["memory"] = mem_report
+                print("bench: memory margin (device total - peak reserved), minimum over %d ranks: %.2f GB; per-GPU batch %d" % (
+                    len(allr), mem_report["margin_gb_min_over_ranks"], args.batch), file=sys.stderr, flush=True)
         if reducer is not None and (world > 1 or reducer.active):
             rep = reducer.overlap_report()
             out["config"]["grad_allreduce_overlap"] = rep

@@ -103,7 +103,7 @@ class Tuning:
         self.ablation = 0        # timing ablations of the 256x256 kernel (tools)
         self.force_splits = 0    # forced K-split count of small problems (tools)
         self.glds = 1            # 1 LDS-DMA staging, 0 register-staged operands
-        self.sched = 0           # four-wave NT launches: 0 auto, 1-5 gemm256v_kernel instruction schedule, 7 gemm256w_kernel
+        self.sched = int(os.environ.get("ONEPEACE_TUNE_SCHED", "0"))  # four-wave NT launches: 0 auto, 1 / 3 gemm256v_kernel schedule, 6 persistent gemm256p_kernel for single problems too (A/B), 7 gemm256w_kernel
         self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
         self.attn_waves = 0      # resident forward kernel: waves per workgroup (0 = production rule; tests / A-B timing)

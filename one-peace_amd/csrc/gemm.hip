@@ -2477,7 +2477,13 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
   if ((T.fullline == 3 || (T.fullline == 2 && fills && EPI != EPI_GEGLU)) && splits == 1 &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0 && a.K >= 128) {
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
-    const int sched = T.sched == 0 ? V_SCHED_DEFAULT : T.sched;
+    // Round 5: single problems with a SHORT K walk their tiles on the persistent kernel as well.  Round 3 measured it 1.5 ... 3 % behind
+    // one tile per workgroup there -- with 16-28 scratch operations (vmcnt(0) waits next to the DMA stream) at every tile boundary; with
+    // the tile walk at ScratchSize 0 it is ahead where tiles are short (K = 1536: q|k|v -1.7 %, FFN up-projection -1 ... -2 %, input
+    // gradients of out-proj / down-projection -1.7 ... -3.6 %), level or behind at K >= 4608 (profiles/r5_blas_compare_sched6_ab.txt);
+    // whole step 700.3 -> 695.2 ms with every four-wave launch persistent (profiles/r5_bench_sched6_samebox_*.json).
+    const bool short_k = (EPI == EPI_BIAS || EPI == EPI_RESID) && a.m_off == 0 && a.K <= 2048;
+    const int sched = T.sched == 0 ? (short_k ? 6 : V_SCHED_DEFAULT) : T.sched;
     switch (sched) {
       case 1: return launch256v<EPI, 1>(a, s, grid, sh5);
       case 3: return launch256v<EPI, 3>(a, s, grid, sh5);

@@ -8,9 +8,18 @@
 //   * fused_dropout_res  residual + droppath(gamma * y), transformer_layer.py:70-88 -> EPI_RESID
 //   * scale * local @ all^T of the contrastive head, image_text_pretrain_loss.py:171-172 -> EPI_F32
 //
-// Kernels (chosen per launch by plan_gemm / launch256): gemm_nt_kernel 128x128 (small launches, described next);
-// gemm256_kernel 256x256 BK = 32 four-stage; gemm256b_kernel 256x256 BK = 64, eight waves of 128x64; gemm256w_kernel the same
-// with four waves of 128x128 (one wave per SIMD); gemm256_tn_kernel / gemm256w_tn_kernel the weight-gradient (TN) pair.
+// Kernels (chosen per launch by plan_gemm / launch256) and the launches each one serves:
+//   gemm256v_kernel / gemm256p_kernel   256x256, four waves of 128x128 (one wave per SIMD); p = persistent + grouped form.  Every
+//                                       bias / residual / plain launch that fills the chip: 15 of the 16 NT launches of a training layer
+//   gemm256b_kernel                     256x256 BK = 64, eight waves of 128x64: GeGLU-epilogue launches that fill the chip (inference,
+//                                       training passes whose FFN is not split into a plain launch + op_ln_geglu_fwd)
+//   gemm256_kernel                      256x256 BK = 32 four-stage: 256x256 plans that do NOT fill the chip, split-K slabs, fp32 outputs,
+//                                       N or K outside the four-wave kernels' rules
+//   gemm_nt_kernel                      128x128 (small launches, tail rows; described next)
+//   gemm256w_tn_kernel / gemm256_tn_kernel   weight gradients C = A^T B outside the grouped launch: four waves for <= 108 output tiles at
+//                                       K >= 16384, eight waves otherwise;  gemm256w_tn_grouped_kernel: all weight gradients of a layer
+// (Round 5 removed round 2's four-wave kernel gemm256w_kernel, the second instruction schedule of gemm256v_kernel and the six timing
+// ablations of gemm256_kernel: tools-only flavours.)
 // Tiling of the 128x128 kernel: one output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
 // 16x16x32 accumulators), BK = 64, two LDS buffers (2 x 32 KiB), one barrier per K-tile.  Operand tiles
 // are [128 rows][64 k] bf16 (128-byte rows) with the 16-byte slot index XOR-ed by (row & 7): the
@@ -153,7 +162,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
     }
   }
   // residual epilogue: ALL residual rows (and row scales) of the MI fragments are requested first -- one load -> wait -> store
-  // chain per fragment left eight HBM latencies in a row per wave, which the four waves of gemm256w_kernel cannot hide
+  // chain per fragment left eight HBM latencies in a row per wave, which the four waves of the one-wave-per-SIMD kernels cannot hide
   typename Vec8<bf16_t>::raw_t rraw[(EPI == EPI_RESID) ? MI : 1][2];
   float rsv[(EPI == EPI_RESID) ? MI : 1];
   if (EPI == EPI_RESID) {
@@ -606,7 +615,7 @@ __device__ __forceinline__ int w_row_to_col256(int p) {
 #define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 #define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 0xF) | ((((n) >> 4) & 3) << 14))
 
-template <int EPI, int ABL = 0>
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -718,8 +727,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
   // pipe; sched_group_barrier spreads the 16 memory instructions between the 32 MFMAs (1 per 2) instead.
   auto step_steady = [&](int kt, const bf16x8 (&cur_w)[4], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[4], bf16x8 (&nxt_x)[8]) {
     WAIT_LGKM0();
-    if (ABL == 3) WAIT_VM(4); else if (ABL != 2 && (ABL < 4 || ABL == 6)) WAIT_VM(8); else WAIT_VM(0);
-    if (ABL != 5) __builtin_amdgcn_s_barrier();
+    WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
     const char* st = smem + ((kt + 1) & (STAGES2 - 1)) * STAGE2_BYTES;  // fragments of the next stage
     char* la = smem + (kt & (STAGES2 - 1)) * STAGE2_BYTES;              // slot being refilled with stage kt+4
     char* lb = la + OPER2_BYTES;
@@ -728,31 +737,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmArgs p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int idx = 2 * j + h, mi = idx >> 2, ni = idx & 3;
-        if (ABL != 1 && ABL != 6)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
-        else
-          asm volatile("" :: "v"(cur_w[ni]), "v"(cur_x[mi]));
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur_w[ni], cur_x[mi], acc[ni][mi], 0, 0, 0);
       }
-      if (ABL >= 4) {  // timing ablation: MFMAs only (4: barriers kept, 5: no barriers); 6: LDS-DMA + barriers only
-        if (j < 4) nxt_w[j] = cur_w[j];
-        else if (j < 12) nxt_x[j - 4] = cur_x[j - 4];
-      } else if (j < 4) {
+      if (j < 4) {
         const int o = (EPI == EPI_GEGLU) ? ((j >> 1) * 128 + (j & 1) * 16) * 64 : j * 16 * 64;
-        if (ABL == 3) nxt_w[j] = cur_w[j];  // 3: the weight operand neither staged nor read (activations through LDS only)
-        else nxt_w[j] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
+        nxt_w[j] = *reinterpret_cast<const bf16x8*>(st + baseW + o);
       } else if (j < 12) {
         nxt_x[j - 4] = *reinterpret_cast<const bf16x8*>(st + baseX + (j - 4) * 1024);
       } else {
         const int i = (j - 12) >> 1;
         const int wbase = (i * 512 + wid * 64) * 16;
-        if (ABL != 2 && (ABL < 4 || ABL == 6)) {
-          if ((j & 1) == 0)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
-                                             (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
-          else if (ABL != 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
-                                             (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
-        }
+        if ((j & 1) == 0)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[i]),
+                                           (__attribute__((address_space(3))) void*)(la + wbase), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[i] + offB[i]),
+                                           (__attribute__((address_space(3))) void*)(lb + wbase), 16, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -974,230 +974,30 @@ __global__ __launch_bounds__(512, 2) void gemm256b_kernel(const GemmArgs p) {
   gemm_epilogue<EPI, 8>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, n0 + wn * 32, g, t);
 }
 
-// =====================================================================================================================
-// Four-wave flavour of the BK = 64 kernel: ONE wave per SIMD, 128 x 128 per wave (2 x 2 waves, 8 x 8 accumulator tiles = 256
-// registers).  Same LDS image, LDS-DMA staging, slot rotation and barrier protocol as gemm256b_kernel; per 32-deep half-step a
-// wave issues 64 MFMAs, the 16 fragment reads of the NEXT half-step (into the other register set) and 8 LDS-DMA ops.  The point:
-// 64 KiB instead of 96 KiB of fragment reads per half-step and CU -- the LDS pipe (DMA writes + fragment reads) is what bounds
-// the eight-wave main loop (profiles/r2_experiments.md section 5).  With a single wave per SIMD nothing hides a stall of that
-// wave, so: every wait is explicit (the compiler's own wait insertion degrades to vmcnt(0)/lgkmcnt(0) next to LDS-DMA, see
-// the note there), the accumulators are pinned in the 256 AGPRs by issuing the MFMAs as inline asm ("+a"; with the builtin the
-// register allocator split them between VGPRs and AGPRs and copied them around the loop), and the steady-state loop is free of
-// branches (what a half-step issues is a compile-time tag; the last two K-tiles are peeled).  Every MFMA group of a half-step
-// carries two fragment reads and one LDS-DMA op.
-// =====================================================================================================================
 #define WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm256w_kernel(const GemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int g = lane >> 4, t = lane & 15;
-  constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
-
-  const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  const int GM = p.gm;
-  const int per_group = GM * p.tiles_n;
-  const int first_m = (pid / per_group) * GM;
-  const int gsz = min(p.tiles_m - first_m, GM);
-  const int in_group = pid % per_group;
-  const int pid_m = first_m + in_group % gsz;
-  const int pid_n = in_group / gsz;
-  const int m0 = pid_m * BM2, n0 = pid_n * BN_OUT;
-  const int nk = p.K / 64;
-
-  // ---- staging: op j (0..7) of an operand tile covers LDS rows j*32 + (tid >> 3), 16-byte slot tid & 7 ----
-  const int srow = tid >> 3;                       // 0..31
-  const int sc = (tid & 7) ^ (srow & 7);
-  const char* baseA = (const char*)p.A;
-  unsigned offA[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int gm = min(m0 + j * 32 + srow, p.M - 1);
-    offA[j] = (unsigned)(((int64_t)gm * p.lda + sc * 8) * 2);
-  }
-  const char* baseB[8];
-  unsigned offB;
-  {
-    const int seg = (EPI == EPI_GEGLU) ? 0 : n0 / p.n_seg;
-    // LDS row j*32 + q  <-  output column w_row_to_col256(j*32 + q) = (uniform in j) + (per lane in q)
-    const int lanecol = (EPI == EPI_GEGLU) ? (((srow & 15) >> 2) * 8 + (srow >> 4) * 4 + (srow & 3))
-                                           : (((srow & 15) >> 2) * 16 + (srow >> 4) * 4 + (srow & 3));
-    offB = (unsigned)(((int64_t)lanecol * p.ldb + sc * 8) * 2);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bf16_t* wb;
-      int col0;
-      if (EPI == EPI_GEGLU) {
-        wb = p.B[j >> 2];
-        col0 = n0 + (j & 3) * 32;
-      } else {
-        wb = p.B[seg];
-        col0 = n0 - seg * p.n_seg + (j >> 1) * 64 + (j & 1) * 8;
-      }
-      baseB[j] = (const char*)(wb + (int64_t)col0 * p.ldb);
-    }
-  }
-
-  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) acc[a][b][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
-  const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
-  auto w_off = [&](int f) {  // byte offset of weight fragment f = blk * 4 + ni inside the operand tile
-    const int blk = f >> 2, ni = f & 3;
-    if (EPI == EPI_GEGLU) return ((ni >> 1) * 128 + (wn * 2 + blk) * 32 + (ni & 1) * 16 + t) * 128;
-    return (wn * 128 + blk * 64 + ni * 16 + t) * 128;
-  };
-
-  int qslot_issue = 0;
-  auto issue_tile = [&](bool is_b) {
-    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const char* src = is_b ? baseB[j] + offB : baseA + offA[j];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
-    }
-    if (is_b) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) baseB[j] += 128;
-    } else {
-      baseA += 128;
-    }
-    qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
-  };
-
-  // One half-step.  cur: fragments of this half (complete); nxt: receives the next half-step's; WHAT: 0 issue an A tile, 1 a B
-  // tile, 2 nothing; READ: whether a next half-step exists.  Group k (8 MFMAs on activation fragment k) carries two fragment reads
-  // and one LDS-DMA op (reads early / DMA late and the reverse measured within 1 % of this uniform order).
-  auto half_step = [&](auto what_tag, auto read_tag, const bf16x8 (&cur_w)[8], const bf16x8 (&cur_x)[8], bf16x8 (&nxt_w)[8],
-                       bf16x8 (&nxt_x)[8], const char* sa, const char* sb, int h) {
-    constexpr int WHAT = decltype(what_tag)::value;
-    constexpr bool READ = decltype(read_tag)::value;
-    char* dst = smem + qslot_issue * SLOT3_BYTES + wid * 1024;
-    auto rd = [&](int r) {  // r = 0..15: weight fragments first (the MFMA groups need all eight of them at once)
-      if (r < 8) nxt_w[r] = *reinterpret_cast<const bf16x8*>(sb + w_off(r) + fsw[h]);
-      else nxt_x[r - 8] = *reinterpret_cast<const bf16x8*>(sa + rowX + (r - 8) * 2048 + fsw[h]);
-    };
-    auto dma = [&](int j) {
-      if (WHAT == 0)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseA + offA[j]),
-                                         (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
-      else if (WHAT == 1)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(baseB[j] + offB),
-                                         (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, 0, 0);
-    };
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-      for (int f = 0; f < 8; ++f)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[f >> 2][f & 3][k]) : "v"(cur_w[f]), "v"(cur_x[k]));
-      if (READ) { rd(2 * k); rd(2 * k + 1); }
-      if (WHAT != 2) dma(k);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (WHAT == 0) {
-      baseA += 128;
-    } else if (WHAT == 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) baseB[j] += 128;
-    }
-    if (WHAT != 2) qslot_issue = qslot_issue == SLOTS3 - 1 ? 0 : qslot_issue + 1;
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using Yes = std::integral_constant<bool, true>;
-  using No = std::integral_constant<bool, false>;
-
-  // ---- prologue: A0 B0 A1 B1 (nk >= 2); fragments of (0,0) ----
-  issue_tile(false);
-  issue_tile(true);
-  issue_tile(false);
-  issue_tile(true);
-  WAIT_VM(16);
-  __builtin_amdgcn_s_barrier();
-  bf16x8 wfA[8], xfA[8], wfB[8], xfB[8];
-  int sa = 0, sb = 1;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) wfA[r] = *reinterpret_cast<const bf16x8*>(smem + sb * SLOT3_BYTES + w_off(r) + fsw[0]);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) xfA[r] = *reinterpret_cast<const bf16x8*>(smem + sa * SLOT3_BYTES + rowX + r * 2048 + fsw[0]);
-  auto step_slots = [&](int& sa1, int& sb1) {
-    sa1 = sa + 2 >= SLOTS3 ? sa + 2 - SLOTS3 : sa + 2;
-    sb1 = sb + 2 >= SLOTS3 ? sb + 2 - SLOTS3 : sb + 2;
-  };
-  auto lgkm0 = [&]() {
-    WAIT_LGKM(0);
-    asm volatile("s_nop 0");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  int i = 0;
-  for (; i + 2 < nk; ++i) {  // steady state: tiles i+2 still to be issued
-    int sa1, sb1;
-    step_slots(sa1, sb1);
-    lgkm0();
-    half_step(I0{}, Yes{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);   // (i,0): A(i+2)
-    WAIT_LGKM(0);
-    WAIT_VM(8);
-    __builtin_amdgcn_s_barrier();
-    half_step(I1{}, Yes{}, wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0);  // (i,1): B(i+2)
-    sa = sa1;
-    sb = sb1;
-  }
-  {  // tile nk-2: nothing left to issue, tile nk-1 is in flight
-    int sa1, sb1;
-    step_slots(sa1, sb1);
-    lgkm0();
-    half_step(I2{}, Yes{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);
-    WAIT_LGKM(0);
-    WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
-    half_step(I2{}, Yes{}, wfB, xfB, wfA, xfA, smem + sa1 * SLOT3_BYTES, smem + sb1 * SLOT3_BYTES, 0);
-    sa = sa1;
-    sb = sb1;
-  }
-  {  // tile nk-1
-    lgkm0();
-    half_step(I2{}, Yes{}, wfA, xfA, wfB, xfB, smem + sa * SLOT3_BYTES, smem + sb * SLOT3_BYTES, 1);
-    lgkm0();
-    half_step(I2{}, No{}, wfB, xfB, wfA, xfA, smem, smem, 0);
-  }
-  // the accumulators were written by inline-asm MFMAs the hazard recogniser does not see: let the last ones retire
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-  gemm_epilogue<EPI, 8>(p, p.C, acc[0], m0 + wm * 128, n0 + wn * 128, n0 + (wn * 2) * 32, g, t);
-  gemm_epilogue<EPI, 8>(p, p.C, acc[1], m0 + wm * 128, n0 + wn * 128 + 64, n0 + (wn * 2 + 1) * 32, g, t);
-}
-
 // =====================================================================================================================
-// gemm256v_kernel: the four-wave kernel above with (a) LDS-DMA through buffer descriptors -- `buffer_load_dwordx4 v, s[rsrc],
-// s_off offen lds`: the K position travels in the descriptor's base address (scalar adds), so the steady loop has no per-load
-// 64-bit VALU address add -- and (b) an
-// instruction stream in which every gap between two MFMAs carries AT MOST ONE memory instruction, placed by a compile-time table
-// (vs_read / vs_dma): with one wave per SIMD the matrix pipe is fed by a single in-order instruction stream, a 16x16x32 MFMA
-// occupies it for 16 cycles, and whatever the wave has to issue between two MFMAs beyond ~12 cycles idles it.  PMC of
-// gemm256w_kernel (profiles/pmc/r2_gemm256w_nt_qkv_b128.txt): matrix pipe 56 % busy, 26 % of the wave's cycles are the issue of
-// non-MFMA instructions -- it issues 8 MFMAs back to back and then a burst {address add, M0, 2 ds_read_b128, LDS-DMA}.
-// Same LDS image, slot rotation, barrier protocol and per-accumulator MFMA order as gemm256w_kernel / gemm256b_kernel:
-// bit-identical results.  SCHED selects where a half-step's 16 fragment reads and 8 LDS-DMA ops go (tools/gemm_sched_ab.py;
-// five placements were measured, profiles/r3_gemm_sched_ab.txt: all within 1 % of each other, all 1 ... 2.5 % ahead of gemm256w):
-//   1  after every 8th MFMA: 2 reads + 1 DMA (gemm256w's placement; isolates the effect of the buffer loads)
-//   3  per 8 MFMAs: read after the 1st, read after the 4th, DMA after the 6th (production)
+// gemm256v_kernel: the four-wave 256 x 256 NT kernel (production for every launch that fills the chip; gemm256p_kernel below is its
+// persistent / grouped form).  ONE wave per SIMD, 128 x 128 per wave (2 x 2 waves, 8 x 8 accumulator tiles = 256 AGPRs): 64 KiB
+// instead of 96 KiB of fragment reads per 32-deep half-step and CU against the eight-wave kernels -- the LDS pipe (DMA writes +
+// fragment reads) is what bounds their main loop (profiles/r2_experiments.md section 5).  Same LDS image (BK = 64, 128-byte rows,
+// five 32 KiB slots cycled A0 B0 A1 B1 ...), barrier protocol and per-accumulator MFMA order as gemm256b_kernel: bit-identical
+// results.  With a single wave per SIMD nothing hides a stall of that wave, so: every wait is explicit (the compiler's own wait
+// insertion degrades to vmcnt(0) / lgkmcnt(0) next to LDS-DMA), the accumulators are pinned in the AGPRs by issuing the MFMAs as
+// inline asm ("+a"), the steady-state loop is free of branches, and
+// (a) LDS-DMA goes through buffer descriptors -- `buffer_load_dwordx4 v, s[rsrc], s_off offen lds`: the K position travels in the
+//     descriptor's base address (scalar adds), no per-load 64-bit VALU address add --
+// (b) every gap between two MFMAs carries AT MOST ONE memory instruction, placed by a compile-time table (vs_read / vs_dma): a
+//     16x16x32 MFMA occupies the matrix pipe for 16 cycles, and whatever the wave has to issue between two MFMAs beyond ~12 cycles
+//     idles it.  (Round 2's four-wave kernel gemm256w -- bursts of {address add, M0, 2 ds_read_b128, LDS-DMA} after every 8th MFMA:
+//     matrix pipe 56 % busy, profiles/pmc/r2_gemm256w_nt_qkv_b128.txt -- and the four other placements measured in round 3,
+//     profiles/r3_gemm_sched_ab.txt, all within 1 % of each other, left the source in round 5.)
+// Placement (SCHED 3): per 8 MFMAs a fragment read after the 1st and after the 4th, the LDS-DMA op after the 6th.
 // =====================================================================================================================
 __host__ __device__ constexpr int vs_read(int S, int i, int which) {  // fragment read `which` (0/1) issued after MFMA i, or -1
-  if (S == 1) return (i & 7) == 7 ? 2 * (i >> 3) + which : -1;
   return which != 0 ? -1 : (i & 7) == 0 ? 2 * (i >> 3) : (i & 7) == 3 ? 2 * (i >> 3) + 1 : -1;
 }
 __host__ __device__ constexpr int vs_dma(int S, int i) {  // LDS-DMA op issued after MFMA i, or -1
-  if (S == 1) return (i & 7) == 7 ? i >> 3 : -1;
   return (i & 7) == 5 ? i >> 3 : -1;
 }
 
@@ -1421,7 +1221,7 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
 // at a tile boundary: the loop that issues K-tile i+2 of the current tile issues K-tiles 0 and 1 of the NEXT tile during its
 // last two trips, and the last half-step reads the next tile's first fragments.  What a one-tile workgroup pays per tile --
 // dispatch, kernel-argument loads, address set-up, the latency of the first operand tiles, and an epilogue whose stores have
-// to drain before the CU gets its next workgroup (K-scan of gemm256w_kernel: 26 us per three-round launch, 20 % of a
+// to drain before the CU gets its next workgroup (K-scan of round 2's one-tile four-wave kernel: 26 us per three-round launch, 20 % of a
 // K = 1536 launch) -- is paid once per launch or overlaps with the next tile's main loop.
 // Grouped: the tile list may span up to three PROBLEMS that share N, K and the epilogue but have their own activation
 // matrix, row count, weights, bias, layer-scale vector, residual and outputs -- the three modality FFNs of an encoder layer as
@@ -1839,7 +1639,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(const GemmArgs p) {
   tn_epilogue<EPI, 4>(p, Cout, acc, m0 + wm * 128, n0 + wn * 64, g, t);
 }
 
-// Four-wave flavour of the TN kernel (one wave per SIMD, 128 x 128 per wave; see gemm256w_kernel): the same four-stage
+// Four-wave flavour of the TN kernel (one wave per SIMD, 128 x 128 per wave; see gemm256v_kernel): the same four-stage
 // [32 k][256] LDS image and transpose-read fragments, 32 ds_read_b64_tr_b16 per 64 MFMAs and wave instead of 24 per 32, i.e. a
 // third fewer LDS bytes per MFMA; accumulators pinned in AGPRs (inline-asm MFMA), steady state unrolled over both fragment sets.
 template <int EPI>
@@ -2386,12 +2186,12 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
 //              128 x 128 when K >= 3072, eight waves of 128 x 64 otherwise), 1 BK = 32 four-stage, 2 eight-wave full-line, 3 four-wave
 //   bits 4-6   tail-rows split: 0 default (when it saves a round and K >= 1024), 1 off, 3 whenever it saves a round, 4 always
 //   bits 7-11  M-tiles per L2 group of the 256x256 kernels (0 = auto)
-//   bits 12-14 timing ablation of the 256x256 BK = 32 kernel (tools only; wrong results)
+//   bits 12-14 unused (rounds 1-4: timing ablations of the BK = 32 kernel)
 //   bits 15-18 forced K-split count of small problems (tools only)
 //   bit  19    register-staged operand path instead of LDS-DMA (128x128 kernel; tests)
-//   bits 20-22 four-wave NT launches: 0 auto, 1 / 3 gemm256v_kernel with that instruction schedule, 6 gemm256p_kernel (persistent),
-//              7 gemm256w_kernel (tools, tests)
-struct GemmTune { int tile_mode, fullline, tail_rows, gm, ablation, force_splits, glds, sched; };
+//   bits 20-22 four-wave NT launches: 0 auto (persistent gemm256p_kernel for K <= 2048, else gemm256v_kernel), 3 gemm256v_kernel,
+//              6 gemm256p_kernel; op_gemm_nt_grouped: 7 = one tile per workgroup instead of the persistent walk (tests, A/B)
+struct GemmTune { int tile_mode, fullline, tail_rows, gm, force_splits, glds, sched; };
 static GemmTune decode_tune(int64_t t) {
   GemmTune T;
   T.tile_mode = (int)(t & 3);
@@ -2400,15 +2200,13 @@ static GemmTune decode_tune(int64_t t) {
   const int tr = (int)((t >> 4) & 7);
   T.tail_rows = tr == 0 ? 1 : tr - 1;         // internal: 0 off, 1 default, 2 whenever it saves a round, 3 always
   T.gm = (int)((t >> 7) & 31);
-  T.ablation = (int)((t >> 12) & 7);
   T.force_splits = (int)((t >> 15) & 15);
   T.glds = ((t >> 19) & 1) ? 0 : 1;
   T.sched = (int)((t >> 20) & 7);
   return T;
 }
 
-constexpr int V_SCHED_DEFAULT = 3;  // kernel of the four-wave NT launches when the tune word does not name one: gemm256v_kernel, schedule 3
-                                    // (-1.3 ... -1.9 % over gemm256w_kernel = 7 on the 4B shapes, profiles/r3_gemm_sched_ab.txt)
+constexpr int V_SCHED_DEFAULT = 3;  // four-wave NT launches with K > 2048 when the tune word does not name a kernel: gemm256v_kernel
 
 template <int EPI, int SCHED>
 int launch256v(const GemmArgs& a, hipStream_t s, dim3 grid, size_t sh) {
@@ -2484,20 +2282,10 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
     // whole step 700.3 -> 695.2 ms with every four-wave launch persistent (profiles/r5_bench_sched6_samebox_*.json).
     const bool short_k = (EPI == EPI_BIAS || EPI == EPI_RESID) && a.m_off == 0 && a.K <= 2048;
     const int sched = T.sched == 0 ? (short_k ? 6 : V_SCHED_DEFAULT) : T.sched;
-    switch (sched) {
-      case 1: return launch256v<EPI, 1>(a, s, grid, sh5);
-      case 3: return launch256v<EPI, 3>(a, s, grid, sh5);
-      case 6:
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
-          if (a.m_off == 0) return launch256p<EPI>(group_of(a, EPI), s, true);
-        }
-        return launch256v<EPI, 3>(a, s, grid, sh5);
-      default: break;
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+      if (sched == 6 && a.m_off == 0) return launch256p<EPI>(group_of(a, EPI), s, true);
     }
-    OP_ENSURE_LDS((gemm256w_kernel<EPI>), (int)sh5, "gemm256w");
-    hipLaunchKernelGGL((gemm256w_kernel<EPI>), grid, dim3(256), sh5, s, a);
-    OP_LAUNCH_CHECK();
-    return OP_OK;
+    return launch256v<EPI, 3>(a, s, grid, sh5);
   }
   // T.fullline: 0 BK = 32, 1 full-line always, 2 (default) full-line when the launch fills every CU at least once
   if ((T.fullline == 1 || (T.fullline == 2 && fills)) &&
@@ -2505,24 +2293,6 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
     const size_t sh5 = (size_t)SLOTS3 * SLOT3_BYTES;
     OP_ENSURE_LDS((gemm256b_kernel<EPI>), (int)sh5, "gemm256b");
     hipLaunchKernelGGL((gemm256b_kernel<EPI>), grid, dim3(512), sh5, s, a);
-  } else if (EPI == EPI_BIAS && T.ablation == 1) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 1>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && T.ablation == 2) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 2>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && T.ablation == 3) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 3>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && T.ablation == 4) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 4>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && T.ablation == 5) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 5>), grid, dim3(512), sh, s, a);
-  } else if (EPI == EPI_BIAS && T.ablation == 6) {
-    hipFuncSetAttribute((const void*)gemm256_kernel<EPI_BIAS, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS, 6>), grid, dim3(512), sh, s, a);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<EPI>), grid, dim3(512), sh, s, a);
   }

@@ -100,7 +100,6 @@ class Tuning:
         self.fullline = 2        # flavour of the 256x256 NT kernel: 0 BK = 32, 1 eight-wave full-line, 2 auto, 3 four-wave full-line
         self.tail_rows = 1       # 0 off, 1 default, 2 whenever it saves a round, 3 always
         self.gm = 0              # M-tiles per L2 group (0 auto)
-        self.ablation = 0        # timing ablations of the 256x256 kernel (tools)
         self.force_splits = 0    # forced K-split count of small problems (tools)
         self.glds = 1            # 1 LDS-DMA staging, 0 register-staged operands
         self.sched = int(os.environ.get("ONEPEACE_TUNE_SCHED", "0"))  # four-wave NT launches: 0 auto, 1 / 3 gemm256v_kernel schedule, 6 persistent gemm256p_kernel for single problems too (A/B), 7 gemm256w_kernel
@@ -118,7 +117,7 @@ class Tuning:
     def gemm(self):
         fl = {2: 0, 0: 1, 1: 2, 3: 3}.get(self.fullline, 0)
         tr = 0 if self.tail_rows == 1 else self.tail_rows + 1
-        return (self.tile_mode | fl << 2 | tr << 4 | (self.gm & 31) << 7 | (self.ablation & 7) << 12 | (self.force_splits & 15) << 15
+        return (self.tile_mode | fl << 2 | tr << 4 | (self.gm & 31) << 7 | (self.force_splits & 15) << 15
                 | (0 if self.glds else 1) << 19 | (self.sched & 7) << 20)
 
     def attn_fwd(self):
@@ -155,7 +154,7 @@ class _LibProxy:
             if 0 <= mode - 20 <= 3:  # other values were ignored by the round-1 C knob as well
                 TUNE.fullline = mode - 20
         elif mode >= 10:
-            TUNE.ablation = mode - 10
+            pass  # (rounds 1-4: timing ablations of the BK = 32 kernel, removed in round 5)
         else:
             TUNE.tile_mode = mode
         return old

@@ -38,7 +38,6 @@ def sep_dgrad_w0():  # dxln2 = dh0 @ W0 (N = H, K = F)
 
 
 cases = {
-    "GeGLU": (sep_geglu, lambda: hip.gemm_nt_grouped(xs, list(zip(w0, w1)), outs=og, epilogue=hip.EPI_GEGLU, h0s=h0, h1s=h1), 4.0 * sum(Ms) * F * H),
     "down-proj+resid": (sep_ffn2, lambda: hip.gemm_nt_grouped(gs, w2, biases=b2, outs=oh, epilogue=hip.EPI_RESID, h0s=y, resids=res, gammas=gam), 2.0 * sum(Ms) * F * H),
     "dgrad N=6144 K=1536": (sep_dgrad_w2, lambda: hip.gemm_nt_grouped(xs, w2t, outs=og), 2.0 * sum(Ms) * F * H),
     "dgrad N=1536 K=6144": (sep_dgrad_w0, lambda: hip.gemm_nt_grouped(gs, w2, outs=oh), 2.0 * sum(Ms) * F * H),

@@ -48,16 +48,16 @@ out = {
     "what": "HBM-side bytes per GEMM-family launch (all gemm* kernels; split-K folds are not counted as launches), one bench.py step",
     "command": "tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --kernel-include-regex 'gemm|splitk' -- "
                "python bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline --no-skip-leg --no-power-probe (two separate passes + two calibration launches each)",
-    "round": 4, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
+    "round": 5, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
     "fetch_size_correction": fc, "write_size_correction": wc,
     "calibration": "tools/pmc_calib.py: A[32896,6144] bf16 read exactly once (404 MB > 256 MB Infinity Cache)",
     "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
     "by_kernel_read_bytes_per_launch": {k: v[0] * 1024.0 * fc / v[1] for k, v in res["FETCH_SIZE"]["bench_by_kernel_kb"].items()},
     "by_kernel_write_bytes_per_launch": {k: v[0] * 1024.0 * wc / v[1] for k, v in res["WRITE_SIZE"]["bench_by_kernel_kb"].items()},
     "by_kernel_launches": {k: v[1] for k, v in res["FETCH_SIZE"]["bench_by_kernel_kb"].items()},
-    "kernel_keys": "s = gemm_nt_kernel (128x128), a / b / w = gemm256 / gemm256b / gemm256w_kernel, v = gemm256v_kernel (four waves, production), "
-                   "p = gemm256p_kernel (grouped launches), tn / wtn = gemm256_tn_kernel / gemm256w_tn_kernel, gtn = gemm256w_tn_grouped_kernel (round 4: all weight "
-                   "gradients of a layer, no split-K slabs)",
+    "kernel_keys": "s = gemm_nt_kernel (128x128), a / b = gemm256 / gemm256b_kernel, v = gemm256v_kernel (four waves, K > 2048), "
+                   "p = gemm256p_kernel (persistent: grouped launches and, since round 5, single problems with K <= 2048), tn / wtn = gemm256_tn_kernel / "
+                   "gemm256w_tn_kernel, gtn = gemm256w_tn_grouped_kernel (all weight gradients of a layer; round 5: wave queues)",
     "note": "counter bytes include Infinity-Cache hits (MI355X_MICROARCH.md); weight panels re-fetched per M-tile group are mostly such hits",
 }
 json.dump(out, open(sys.argv[1], "w"), indent=1)

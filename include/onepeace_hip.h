@@ -132,7 +132,7 @@ int op_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* s
 int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0, const void* B1, int64_t ldb, const float* sb0,
                    const float* sb1, const void* bias, void* C, int64_t ldc, void* h0, void* h1, const void* resid, int64_t ldr,
                    const void* gamma, const float* rowscale, int64_t rows_per_sample, int64_t M, int64_t N, int64_t K, int epilogue,
-                   void* stream);
+                   int64_t tune, void* stream);
 
 /* ---- attention ---------------------------------------------------------------------------------------------------
  * Replaces multihead_attention.py:102-115 (bmm QK^T, += attn_mask, fp32 softmax, bmm PV) and the xformers seam

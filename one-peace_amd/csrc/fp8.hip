@@ -16,6 +16,8 @@
 // LDS rows, XOR swizzle and LDS-DMA staging; half the LDS and L2 bytes per flop of the bf16 kernel).
 // Roofline: MFMA, dense fp8 peak 5 PFLOP/s; algorithmic work 2*M*N*K flops per launch.
 #include "common.h"
+#include <string.h>
+#include "gemm_epilogue_v.h"  // GemmArgs, epilogue_v<EPI, SCALED> (shared with gemm.hip)
 
 namespace {
 
@@ -269,6 +271,218 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
   }
 }
 
+// =====================================================================================================================
+// gemm256f8_kernel (round 5): the fp8 GEMM on the skeleton of the bf16 production kernel gemm256v_kernel (csrc/gemm.hip) --
+// 256 x 256 tile, four waves (one per SIMD) of 128 x 128, accumulators pinned in the 256 AGPRs by inline-asm MFMAs, five 32 KiB LDS
+// slots cycled A0 B0 A1 B1 A2 ..., LDS-DMA through buffer descriptors whose base carries the K position (K-tiles past the end are
+// fetched through EMPTY descriptors: one uniform loop), at most one memory instruction between two MFMAs, activation fragment as
+// FIRST operand so that the epilogue (epilogue_v<EPI, SCALED>) writes 16-byte coalesced rows.  An fp8 K-tile is 128 elements = the
+// same 128-byte LDS rows, swizzle and DMA pattern as a 64-deep bf16 K-tile: twice the flops per staged byte.
+// What differs is the register blocking: an operand of v_mfma_scale_f32_16x16x128_f8f6f4 is 32 bytes per lane (8 VGPRs) -- the two
+// 16-byte chunks (g) and (4 + g) of the lane's row, i.e. the two "halves" the bf16 kernel feeds to two K = 32 MFMAs; the K
+// permutation is the same for both operands, so the sums are those of the natural order -- and double-buffering all 16 fragments of
+// a wave would take 256 VGPRs.  So per K-tile: the 8 activation fragments are double-buffered (2 x 64 VGPRs), the weight fragments
+// travel in two quarter sets of 4 (2 x 32 VGPRs): phase A runs the 32 MFMAs of weight fragments 0-3 while fragments 4-7 of the SAME
+// tile are read, phase B those of 4-7 while the next tile's activation fragments and weight fragments 0-3 are read (24 reads + 8
+// DMA ops: one per MFMA gap -- an fp8 MFMA holds the pipe for 32 cycles, twice a bf16 one).  K % 256 == 0 (two K-tiles per trip).
+// Block scales: all E8M0 = 2^0, the per-row fp32 scales are applied by the epilogue (see the file header).
+// =====================================================================================================================
+constexpr int F8_SLOT_BYTES = 256 * 128;  // one operand K-tile: 256 rows x 128 fp8
+constexpr int F8_SLOTS = 5;
+#define F8_WAIT_LGKM(n) __builtin_amdgcn_s_waitcnt(0xC07F | ((n) << 8))
+#define F8_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 0xF) | ((((n) >> 4) & 3) << 14))
+
+struct F8Args256 { GemmArgs g; const float* sa; const float* sb; };  // g.A / g.B[0]: fp8 bytes; g.lda / g.ldb / g.K in BYTES = elements
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm256f8_kernel(const F8Args256 q) {
+  static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "gemm256f8_kernel: plain / bias and residual epilogues");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GemmArgs& p = q.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int g = lane >> 4, t = lane & 15;
+
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int GM = p.gm;
+  const int per_group = GM * p.tiles_n;
+  const int first_m = (pid / per_group) * GM;
+  const int gsz = min(p.tiles_m - first_m, GM);
+  const int in_group = pid % per_group;
+  const int pid_m = first_m + in_group % gsz;
+  const int pid_n = in_group / gsz;
+  const int m0 = pid_m * 256, n0 = pid_n * 256;
+  const int nk = p.K / 128;
+
+  // ---- staging (gemm256v_kernel): op j of an operand tile covers LDS rows j*32 + (tid >> 3), 16-byte slot tid & 7 ----
+  const int srow = tid >> 3;
+  const int sc = (tid & 7) ^ (srow & 7);
+  unsigned offA[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int gm = min(m0 + j * 32 + srow, p.M - 1);
+    offA[j] = (unsigned)((int64_t)gm * p.lda + sc * 16);
+  }
+  const int nrecA = (int)(((int64_t)p.M - 1) * p.lda + p.K);
+  const int lanecol = (srow & 15) * 8 + (srow >> 4);  // the column map of epilogue_v (VMAP)
+  const unsigned offB = (unsigned)((int64_t)lanecol * p.ldb + sc * 16);
+  unsigned soffB[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) soffB[j] = (unsigned)((int64_t)(n0 + (j >> 2) * 128 + ((j >> 1) & 1) * 4 + (j & 1) * 2) * p.ldb);
+  const char* ptrA = (const char*)p.A;
+  const char* ptrB = (const char*)p.B[0];
+  const int nrecB = (int)(((int64_t)p.N - 1) * p.ldb + p.K);
+  int ktA = 0, ktB = 0;
+
+  f32x4 acc[2][4][8];  // [64-column block][ni][mi]
+
+  const int fsw[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
+  const int rowX = (wm * 128 + t) * 128;  // + mi * 2048
+  auto w_off = [&](int f) { return (wn * 128 + (f >> 2) * 64 + (f & 3) * 16 + t) * 128; };
+
+  int qslot_issue = 0;
+  auto rsrc_a = [&]() {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(ptrA + (int64_t)ktA * 128), 0, ktA < nk ? nrecA - ktA * 128 : 0, 0x00020000);
+  };
+  auto rsrc_b = [&]() {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(ptrB + (int64_t)ktB * 128), 0, ktB < nk ? nrecB - ktB * 128 : 0, 0x00020000);
+  };
+  auto dma_a = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offA[j], 0, 0, 0);
+  };
+  auto dma_b = [&](const __amdgpu_buffer_rsrc_t& r, char* dst, int j) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(dst + j * 4096), 16, offB, soffB[j], 0, 0);
+  };
+  auto advance = [&](bool is_b) {
+    if (is_b) ++ktB; else ++ktA;
+    qslot_issue = qslot_issue == F8_SLOTS - 1 ? 0 : qslot_issue + 1;
+  };
+  auto issue_tile = [&](bool is_b) {
+    char* dst = smem + qslot_issue * F8_SLOT_BYTES + wid * 1024;
+    const __amdgpu_buffer_rsrc_t ra = rsrc_a(), rb = rsrc_b();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (is_b) dma_b(rb, dst, j); else dma_a(ra, dst, j);
+    }
+    advance(is_b);
+  };
+
+  struct Frag { u32x4 h[2]; };  // the two 16-byte chunks (g), (4 + g) of the lane's row = one 32-byte MFMA operand
+  auto operand = [](const Frag& f) {
+    return (i32x8){(int)f.h[0][0], (int)f.h[0][1], (int)f.h[0][2], (int)f.h[0][3], (int)f.h[1][0], (int)f.h[1][1], (int)f.h[1][2], (int)f.h[1][3]};
+  };
+  const int one = E8M0_ONE;
+  auto mfma = [&](int k, int f, const Frag (&x)[8], const Frag (&w)[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass of hipcc checks asm constraints against x86: a 32-byte "v" operand is an error there,
+    // reported nowhere -- the kernel's host stub just goes missing from the object)
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                 : "+a"(acc[f >> 2][f & 3][k])
+                 : "v"(operand(x[k])), "v"(operand(w[f & 3])), "v"(one));
+#endif
+  };
+  auto rd_x = [&](Frag (&x)[8], const char* sa_, int r) {  // r = 0..15: fragment r >> 1, half r & 1
+    x[r >> 1].h[r & 1] = *reinterpret_cast<const u32x4*>(sa_ + rowX + (r >> 1) * 2048 + fsw[r & 1]);
+  };
+  auto rd_w = [&](Frag (&w)[4], const char* sb_, int first, int r) {  // r = 0..7: weight fragment first + (r >> 1), half r & 1
+    w[r >> 1].h[r & 1] = *reinterpret_cast<const u32x4*>(sb_ + w_off(first + (r >> 1)) + fsw[r & 1]);
+  };
+
+  // One K-tile.  Phase A: 32 MFMAs of weight fragments 0-3 (w_lo) on x_cur; reads fragments 4-7 of the same tile into w_hi; DMA of the
+  // activation tile two ahead.  Barrier (the next tile has landed; every wave is done with this tile's slots).  Phase B: 32 MFMAs of
+  // w_hi; reads the next tile's activation fragments into x_nxt and its weight fragments 0-3 into w_lo; DMA of the weight tile two ahead.
+  auto tile_step = [&](const Frag (&x_cur)[8], Frag (&x_nxt)[8], Frag (&w_lo)[4], Frag (&w_hi)[4], const char* sa_, const char* sb_,
+                       const char* sa1_, const char* sb1_) {
+    {
+      char* dst = smem + qslot_issue * F8_SLOT_BYTES + wid * 1024;
+      const __amdgpu_buffer_rsrc_t r0 = rsrc_a();
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        mfma(i >> 2, i & 3, x_cur, w_lo);
+        if (i & 1) {  // 16 gaps: 8 reads first, then the 8 DMA ops
+          __builtin_amdgcn_sched_barrier(0);
+          const int o = i >> 1;
+          if (o < 8) rd_w(w_hi, sb_, 4, o); else dma_a(r0, dst, o - 8);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      advance(false);
+    }
+    F8_WAIT_LGKM(0);
+    F8_WAIT_VM(8);
+    __builtin_amdgcn_s_barrier();
+    {
+      char* dst = smem + qslot_issue * F8_SLOT_BYTES + wid * 1024;
+      const __amdgpu_buffer_rsrc_t r0 = rsrc_b();
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        mfma(i >> 2, 4 + (i & 3), x_cur, w_hi);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((i & 3) == 3) dma_b(r0, dst, i >> 2);         // 8 DMA ops
+        else {
+          const int o = (i >> 2) * 3 + (i & 3);           // 24 reads: weight fragments 0-3 of the next tile first, then its activations
+          if (o < 8) rd_w(w_lo, sb1_, 0, o); else rd_x(x_nxt, sa1_, o - 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      advance(true);
+    }
+  };
+
+  // ---- prologue: A0 B0 A1 B1; accumulators cleared under the latency of the first loads; fragments of tile 0 ----
+  issue_tile(false);
+  issue_tile(true);
+  issue_tile(false);
+  issue_tile(true);
+  {
+    const bf16x8 zf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(acc[a][b][c]) : "v"(zf));
+  }
+  F8_WAIT_VM(16);
+  __builtin_amdgcn_s_barrier();
+  Frag x0[8], x1[8], wlo[4], whi[4];
+  int sa = 0, sb = 1;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) rd_w(wlo, smem + sb * F8_SLOT_BYTES, 0, r);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) rd_x(x0, smem + sa * F8_SLOT_BYTES, r);
+  int nk_last = nk;
+  asm volatile("" : "+s"(nk_last));
+  auto nxt_slot = [](int s) { return s + 2 >= F8_SLOTS ? s + 2 - F8_SLOTS : s + 2; };
+  for (int i = 0; i < nk; i += 2) {  // two K-tiles per trip: the activation fragment sets swap roles every tile
+    const int sa1 = nxt_slot(sa), sb1 = nxt_slot(sb), sa2 = nxt_slot(sa1), sb2 = nxt_slot(sb1);
+    F8_WAIT_LGKM(0);
+    asm volatile("s_nop 0");
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step(x0, x1, wlo, whi, smem + sa * F8_SLOT_BYTES, smem + sb * F8_SLOT_BYTES, smem + sa1 * F8_SLOT_BYTES, smem + sb1 * F8_SLOT_BYTES);
+    F8_WAIT_LGKM(0);
+    asm volatile("s_nop 0");
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step(x1, x0, wlo, whi, smem + sa1 * F8_SLOT_BYTES, smem + sb1 * F8_SLOT_BYTES, smem + sa2 * F8_SLOT_BYTES, smem + sb2 * F8_SLOT_BYTES);
+    sa = sa2;
+    sb = sb2;
+    // the last MFMAs retire INSIDE the loop body on the last trip (see gemm256v_kernel: accumulator copies on the loop-exit edge)
+    if (i + 2 >= nk_last) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");
+  }
+  // the empty fetches and the unused fragment reads behind the last tile must be gone before the epilogue reuses registers
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  epilogue_v<EPI, true>(p, acc, m0 + wm * 128, n0 + wn * 128, g, t, nullptr, false, q.sa, q.sb);
+}
+
+template <int EPI>
+int launch_fp8_256(const F8Args256& a, hipStream_t s) {
+  const size_t sh = (size_t)F8_SLOTS * F8_SLOT_BYTES;
+  OP_ENSURE_LDS((gemm256f8_kernel<EPI>), (int)sh, "gemm256f8");
+  hipLaunchKernelGGL((gemm256f8_kernel<EPI>), dim3(a.g.tiles_m * a.g.tiles_n), dim3(256), sh, s, a);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
 template <int EPI>
 int launch_fp8(const Fp8Args& a, hipStream_t s) {
   const size_t sh = 4 * 128 * 128;
@@ -304,11 +518,13 @@ int op_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* s
 // C[M,N] (bf16) = epilogue( (A8 . B8^T)[m][n] * sa[m] * sb[n] )  with A8 [M,K] / B8 [N,K] fp8 e4m3 (row strides in bytes) and
 // per-row fp32 scales.  epilogue: 0 bias; 2 GeGLU (B0 = wi_0, B1 = wi_1 with scales sb0 / sb1; C = gelu(h0) * h1, optional
 // h0 / h1 outputs); 3 residual (C = resid + rowscale[m / rows_per_sample] * gamma[n] * (acc + bias[n]), optional h0 = acc + bias).
-// K % 128 == 0, N % 8 == 0, lda / ldb % 16 == 0.
+// K % 128 == 0, N % 8 == 0, lda / ldb % 16 == 0.  Launches that fill the chip with 256 x 256 tiles (N % 256 == 0, K % 256 == 0, plain /
+// bias or residual epilogue) run on gemm256f8_kernel, everything else on the 128 x 128 kernel; tune bit 0 forces the latter.
 int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0, const void* B1, int64_t ldb, const float* sb0,
                    const float* sb1, const void* bias, void* C, int64_t ldc, void* h0, void* h1, const void* resid, int64_t ldr,
                    const void* gamma, const float* rowscale, int64_t rows_per_sample, int64_t M, int64_t N, int64_t K, int epilogue,
-                   void* stream) {
+                   int64_t tune, void* stream) {
+  const bool tune_small = (tune & 1) != 0;  // tune bit 0: keep the 128 x 128 kernel (tests, A/B)
   OP_CHECK_ARG(A8 && sa && B0 && sb0 && C, "gemm_nt_fp8: null pointer");
   OP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && K % 128 == 0 && N % 8 == 0 && lda % 16 == 0 && ldb % 16 == 0 && ldc % 8 == 0,
                "gemm_nt_fp8: K %% 128, N %% 8, lda/ldb %% 16, ldc %% 8 required (M=%lld N=%lld K=%lld)", (long long)M, (long long)N,
@@ -332,7 +548,21 @@ int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0,
   if (epilogue == F8_EPI_RESID) OP_CHECK_ARG(resid, "gemm_nt_fp8: residual epilogue needs resid");
   const int slot = op_prof_begin(3, flops, stream);
   int rc;
-  if (epilogue == F8_EPI_GEGLU) {
+  // round 5: launches that fill the chip with 256 x 256 tiles take the four-wave kernel (plain / bias and residual epilogues)
+  const bool big = epilogue != F8_EPI_GEGLU && N % 256 == 0 && K % 256 == 0 && ((M + 255) / 256) * (N / 256) >= 256 &&
+                   (M - 1) * lda + K < ((int64_t)1 << 31) && (N - 1) * ldb + K < ((int64_t)1 << 31) && M * ldc < ((int64_t)1 << 30) &&
+                   (!resid || M * ldr < ((int64_t)1 << 30)) && !(tune_small);
+  if (big) {
+    F8Args256 b;
+    memset(&b, 0, sizeof(b));
+    b.g.A = (const bf16_t*)A8; b.g.lda = lda; b.g.B[0] = (const bf16_t*)B0; b.g.ldb = ldb; b.g.n_seg = (int)N;
+    b.g.bias[0] = (const bf16_t*)bias; b.g.C = C; b.g.ldc = ldc; b.g.H0 = (bf16_t*)h0; b.g.resid = (const bf16_t*)resid; b.g.ldr = ldr;
+    b.g.gamma = (const bf16_t*)gamma; b.g.rowscale = rowscale; b.g.rows_per_sample = a.rows_per_sample;
+    b.g.M = (int)M; b.g.N = (int)N; b.g.K = (int)K; b.g.tiles_m = ceil_div(M, 256); b.g.tiles_n = (int)(N / 256);
+    b.g.gm = b.g.tiles_n <= 8 ? 1 : 8;
+    b.sa = sa; b.sb = sb0;
+    rc = epilogue == F8_EPI_RESID ? launch_fp8_256<EPI_RESID>(b, s) : launch_fp8_256<EPI_BIAS>(b, s);
+  } else if (epilogue == F8_EPI_GEGLU) {
     a.tiles_n = ceil_div(N, 64);
     rc = launch_fp8<F8_EPI_GEGLU>(a, s);
   } else {

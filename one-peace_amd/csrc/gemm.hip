@@ -40,38 +40,12 @@
 #include <type_traits>
 #include <vector>
 
+#include "gemm_epilogue_v.h"  // EPI_*, GemmArgs, xcd_remap, resid_out, epilogue_v (shared with fp8.hip)
+
 namespace {
-
-enum { EPI_BIAS = 0, EPI_F32 = 1, EPI_GEGLU = 2, EPI_RESID = 3 };
-
-struct GemmArgs {
-  const bf16_t* A; int64_t lda;
-  const bf16_t* B[3]; int64_t ldb; int n_seg;
-  const bf16_t* bias[3];
-  void* C; int64_t ldc;
-  bf16_t* H0; bf16_t* H1;
-  const bf16_t* resid; int64_t ldr;
-  const bf16_t* gamma; const float* rowscale; int rows_per_sample;
-  const float* alpha;
-  int M, N, K;
-  int tiles_m, tiles_n;
-  int kt_per_split;   // K-tiles handled by one workgroup (split-K along blockIdx.y); 0 = all
-  int64_t slab;       // elements between split-K output slabs
-  int gm;             // 256x256 kernels: M-tiles per L2 group (tile order: gm M-tiles x all N-tiles, M fastest)
-  int m_off;          // row index of A's first row in the caller's matrix (rowscale lookup of a tail-rows launch)
-};
 
 constexpr int BM = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-
-__device__ __forceinline__ int xcd_remap(int b, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-// resid + rowscale * gamma * y with the roundings pinned (product of the two scales, then one fused multiply-add): every epilogue
-// that applies the residual form -- in-kernel or in the split-K fold -- gives the same bits whatever the optimiser would contract.
-__device__ __forceinline__ float resid_out(float r, float rs, float gv, float y) { return __builtin_fmaf(__fmul_rn(rs, gv), y, r); }
 
 // LDS row p of the weight tile -> output column (relative to the tile) it feeds.
 template <int EPI>
@@ -226,189 +200,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
       for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
       Vec8<bf16_t>::store(C, lo);
       if (second) Vec8<bf16_t>::store(C + 8, hi);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Epilogue of the FOUR-WAVE kernels (gemm256v / gemm256p; plain / bias and residual forms): same arithmetic, operation for
-// operation, as gemm_epilogue above (bit-identical output), with the accumulators in the OTHER orientation.
-//
-// What the time stamps inside gemm256v_kernel said (tools/gemm_timeline.py, profiles/r3_gemm_timeline.txt): the shared epilogue
-// costs 4.3 us per tile in its plain form and 13 us in the residual form even with 48 workgroups on the chip, 5-6 / 16-18 us
-// with 256 -- 11 % of a K = 1536 launch.  Ablations of the same build: the arithmetic alone (accumulator reads, bias, bf16
-// conversion; stores replaced by a register sink) takes 0.9 us, the 32 stores alone (of a constant) take 4.2 us.  Re-writing the
-// arithmetic (1425 -> 630 instructions) and making the four lanes of a row cover 64 contiguous bytes changed nothing: the
-// texture addresser coalesces ADJACENT lanes only, and in the "weights as first operand" orientation adjacent lanes (t, t + 1)
-// are different ROWS -- every lane's 16 bytes went to the L2 as a request of their own, 64 requests per instruction, ~69 cycles
-// per store instruction and CU.
-//
-// So the kernels that end here issue their MFMAs with the ACTIVATION fragment as first operand (same fragments, same LDS
-// reads, operands swapped): accumulator acc[blk][ni][mi][r] of lane (g, t) is then row mi*16 + g*4 + r of the wave's 128 rows
-// and the weight-tile row blk*64 + ni*16 + t, and the weight rows are staged so that this is COLUMN t*8 + blk*4 + ni of the
-// wave's 128 columns (VMAP).  Per (mi, r) a lane holds 8 contiguous columns = one 16-byte store; the 16 lanes of a g-group
-// write one whole 256-byte row segment, a store instruction writes four of them: fully coalesced, 32 stores per wave.
-// C, the residual and the branch output go through buffer descriptors based at the wave's first row / column whose size ends
-// at the last valid row (rows >= M are dropped / read as zero by the hardware: no guards); the per-lane offset is ONE VGPR,
-// the row of a (mi, r) pair an SGPR offset.  N % 256 == 0 and n_seg % 256 == 0 (launch conditions).
-//
-// NOTE on the stores: `buffer_store_dwordx4 ... s_off offen` reads its data VGPRs late, and hipcc (ROCm 7.2) does not keep a
-// following VALU write of those VGPRs away from it -- neither across a block boundary nor inside a block (its hazard table has
-// the rule for an immediate offset only).  Seen as dword 1 of lanes 12-15 of every 16-lane row of a store going out overwritten
-// (tools/gemm_epi_debug.py), first behind a per-store branch, then in straight-line code with a separate `s_nop` statement that
-// the scheduler had moved behind the overwriting instruction.  Every store here is therefore ONE asm statement that contains
-// its own wait states (store_b128_padded) -- behind it for the data VGPRs, and in front of it for its SGPR operands, which an
-// opaque asm statement does not get from the compiler either -- and tools/check_mfma_hazards.py looks for both patterns in the
-// compiled ISA.
-// ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void unpack_bf16x8(const u32x4& raw, float (&f)[8]) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f[2 * q] = __builtin_bit_cast(float, raw[q] << 16);
-    f[2 * q + 1] = __builtin_bit_cast(float, raw[q] & 0xffff0000u);
-  }
-}
-__device__ __forceinline__ u32x4 pack_bf16x8(const float (&f)[8]) {
-  bf16x8 v;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (bf16_t)f[j];
-  return __builtin_bit_cast(u32x4, v);
-}
-
-// 16-byte buffer store + the wait states that keep the next writer of its data VGPRs away (one asm statement: a separate
-// s_nop was scheduled BEHIND such writers; see the note above).  Descriptor: raw buffer, base / size in bytes.
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, int nbytes) {
-  const uint64_t a = (uint64_t)base;
-  return (u32x4){(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) & 0xffffu,
-                 (unsigned)__builtin_amdgcn_readfirstlane(nbytes), 0x00020000u};
-}
-__device__ __forceinline__ void store_b128_padded(const u32x4& data, const u32x4& rsrc, int voff, int soff) {
-  // (s_nop 4 in front: the SGPR operands may have been written by the SALU / v_readfirstlane just before -- 5 wait states that the
-  // hazard recogniser cannot insert for an instruction it does not see; without them a store went out with the PREVIOUS row offset)
-  // `nt`: the output is written once and not read again by this launch -- without the hint every round leaves 128 KiB of dirty
-  // lines per CU (the whole 4 MiB of an XCD's L2) in front of the operand panels (tools/gemm_lib_ab.py: -5 % on the N = 12288
-  // up-projection, -10 % on the K = 1536 residual launch, +-1 % elsewhere; sc1 / sc0 sc1 nt measured no better)
-#ifndef OP_EXP_STORE_BITS
-#define OP_EXP_STORE_BITS " nt"
-#endif
-  asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" OP_EXP_STORE_BITS "\n\ts_nop 1" ::"v"(data), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-
-template <int EPI>
-__device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4][8], int mrow0, int ncol0, int g, int t,
-                                           const bf16_t* bias_of_tile = nullptr, const bool tile_bias = false) {
-  // tile_bias (a compile-time constant at every call site): the caller hands over the bias vector of the weight segment its tile
-  // lies in (n_seg % 256 == 0) instead of the table p.bias[] -- gemm256p_kernel builds its GemmArgs per tile in registers, and ONE
-  // dynamically indexed member put the whole struct into scratch (round 4: 232-288 bytes per lane, 16-28 scratch operations per tile)
-  static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "epilogue_v: plain / bias and residual epilogues only");
-  const int rows_left = min(p.M - mrow0, 128);  // wave-uniform
-  if (rows_left <= 0) return;
-  const int ldc = (int)p.ldc;
-  const int nrec = ((rows_left - 1) * ldc + 128) * 2;
-  const u32x4 rc = raw_rsrc((bf16_t*)p.C + (int64_t)mrow0 * p.ldc + ncol0, nrec);
-  const int voff = (g * 4 * ldc + t * 8) * 2;  // + ((mi*16 + r) * ldc) * 2 as the scalar offset
-  const int seg = ncol0 / p.n_seg;
-  const bf16_t* bp = tile_bias ? bias_of_tile : p.bias[seg];
-  // the lane's 8 columns: acc[j >> 2][j & 3][mi][r] <-> column t*8 + j
-  // (accumulator reads as volatile asm: they keep their place between the -- volatile -- stores.  Plain reads are hoisted ahead of
-  // the whole epilogue by the register allocator's live-range splitting and the surplus spilled: the last 12-24 bytes of scratch)
-  auto row_of = [&](int mi, int r, float (&o)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[j]) : "a"(acc[j >> 2][j & 3][mi][r]));
-  };
-
-  if constexpr (EPI == EPI_BIAS) {
-    auto stores = [&](auto bias_tag) {
-      constexpr bool BIAS = decltype(bias_tag)::value;
-      float bv[8];
-      if constexpr (BIAS) unpack_bf16x8(*reinterpret_cast<const u32x4*>(bp + (ncol0 - seg * p.n_seg) + t * 8), bv);
-#pragma unroll
-      for (int mi = 0; mi < 8; ++mi) {
-        // (one fragment row block at a time: left alone the scheduler hoists accumulator reads of later blocks over the stores and
-        // spills what does not fit -- the four-wave kernels own all 256 + 256 registers)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float o[8];
-          row_of(mi, r, o);
-          if constexpr (BIAS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += bv[j];
-          }
-#if defined(OP_EXP_EPI) && OP_EXP_EPI == 1  // (tools/gemm_timeline.py ablations: 1 = arithmetic without the stores, 2 = stores without arithmetic)
-          { const u32x4 pk = pack_bf16x8(o); asm volatile("" ::"v"(pk)); }
-#elif defined(OP_EXP_EPI) && OP_EXP_EPI == 2
-          store_b128_padded((u32x4){0u, 0u, 0u, 0u}, rc, voff, (mi * 16 + r) * ldc * 2);
-#else
-          store_b128_padded(pack_bf16x8(o), rc, voff, (mi * 16 + r) * ldc * 2);
-#endif
-        }
-      }
-    };
-    if (bp) stores(std::true_type{});
-    else stores(std::false_type{});
-  } else {
-    const int ldr = (int)p.ldr;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + (int64_t)mrow0 * p.ldr + ncol0), 0,
-                                                                        ((rows_left - 1) * ldr + 128) * 2, 0x00020000);
-    const int voff_r = (g * 4 * ldr + t * 8) * 2;
-    // rowscale index of a row by multiply-high: exact while (rows + m_off) * rows_per_sample < 2^32 (else a true division)
-    const unsigned rps = (unsigned)p.rows_per_sample;
-    const bool exact = p.rowscale && (uint64_t)((unsigned)(p.M + p.m_off)) * rps < (1ull << 32) && rps > 1;
-    const unsigned magic = exact ? 0xffffffffu / rps + 1u : 0u;
-    // residual rows (and their row scales) in chunks of two 16-row fragments (8 rows per lane: 8 loads, 32 + 8 VGPRs), one chunk
-    // ahead of the arithmetic: the first chunk's latency is exposed (together with the bias / gamma loads), the later ones hide
-    u32x4 rraw[2][2][4];
-    float rsv[2][2][4];
-    auto load_chunk = [&](int c, u32x4 (&dst)[2][4], float (&rs)[2][4]) {  // chunk c: fragments mi = 2c, 2c + 1
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = (c * 2 + m2) * 16 + r;  // + g * 4 in the lane offset
-          // (plain loads: a non-temporal hint made the K = 1536 residual launch 7 % slower, tools/gemm_lib_ab.py)
-          dst[m2][r] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff_r, row * ldr * 2, 0);
-          if (p.rowscale) {
-            const unsigned mc = (unsigned)(min(mrow0 + row + g * 4, p.M - 1) + p.m_off);
-            rs[m2][r] = p.rowscale[exact ? __umulhi(mc, magic) : mc / rps];
-          } else {
-            rs[m2][r] = 1.f;
-          }
-        }
-    };
-    load_chunk(0, rraw[0], rsv[0]);
-    float bv[8], gv[8];
-    {
-      u32x4 braw = (u32x4){0u, 0u, 0u, 0u}, graw = (u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-      if (bp) braw = *reinterpret_cast<const u32x4*>(bp + (ncol0 - seg * p.n_seg) + t * 8);
-      if (p.gamma) graw = *reinterpret_cast<const u32x4*>(p.gamma + ncol0 + t * 8);
-      unpack_bf16x8(braw, bv);
-      unpack_bf16x8(graw, gv);
-    }
-    const bool has_y = p.H0 != nullptr;
-    const u32x4 ry = raw_rsrc(p.H0 + (int64_t)mrow0 * p.ldc + ncol0, has_y ? nrec : 0);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (c + 1 < 4) load_chunk(c + 1, rraw[(c + 1) & 1], rsv[(c + 1) & 1]);
-#pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
-        __builtin_amdgcn_sched_barrier(0);  // (as above)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int mi = c * 2 + m2;
-          const int soff = (mi * 16 + r) * ldc * 2;
-          const float rs = rsv[c & 1][m2][r];
-          float o[8], rv[8];
-          row_of(mi, r, o);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] += bv[j];
-          if (has_y) store_b128_padded(pack_bf16x8(o), ry, voff, soff);  // branch output y (pre layer-scale)
-          unpack_bf16x8(rraw[c & 1][m2][r], rv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = resid_out(rv[j], rs, gv[j], o[j]);
-          store_b128_padded(pack_bf16x8(o), rc, voff, soff);
-        }
-      }
     }
   }
 }

@@ -69,7 +69,7 @@ SIGNATURES = {
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
     "op_attn_bwd": (c_int, [P, P, P, I64, P, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
-    "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, P]),
+    "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, I64, P]),
     "op_rows_gather": (c_int, [P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
     "op_rows_merge": (c_int, [P, P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
 }
@@ -103,6 +103,7 @@ class Tuning:
         self.force_splits = 0    # forced K-split count of small problems (tools)
         self.glds = 1            # 1 LDS-DMA staging, 0 register-staged operands
         self.sched = int(os.environ.get("ONEPEACE_TUNE_SCHED", "0"))  # four-wave NT launches: 0 auto, 1 / 3 gemm256v_kernel schedule, 6 persistent gemm256p_kernel for single problems too (A/B), 7 gemm256w_kernel
+        self.fp8_small = 0       # op_gemm_nt_fp8: 1 = keep the 128 x 128 kernel (tests, A/B)
         self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
         self.attn_waves = 0      # resident forward kernel: waves per workgroup (0 = production rule; tests / A-B timing)
@@ -409,7 +410,7 @@ def gemm_nt_fp8(A8, sa, B8s, sbs, bias=None, out=None, epilogue=EPI_BIAS, h0=Non
     _check(lib().op_gemm_nt_fp8(ptr(A8), A8.stride(0), ptr(sa), ptr(B8s[0]), ptr(B1), B8s[0].stride(0), ptr(sbs[0]), ptr(sb1),
                                 ptr(bias), ptr(out), out.stride(0), ptr(h0), ptr(h1), ptr(resid),
                                 resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale), rows_per_sample, M, N, K,
-                                epilogue, stream()), "op_gemm_nt_fp8")
+                                epilogue, int(TUNE.fp8_small), stream()), "op_gemm_nt_fp8")
     return out
 
 

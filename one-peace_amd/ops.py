@@ -42,6 +42,7 @@ def refresh_weight_cache():
     # reading these addresses, and an eager step must not pay a cache miss per weight either
     if not FP8_FFN and _fp8_cache:  # the opt-in variant was switched off: nothing reads these copies any more
         _fp8_cache.clear()
+        _fp8_pairs.clear()
     for k, (ref, _, qs) in list(_fp8_cache.items()):
         w = ref()
         if w is None:
@@ -109,12 +110,15 @@ def set_fp8_ffn(on):
 
 
 def _fp8_weight(w):
-    """(fp8 bytes, row scales) of a weight [out, in]; a derived buffer like the transposed dgrad copies, re-quantised when
-    the weight changes (parameter version / optimiser epoch)."""
+    """(fp8 bytes, row scales) of a weight [out, in]; a derived buffer like the transposed dgrad copies, re-quantised IN PLACE when
+    the weight changes (parameter version / optimiser epoch): the buffers keep their addresses."""
     key = id(w)
     ver = (w._version, w.data_ptr(), _cache_epoch)
     hit = _fp8_cache.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == ver:
+    if hit is not None and hit[0]() is w:
+        if hit[1] != ver:
+            hip.quant_fp8_rows(w.detach(), out=hit[2])
+            _fp8_cache[key] = (hit[0], ver, hit[2])
         return hit[2]
     if len(_fp8_cache) > 4096:
         for k in [k for k, v in _fp8_cache.items() if v[0]() is None]:
@@ -122,6 +126,32 @@ def _fp8_weight(w):
     qs = hip.quant_fp8_rows(w.detach())
     _fp8_cache[key] = (weakref.ref(w), ver, qs)
     return qs
+
+
+_fp8_pairs = {}
+
+
+def _fp8_weight_pair(w0, w1):
+    """wi_0 | wi_1 as ONE fp8 matrix [2F, H] + scales [2F] (the plain N = 2F up-projection of the training forward): the two weights'
+    cache entries are views of the halves, so the per-weight refresh keeps the pair current in place."""
+    key = (id(w0), id(w1))
+    hit = _fp8_pairs.get(key)
+    if hit is None or hit[0]() is not w0 or hit[1]() is not w1:
+        F0, K = w0.shape
+        q = torch.empty(F0 + w1.shape[0], K, dtype=torch.uint8, device=w0.device)
+        sc = torch.empty(F0 + w1.shape[0], dtype=torch.float32, device=w0.device)
+        for w, lo, hi in ((w0, 0, F0), (w1, F0, q.shape[0])):
+            view = (q[lo:hi], sc[lo:hi])
+            hip.quant_fp8_rows(w.detach(), out=view)
+            _fp8_cache[id(w)] = (weakref.ref(w), (w._version, w.data_ptr(), _cache_epoch), view)
+        if len(_fp8_pairs) > 1024:
+            for k in [k for k, v in _fp8_pairs.items() if v[0]() is None or v[1]() is None]:
+                del _fp8_pairs[k]
+        hit = _fp8_pairs[key] = (weakref.ref(w0), weakref.ref(w1), (q, sc))
+    else:
+        _fp8_weight(w0)
+        _fp8_weight(w1)
+    return hit[2]
 
 
 def _round_up(n, m):
@@ -614,12 +644,17 @@ def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True, grad=None):
     Fd = P["w0"].shape[0]
     h0 = h1 = None
     fp8 = FP8_FFN and x_mid.shape[1] % 128 == 0 and Fd % 128 == 0
-    split = grad and not fp8 and _geglu_split(Fd, P["fln_w"])
+    split = grad and _geglu_split(Fd, P["fln_w"])
     if keep and not split:
         h0 = torch.empty(x_mid.shape[0], Fd, dtype=x_mid.dtype, device=x_mid.device)
         h1 = torch.empty_like(h0)
     if split:  # plain wi_0 | wi_1 up-projection; GELU, gate and the inner LayerNorm in one HBM-bound pass
-        hh = hip.gemm_nt(xln2, [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd)
+        if fp8:  # (round 5: the fp8 variant takes the same route -- its GELU no longer sits in a GEMM epilogue either)
+            xq, xs = hip.quant_fp8_rows(xln2)
+            w01q, w01s = _fp8_weight_pair(P["w0"], P["w1"])
+            hh = hip.gemm_nt_fp8(xq, xs, [w01q], [w01s])
+        else:
+            hh = hip.gemm_nt(xln2, [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd)
         h0, h1 = hh[:, :Fd], hh[:, Fd:]
         gln, mean_f, rstd_f = hip.ln_geglu_fwd(h0, h1, P["fln_w"], P["fln_b"])
     elif fp8:  # opt-in: e4m3 operands with per-row scales, fp32 accumulation (csrc/fp8.hip)
@@ -1014,10 +1049,17 @@ class FfnBranchMultiFn(torch.autograd.Function):
         mean_f = torch.empty(N, dtype=torch.float32, device=dev) if (keep or split) and has_fln else None
         rstd_f = torch.empty(N, dtype=torch.float32, device=dev) if (keep or split) and has_fln else None
         L = hip.lib()
+        fp8 = FP8_FFN and split and H % 256 == 0 and Fd % 256 == 0  # (round 5) the opt-in fp8 forward: training (split) form only
+        if fp8:
+            xq, xs = hip.quant_fp8_rows(xln2)  # all rows of all streams in one pass (rows are quantised independently)
         for sg, P in zip(segs, own):
             r = slice(sg.row0, sg.end)
             if split:
-                hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd, out=hh[r])
+                if fp8:
+                    w01q, w01s = _fp8_weight_pair(P["w0"], P["w1"])
+                    hip.gemm_nt_fp8(xq[r], xs[r], [w01q], [w01s], out=hh[r])
+                else:
+                    hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd, out=hh[r])
                 hip.ln_geglu_fwd(h0[r], h1[r], P["fln_w"], P["fln_b"], out=gln[r], mean=mean_f[r], rstd=rstd_f[r])
                 continue
             hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0[r] if keep else None, h1=h1[r] if keep else None, out=g[r])
@@ -1028,6 +1070,14 @@ class FfnBranchMultiFn(torch.autograd.Function):
         y2 = torch.empty_like(x2) if keep and want_y else None
         out = torch.empty_like(x2)
         rs = [slice(sg.row0, sg.end) for sg in segs]
+        if fp8:  # one fp8 launch per modality (the grouped persistent launch is bf16 only)
+            gq, gs = hip.quant_fp8_rows(gln)
+            for sg, P, r, ps in zip(segs, own, rs, pss):
+                w2q, w2s = _fp8_weight(P["w2"])
+                hip.gemm_nt_fp8(gq[r], gs[r], [w2q], [w2s], bias=P["b2"], epilogue=hip.EPI_RESID, resid=x2[r], gamma=shared["g2"], rowscale=ps,
+                                rows_per_sample=sg.S, h0=y2[r] if y2 is not None else None, out=out[r])
+            acts = dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2) if keep else None
+            return out, acts
         grouped = hip.gemm_nt_grouped([gln[r] for r in rs], [P["w2"] for P in own], biases=[P["b2"] for P in own], outs=[out[r] for r in rs],
                                       epilogue=hip.EPI_RESID, h0s=[y2[r] for r in rs] if y2 is not None else None,
                                       resids=[x2[r] for r in rs], gammas=[shared["g2"]] * nseg, rowscales=list(pss),

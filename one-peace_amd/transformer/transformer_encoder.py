@@ -150,12 +150,18 @@ class TransformerEncoder(nn.Module):
     def multi_possible(self, device=None, dtype=None):
         """The preconditions of a lock-step pass that do not need the adapters' outputs (ModelWrapper.forward_multi asks BEFORE it runs
         the adapters: otherwise a pass that does not qualify -- CPU, fp32, layerdrop -- ran every adapter twice): the HIP
-        path for the activations' device / dtype, no layerdrop in training, fused layers, and no opt-in fp8 FFN (the lock-step FFN
-        launches are bf16 only: with ops.set_fp8_ffn(True) the streams run one by one on the fp8 kernels instead of silently in bf16)."""
+        path for the activations' device / dtype, no layerdrop in training, fused layers; with the opt-in fp8 FFN (ops.set_fp8_ffn) only
+        TRAINING passes whose FFN takes the split form (plain up-projection + op_ln_geglu_fwd: the form the lock-step fp8 launches exist
+        in since round 5) -- any other pass runs stream by stream on the fp8 kernels instead of silently in bf16."""
         if device is not None and not (torch.device(device).type == "cuda" and dtype == torch.bfloat16):
             return False
-        if ops.FP8_FFN or (self.encoder_layerdrop > 0.0 and self.training):
+        if self.encoder_layerdrop > 0.0 and self.training:
             return False
+        if ops.FP8_FFN:
+            l0 = self.layers[0] if len(self.layers) else None
+            if not (self.training and torch.is_grad_enabled() and l0 is not None and getattr(l0.cfg, "scale_fc", False) and ops.GEGLU_SPLIT
+                    and l0.embed_dim % 256 == 0 and l0.ffn_embed_dim % 256 == 0):
+                return False
         return all(any(getattr(layer, "fused_supported", lambda e: False)(m) for m in ("text", "image", "audio")) for layer in self.layers)
 
     def multi_ok(self, infos):

@@ -96,6 +96,20 @@ def test_no_compiler_instruction_touches_an_accumulator_behind_an_inline_asm_mfm
     _assert_scratch(C.resource_usage(isa), GEMM_SCRATCH_ALLOWED)
 
 
+@pytest.mark.skipif(shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None, reason="needs hipcc")
+def test_fp8_four_wave_kernel_keeps_the_same_rules(tmp_path):
+    """Round 5: gemm256f8_kernel (csrc/fp8.hip) pins its accumulators the same way -- same walk, with the longer latency of the 16-pass
+    fp8 MFMA; every fp8 kernel at ScratchSize 0."""
+    isa = C.compile_isa(str(tmp_path), "fp8")
+    kernels, problems = C.check(isa)
+    assert kernels >= 5
+    assert problems == [], problems[:5]
+    usage = C.resource_usage(isa)
+    assert any("gemm256f8_kernel" in n for n in usage)
+    bad = [n for n, u in usage.items() if u.get("ScratchSize", 0) > 0]
+    assert not bad, bad
+
+
 def test_inflight_load_checker_sees_a_copy_of_a_register_that_is_still_being_loaded():
     """Round 4: inline-asm loads of the persistent attention kernels (tools/check_mfma_hazards.py: check_inflight_asm_loads)."""
     bad = """_Z3foov:

@@ -1256,6 +1256,46 @@ def test_fp8_gemm_bias_and_residual(M, N, K):
     assert_close(out_r, resid + rs * gamma * exact, what="fp8 residual epilogue")
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 256), (11000, 1536, 1536), (8200, 3072, 768), (10369, 1536, 6144)])
+def test_fp8_four_wave_kernel_on_launches_that_fill_the_chip(M, N, K):
+    """Round 5: gemm256f8_kernel -- 256 x 256 tiles, four waves, the skeleton of the bf16 production kernel -- takes every fp8 launch with
+    >= 256 tiles (N % 256 == 0, K % 256 == 0; plain / bias and residual epilogues).  Against the exact product of the DEQUANTISED operands
+    (fp32), against the 128 x 128 kernel on the same quantised operands (same numbers, other summation order: equal up to the last bf16
+    digit of a few elements) and against the bf16 GEMM (the variant's tolerance); ragged last M-tile, per-sample row scales, second output."""
+    hip = hipmod()
+    assert ((M + 255) // 256) * (N // 256) >= 256
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    bias, gamma = rnd(N, seed=3), rnd(N, seed=4)
+    resid = rnd(M, N, seed=5)
+    rps = 7
+    ps = (torch.arange((M + rps - 1) // rps) % 3 != 0).float() / 0.7
+    xq, xs = hip.quant_fp8_rows(dev_bf16(x))
+    wq, ws = hip.quant_fp8_rows(dev_bf16(w))
+    exact = _deq(xq.cpu(), xs.cpu()) @ _deq(wq.cpu(), ws.cpu()).t() + bias
+    res = {}
+    for small in (0, 1):
+        hip.TUNE.fp8_small = small
+        try:
+            y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            res[small] = (hip.gemm_nt_fp8(xq, xs, [wq], [ws], bias=dev_bf16(bias)), hip.gemm_nt_fp8(xq, xs, [wq], [ws]),
+                          hip.gemm_nt_fp8(xq, xs, [wq], [ws], bias=dev_bf16(bias), epilogue=hip.EPI_RESID, resid=dev_bf16(resid),
+                                          gamma=dev_bf16(gamma), rowscale=ps.to(DEV), rows_per_sample=rps, h0=y), y)
+            torch.cuda.synchronize()
+        finally:
+            hip.TUNE.fp8_small = 0
+    out, plain, out_r, y = res[0]
+    assert_close(out, exact, what="fp8 four-wave kernel vs dequantised operands")
+    assert_close(plain, exact - bias, what="fp8 four-wave kernel, no bias")
+    rs = ps.repeat_interleave(rps)[:M, None]
+    assert_close(y, exact, what="fp8 four-wave branch output")
+    assert_close(out_r, resid + rs * gamma * exact, what="fp8 four-wave residual epilogue")
+    for a, b in zip(res[0], res[1]):
+        d = (a.float() - b.float()).abs()
+        assert float(d.max()) <= 2.0 ** -6 * float(b.float().abs().max()) and float((d > 0).float().mean()) < 2e-2, (float(d.max()), float((d > 0).float().mean()))
+    ref16 = hip.gemm_nt(dev_bf16(x), [dev_bf16(w)], [dev_bf16(bias)])
+    assert rel_fro(out.float(), ref16.float()) <= FP8_TOL
+
+
 @pytest.mark.parametrize("M,F_,K", [(200, 256, 128), (515, 1024, 256), (130, 6144, 1536)])
 def test_fp8_gemm_geglu(M, F_, K):
     hip = hipmod()

@@ -28,6 +28,7 @@ import sys
 import tempfile
 
 NEED = 18  # wait states between an 8-pass XDL write and a non-MFMA read / overwrite of the result
+NEED_F8 = 34  # ... a 16-pass one (v_mfma_scale_f32_16x16x128_f8f6f4 on fp8 operands: twice as long in the pipe)
 SGPR_NEED = 5   # wait states between an SALU / v_readfirstlane write of an SGPR and an inline-asm VMEM instruction that reads it
 STORE_NEED = 2  # wait states between a >= 12-byte buffer store with an SGPR offset and a VALU write of its data VGPRs
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -207,8 +208,10 @@ def check_lines(lines):
         op = code.split()[0]
         if in_asm:
             if op.startswith("v_mfma"):
+                # (the fp8 MX form v_mfma_scale_f32_16x16x128_f8f6f4 runs 8 passes, twice the 16x16x32 bf16 form: its result is
+                # NEED_F8 wait states away; `wrote` keeps the time from which the register may be touched)
                 for r in agprs(code.split(None, 1)[1].split(",")[0]):
-                    wrote[r] = now
+                    wrote[r] = now + (NEED_F8 - NEED if "f8f6f4" in op else 0)
         else:
             for r in agprs(code):
                 if r in wrote and now - wrote[r] < NEED:

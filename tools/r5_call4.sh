@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 5, call 4: the four-wave fp8 kernel (gemm256f8_kernel): parity tests, per-launch rates against the 128 x 128 fp8 kernel and bf16,
+# BASELINE configs[4] step with and without --fp8 (20 timed steps each: final losses side by side)
+R=$GRAFT_REPO_ROOT; d=$R/gpurun_out/r5c4; mkdir -p $d
+cd $R
+timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -x -q -k "fp8 or graph_replay" > $d/pytest_fp8.txt 2>&1; tail -4 $d/pytest_fp8.txt
+timeout 300 python tools/fp8_bench.py > $d/fp8_bench.txt 2>&1; grep -v amdgpu.ids $d/fp8_bench.txt
+for v in bf16 fp8 bf16 fp8; do
+  extra=""; [ $v = fp8 ] && extra="--fp8"
+  timeout 500 python bench.py --config 4 --steps 20 --warmup 3 --no-cpu-baseline --no-power-probe --no-skip-leg $extra > $d/bench_config4_$v.txt 2>&1
+  tail -1 $d/bench_config4_$v.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('config 4 $v', d['ms_per_step'], d['value'], r.get('frac'), r.get('fp8_gemm'), d['config'].get('final_loss'))" || tail -5 $d/bench_config4_$v.txt
+done

@@ -127,6 +127,13 @@ int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, in
  * forward GEMMs of transformer_layer.py:54-67,149-157.  Per-row quantisation (x ~= q * scale[row], q = e4m3 of x * 448 / amax_row),
  * fp32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4, dequantisation by scale_a[m] * scale_b[n] in the epilogue. */
 int op_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t cols, void* stream);
+/* Round 5 (ABI 6): op_layernorm_fwd (bf16, no GELU) / op_ln_geglu_fwd that ALSO write their output row-quantised to fp8 e4m3 -- q8
+ * [rows, cols] bytes, q8_scale [rows] fp32, bit-identical to op_quant_fp8_rows(y) -- so that the fp8 FFN forward needs no
+ * quantisation pass of its own (transformer_layer.py:196-199: the sub-LayerNorm in front of the FFN; :149-157: LayerNorm(F)). */
+int op_layernorm_fwd_q8(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, void* q8, float* q8_scale,
+                        int64_t rows, int64_t cols, float eps, void* stream);
+int op_ln_geglu_fwd_q8(const void* h0, const void* h1, int64_t ldh, const void* w, const void* b, void* y, float* mean, float* rstd, void* q8,
+                       float* q8_scale, int64_t rows, int64_t cols, float eps, void* stream);
 /* epilogue 0: + bias; 2: GeGLU (B0 = wi_0, B1 = wi_1, scales sb0 / sb1, optional h0 / h1); 3: residual epilogue of op_gemm_nt.
  * A8 [M,K], B8 [N,K] fp8 bytes (row strides lda / ldb in bytes, multiples of 16); K % 128 == 0; C / h0 / h1 / resid bf16. */
 int op_gemm_nt_fp8(const void* A8, int64_t lda, const float* sa, const void* B0, const void* B1, int64_t ldb, const float* sb0,

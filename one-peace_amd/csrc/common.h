@@ -67,6 +67,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- per-row e4m3 quantisation (csrc/fp8.hip; fused outputs of the LayerNorm kernels) -------------
+// scale = amax / 448 (1 for an all-zero row), q = e4m3(clamp(x / scale)): ONE definition for the stand-alone pass and the fused outputs.
+#define OP_FP8_MAX 448.0f
+__device__ __forceinline__ float fp8_row_scale(float amax) { return amax > 0.f ? amax * (1.0f / OP_FP8_MAX) : 1.0f; }
+__device__ __forceinline__ u32x2 fp8_pack8(const float (&v)[8], float inv) {
+  float e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = fminf(fmaxf(v[j] * inv, -OP_FP8_MAX), OP_FP8_MAX);  // (the clamp guards the rounding of amax * inv)
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
+  return (u32x2){(unsigned)w0, (unsigned)w1};
+}
+
 // ---- 8-element vector load/store with fp32 math --------------------------------------------------
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {

@@ -249,25 +249,14 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
     }
   }
   amax = wave_max(amax);
-  const float sc = amax > 0.f ? amax * (1.0f / FP8_MAX) : 1.0f;
+  const float sc = fp8_row_scale(amax);
   const float inv = 1.0f / sc;
   if (lane == 0) scale[row] = sc;
   uint8_t* qr = q + row * ldq;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int c = (i * 64 + lane) * 8;
-    if (c < cols) {
-      int w0 = 0, w1 = 0;
-      // (values are within +-448 by construction; clamp guards the rounding of amax * inv)
-      float e[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) e[j] = fminf(fmaxf(v[i][j] * inv, -FP8_MAX), FP8_MAX);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[0], e[1], w0, false);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(e[2], e[3], w0, true);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[4], e[5], w1, false);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(e[6], e[7], w1, true);
-      *reinterpret_cast<u32x2*>(qr + c) = (u32x2){(unsigned)w0, (unsigned)w1};
-    }
+    if (c < cols) *reinterpret_cast<u32x2*>(qr + c) = fp8_pack8(v[i], inv);
   }
 }
 

@@ -38,11 +38,28 @@ __device__ __forceinline__ float group_sum(float v, float* red) {
   return t;
 }
 
-template <typename T, int CH, int NW, bool GELU, bool NT>  // NT: non-temporal row accesses (tensors far beyond the caches: training)
+template <int NW>
+__device__ __forceinline__ float group_max(float v, float* red) {
+  v = wave_max(v);
+  if (NW == 1) return v;
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wid] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// Q8 (round 5; bf16, no GELU): the row is ALSO written as fp8 e4m3 with a per-row scale -- exactly what op_quant_fp8_rows makes of the
+// bf16 output (amax over the bf16-rounded values), without its pass over the output: the operand of the fp8 FFN GEMMs (csrc/fp8.hip).
+template <typename T, int CH, int NW, bool GELU, bool NT, bool Q8 = false>  // NT: non-temporal row accesses (tensors far beyond the caches: training)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                      const T* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                     int64_t rows, int cols, float eps) {
+                                                     int64_t rows, int cols, float eps, uint8_t* __restrict__ q8 = nullptr,
+                                                     float* __restrict__ q8_scale = nullptr) {
   __shared__ float red[4];
   constexpr int G = 64 * NW;
   const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
@@ -107,6 +124,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     }
     const float rstd = rsqrtf(group_sum<NW>(ss, red) * inv + eps);
     T* yr = y + row * (int64_t)cols;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
@@ -118,7 +136,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
           o[j] = GELU ? gelu_erf(t) : t;
         }
         store_sel<T, NT>(yr + c, o);
+        if constexpr (Q8) {  // the output as the next reader sees it (rounded to T); v is free now
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v[i][j] = (float)(T)o[j]; amax = fmaxf(amax, fabsf(v[i][j])); }
+        }
       }
+    }
+    if constexpr (Q8) {
+      const float sc = fp8_row_scale(group_max<NW>(amax, red));
+      const float qinv = 1.0f / sc;
+      uint8_t* qr = q8 + row * (int64_t)cols;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) *reinterpret_cast<u32x2*>(qr + c) = fp8_pack8(v[i], qinv);
+      }
+      if (tig == 0) q8_scale[row] = sc;
     }
     if (tig == 0) {
       if (mean_out) mean_out[row] = mean;
@@ -134,11 +167,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // per element, 13 % of the fused-epilogue GEMM: one wave per SIMD cannot hide it) out of the GEMM's epilogue and into a kernel
 // that is HBM-bound with VALU to spare; the product is rounded to bf16 before the statistics, exactly as the backward
 // (ln_geglu_bwd_kernel) re-creates it.  Algorithmic bytes: 2 reads + 1 write of [rows, cols] bf16.
-template <int CH, int NW>
+template <int CH, int NW, bool Q8 = false>  // Q8: see ln_fwd_kernel
 __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(const bf16_t* __restrict__ h0, const bf16_t* __restrict__ h1,
                                                            int64_t ldh, const bf16_t* __restrict__ w, const bf16_t* __restrict__ b,
                                                            bf16_t* __restrict__ y, float* __restrict__ mean_out,
-                                                           float* __restrict__ rstd_out, int64_t rows, int cols, float eps) {
+                                                           float* __restrict__ rstd_out, int64_t rows, int cols, float eps,
+                                                           uint8_t* __restrict__ q8 = nullptr, float* __restrict__ q8_scale = nullptr) {
   __shared__ float red[4];
   constexpr int G = 64 * NW;
   const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
@@ -210,6 +244,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(c
     }
     const float rstd = rsqrtf(group_sum<NW>(ss, red) * inv + eps);
     bf16_t* yr = y + row * (int64_t)cols;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
@@ -218,7 +253,22 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_fwd_kernel(c
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * wv[i][j] + bv[i][j];
         Vec8<bf16_t>::store_nt(yr + c, o);
+        if constexpr (Q8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v[i][j] = (float)(bf16_t)o[j]; amax = fmaxf(amax, fabsf(v[i][j])); }
+        }
       }
+    }
+    if constexpr (Q8) {
+      const float sc = fp8_row_scale(group_max<NW>(amax, red));
+      const float qinv = 1.0f / sc;
+      uint8_t* qr = q8 + row * (int64_t)cols;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int c = (tig + G * i) * 8;
+        if (c < cols) *reinterpret_cast<u32x2*>(qr + c) = fp8_pack8(v[i], qinv);
+      }
+      if (tig == 0) q8_scale[row] = sc;
     }
     if (tig == 0) {
       if (mean_out) mean_out[row] = mean;
@@ -598,6 +648,30 @@ int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float
   return OP_EINVAL;
 }
 
+// op_layernorm_fwd for bf16 without GELU that ALSO writes the output row-quantised to fp8 e4m3: q8 [rows, cols] bytes and
+// q8_scale [rows] fp32, bit-identical to op_quant_fp8_rows(y) -- the activation operand of op_gemm_nt_fp8 without a pass of its own
+// (the sub-LayerNorm in front of the FFN, transformer_layer.py:196-199, when the opt-in fp8 forward is on).
+int op_layernorm_fwd_q8(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, void* q8, float* q8_scale,
+                        int64_t rows, int64_t cols, float eps, void* stream) {
+  OP_CHECK_ARG(x && y && q8 && q8_scale, "layernorm_fwd_q8: null pointer");
+  OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192, "layernorm_fwd_q8: cols=%lld unsupported", (long long)cols);
+  if (rows == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define LN_Q(CH, NW)                                                                                                                         \
+  hipLaunchKernelGGL((ln_fwd_kernel<bf16_t, CH, NW, false, false, true>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s,        \
+                     (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, (int)cols, eps, (uint8_t*)q8, q8_scale)
+  if (cols <= 512) LN_Q(1, 1);
+  else if (cols <= 1024) LN_Q(2, 1);
+  else if (cols <= 1536) LN_Q(3, 1);
+  else if (cols <= 2048) LN_Q(4, 1);
+  else if (cols <= 4096) LN_Q(2, 4);
+  else if (cols <= 6144) LN_Q(3, 4);
+  else LN_Q(4, 4);
+#undef LN_Q
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
 // dx = LN backward (+ add, the gradient arriving through the residual path, optional and may alias dx)
 int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
                      const void* add, void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
@@ -646,6 +720,31 @@ int op_ln_geglu_fwd(const void* h0, const void* h1, int64_t ldh, const void* w, 
   else if (cols <= 6144) LNG_F(3, 4);
   else LNG_F(4, 4);
 #undef LNG_F
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// op_ln_geglu_fwd that also writes the row-quantised fp8 copy of its output (see op_layernorm_fwd_q8): the operand of the fp8 down-projection.
+int op_ln_geglu_fwd_q8(const void* h0, const void* h1, int64_t ldh, const void* w, const void* b, void* y, float* mean, float* rstd, void* q8,
+                       float* q8_scale, int64_t rows, int64_t cols, float eps, void* stream) {
+  OP_CHECK_ARG(h0 && h1 && y && q8 && q8_scale, "ln_geglu_fwd_q8: null pointer");
+  if (ldh <= 0) ldh = cols;
+  OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192 && ldh >= cols && ldh % 8 == 0, "ln_geglu_fwd_q8: cols=%lld ldh=%lld unsupported",
+               (long long)cols, (long long)ldh);
+  if (rows == 0) return OP_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define LNG_Q(CH, NW)                                                                                                       \
+  hipLaunchKernelGGL((ln_geglu_fwd_kernel<CH, NW, true>), dim3(ln_grid(rows, NW, OP_LN_GEGLU_BLOCKS_FWD)), dim3(NW == 1 ? 256 : 64 * NW), 0, s, \
+                     (const bf16_t*)h0, (const bf16_t*)h1, ldh, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, mean, rstd, rows, \
+                     (int)cols, eps, (uint8_t*)q8, q8_scale)
+  if (cols <= 512) LNG_Q(1, 1);
+  else if (cols <= 1024) LNG_Q(2, 1);
+  else if (cols <= 1536) LNG_Q(3, 1);
+  else if (cols <= 2048) LNG_Q(4, 1);
+  else if (cols <= 4096) LNG_Q(2, 4);
+  else if (cols <= 6144) LNG_Q(3, 4);
+  else LNG_Q(4, 4);
+#undef LNG_Q
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

@@ -69,6 +69,8 @@ SIGNATURES = {
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
     "op_attn_bwd": (c_int, [P, P, P, I64, P, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
+    "op_layernorm_fwd_q8": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, P]),
+    "op_ln_geglu_fwd_q8": (c_int, [P, P, I64, P, P, P, P, P, P, P, I64, I64, c_float, P]),
     "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, I64, P]),
     "op_rows_gather": (c_int, [P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
     "op_rows_merge": (c_int, [P, P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
@@ -258,7 +260,9 @@ def _req(t, name, dtype=None):
 # ---------------------------------------------------------------------------------------------------
 # thin tensor-level wrappers (no autograd here; see ops.py)
 # ---------------------------------------------------------------------------------------------------
-def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True):
+def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True, q8=False):
+    """q8=True (bf16, no GELU): returns (y, mean, rstd, (fp8 bytes, row scales)) -- the output also row-quantised to e4m3, bit-identical
+    to quant_fp8_rows(y), without a pass of its own."""
     _req(x2d, "x")
     rows, cols = x2d.shape
     y = torch.empty_like(x2d)
@@ -266,6 +270,13 @@ def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True):
     if want_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    if q8:
+        assert not gelu and x2d.dtype == torch.bfloat16
+        q = torch.empty(rows, cols, dtype=torch.uint8, device=x2d.device)
+        qs = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+        _check(lib().op_layernorm_fwd_q8(ptr(x2d), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), ptr(q), ptr(qs), rows, cols, eps, stream()),
+               "op_layernorm_fwd_q8")
+        return y, mean, rstd, (q, qs)
     _check(lib().op_layernorm_fwd(ptr(x2d), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
                                   int(gelu), _dt(x2d), stream()), "op_layernorm_fwd")
     return y, mean, rstd
@@ -573,14 +584,20 @@ def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False, 
     return dh0, dh1, dw, db
 
 
-def ln_geglu_fwd(h0, h1, w, b, eps=1e-5, want_stats=True, out=None, mean=None, rstd=None):
-    """LayerNorm_F(bf16(gelu(h0) * h1)); h0 / h1 may be column blocks of one wider matrix.  Returns y, mean, rstd."""
+def ln_geglu_fwd(h0, h1, w, b, eps=1e-5, want_stats=True, out=None, mean=None, rstd=None, q8=None):
+    """LayerNorm_F(bf16(gelu(h0) * h1)); h0 / h1 may be column blocks of one wider matrix.  Returns y, mean, rstd.
+    q8 = (fp8 bytes [rows, cols], scales [rows]): also filled with the row-quantised output (see layernorm_fwd)."""
     rows, cols = h0.shape
     assert h0.stride(0) == h1.stride(0) and h0.stride(1) == 1 and h1.stride(1) == 1
     y = out if out is not None else torch.empty(rows, cols, dtype=h0.dtype, device=h0.device)
     if want_stats and mean is None:
         mean = torch.empty(rows, dtype=torch.float32, device=h0.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=h0.device)
+    if q8 is not None:
+        assert q8[0].is_contiguous() and q8[0].shape == (rows, cols) and y.is_contiguous()
+        _check(lib().op_ln_geglu_fwd_q8(ptr(h0), ptr(h1), h0.stride(0), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), ptr(q8[0]), ptr(q8[1]),
+                                        rows, cols, eps, stream()), "op_ln_geglu_fwd_q8")
+        return y, mean, rstd
     _check(lib().op_ln_geglu_fwd(ptr(h0), ptr(h1), h0.stride(0), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps, stream()),
            "op_ln_geglu_fwd")
     return y, mean, rstd

@@ -640,23 +640,27 @@ def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True, grad=None):
     GeGLU epilogue (one store instead of three; h0 / h1 rounded to bf16 only in the split form: a bf16-level train / eval difference)."""
     if grad is None:
         grad = keep
-    xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
     Fd = P["w0"].shape[0]
     h0 = h1 = None
     fp8 = FP8_FFN and x_mid.shape[1] % 128 == 0 and Fd % 128 == 0
     split = grad and _geglu_split(Fd, P["fln_w"])
+    xq8 = gq8 = None
+    if fp8 and split:  # (round 5) the fp8 operands come out of the kernels that produce the bf16 rows: no quantisation passes
+        xln2, mean2, rstd2, xq8 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep, q8=True)
+    else:
+        xln2, mean2, rstd2 = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"], want_stats=keep)
     if keep and not split:
         h0 = torch.empty(x_mid.shape[0], Fd, dtype=x_mid.dtype, device=x_mid.device)
         h1 = torch.empty_like(h0)
     if split:  # plain wi_0 | wi_1 up-projection; GELU, gate and the inner LayerNorm in one HBM-bound pass
         if fp8:  # (round 5: the fp8 variant takes the same route -- its GELU no longer sits in a GEMM epilogue either)
-            xq, xs = hip.quant_fp8_rows(xln2)
             w01q, w01s = _fp8_weight_pair(P["w0"], P["w1"])
-            hh = hip.gemm_nt_fp8(xq, xs, [w01q], [w01s])
+            hh = hip.gemm_nt_fp8(xq8[0], xq8[1], [w01q], [w01s])
+            gq8 = (torch.empty(hh.shape[0], Fd, dtype=torch.uint8, device=hh.device), torch.empty(hh.shape[0], dtype=torch.float32, device=hh.device))
         else:
             hh = hip.gemm_nt(xln2, [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd)
         h0, h1 = hh[:, :Fd], hh[:, Fd:]
-        gln, mean_f, rstd_f = hip.ln_geglu_fwd(h0, h1, P["fln_w"], P["fln_b"])
+        gln, mean_f, rstd_f = hip.ln_geglu_fwd(h0, h1, P["fln_w"], P["fln_b"], q8=gq8)
     elif fp8:  # opt-in: e4m3 operands with per-row scales, fp32 accumulation (csrc/fp8.hip)
         xq, xs = hip.quant_fp8_rows(xln2)
         (w0q, w0s), (w1q, w1s) = _fp8_weight(P["w0"]), _fp8_weight(P["w1"])
@@ -671,7 +675,7 @@ def _ffn_forward(x_mid, P, S, ps2, keep, want_y=True, grad=None):
         gln, mean_f, rstd_f = g, None, None
     y2 = torch.empty_like(x_mid) if keep and want_y else None
     if fp8:
-        gq, gs = hip.quant_fp8_rows(gln)
+        gq, gs = gq8 if gq8 is not None else hip.quant_fp8_rows(gln)
         w2q, w2s = _fp8_weight(P["w2"])
         out = hip.gemm_nt_fp8(gq, gs, [w2q], [w2s], bias=P["b2"], epilogue=hip.EPI_RESID, resid=x_mid, gamma=P["g2"], rowscale=ps2,
                               rows_per_sample=S, h0=y2)
@@ -1034,10 +1038,15 @@ class FfnBranchMultiFn(torch.autograd.Function):
         own = [dict(zip(FFN_OWN, params[3 + 6 * i:9 + 6 * i])) for i in range(nseg)]
         N, H = x2.shape
         Fd = own[0]["w0"].shape[0]
-        xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep)
         dev, dt = x2.device, x2.dtype
         has_fln = own[0]["fln_w"] is not None
         split = (keep if grad is None else grad) and _geglu_split(Fd, own[0]["fln_w"])  # (by the kind of pass, not by `keep`: see _ffn_forward)
+        fp8 = FP8_FFN and split and H % 256 == 0 and Fd % 256 == 0  # (round 5) the opt-in fp8 forward: training (split) form only
+        if fp8:  # all rows of all streams: the fp8 operand comes out of the LayerNorm kernel itself
+            xln2, mean2, rstd2, (xq, xs) = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep, q8=True)
+            gq, gs = torch.empty(N, Fd, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.float32, device=dev)
+        else:
+            xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep)
         if split:
             hh = torch.empty(N, 2 * Fd, dtype=dt, device=dev)
             g, h0, h1 = None, hh[:, :Fd], hh[:, Fd:]
@@ -1049,9 +1058,6 @@ class FfnBranchMultiFn(torch.autograd.Function):
         mean_f = torch.empty(N, dtype=torch.float32, device=dev) if (keep or split) and has_fln else None
         rstd_f = torch.empty(N, dtype=torch.float32, device=dev) if (keep or split) and has_fln else None
         L = hip.lib()
-        fp8 = FP8_FFN and split and H % 256 == 0 and Fd % 256 == 0  # (round 5) the opt-in fp8 forward: training (split) form only
-        if fp8:
-            xq, xs = hip.quant_fp8_rows(xln2)  # all rows of all streams in one pass (rows are quantised independently)
         for sg, P in zip(segs, own):
             r = slice(sg.row0, sg.end)
             if split:
@@ -1060,7 +1066,8 @@ class FfnBranchMultiFn(torch.autograd.Function):
                     hip.gemm_nt_fp8(xq[r], xs[r], [w01q], [w01s], out=hh[r])
                 else:
                     hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], n_seg=Fd, N=2 * Fd, out=hh[r])
-                hip.ln_geglu_fwd(h0[r], h1[r], P["fln_w"], P["fln_b"], out=gln[r], mean=mean_f[r], rstd=rstd_f[r])
+                hip.ln_geglu_fwd(h0[r], h1[r], P["fln_w"], P["fln_b"], out=gln[r], mean=mean_f[r], rstd=rstd_f[r],
+                                 q8=(gq[r], gs[r]) if fp8 else None)
                 continue
             hip.gemm_nt(xln2[r], [P["w0"], P["w1"]], epilogue=hip.EPI_GEGLU, h0=h0[r] if keep else None, h1=h1[r] if keep else None, out=g[r])
             if has_fln:
@@ -1071,7 +1078,6 @@ class FfnBranchMultiFn(torch.autograd.Function):
         out = torch.empty_like(x2)
         rs = [slice(sg.row0, sg.end) for sg in segs]
         if fp8:  # one fp8 launch per modality (the grouped persistent launch is bf16 only)
-            gq, gs = hip.quant_fp8_rows(gln)
             for sg, P, r, ps in zip(segs, own, rs, pss):
                 w2q, w2s = _fp8_weight(P["w2"])
                 hip.gemm_nt_fp8(gq[r], gs[r], [w2q], [w2s], bias=P["b2"], epilogue=hip.EPI_RESID, resid=x2[r], gamma=shared["g2"], rowscale=ps,

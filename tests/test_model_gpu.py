@@ -1362,6 +1362,60 @@ def test_stage2_pretraining_skips_frozen_weight_gradients(golden_dir):
     assert n > 20
 
 
+def test_fp8_ffn_forward_in_the_lock_step_pass():
+    """Round 5: with ops.set_fp8_ffn(True) a TRAINING lock-step pass keeps the lock-step form (it used to fall back to one pass per
+    modality): LayerNorm2 / op_ln_geglu_fwd emit the fp8 operands, the plain N = 2F up-projection and the down-projection + residual run
+    on the fp8 kernels per modality.  Same loss bits as the fp8 passes taken one by one (per row the same kernels), and within the
+    variant's tolerance of the bf16 step; every gradient finite (backward = bf16 kernels on the saved bf16 activations)."""
+    from one_peace_amd import ops as _ops
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.transformer import transformer_encoder as TE
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=256, ffn_embed_dim=512, layers=2, attention_heads=4, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B = 5
+    inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    res = {}
+    used = {"multi": 0, "fp8": 0}
+    orig_multi, orig_f8 = TE.TransformerEncoder.forward_multi, _ops.hip.gemm_nt_fp8
+
+    def counted(self, infos):
+        used["multi"] += 1
+        return orig_multi(self, infos)
+
+    def counted_f8(*a, **k):
+        used["fp8"] += 1
+        return orig_f8(*a, **k)
+    for mode in ("bf16", "fp8 lock-step", "fp8 one by one"):
+        enc = one_peace_encoder_config(drop_path_rate=0.0, layer_scale_init_value=1e-1, **cfg)
+        torch.manual_seed(0)
+        m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+        m = m.to(DEV).to(torch.bfloat16).train()
+        old = _ops.set_fp8_ffn(mode != "bf16")
+        TE.TransformerEncoder.forward_multi, _ops.hip.gemm_nt_fp8 = counted, counted_f8
+        used["multi"] = used["fp8"] = 0
+        try:
+            loss, _, _ = TriModalContrastiveCriterion(None, 0.0, lock_step=mode != "fp8 one by one")(m, {"net_input": inp, "nsentences": B})
+            m.zero_grad()
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            _ops.set_fp8_ffn(old)
+            TE.TransformerEncoder.forward_multi, _ops.hip.gemm_nt_fp8 = orig_multi, orig_f8
+        assert used["multi"] == (0 if mode == "fp8 one by one" else 1), (mode, used)
+        assert used["fp8"] == (0 if mode == "bf16" else 2 * 3 * 2), (mode, used)  # 2 layers x 3 modalities x (up, down)
+        res[mode] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+    assert res["fp8 lock-step"][0] == res["fp8 one by one"][0], (res["fp8 lock-step"][0], res["fp8 one by one"][0])
+    assert abs(res["fp8 lock-step"][0] - res["bf16"][0]) <= 2e-2 * abs(res["bf16"][0]), (res["fp8 lock-step"][0], res["bf16"][0])
+    for n, g8 in res["fp8 lock-step"][1].items():
+        g16 = res["bf16"][1][n]
+        assert g8.isfinite().all(), n
+        assert float((g8 - g16).norm()) <= 0.2 * float(g16.norm()) + 2e-3, (n, float((g8 - g16).norm()), float(g16.norm()))
+
+
 @pytest.mark.parametrize("fp8", [False, True])
 def test_train_step_graph_replay_matches_eager_training(fp8):
     """graphs.TrainStepGraph: zero-grad + three forwards + ITC/ATC + the whole backward (custom autograd functions, in-place

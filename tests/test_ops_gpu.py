@@ -1256,7 +1256,34 @@ def test_fp8_gemm_bias_and_residual(M, N, K):
     assert_close(out_r, resid + rs * gamma * exact, what="fp8 residual epilogue")
 
 
-@pytest.mark.parametrize("M,N,K", [(16384, 1024, 256), (11000, 1536, 1536), (8200, 3072, 768), (10369, 1536, 6144)])
+@pytest.mark.parametrize("rows,cols", [(77, 256), (300, 1536), (129, 2048), (200, 6144), (66, 8192)])
+def test_layernorm_kernels_emit_the_fp8_operand_of_the_next_gemm(rows, cols):
+    """Round 5: op_layernorm_fwd_q8 / op_ln_geglu_fwd_q8 write, next to their bf16 output, the row-quantised e4m3 copy the fp8 FFN GEMMs
+    read -- bit-identical (codes and scales) to op_quant_fp8_rows of that bf16 output, and the bf16 output / statistics identical to the
+    plain kernels': the quantisation passes of the fp8 forward (0.22 ms per layer and stream at 50 240 rows) are gone, not moved."""
+    hip = hipmod()
+    x = dev_bf16(rnd(rows, cols, seed=1, scale=2.0))
+    x[3] = 0.0
+    w, b = dev_bf16(1 + 0.1 * rnd(cols, seed=2)), dev_bf16(0.1 * rnd(cols, seed=3))
+    y0, m0, r0 = hip.layernorm_fwd(x, w, b)
+    y1, m1, r1, (q, qs) = hip.layernorm_fwd(x, w, b, q8=True)
+    assert torch.equal(y0, y1) and torch.equal(m0, m1) and torch.equal(r0, r1)
+    q_ref, s_ref = hip.quant_fp8_rows(y0)
+    assert torch.equal(q, q_ref) and torch.equal(qs, s_ref)
+    # a zero-input row: LayerNorm gives the bias there; an all-zero OUTPUT row (no affine) must not divide by zero
+    y2, _, _, (q2, qs2) = hip.layernorm_fwd(torch.zeros_like(x), None, None, q8=True)
+    assert float(y2.abs().max()) == 0 and float(q2.float().abs().max()) == 0 and torch.equal(qs2, torch.ones_like(qs2))
+    h = dev_bf16(rnd(rows, 2 * cols, seed=4))
+    h0, h1 = h[:, :cols], h[:, cols:]
+    g0, gm0, gr0 = hip.ln_geglu_fwd(h0, h1, w, b)
+    gq = (torch.empty(rows, cols, dtype=torch.uint8, device=DEV), torch.empty(rows, dtype=torch.float32, device=DEV))
+    g1, gm1, gr1 = hip.ln_geglu_fwd(h0, h1, w, b, q8=gq)
+    assert torch.equal(g0, g1) and torch.equal(gm0, gm1) and torch.equal(gr0, gr1)
+    q_ref, s_ref = hip.quant_fp8_rows(g0)
+    assert torch.equal(gq[0], q_ref) and torch.equal(gq[1], s_ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 256), (11000, 1536, 1536), (8200, 3072, 768), (11009, 1536, 6144)])
 def test_fp8_four_wave_kernel_on_launches_that_fill_the_chip(M, N, K):
     """Round 5: gemm256f8_kernel -- 256 x 256 tiles, four waves, the skeleton of the bf16 production kernel -- takes every fp8 launch with
     >= 256 tiles (N % 256 == 0, K % 256 == 0; plain / bias and residual epilogues).  Against the exact product of the DEQUANTISED operands

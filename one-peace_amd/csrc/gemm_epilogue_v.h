@@ -122,17 +122,23 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
   // (accumulator reads as volatile asm: they keep their place between the -- volatile -- stores.  Plain reads are hoisted ahead of
   // the whole epilogue by the register allocator's live-range splitting and the surplus spilled: the last 12-24 bytes of scratch)
   float sbv[8];
+  u32x4 sav[8];  // row scales of the lane's 32 rows: rows mi*16 + g*4 .. + 3 are four consecutive floats (one 16-byte load per mi)
   if constexpr (SCALED) {
     const float* sp = sb + (ncol0 - seg * p.n_seg) + t * 8;
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { sbv[j] = s0[j]; sbv[4 + j] = s1[j]; }
+    // all of them up front through a descriptor that ends at the last valid row (rows past M read 0: never stored).  One load per
+    // row between the stores -- which carry a "memory" clobber -- would expose a full memory latency 32 times per wave.
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(sa + mrow0), 0, rows_left * 4, 0x00020000);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) sav[mi] = __builtin_amdgcn_raw_buffer_load_b128(rsa, g * 16, mi * 64, 0);
   }
   auto row_of = [&](int mi, int r, float (&o)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[j]) : "a"(acc[j >> 2][j & 3][mi][r]));
-    if constexpr (SCALED) {  // rows past M read the last row's scale (their stores are dropped by the descriptor)
-      const float sr = sa[min(mrow0 + mi * 16 + g * 4 + r, p.M - 1)];
+    if constexpr (SCALED) {
+      const float sr = __builtin_bit_cast(float, sav[mi][r]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] *= sr * sbv[j];
     }

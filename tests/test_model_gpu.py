@@ -1390,7 +1390,7 @@ def test_fp8_ffn_forward_in_the_lock_step_pass():
         used["fp8"] += 1
         return orig_f8(*a, **k)
     for mode in ("bf16", "fp8 lock-step", "fp8 one by one"):
-        enc = one_peace_encoder_config(drop_path_rate=0.0, layer_scale_init_value=1e-1, **cfg)
+        enc = one_peace_encoder_config(drop_path_rate=0.0, layer_scale_init_value=1e-1, checkpoint_activations=False, **cfg)
         torch.manual_seed(0)
         m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
         m = m.to(DEV).to(torch.bfloat16).train()

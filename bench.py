@@ -599,6 +599,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = hip.profile_kernels.collect(4) if profiled_steps else None
+    algo_bytes_timed = hip.GEMM_ALGO_BYTES[0]  # (snapshot: the skip leg below launches GEMMs too -- rounds 3-4 counted its bytes in)
     skip_leg = None
     fusion = getattr(getattr(model, "encoder_wrapper", None), "fusion_model", None)
     if (train and world == 1 and not micro and args.config == 3 and not full and not args.skip_dropped and not args.no_skip_leg
@@ -738,7 +739,7 @@ def main():
                                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "launches": g["count"], "avg_launch_ms": g["ms"] / g["count"],
                                "profiled_steps": profiled_steps,
-                               "algorithmic_bytes_per_launch": hip.GEMM_ALGO_BYTES[0] * profiled_steps / args.steps / max(1, g["count"]),
+                               "algorithmic_bytes_per_launch": algo_bytes_timed * profiled_steps / args.steps / max(1, g["count"]),
                                "gemm_share_of_step": g["ms"] / (ms * profiled_steps),
                                "attention_fwd_tflops": (prof[1]["work"] / (prof[1]["ms"] * 1e-3) / 1e12) if prof[1]["count"] else None,
                                "attention_bwd_tflops": (prof[2]["work"] / (prof[2]["ms"] * 1e-3) / 1e12) if prof[2]["count"] else None}

@@ -138,7 +138,8 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(o[j]) : "a"(acc[j >> 2][j & 3][mi][r]));
     if constexpr (SCALED) {
-      const float sr = __builtin_bit_cast(float, sav[mi][r]);
+      const unsigned sbits = sav[mi][r];  // (through a scalar: __builtin_bit_cast of a vector-element lvalue reads element 0 -- hipcc 7.2)
+      const float sr = __builtin_bit_cast(float, sbits);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] *= sr * sbv[j];
     }

@@ -293,6 +293,11 @@ def main():
     ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the reported metric needs 40")
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
+    ap.add_argument("--recompute-cheap", action="store_true",
+                    help="keep the layer activations EXCEPT the four LayerNorm-type outputs only weight gradients read; backward re-creates "
+                         "them (ops.set_recompute_cheap: -63 GB at the headline batch for +3 LayerNorm / +1 LN-GeGLU passes per layer).  "
+                         "Switched on automatically, before the per-GPU batch is halved, when the free memory after model + optimiser + "
+                         "RCCL set-up does not hold every activation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss-curve", action="store_true", help="record the loss of every timed step in config.loss_curve (same batch every step)")
     ap.add_argument("--no-lock-step", action="store_true",
@@ -510,12 +515,25 @@ def main():
             dist.all_reduce(free_t, op=dist.ReduceOp.MIN)
         mem_report["free_gb_after_model_optimizer_collectives_min_over_ranks"] = float(free_t.item())
         free_gb = float(free_t.item()) + torch.cuda.memory_reserved(device) / 1e9 - torch.cuda.memory_allocated(device) / 1e9
-        per_tok_gb = (0.25 / 571 if args.recompute else 1.64 / 571) * 1.0737 * args.layers / LAYERS
         changed = False
         passes = 5.0 / 3.0 if full else 1.0  # the full objective keeps five passes (two teachers, three students) instead of ~three
-        while args.batch > 1 and per_tok_gb * sum(modal.values()) * args.batch * passes > free_gb - 4.0:
+
+        def kept_gb():  # 1.64 GB per 571-token tuple kept in full, 32 / 46 of it at the cheap level, 0.25 under checkpoint_activations
+            per_tuple = 0.25 if args.recompute else 1.64 * 32.0 / 46.0 if args.recompute_cheap else 1.64
+            return per_tuple / 571 * 1.0737 * args.layers / LAYERS * sum(modal.values()) * args.batch * passes
+        # cushion: 4 GB + the 7.8 GB of transposed dgrad weights the first backward allocates (ops._transposed); world 1 at b = 128
+        # measures 287.5 GB peak reserved of 309.2 (config.memory), i.e. ~20 GB really are left for whatever RCCL adds at world > 1
+        while args.batch > 1 and kept_gb() > free_gb - 12.0:
+            if not args.recompute and not args.recompute_cheap and not args.fp8 and not args.graphs:
+                args.recompute_cheap = True  # first resort: the same batch with 30 % fewer kept bytes (+~5 % step time; halving costs ~15 %)
+                print("bench: %.0f GB free after model + optimiser + collectives set-up: LayerNorm outputs are re-created in backward "
+                      "(--recompute-cheap) instead of kept" % free_gb, file=sys.stderr, flush=True)
+                continue
             args.batch //= 2
             changed = True
+        if args.recompute_cheap:
+            from one_peace_amd import ops
+            ops.set_recompute_cheap(True)
         if changed:
             print("bench: %.0f GB free after model + optimiser + collectives set-up, per-GPU batch reduced to %d" % (
                 free_gb, args.batch), file=sys.stderr, flush=True)
@@ -679,7 +697,9 @@ def main():
                        "collectives": ("%s: broadcast, [k,b,H] all-gather, bucketed gradient all-reduce" % dist.get_backend()
                                        if dist.is_initialized() else "none (single process)"),
                        "activation_recompute": ("n/a (no-grad forward)" if not train else
-                                                "per layer (the reference's checkpoint_activations: true)" if args.recompute
+                                                "per layer (the reference's checkpoint_activations: true)" if args.recompute else
+                                                "cheap level: layer activations kept in HBM except the four LayerNorm-type outputs only weight "
+                                                "gradients read, which backward re-creates (ops.set_recompute_cheap)" if args.recompute_cheap
                                                 else "off: layer activations are kept in HBM (288 GB/GPU)"),
                        "algorithmic_tflop_per_sample": None if full else fl / 1e12,
                        "step_algorithmic_tflops_per_gpu": None if full else fl * args.batch / (ms / 1e3) / 1e12,

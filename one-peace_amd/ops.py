@@ -109,6 +109,25 @@ def set_fp8_ffn(on):
     return old
 
 
+# --------------------------------------------------------------------------------------------------------------
+# memory level between "keep every activation" and the reference's checkpoint_activations
+# --------------------------------------------------------------------------------------------------------------
+RECOMPUTE_CHEAP = os.environ.get("ONEPEACE_RECOMPUTE_CHEAP", "0") == "1"
+
+
+def set_recompute_cheap(on):
+    """With save_acts=True, do NOT keep the four row matrices a LayerNorm-type pass can re-create from tensors that are kept anyway:
+    LN1(x), the attention sub-LayerNorm's output, LN2(x_mid) and LN_F(gelu(h0) * h1) -- they are read only by the weight-gradient
+    GEMMs.  Backward re-runs the same kernels on the same inputs (bit-identical operands, so bit-identical gradients): 14 H of the
+    46 H bytes kept per token and layer = 63 GB at the headline batch (128 tuples x 571 tokens x 40 layers) for 3 LayerNorm + 1
+    LN-GeGLU forward passes per layer in backward (+33 ms of a 700 ms step).  bench.py switches it on instead of halving the per-GPU
+    batch when RCCL's buffers leave too little room on a multi-GPU node (pretrain_vl_3B.yaml:93 checkpoint_activations is the
+    reference's only level)."""
+    global RECOMPUTE_CHEAP
+    old, RECOMPUTE_CHEAP = RECOMPUTE_CHEAP, bool(on)
+    return old
+
+
 def _fp8_weight(w):
     """(fp8 bytes, row scales) of a weight [out, in]; a derived buffer like the transposed dgrad copies, re-quantised IN PLACE when
     the weight changes (parameter version / optimiser epoch): the buffers keep their addresses."""
@@ -822,6 +841,11 @@ class AttnBranchFn(torch.autograd.Function):
                 acts["aln"] = None if P["aln_w"] is not None else acts["aln"]
             if not (needs["wq"] or needs["wk"] or needs["wv"]):
                 acts["xln1"] = None
+        ctx.cheap = keep and bool(int(save_acts) & 4)
+        if ctx.cheap:  # (set_recompute_cheap) re-created in backward from x2 / attn, which are kept anyway
+            acts["xln1"] = None
+            if P["aln_w"] is not None:
+                acts["aln"] = None
         _save(ctx, keep, acts, x2, rowscale, *params)
         return x_mid
 
@@ -840,6 +864,11 @@ class AttnBranchFn(torch.autograd.Function):
         want_dbias = [sg.bias is not None and sg.bias.image.requires_grad for sg in segs]
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_a", "rstd_a", "y1", "xln1", "aln"))
+            if ctx.cheap:  # the weight-gradient operands that were not kept: the same kernels on the same rows, bit for bit
+                if needs["wq"] or needs["wk"] or needs["wv"]:
+                    A["xln1"] = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"])[0]
+                if needs["wo"] and P["aln_w"] is not None:
+                    A["aln"] = hip.layernorm_fwd(A["attn"], P["aln_w"], P["aln_b"])[0]
         else:  # recompute (the reference's checkpoint_activations behaviour)
             _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True)
         if not dx_mid.is_contiguous():
@@ -950,6 +979,11 @@ class FfnBranchFn(torch.autograd.Function):
                 acts["gln"] = None
             if not (needs["w0"] or needs["w1"]):
                 acts["xln2"] = None
+        ctx.cheap = keep and bool(int(save_acts) & 4) and not FP8_FFN
+        if ctx.cheap:  # (set_recompute_cheap)
+            acts["xln2"] = None
+            if _geglu_split(P["w0"].shape[0], P["fln_w"]):  # LN_F(gelu(h0) * h1) comes back from the kept h0 | h1
+                acts["gln"] = None
         _save(ctx, keep, acts, x2, ps, *params)
         return out.view(B, S, H)
 
@@ -963,6 +997,11 @@ class FfnBranchFn(torch.autograd.Function):
         need_x = bool(ctx.needs_input_grad[0])
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_f", "rstd_f", "y2", "gln", "xln2"))
+            if ctx.cheap:
+                if needs["w0"] or needs["w1"]:
+                    A["xln2"] = hip.layernorm_fwd(x_mid, P["ln2_w"], P["ln2_b"])[0]
+                if needs["w2"] and A["gln"] is None:
+                    A["gln"] = hip.ln_geglu_fwd(A["h0"], A["h1"], P["fln_w"], P["fln_b"])[0]
         else:
             _, A = _ffn_forward(x_mid, P, S, ps, True)
         N = B * S
@@ -1123,6 +1162,11 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 acts["xln2"] = None
             if has_fln and not any(nd["w2@%d" % i] for i in range(nseg)):
                 acts["gln"] = None
+        ctx.cheap = keep and bool(int(save_acts) & 4) and not FP8_FFN
+        if ctx.cheap:  # (set_recompute_cheap)
+            acts["xln2"] = None
+            if _geglu_split(Fd, params[5]):
+                acts["gln"] = None
         _save(ctx, keep, acts or {}, x2, *[ps for ps in pss], *params)
         ctx.n_ps = len(pss)
         return out
@@ -1140,6 +1184,14 @@ class FfnBranchMultiFn(torch.autograd.Function):
         need_x = bool(ctx.needs_input_grad[0])
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_f", "rstd_f", "y2", "gln", "xln2"))
+            if ctx.cheap:
+                if any(needs["%s@%d" % (n, i)] for i in range(nseg) for n in ("w0", "w1")):
+                    A["xln2"] = hip.layernorm_fwd(x2, P["ln2_w"], P["ln2_b"])[0]
+                if A["gln"] is None and any(needs["w2@%d" % i] for i in range(nseg)):
+                    A["gln"] = torch.empty(N, Fd, dtype=x2.dtype, device=x2.device)
+                    for i, sg in enumerate(segs):
+                        r = slice(sg.row0, sg.end)
+                        hip.ln_geglu_fwd(A["h0"][r], A["h1"][r], P["fln_w@%d" % i], P["fln_b@%d" % i], out=A["gln"][r], want_stats=False)
         else:  # recompute (the reference's checkpoint_activations behaviour)
             _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, True)
         if not dout.is_contiguous():
@@ -1294,10 +1346,11 @@ def attn_branch_multi(x2, segs, ps_rows, heads, params, save_acts=False, kept=No
 
 
 def _save_flags(save_acts):
-    """bit 0: keep the activations; bit 1: autograd is recording (inside Function.forward grad mode is always off).  The GeGLU form of
+    """bit 0: keep the activations; bit 1: autograd is recording (inside Function.forward grad mode is always off); bit 2: keep them
+    WITHOUT the four LayerNorm-type outputs backward can re-create (set_recompute_cheap).  The GeGLU form of
     the FFN is chosen by bit 1 -- not by which parameters happen to be trainable: a frozen branch (stage-2 pretraining) and a trainable
     one must give the same forward bits, and so must a checkpointed forward and its recomputation."""
-    return int(bool(save_acts)) | (2 if torch.is_grad_enabled() else 0)
+    return int(bool(save_acts)) | (2 if torch.is_grad_enabled() else 0) | (4 if RECOMPUTE_CHEAP and save_acts else 0)
 
 
 def ffn_branch(x, ps, params, save_acts=False):

@@ -981,6 +981,54 @@ def test_lock_step_pass_matches_one_forward_per_modality(flat, drop_path, recomp
     assert n_exact > 40 and n_close > 20
 
 
+@pytest.mark.parametrize("lock", [False, True])
+def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock):
+    """ops.set_recompute_cheap: the memory level between "keep everything" and checkpoint_activations -- the four
+    LayerNorm-type outputs only weight gradients read (LN1(x), the attention sub-LayerNorm's output, LN2(x_mid), LN_F(gelu(h0) h1))
+    are re-created in backward by the same kernels on the same kept rows.  Loss and EVERY gradient must be bit-identical to the
+    keep-everything run, and less memory must be held between forward and backward.  lock: the lock-step pass (AttnBranchFn over all
+    rows + FfnBranchMultiFn) or one pass per modality (AttnBranchFn + FfnBranchFn)."""
+    from one_peace_amd import ops
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=256, ffn_embed_dim=512, layers=3, attention_heads=4, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)  # F % 256 == 0: the split GeGLU form, whose LN_F output the cheap level drops
+    B = 6
+    inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    res = {}
+    old = ops.set_recompute_cheap(False)
+    try:
+        for cheap in (False, True):
+            ops.set_recompute_cheap(cheap)
+            enc = one_peace_encoder_config(drop_path_rate=0.0, layer_scale_init_value=1e-1, checkpoint_activations=False, **cfg)
+            torch.manual_seed(0)
+            m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+            m = m.to(DEV).to(torch.bfloat16).train()
+            fl = FlatParameters(m)
+            fl.zero_grad()
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            loss, _, _ = TriModalContrastiveCriterion(None, 0.0, lock_step=lock)(m, {"net_input": inp, "nsentences": B})
+            torch.cuda.synchronize()
+            held = torch.cuda.memory_allocated() - base
+            loss.backward()
+            torch.cuda.synchronize()
+            res[cheap] = (float(loss.detach()), held, {n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None})
+            del m, fl, loss
+    finally:
+        ops.set_recompute_cheap(old)
+    assert res[True][0] == res[False][0]
+    assert len(res[True][2]) == len(res[False][2]) > 60
+    for n, g in res[False][2].items():
+        assert torch.equal(res[True][2][n], g), (n, float((res[True][2][n].float() - g.float()).abs().max()))
+    # 14 H of the 46 H bytes kept per token and layer are gone (adapters, head and bias images dilute it at this micro size)
+    assert res[True][1] < 0.88 * res[False][1], (res[True][1], res[False][1])
+
+
 @pytest.mark.parametrize("flat,recompute", [(False, False), (True, False), (True, True)])
 def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(flat, recompute):
     """TransformerEncoder.skip_dropped_branches: every residual branch of the lock-step pass is computed for the samples stochastic

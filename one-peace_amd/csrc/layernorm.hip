@@ -38,6 +38,23 @@ __device__ __forceinline__ float group_sum(float v, float* red) {
   return t;
 }
 
+// Two sums with ONE barrier pair (the backward kernels need mean(dy w) and mean(dy w xhat) of the same row); red: >= 2 * NW floats.
+template <int NW>
+__device__ __forceinline__ void group_sum2(float& a, float& b, float* red) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (NW == 1) return;
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) { red[wid] = a; red[NW + wid] = b; }
+  __syncthreads();
+  float ta = 0.f, tb = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { ta += red[i]; tb += red[NW + i]; }
+  a = ta;
+  b = tb;
+}
+
 template <int NW>
 __device__ __forceinline__ float group_max(float v, float* red) {
   v = wave_max(v);
@@ -354,8 +371,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
       }
     }
-    const float c1 = group_sum<NW>(s1, red) * inv;
-    const float c2 = group_sum<NW>(s2, red) * inv;
+    group_sum2<NW>(s1, s2, red);
+    const float c1 = s1 * inv, c2 = s2 * inv;
     T* dr = dx + row * (int64_t)cols;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -427,16 +444,19 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
   const int64_t row0 = (NW == 1) ? ((int64_t)blockIdx.x * 4 + wid) : blockIdx.x;
   const int64_t rstep = (NW == 1) ? (int64_t)gridDim.x * 4 : gridDim.x;
   const float inv = 1.0f / (float)cols;
-  float wv[CH][8], dwa[CH][8], dba[CH][8];
+  float dwa[CH][8], dba[CH][8];
+  bf16x8 wraw[CH];  // the LayerNorm weight stays packed (4 registers per 8 columns; unpacked where it is used: one VALU op per element)
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
     const int c = (tig + G * i) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { wv[i][j] = 1.f; dwa[i][j] = 0.f; dba[i][j] = 0.f; }
-    if (c < cols && w) Vec8<bf16_t>::load(w + c, wv[i]);
+    for (int j = 0; j < 8; ++j) { dwa[i][j] = 0.f; dba[i][j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wraw[i][j] = (bf16_t)1.0f;
+    if (c < cols && w) wraw[i] = Vec8<bf16_t>::ldraw(w + c);
   }
-  // Registers: the row is kept as raw bf16 (h0, h1) + fp32 dy*w across the two block reductions and the GELU pieces are
-  // recomputed for the output pass, so that the NEXT row's three operands can already be in flight.
+  // Registers (<= 256 for two waves per SIMD): the row is kept as raw bf16 (h0, h1) + fp32 dy*w, Phi(h0) and gelu'(h0) across the two
+  // block reductions, so that the NEXT row's three operands can already be in flight.
   bf16x8 r0[CH], r1[CH], rg[CH], n0[CH], n1[CH], ng[CH];
   if (row0 < rows) {
 #pragma unroll
@@ -464,7 +484,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
         }
       }
     }
-    float gw[CH][8], cdfs[CH][8];
+    float gw[CH][8], cdfs[CH][8], gps[CH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -474,26 +494,30 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
         Vec8<bf16_t>::cvt(r0[i], a);
         Vec8<bf16_t>::cvt(r1[i], b);
         Vec8<bf16_t>::cvt(rg[i], gw[i]);
+        float wv[8];
+        asm volatile("" : "+v"(wraw[i]));  // (keeps the unpacking inside the row loop: hoisted, it is 24 registers again)
+        Vec8<bf16_t>::cvt(wraw[i], wv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float cdf, pdf;
           gelu_parts(a[j], cdf, pdf);
           cdfs[i][j] = cdf;
+          gps[i][j] = cdf + a[j] * pdf;  // gelu'(h0): kept for the output pass (round 5: that pass took a second exponential per element)
           // the forward rounded g to bf16 before the LayerNorm statistics were taken
           const float gval = (float)(bf16_t)(a[j] * cdf * b[j]);
           const float xh = (gval - mean) * rstd;
           const float d = gw[i][j];
           dwa[i][j] += d * xh;
           dba[i][j] += d;
-          const float t = d * wv[i][j];
+          const float t = d * wv[j];
           gw[i][j] = t;
           s1 += t;
           s2 += t * xh;
         }
       }
     }
-    const float c1 = group_sum<NW>(s1, red) * inv;
-    const float c2 = group_sum<NW>(s2, red) * inv;
+    group_sum2<NW>(s1, s2, red);
+    const float c1 = s1 * inv, c2 = s2 * inv;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
@@ -503,13 +527,11 @@ __global__ __launch_bounds__(NW == 1 ? 256 : 64 * NW) void ln_geglu_bwd_kernel(c
         Vec8<bf16_t>::cvt(r1[i], b);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float cdf = cdfs[i][j];  // kept from the first pass; only the density needs its exponential again
-          const float pdf = 0.39894228040143267794f * __expf(-0.5f * a[j] * a[j]);
-          const float ge = a[j] * cdf;
+          const float ge = a[j] * cdfs[i][j];  // Phi(h0) and gelu'(h0) are kept from the first pass: no transcendental here
           const float xh = ((float)(bf16_t)(ge * b[j]) - mean) * rstd;
           // the unfused path rounded dg to bf16 between the two kernels; keep fp32 here
           const float dg = rstd * (gw[i][j] - c1 - xh * c2);
-          o0[j] = dg * b[j] * (cdf + a[j] * pdf);
+          o0[j] = dg * b[j] * gps[i][j];
           o1[j] = dg * ge;
         }
         Vec8<bf16_t>::store_nt(dh0 + row * ldd + c, o0);

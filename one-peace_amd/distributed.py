@@ -35,7 +35,21 @@ def init_distributed(backend=None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         warm_up_collectives()
+    if world > 1 and backend == "nccl" and "ONEPEACE_TUNE_SCHED" not in os.environ:
+        share_cus_with_collectives()
     return rank, world, local
+
+
+def share_cus_with_collectives():
+    """NT GEMM launches as one tile per workgroup (tune sched 7: gemm256v_kernel, bit-identical results) while RCCL kernels share the
+    GPU with backward.  The persistent form (one workgroup per CU walking tiles blockIdx, blockIdx + 256, ...: -0.5 ... -3.6 % per launch
+    on an otherwise idle GPU) assumes every workgroup gets its CU at once; a four-wave GEMM workgroup owns its CU's whole register file
+    and LDS, so the c CUs an all-reduce kernel holds are c workgroups that start only when others END -- the launch then takes up to
+    twice its time, where thousands of one-tile workgroups simply flow onto the CUs that are free (T + r c / 256).  The grouped
+    weight-gradient launch draws tickets and needs no such switch.  (Reasoned from the dispatch rules, not measured: no multi-GPU node in
+    this environment; ONEPEACE_TUNE_SCHED=0 keeps the single-GPU rule.)"""
+    from . import hip
+    hip.TUNE.sched = 7
 
 
 def warm_up_collectives():

@@ -43,7 +43,7 @@ def init_distributed(backend=None):
 def share_cus_with_collectives():
     """NT GEMM launches as one tile per workgroup (tune sched 7: gemm256v_kernel, bit-identical results) while RCCL kernels share the
     GPU with backward.  The persistent form (one workgroup per CU walking tiles blockIdx, blockIdx + 256, ...: -0.5 ... -3.6 % per launch
-    on an otherwise idle GPU) assumes every workgroup gets its CU at once; a four-wave GEMM workgroup owns its CU's whole register file
+    in isolation, level in the whole step: 700.5 / 701.1 against 699.8 / 698.2 ms on one box, profiles/r5_bench_nt_*_samebox_1gpu.json) assumes every workgroup gets its CU at once; a four-wave GEMM workgroup owns its CU's whole register file
     and LDS, so the c CUs an all-reduce kernel holds are c workgroups that start only when others END -- the launch then takes up to
     twice its time, where thousands of one-tile workgroups simply flow onto the CUs that are free (T + r c / 256).  The grouped
     weight-gradient launch draws tickets and needs no such switch.  (Reasoned from the dispatch rules, not measured: no multi-GPU node in

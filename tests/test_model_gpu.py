@@ -1023,14 +1023,12 @@ def test_fused_encoder_returns_all_hiddens_and_honours_layerdrop():
                 _force_torch_path(m, True)
                 o_t = run(train, seed)
                 _force_torch_path(m, False)
-            S_t = inp["src_tokens"].shape[1]
             for key in ("text_encoder_states", "image_encoder_states"):
                 assert len(o_h[key]) == len(o_t[key]) == n_run, (key, len(o_h[key]), len(o_t[key]))
                 for a, b in zip(o_h[key], o_t[key]):
                     assert a.shape == b.shape and a.shape[1] == 3
                     # two bf16 paths against each other (each is held to 1.5e-2 of fp32 elsewhere): 1.5e-2 * sqrt(2) + margin
                     assert rel_fro(a.float(), b.float()) <= 2.5e-2, (key, rel_fro(a.float(), b.float()))
-            assert o_h["text_encoder_states"][0].shape[0] == S_t if n_run else True
             assert o_h["audio_encoder_states"] == []
             assert rel_fro(o_h["encoder_out"][0].float(), o_t["encoder_out"][0].float()) <= 2.5e-2
     finally:

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -106,9 +106,15 @@ int64_t op_gemm_tn_grouped_counter_bytes(void);
  * not suffice. */
 int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int64_t workgroups, int64_t tune,
                                 int32_t* out, int64_t cap);
+/* (ABI 7) W / ldw / rowdot: nullable HOST arrays; for a problem with rowdot[i] != NULL (requires accumulate[i], M_i and N_i multiples
+ * of 256, W_i [M_i, N_i] bf16 16-byte aligned, ldw_i % 8 == 0) the launch also adds  rowdot_i[m] += sum_n W_i[m][n] * P_i[m][n]  (fp32
+ * atomics; P_i = THIS launch's fp32 product A_i^T B_i before it is rounded into C_i).  With A = gamma-scaled output gradient of a
+ * residual branch, B = input of the branch's last Linear and W = that Linear's weight, rowdot / gamma is the layer-scale gradient
+ * sum_rows rowscale * dout * (x W^T) -- see op_gamma_grad_finish -- and the branch output y never has to be kept for backward
+ * (one_peace/models/transformer/transformer_layer.py:70-88). */
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
-                       void* counters, int64_t tune, void* stream);
+                       const void* const* W, const int64_t* ldw, float* const* rowdot, void* counters, int64_t tune, void* stream);
 /* `tune` (op_gemm_nt, op_gemm_tn, op_gemm_plan): per-call tuning word, 0 = what production uses.  The library keeps NO tuning
  * state, so every entry point is a pure function of its arguments; tests and tools select a kernel flavour with the call:
  * bits 0-1 tile (0 auto: a cost model picks 128x128 or 256x256 tiles, K-splits and the tail-rows split; 1 force 128x128;
@@ -218,11 +224,20 @@ int op_colsum_segments(const void* x, void* out0, void* out1, void* out2, void* 
 /* Backward of out = resid + rowscale[m/rps] * gamma[n] * y[m][n] (layer-scale + drop-path residual,
  * one_peace/models/transformer/transformer_layer.py:70-88,190-196,224-226) in one pass:
  * dbranch = rowscale*gamma*dout; dgamma (+)= sum_m rowscale*dout*y; dbias (+)= sum_m dbranch.  Nullable: y+dgamma, gamma,
- * rowscale, dbias. */
+ * rowscale, dbias, g0.  (ABI 7) g0 (fp32 [N], overwritten): sum_m rowscale*dout, i.e. dbias WITHOUT the gamma factor -- what
+ * op_gamma_grad_finish multiplies with the last Linear's bias when dgamma is taken from the weight gradient instead of from y. */
 int64_t op_resid_bwd_workspace_bytes(int64_t N);
 int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
-                 void* dbranch, void* dgamma, void* dbias, void* workspace, int64_t M, int64_t N, int accumulate,
+                 void* dbranch, void* dgamma, void* dbias, float* g0, void* workspace, int64_t M, int64_t N, int accumulate,
                  void* stream);
+/* (ABI 7) Layer-scale gradient of a residual branch  out = resid + rowscale * gamma * (x W^T + b)  WITHOUT the branch output:
+ *   dgamma[n] (+)= rowdot[n] / gamma[n] + sum_i b_i[n] * g0_i[n]      (rowdot[n] := 0 afterwards: the buffer is re-armed)
+ * rowdot: op_gemm_tn_grouped's side product over the gamma-scaled gradient (= gamma[n] * sum_k W[n][k] * ((rowscale*dout)^T x)[n][k]);
+ * (b_i, g0_i): bias of the last Linear and op_resid_bwd's g0 for up to three weight sets that share gamma (the three modality FFNs of
+ * a lock-step layer, transformer_layer.py:203-226; b_i NULL = no bias).  gamma[n] == 0: the rowdot term is dropped (y is not
+ * recoverable from a zero-scaled gradient).  dgamma: bf16 [N]. */
+int op_gamma_grad_finish(float* rowdot, const void* gamma, const void* b0, const float* g00, const void* b1, const float* g01,
+                         const void* b2, const float* g02, void* dgamma, int64_t N, int accumulate, void* stream);
 /* Backward of LayerNorm_F(gelu(h0) * h1) w.r.t. h0, h1 and the LayerNorm affine in one pass (the FFN's GeGLU + inner
  * sub-LayerNorm, transformer_layer.py:64-67,111-118); mean/rstd: forward statistics.  workspace: op_layernorm_bwd_workspace_bytes.
  * ldh: row stride of h0 / h1 (0 = cols).  ldd: row stride (elements) of dh0 / dh1, 0 = cols -- the two gradients may be the halves of one [rows, 2 * cols] matrix, which

@@ -230,13 +230,15 @@ __global__ __launch_bounds__(256) void partials_reduce3_kernel(const float* __re
                                                                const float* __restrict__ p2, const bf16_t* __restrict__ m0,
                                                                const bf16_t* __restrict__ m1, const bf16_t* __restrict__ m2,
                                                                T* __restrict__ o0, T* __restrict__ o1, T* __restrict__ o2,
-                                                               int parts, int64_t pstride, int N, int accumulate) {
+                                                               int parts, int64_t pstride, int N, int accumulate,
+                                                               float* __restrict__ f2 = nullptr) {  // f2: job 2 in fp32, overwritten
   __shared__ float red[8][33];
   const int job = blockIdx.y;
   const float* part = job == 0 ? p0 : (job == 1 ? p1 : p2);
   const bf16_t* mul = job == 0 ? m0 : (job == 1 ? m1 : m2);
   T* out = job == 0 ? o0 : (job == 1 ? o1 : o2);
-  if (out == nullptr) return;  // uniform
+  float* outf = job == 2 ? f2 : nullptr;
+  if (out == nullptr && outf == nullptr) return;  // uniform
   const int c = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + c;
   float a = 0.f;
@@ -251,7 +253,8 @@ __global__ __launch_bounds__(256) void partials_reduce3_kernel(const float* __re
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += red[i][c];
     if (mul) t *= (float)mul[n];
-    out[n] = (T)(t + (accumulate ? (float)out[n] : 0.f));
+    if (outf) outf[n] = t;
+    else out[n] = (T)(t + (accumulate ? (float)out[n] : 0.f));
   }
 }
 

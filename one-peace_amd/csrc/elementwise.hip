@@ -130,6 +130,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
   }
 }
 
+// Layer-scale gradient from the weight gradient's side product (op_gemm_tn_grouped: rowdot) instead of from the branch output.
+__global__ __launch_bounds__(256) void gamma_grad_finish_kernel(float* __restrict__ rowdot, const bf16_t* __restrict__ gamma,
+                                                                const bf16_t* __restrict__ b0, const float* __restrict__ g00,
+                                                                const bf16_t* __restrict__ b1, const float* __restrict__ g01,
+                                                                const bf16_t* __restrict__ b2, const float* __restrict__ g02,
+                                                                bf16_t* __restrict__ dgamma, int N, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float gm = (float)gamma[n];
+  float t = gm != 0.f ? rowdot[n] / gm : 0.f;
+  rowdot[n] = 0.f;
+  if (g00) t += (b0 ? (float)b0[n] : 0.f) * g00[n];
+  if (g01) t += (b1 ? (float)b1[n] : 0.f) * g01[n];
+  if (g02) t += (b2 ? (float)b2[n] : 0.f) * g02[n];
+  dgamma[n] = (bf16_t)(t + (accumulate ? (float)dgamma[n] : 0.f));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // residual-branch backward in one pass (transformer_layer.py:70-88):  out = resid + rs[m] * gamma[n] * y[m][n]
 //   dbranch[m][n] = rs[m] * gamma[n] * dout[m][n]
@@ -697,29 +714,43 @@ int64_t op_resid_bwd_workspace_bytes(int64_t N) { return 2 * (int64_t)CS_MAX_PAR
 //   dbranch = rowscale * gamma * dout;  dgamma (+)= sum_m rowscale * dout * y;  dbias (+)= sum_m dbranch
 // gamma, rowscale, y/dgamma, dbias nullable; dgamma/dbias are bf16 [N]; accumulate: add into them instead of overwriting.
 int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
-                 void* dbranch, void* dgamma, void* dbias, void* workspace, int64_t M, int64_t N, int accumulate,
+                 void* dbranch, void* dgamma, void* dbias, float* g0, void* workspace, int64_t M, int64_t N, int accumulate,
                  void* stream) {
   OP_CHECK_ARG(dout && dbranch, "resid_bwd: null pointer");
   OP_CHECK_ARG(N > 0 && N % 8 == 0, "resid_bwd: N must be a multiple of 8");
   OP_CHECK_ARG(!dgamma || y, "resid_bwd: dgamma needs y");
-  OP_CHECK_ARG(!(dgamma || dbias) || workspace, "resid_bwd: dgamma/dbias requested without workspace");
-  if (M == 0) return OP_OK;
+  OP_CHECK_ARG(!(dgamma || dbias || g0) || workspace, "resid_bwd: dgamma/dbias/g0 requested without workspace");
+  if (M == 0) {
+    if (g0) (void)hipMemsetAsync(g0, 0, (size_t)N * sizeof(float), (hipStream_t)stream);
+    return OP_OK;
+  }
   hipStream_t s = (hipStream_t)stream;
   int parts = (int)((M + 63) / 64);
   if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
   if (parts < 1) parts = 1;
-  float* ws = (dgamma || dbias) ? (float*)workspace : nullptr;
+  float* ws = (dgamma || dbias || g0) ? (float*)workspace : nullptr;
   hipLaunchKernelGGL(resid_bwd_kernel, dim3(ceil_div(N, 512), parts), dim3(256), 0, s, (const bf16_t*)dout,
                      (const bf16_t*)(dgamma ? y : nullptr), (const bf16_t*)gamma, rowscale,
                      (int)(rows_per_sample > 0 ? rows_per_sample : 1), (bf16_t*)dbranch, ws, M, (int)N);
   OP_LAUNCH_CHECK();
   if (ws) {
-    hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(N, 32), 2), dim3(256), 0, s, ws,
-                       ws + (int64_t)parts * N, (const float*)nullptr, (const bf16_t*)nullptr, (const bf16_t*)gamma,
+    // job 0: dgamma from sum rs*dout*y; job 1: dbias = gamma * sum rs*dout; job 2 (g0): the same partials without gamma, fp32
+    hipLaunchKernelGGL((partials_reduce3_kernel<bf16_t>), dim3(ceil_div(N, 32), g0 ? 3 : 2), dim3(256), 0, s, ws,
+                       ws + (int64_t)parts * N, ws + (int64_t)parts * N, (const bf16_t*)nullptr, (const bf16_t*)gamma,
                        (const bf16_t*)nullptr, (bf16_t*)dgamma, (bf16_t*)dbias, (bf16_t*)nullptr, parts, N, (int)N,
-                       accumulate);
+                       accumulate, g0);
     OP_LAUNCH_CHECK();
   }
+  return OP_OK;
+}
+
+// dgamma[n] (+)= rowdot[n] / gamma[n] + sum_i b_i[n] * g0_i[n];  rowdot[n] = 0  (see include/onepeace_hip.h)
+int op_gamma_grad_finish(float* rowdot, const void* gamma, const void* b0, const float* g00, const void* b1, const float* g01,
+                         const void* b2, const float* g02, void* dgamma, int64_t N, int accumulate, void* stream) {
+  OP_CHECK_ARG(rowdot && gamma && dgamma && N > 0, "gamma_grad_finish: null pointer");
+  hipLaunchKernelGGL(gamma_grad_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, rowdot, (const bf16_t*)gamma,
+                     (const bf16_t*)b0, g00, (const bf16_t*)b1, g01, (const bf16_t*)b2, g02, (bf16_t*)dgamma, (int)N, accumulate);
+  OP_LAUNCH_CHECK();
   return OP_OK;
 }
 

@@ -1626,6 +1626,9 @@ struct TnProb {
   const bf16_t* A; const bf16_t* B; bf16_t* C;  // C[M,N] (+)= A[K,M]^T B[K,N]
   int64_t lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n, accumulate;
+  // optional (round 5): rowdot[m] += sum_n W[m][n] * (this launch's fp32 product)[m][n] -- the layer-scale gradient of a residual
+  // branch taken from the weight gradient of its last Linear (transformer_layer.py:70-88; see op_gemm_tn_grouped)
+  const bf16_t* W; int64_t ldw; float* rowdot;
 };
 // A queue is a list of RUNS: `n` consecutive slots of one problem's slot order (below), from slot0 on.
 struct TnRun { int prob_n; int slot0; };  // prob_n = problem << 24 | n
@@ -1682,14 +1685,23 @@ __host__ __device__ __forceinline__ bool tn_decode(const TnGroupArgs& p, int x, 
 // took one lane at a time -- 20 us of a tile.)  The old values travel in two batches of eight while the block is parked / while the
 // first batch is folded; `between` (the next ticket's draw) runs after the first half so that its returning atomic is not in front
 // of loads the wave waits for.  GUARD: tiles on the matrix edge (M, N are multiples of 8: a lane's 8 columns are in or out together).
+// rowdot != nullptr (full tiles, accumulate): the fp32 block is also multiplied with the same block of W and summed along the rows -- a lane folds its 8
+// columns of 16 rows over both 64-column halves, the 8 lanes of a row are folded by three shuffles, one atomic per row and wave.
+// (ROWDOT is a run-time, wave-uniform switch of the <ACCUM, !GUARD> instantiation: a fifth inlined copy of the epilogue made the register
+// allocator hoist accumulator reads over the branches and spill 243 dwords per lane.)
 template <bool ACCUM, bool GUARD, typename F>
 __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&acc)[2][4][8], int mrow0, int nbase, int M, int N, int lane, char* wlds,
-                                                F between) {
+                                                F between, const bf16_t* Wm = nullptr, int64_t ldw = 0, float* rowdot = nullptr) {
+  const bool ROWDOT = ACCUM && !GUARD && rowdot != nullptr;
   const int g = lane >> 4, t = lane & 15;
   const int rrow = lane >> 3, cp = lane & 7;
+  float rd[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rd[i] = 0.f;
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     bf16_t* cbase = C + (int64_t)(mrow0 + rrow) * ldc + nbase + blk * 64 + cp * 8;
+    const bf16_t* wbase = ROWDOT ? Wm + (int64_t)(mrow0 + rrow) * ldw + nbase + blk * 64 + cp * 8 : nullptr;
     const bool col_ok = !GUARD || nbase + blk * 64 + cp * 8 < N;
     auto ok = [&](int i) { return !GUARD || (col_ok && mrow0 + rrow + i * 8 < M); };
     bf16x8 old[8];
@@ -1709,7 +1721,7 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
-      bf16x8 nxt[8];
+      bf16x8 nxt[8], wrow[4];
       if (ACCUM && hb == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1718,6 +1730,10 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        if (ROWDOT && (i & 3) == 0) {  // W rows four at a time (the kernel sits at 254 of 256 VGPRs: eight in flight spilled)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) wrow[j] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(hb * 8 + i + j) * 8 * ldw);
+        }
         const int row = (hb * 8 + i) * 8 + rrow;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + row * 256 + (((2 * cp) ^ (row & 15)) << 4));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(wlds + row * 256 + (((2 * cp + 1) ^ (row & 15)) << 4));
@@ -1728,6 +1744,12 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
           w[4 + r] = (bf16_t)(ACCUM ? (float)old[i][4 + r] + hi[r] : hi[r]);
         }
         if (ok(hb * 8 + i)) *reinterpret_cast<bf16x8*>(cbase + (int64_t)(hb * 8 + i) * 8 * ldc) = w;
+        if (ROWDOT) {
+          float sdot = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sdot += lo[r] * (float)wrow[i & 3][r] + hi[r] * (float)wrow[i & 3][4 + r];
+          rd[hb * 8 + i] += sdot;
+        }
       }
       if (ACCUM && hb == 0) {
 #pragma unroll
@@ -1740,6 +1762,16 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (ROWDOT) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float v = rd[i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      if (cp == 0) atomicAdd(rowdot + mrow0 + rrow + i * 8, v);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupArgs p) {
@@ -1749,21 +1781,6 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
   const int g = lane >> 4, t = lane & 15;
-
-  // ---- tile-independent: transpose-read provider addresses (see gemm256w_tn_kernel) ----
-  const int krow = g * 8 + (t >> 2);
-  const int rowoff = krow * 512;
-  int rdX[8], rdW[8];
-#pragma unroll
-  for (int mi = 0; mi < 8; ++mi) {
-    const int chunk = wm * 16 + mi * 2 + ((t & 3) >> 1);
-    rdX[mi] = rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
-  }
-#pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    const int chunk = wn * 16 + f * 2 + ((t & 3) >> 1);
-    rdW[f] = OPER2_BYTES + rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t & 1) * 8;
-  }
 
   // ---- queue state of the fetching thread (thread 0): home queue first, then the others in turn ----
   const int home = blockIdx.x & 7;
@@ -1818,6 +1835,25 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
     TLG(1, __builtin_amdgcn_s_memrealtime());
     TLG_CYC0();
     if (valid) {
+      // ---- transpose-read provider addresses (see gemm256w_tn_kernel).  Tile-independent, but derived PER TILE from an opaque copy of the
+      // lane number: 16 registers that are only live in the main loop -- kept across the epilogue (which since round 5 may carry the
+      // row-dot side product) they pushed seven kernel-lifetime values into scratch ----
+      int lane_t = lane;
+      asm volatile("" : "+v"(lane_t));
+      const int g_ = lane_t >> 4, t_ = lane_t & 15;
+      const int krow = g_ * 8 + (t_ >> 2);
+      const int rowoff = krow * 512;
+      int rdX[8], rdW[8];
+#pragma unroll
+      for (int mi = 0; mi < 8; ++mi) {
+        const int chunk = wm * 16 + mi * 2 + ((t_ & 3) >> 1);
+        rdX[mi] = rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t_ & 1) * 8;
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int chunk = wn * 16 + f * 2 + ((t_ & 3) >> 1);
+        rdW[f] = OPER2_BYTES + rowoff + ((chunk ^ swzA_tn(krow)) << 4) + (t_ & 1) * 8;
+      }
       const TnProb& q = p.pr[prob];
       const int M = q.M, N = q.N;
       const int64_t lda = q.lda, ldb = q.ldb;
@@ -1941,7 +1977,7 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
         char* wlds = smem + wid * 32768;
         const int mr = m0 + wm * 128, nb = n0 + wn * 128;
         if (m0 + 256 <= M && n0 + 256 <= N) {  // (uniform) tile inside the matrix
-          if (q.accumulate) tn_epilogue_lds<true, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
+          if (q.accumulate) tn_epilogue_lds<true, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next, q.W, q.ldw, q.rowdot);  // (rowdot: host checked accumulate, M, N % 256 == 0)
           else tn_epilogue_lds<false, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
         } else {
           if (q.accumulate) tn_epilogue_lds<true, true>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
@@ -2671,7 +2707,7 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
 // tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = round 4's solo workgroups (see the kernel).
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
-                       void* counters, int64_t tune, void* stream) {
+                       const void* const* W, const int64_t* ldw, float* const* rowdot, void* counters, int64_t tune, void* stream) {
   OP_CHECK_ARG(nprob >= 1 && nprob <= TN_MAX_PROB, "gemm_tn_grouped: %lld problems (1 ... %d)", (long long)nprob, TN_MAX_PROB);
   OP_CHECK_ARG(A && lda && B && ldb && C && ldc && M && N && K && accumulate && counters, "gemm_tn_grouped: null pointer");
   int order[TN_MAX_PROB];
@@ -2701,6 +2737,12 @@ int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, 
     q.M = (int)M[s]; q.N = (int)N[s]; q.K = (int)K[s];
     q.tiles_m = ceil_div(M[s], 256); q.tiles_n = ceil_div(N[s], 256);
     q.accumulate = accumulate[s] != 0;
+    if (rowdot != nullptr && rowdot[s] != nullptr) {  // (the side product rides on the full-tile accumulate epilogue)
+      OP_CHECK_ARG(W != nullptr && ldw != nullptr && W[s] != nullptr && q.accumulate && M[s] % 256 == 0 && N[s] % 256 == 0 && ldw[s] % 8 == 0 &&
+                       ((uintptr_t)W[s] & 15) == 0,
+                   "gemm_tn_grouped: problem %d: rowdot needs W (16-byte aligned, ldw %% 8 == 0), accumulate and M, N multiples of 256", s);
+      q.W = (const bf16_t*)W[s]; q.ldw = ldw[s]; q.rowdot = rowdot[s];
+    }
     tiles += (int64_t)q.tiles_m * q.tiles_n;
     work += 2.0 * (double)M[s] * (double)N[s] * (double)K[s];
   }

@@ -40,14 +40,15 @@ SIGNATURES = {
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
     "op_gemm_tn_grouped_counter_bytes": (I64, []),
     "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, I64, I64, P, I64]),
-    "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
+    "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
     "op_transpose_desc_bytes": (I64, []),
     "op_colsum_workspace_bytes": (I64, [I64]),
     "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
     "op_resid_bwd_workspace_bytes": (I64, [I64]),
-    "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, I64, I64, c_int, P]),
+    "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, P, I64, I64, c_int, P]),
+    "op_gamma_grad_finish": (c_int, [P, P, P, P, P, P, P, P, P, I64, c_int, P]),
     "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, P, P, P, I64, I64, c_int, P]),
     "op_ln_geglu_fwd": (c_int, [P, P, I64, P, P, P, P, P, I64, I64, c_float, P]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
@@ -471,8 +472,9 @@ TN_GROUP_MAX = 16
 
 def gemm_tn_grouped(problems, tune=0):
     """ONE persistent launch for up to 16 weight-gradient GEMMs, no split-K (csrc/gemm.hip: gemm256w_tn_grouped_kernel).
-    problems: [(A_km [K, M], B_kn [K, N], out [M, N] bf16, accumulate)].  Returns False (nothing launched) when a problem does not
-    qualify for the transpose-read kernel -- the caller then runs gemm_tn per problem."""
+    problems: [(A_km [K, M], B_kn [K, N], out [M, N] bf16, accumulate[, (W [M, N] bf16, rowdot fp32 [M])])].  Returns False (nothing
+    launched) when a problem does not qualify for the transpose-read kernel -- the caller then runs gemm_tn per problem.
+    (W, rowdot): rowdot[m] += sum_n W[m][n] * (this launch's fp32 product)[m][n] -- see gamma_grad_finish."""
     n = len(problems)
     dev = problems[0][0].device
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
@@ -482,13 +484,18 @@ def gemm_tn_grouped(problems, tune=0):
     arr = lambda vals: (c_int64 * n)(*vals)  # noqa: E731
     As, Bs, Cs = [q[0] for q in problems], [q[1] for q in problems], [q[2] for q in problems]
     acc = (ctypes.c_int32 * n)(*[int(bool(q[3])) for q in problems])
+    side = [q[4] if len(q) > 4 and q[4] is not None else (None, None) for q in problems]
+    Ws, Rs = [w for w, _ in side], [r for _, r in side]
+    has_side = any(r is not None for r in Rs)
     rc = lib().op_gemm_tn_grouped(n, _ptr_array(As, n), arr([a.stride(0) for a in As]), _ptr_array(Bs, n), arr([b.stride(0) for b in Bs]),
                                   _ptr_array(Cs, n), arr([c.stride(0) for c in Cs]), arr([a.shape[1] for a in As]),
-                                  arr([b.shape[1] for b in Bs]), arr([a.shape[0] for a in As]), acc, ptr(ctr), int(tune), stream())
+                                  arr([b.shape[1] for b in Bs]), arr([a.shape[0] for a in As]), acc,
+                                  _ptr_array(Ws, n) if has_side else None, arr([w.stride(0) if w is not None else 0 for w in Ws]) if has_side else None,
+                                  _ptr_array(Rs, n) if has_side else None, ptr(ctr), int(tune), stream())
     if rc == -95:
         return False
     _check(rc, "op_gemm_tn_grouped")
-    for a, b, c, ac in problems:
+    for a, b, c, ac in [q[:4] for q in problems]:
         K, M = a.shape
         GEMM_ALGO_BYTES[0] += 2 * (K * M + K * b.shape[1] + M * b.shape[1] * (2 if ac else 1))
     GEMM_ALGO_BYTES[1] += 1
@@ -547,9 +554,10 @@ def colsum_segments(x, seg_cols, outs=None, accumulate=False):
     return outs
 
 
-def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma=None, dbias=None, accumulate=False):
+def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma=None, dbias=None, accumulate=False, g0=None):
     """dbranch = rowscale*gamma*dout plus the column reductions dgamma / dbias in one pass.  dgamma / dbias: True
-    (allocate), a bf16 [N] tensor (write or, with accumulate, add into it) or None (skip)."""
+    (allocate), a bf16 [N] tensor (write or, with accumulate, add into it) or None (skip).  g0: fp32 [N] that receives
+    sum_m rowscale*dout (dbias without the gamma factor: gamma_grad_finish's operand)."""
     M, N = dout.shape
     out = torch.empty_like(dout)
     if dgamma is True:
@@ -557,11 +565,24 @@ def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma
     if dbias is True:
         dbias = torch.empty(N, dtype=dout.dtype, device=dout.device)
     ws = None
-    if dgamma is not None or dbias is not None:
+    if dgamma is not None or dbias is not None or g0 is not None:
         ws = workspace(lib().op_resid_bwd_workspace_bytes(N), dout.device, "resid")
+    assert g0 is None or (g0.dtype == torch.float32 and g0.is_contiguous() and g0.numel() == N)
     _check(lib().op_resid_bwd(ptr(dout), ptr(y if dgamma is not None else None), ptr(gamma), ptr(rowscale), rows_per_sample,
-                              ptr(out), ptr(dgamma), ptr(dbias), ptr(ws), M, N, int(accumulate), stream()), "op_resid_bwd")
+                              ptr(out), ptr(dgamma), ptr(dbias), ptr(g0), ptr(ws), M, N, int(accumulate), stream()), "op_resid_bwd")
     return out, dgamma, dbias
+
+
+def gamma_grad_finish(rowdot, gamma, pairs, dgamma, accumulate):
+    """dgamma (+)= rowdot / gamma + sum_i b_i * g0_i; rowdot is zeroed (re-armed).  rowdot: fp32 [N], the side product of gemm_tn_grouped
+    over the gamma-scaled gradient; pairs: up to three (bias bf16 [N] or None, g0 fp32 [N])."""
+    assert rowdot.dtype == torch.float32 and len(pairs) <= 3 and dgamma.dtype == torch.bfloat16 and gamma.dtype == torch.bfloat16
+    flat = []
+    for b, g0 in list(pairs) + [(None, None)] * (3 - len(pairs)):
+        flat += [ptr(b), ptr(g0)]
+    _check(lib().op_gamma_grad_finish(ptr(rowdot), ptr(gamma), *flat, ptr(dgamma), rowdot.numel(), int(accumulate), stream()),
+           "op_gamma_grad_finish")
+    return dgamma
 
 
 def ln_geglu_bwd(dy, h0, h1, w, mean, rstd, dw=None, db=None, accumulate=False, need_wgrad=True, dh0=None, dh1=None):

@@ -249,14 +249,15 @@ class _WgradQueue:
     kept alive until the launch is enqueued; the reducer hears about a parameter only after that."""
 
     def __init__(self):
-        self.items, self.done, self.armed, self.epoch = [], [], False, 0
+        self.items, self.done, self.after, self.armed, self.epoch = [], [], [], False, 0
 
     def reset(self):
         """Forget everything a backward pass that raised left behind (the engine does not run queue_callback callbacks then):
         stale operands must not be accumulated into the freshly zeroed gradients of the next step, and the end-of-backward
         safety net has to be registered again.  Called by distributed.FlatParameters.zero_grad / BucketedGradReducer.reset."""
-        self.items, self.done, self.armed = [], [], False
+        self.items, self.done, self.after, self.armed = [], [], [], False
         self.epoch += 1
+        _rowdot_pool.clear()  # (a launch that never ran leaves its side-product buffer un-armed)
 
     @staticmethod
     def _span(out):
@@ -264,15 +265,19 @@ class _WgradQueue:
         lo = out.data_ptr()
         return lo, lo + ((out.shape[0] - 1) * out.stride(0) + out.shape[1]) * out.element_size()
 
-    def add(self, dy, x, out, params):
+    def add(self, dy, x, out, params, side=None, after=None):
+        """side: (W, rowdot) -- the launch also adds sum_n W[m][n] * product[m][n] to rowdot[m] (hip.gemm_tn_grouped);
+        after: called once the launch that holds this problem is enqueued (before the parameters are reported)."""
         lo, hi = self._span(out)
         for it in self.items:  # the grouped launch read-modify-writes C tiles without ordering between problems: two
             l2, h2 = self._span(it[2])  # contributions to one (overlapping) view go out as two launches, stream-ordered
             if lo < h2 and l2 < hi:
                 self.flush()
                 break
-        self.items.append((dy, x, out, True))
+        self.items.append((dy, x, out, True, side))
         self.done.extend(params)
+        if after is not None:
+            self.after.append(after)
         if not self.armed:  # safety net: whatever is still queued when autograd finishes this backward pass goes out then
             self.armed = True
             epoch = self.epoch
@@ -287,12 +292,19 @@ class _WgradQueue:
         self.flush()
 
     def flush(self):
-        items, done = self.items, self.done
-        self.items, self.done = [], []
+        items, done, after = self.items, self.done, self.after
+        self.items, self.done, self.after = [], [], []
         if items:
             if len(items) == 1 or not hip.gemm_tn_grouped(items):  # a lone problem keeps the split-K launch of op_gemm_tn
-                for dy, x, out, _ in items:
-                    hip.gemm_tn(dy, x, out, True)
+                for dy, x, out, _, side in items:
+                    if side is None:
+                        hip.gemm_tn(dy, x, out, True)
+                    else:  # (rare: the side product rides on the grouped launch only) the product once, used twice
+                        prod = hip.gemm_tn(dy, x, None, False)
+                        out.add_(prod)
+                        side[1].add_((side[0].detach().float() * prod.float()).sum(1))
+        for f in after:
+            f()
         for q in done:
             _direct_grad_done(q)
 
@@ -300,18 +312,61 @@ class _WgradQueue:
 _wgrad_queue = _WgradQueue()
 
 
-def wgrad_into(dy, x, grad_view, params):
-    """grad_view (+)= dy^T x for the flat-buffer gradient views of `params` (one view spanning all of them).  Deferred into the
-    layer's grouped launch when the shape allows, else launched now; either way every parameter's completion is signalled."""
-    K, M = dy.shape
-    if (GROUPED_WGRAD and USE_TN_WGRAD and K % 64 == 0 and K >= 64 and grad_view.stride(0) % 8 == 0 and grad_view.stride(1) == 1
+def _wgrad_queueable(K, M, N, ldy, ldx, grad_view):
+    return (GROUPED_WGRAD and USE_TN_WGRAD and K % 64 == 0 and K >= 64 and grad_view.stride(0) % 8 == 0 and grad_view.stride(1) == 1
             and grad_view.data_ptr() % 16 == 0  # op_gemm_tn_grouped's rule for C: ldc % 8 == 0, 16-byte aligned (else launch now)
-            and hip.gemm_tn_supported(K, M, x.shape[1], dy.stride(0), x.stride(0))):
-        _wgrad_queue.add(dy, x, grad_view, params)
+            and hip.gemm_tn_supported(K, M, N, ldy, ldx))
+
+
+def wgrad_into(dy, x, grad_view, params, side=None, after=None):
+    """grad_view (+)= dy^T x for the flat-buffer gradient views of `params` (one view spanning all of them).  Deferred into the
+    layer's grouped launch when the shape allows, else launched now; either way every parameter's completion is signalled.
+    side / after: see _WgradQueue.add (the caller has checked dgamma_from_wgrad_ok: the problem IS queueable)."""
+    K, M = dy.shape
+    if _wgrad_queueable(K, M, x.shape[1], dy.stride(0), x.stride(0), grad_view):
+        _wgrad_queue.add(dy, x, grad_view, params, side, after)
         return
+    assert side is None and after is None, "wgrad_into: a side product was promised for a problem the grouped launch does not take"
     wgrad(dy, x, out=grad_view, accumulate=True)
     for q in params:
         _direct_grad_done(q)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# layer-scale gradient without the branch output (round 5)
+# --------------------------------------------------------------------------------------------------------------
+# out = resid + ps * gamma * y with y = x W^T + b (transformer_layer.py:70-88).  dgamma[n] = sum_m ps dout[m][n] y[m][n] needs y in
+# backward -- a second output of the residual GEMM (its epilogue then moves three times the bytes of a plain launch) that is kept for
+# backward (2 H bytes per token and branch) and read again by op_resid_bwd.  But
+#     dgamma[n] = sum_k W[n][k] * G[n][k] + b[n] * g0[n],     G = (ps dout)^T x,   g0 = sum_m ps dout,
+# and the weight gradient the step computes anyway is dW = gamma[n] * G (its operand is the gamma-scaled gradient): the grouped
+# weight-gradient launch adds sum_k W * dW (its fp32 accumulators, before they are rounded into the bf16 gradient) to a row vector,
+# op_resid_bwd hands out g0, op_gamma_grad_finish divides by gamma.  y is then neither written nor kept nor read.
+DGAMMA_FROM_WGRAD = os.environ.get("ONEPEACE_DGAMMA_FROM_WGRAD", "1") != "0"
+_rowdot_pool = {}
+
+
+def _rowdot_take(device, n):
+    """A zeroed fp32 [n] buffer; op_gamma_grad_finish re-arms (zeroes) it, after which _rowdot_give returns it to the pool."""
+    pool = _rowdot_pool.setdefault((device, n, torch.cuda.current_stream(device).cuda_stream), [])
+    return pool.pop() if pool else torch.zeros(n, dtype=torch.float32, device=device)
+
+
+def _rowdot_give(buf):
+    _rowdot_pool.setdefault((buf.device, buf.numel(), torch.cuda.current_stream(buf.device).cuda_stream), []).append(buf)
+
+
+def dgamma_from_wgrad_ok(rows, gamma, weights, biases, needs_g, needs_w):  # rows: per weight, the token rows of its gradient GEMM
+    """Forward-time decision (it fixes whether the branch output is written at all): gamma and every last-Linear weight / bias of the
+    branch accumulate in place in the flat gradient buffer, all of them want a gradient, and the weight gradients will ride on the
+    grouped launch with full 256 x 256 tiles."""
+    if not (DGAMMA_FROM_WGRAD and needs_g and all(needs_w) and gamma is not None and _direct_grad(gamma) and gamma.dtype == torch.bfloat16):
+        return False
+    for k, w in zip(rows, weights):
+        if not (_direct_grad(w) and w.is_contiguous() and w.shape[0] % 256 == 0 and w.shape[1] % 256 == 0 and w.data_ptr() % 16 == 0
+                and _wgrad_queueable(k, w.shape[0], w.shape[1], w.shape[0], w.shape[1], w.grad)):
+            return False
+    return all(b is None or _direct_grad(b) for b in biases)
 
 
 def flush_wgrads():
@@ -745,15 +800,17 @@ def _return_grads(names, params, G, direct):
     return out
 
 
-def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs):
+def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs, g0=None):
     """Gradient of  resid + ps * gamma * (y)  w.r.t. the branch output and -- where they are wanted -- gamma and the last
-    Linear's bias, in one pass."""
-    names = tuple(n for n, present in ((gname, gamma is not None), (bname, True)) if present and needs.get(n))
+    Linear's bias, in one pass.  g0 (fp32 [H]): gamma's gradient is NOT taken here (no y: dgamma_from_wgrad_ok); the kernel fills g0
+    with sum_m ps * dout for op_gamma_grad_finish instead."""
+    names = tuple(n for n, present in ((gname, gamma is not None and g0 is None), (bname, True)) if present and needs.get(n))
     tgt, acc = _targets(direct, *names) if names else ([], False)
     t = dict(zip(names, tgt))
     dgamma = (t[gname] if acc else True) if gname in t else None
     dbias = (t[bname] if acc else True) if bname in t else None
-    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc)
+    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc,
+                               g0=g0 if torch.is_tensor(g0) else None)  # (g0 = False: fused mode for a Linear without bias)
     _finish(direct, G, names, tuple({gname: dg, bname: db}[n] for n in names), acc)
     return dy
 
@@ -781,13 +838,25 @@ def _span(direct, order):
 def _weight_grad_fn(ctx, G):
     direct = dict(ctx.direct)
 
-    def weight_grad(name, dyv, xv):
+    def weight_grad(name, dyv, xv, side=None, after=None):
         target = direct.get(name)
         if target is not None:
-            wgrad_into(dyv, xv, target.grad, (target,))
+            wgrad_into(dyv, xv, target.grad, (target,), side, after)
         else:
+            assert side is None and after is None
             G[name] = wgrad(dyv, xv)
     return weight_grad, direct
+
+
+def _gamma_finish_hook(rowdot, gamma_param, pairs, done):
+    """After the grouped launch: dgamma += rowdot / gamma + sum b_i g0_i into gamma's flat gradient view; the buffer goes back to the pool
+    and gamma's in-place contribution is reported (the reducer may all-reduce its bucket)."""
+    def run():
+        hip.gamma_grad_finish(rowdot, gamma_param.detach(), pairs, gamma_param.grad, True)
+        _rowdot_give(rowdot)
+        if done:
+            _direct_grad_done(gamma_param)
+    return run
 
 
 def _save(ctx, keep, acts, *tensors):
@@ -828,7 +897,9 @@ class AttnBranchFn(torch.autograd.Function):
             x2 = hip.rows_gather(x_full, kept)
         N, H = x2.shape
         scale = (H // heads) ** -0.5
-        x_mid, acts = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"])
+        # gamma_1's gradient from the out-proj weight gradient instead of from the branch output (then y1 is never written)
+        ctx.dg_fused = need_grad and dgamma_from_wgrad_ok([N], P["g1"], [P["wo"]], [P["bo"]], needs["g1"], [needs["wo"]])
+        x_mid, acts = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"] and not ctx.dg_fused)
         if kept is not None:
             x_mid = hip.rows_merge(x_full, x_mid, kept)
         ctx.kept = kept
@@ -870,7 +941,7 @@ class AttnBranchFn(torch.autograd.Function):
                 if needs["wo"] and P["aln_w"] is not None:
                     A["aln"] = hip.layernorm_fwd(A["attn"], P["aln_w"], P["aln_b"])[0]
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True)
+            _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True, want_y=not ctx.dg_fused)
         if not dx_mid.is_contiguous():
             dx_mid = dx_mid.contiguous()
         kept, dx_full = ctx.kept, dx_mid
@@ -878,9 +949,16 @@ class AttnBranchFn(torch.autograd.Function):
             dx_mid = hip.rows_gather(dx_full, kept)
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs)
-        if needs["wo"]:
-            weight_grad("wo", dy1, A["aln"])
+        if ctx.dg_fused:
+            g0 = torch.empty(H, dtype=torch.float32, device=dx_mid.device) if P["bo"] is not None else None
+            dy1 = _resid_backward(dx_mid, None, P["g1"], rowscale, rps, "g1", "bo", direct, G, needs, g0=g0 if g0 is not None else False)
+            rowdot = _rowdot_take(dx_mid.device, H)
+            weight_grad("wo", dy1, A["aln"], side=(P["wo"], rowdot),
+                        after=_gamma_finish_hook(rowdot, direct["g1"], [(P["bo"], g0)] if g0 is not None else [], True))
+        else:
+            dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs)
+            if needs["wo"]:
+                weight_grad("wo", dy1, A["aln"])
         upstream = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b")
         dx = None
         if need_x or any(want_dbias) or any(needs[n] for n in upstream):
@@ -969,7 +1047,8 @@ class FfnBranchFn(torch.autograd.Function):
         keep = bool(int(save_acts) & 1) and need_grad
         needs = dict(zip(FFN_PARAMS, ctx.needs_input_grad[3:]))
         # (needs_input_grad is also set inside torch.no_grad() -- the teacher passes of a trainable model: only the flag says "recording")
-        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"], grad=bool(int(save_acts) & 2))
+        ctx.dg_fused = need_grad and dgamma_from_wgrad_ok([B * S], P["g2"], [P["w2"]], [P["b2"]], needs["g2"], [needs["w2"]])
+        out, acts = _ffn_forward(x2, P, S, ps, keep, want_y=needs["g2"] and not ctx.dg_fused, grad=bool(int(save_acts) & 2))
         ctx.dims, ctx.n_params = (B, S, H), len(params)
         ctx.direct = ()
         if need_grad:
@@ -1003,7 +1082,7 @@ class FfnBranchFn(torch.autograd.Function):
                 if needs["w2"] and A["gln"] is None:
                     A["gln"] = hip.ln_geglu_fwd(A["h0"], A["h1"], P["fln_w"], P["fln_b"])[0]
         else:
-            _, A = _ffn_forward(x_mid, P, S, ps, True)
+            _, A = _ffn_forward(x_mid, P, S, ps, True, want_y=not ctx.dg_fused)
         N = B * S
         Fd = P["w0"].shape[0]
         dout2 = dout.reshape(N, H)
@@ -1011,9 +1090,16 @@ class FfnBranchFn(torch.autograd.Function):
             dout2 = dout2.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        dy2 = _resid_backward(dout2, A["y2"], P["g2"], ps, S, "g2", "b2", direct, G, needs)
-        if needs["w2"]:
-            weight_grad("w2", dy2, A["gln"])
+        if ctx.dg_fused:
+            g0 = torch.empty(H, dtype=torch.float32, device=dout2.device) if P["b2"] is not None else None
+            dy2 = _resid_backward(dout2, None, P["g2"], ps, S, "g2", "b2", direct, G, needs, g0=g0 if g0 is not None else False)
+            rowdot = _rowdot_take(dout2.device, H)
+            weight_grad("w2", dy2, A["gln"], side=(P["w2"], rowdot),
+                        after=_gamma_finish_hook(rowdot, direct["g2"], [(P["b2"], g0)] if g0 is not None else [], True))
+        else:
+            dy2 = _resid_backward(dout2, A["y2"], P["g2"], ps, S, "g2", "b2", direct, G, needs)
+            if needs["w2"]:
+                weight_grad("w2", dy2, A["gln"])
         dx = None
         if need_x or any(needs[n] for n in ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b")):
             dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
@@ -1146,7 +1232,10 @@ class FfnBranchMultiFn(torch.autograd.Function):
         if kept is not None:  # the branch runs on the rows of the samples it keeps (segs / pss describe THOSE rows)
             x2 = hip.rows_gather(x_full, kept)
         N, H = x2.shape
-        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]), grad=bool(int(save_acts) & 2))
+        w2s, b2s = [params[3 + 6 * i + 4] for i in range(nseg)], [params[3 + 6 * i + 5] for i in range(nseg)]
+        ctx.dg_fused = need_grad and dgamma_from_wgrad_ok([sg.rows for sg in segs], params[2], w2s, b2s, bool(needs[2]),
+                                                           [bool(needs[3 + 6 * i + 4]) for i in range(nseg)])
+        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]) and not ctx.dg_fused, grad=bool(int(save_acts) & 2))
         if kept is not None:
             out = hip.rows_merge(x_full, out, kept)
         ctx.kept = kept
@@ -1193,7 +1282,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
                         r = slice(sg.row0, sg.end)
                         hip.ln_geglu_fwd(A["h0"][r], A["h1"][r], P["fln_w@%d" % i], P["fln_b@%d" % i], out=A["gln"][r], want_stats=False)
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, True)
+            _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, not ctx.dg_fused)
         if not dout.is_contiguous():
             dout = dout.contiguous()
         kept, dout_full = ctx.kept, dout
@@ -1208,19 +1297,25 @@ class FfnBranchMultiFn(torch.autograd.Function):
         dh = torch.empty(N, 2 * Fd, dtype=dt, device=dev) if upstream else None
         dgln = torch.empty(N, Fd, dtype=dt, device=dev) if upstream else None
         colsets, dg_tmp = [], None
+        fused = ctx.dg_fused  # gamma_2's gradient from the three down-projection weight gradients (no y2: dgamma_from_wgrad_ok)
+        rowdot, pairs = (_rowdot_take(dev, H), []) if fused else (None, None)
         for i, sg in enumerate(segs):
             r = slice(sg.row0, sg.end)
             k = lambda n: "%s@%d" % (n, i)  # noqa: E731
             # residual branch: gamma_2 is shared (its gradient accumulates over the segments), the bias is the modality's own
-            want_g, want_b = needs["g2"], needs[k("b2")]
+            want_g, want_b = needs["g2"] and not fused, needs[k("b2")]
             acc_g, acc_b = "g2" in direct, k("b2") in direct
             tg = direct["g2"].grad if acc_g else (True if want_g else None)
             tb = direct[k("b2")].grad if acc_b else (True if want_b else None)
             if want_g and want_b and acc_g != acc_b:  # one in the flat buffer, one not: two temporaries, folded below
                 tg = tb = True
                 acc_g = acc_b = False
+            g0 = None
+            if fused and P[k("b2")] is not None:
+                g0 = torch.empty(H, dtype=torch.float32, device=dev)
+                pairs.append((P[k("b2")], g0))
             dy2, dg_, db_ = hip.resid_bwd(dout[r], A["y2"][r] if want_g else None, P["g2"], pss[i], sg.S, dgamma=tg if want_g else None,
-                                          dbias=tb if want_b else None, accumulate=(acc_g and want_g) or (acc_b and want_b))
+                                          dbias=tb if want_b else None, accumulate=(acc_g and want_g) or (acc_b and want_b), g0=g0)
             if want_g and not acc_g:
                 dg_tmp = dg_.float() if dg_tmp is None else dg_tmp + dg_.float()
             if want_b:
@@ -1228,7 +1323,10 @@ class FfnBranchMultiFn(torch.autograd.Function):
                     _direct_grad_done(direct[k("b2")])
                 else:
                     G[k("b2")] = db_
-            if needs[k("w2")]:
+            if fused:  # (the hook rides on the last segment's problem: by then every (bias, g0) pair is listed)
+                weight_grad(k("w2"), dy2, A["gln"][r], side=(P[k("w2")], rowdot),
+                            after=_gamma_finish_hook(rowdot, direct["g2"], pairs, True) if i == nseg - 1 else None)
+            elif needs[k("w2")]:
                 weight_grad(k("w2"), dy2, A["gln"][r])
             if not upstream:
                 colsets.append(None)
@@ -1256,7 +1354,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 for n in pair:
                     if needs[n]:
                         weight_grad(n, dpart[n], A["xln2"][r])
-        if needs["g2"]:
+        if needs["g2"] and not fused:
             if "g2" in direct and dg_tmp is None:
                 _direct_grad_done(direct["g2"])
             else:

@@ -1035,6 +1035,74 @@ def test_fused_encoder_returns_all_hiddens_and_honours_layerdrop():
         TL.TransformerEncoderLayer.forward_fused = orig_fused
 
 
+@pytest.mark.parametrize("lock,recompute", [(False, False), (True, False), (True, True)])
+def test_layer_scale_gradient_from_the_weight_gradient_matches_the_branch_output_form(lock, recompute):
+    """ops.dgamma_from_wgrad_ok (round 5): with flat gradients and whole 256 x 256 weight-gradient tiles the residual GEMMs write no
+    branch output y; gamma_1 / gamma_2 get their gradient from the out-proj / down-projection weight gradients (row dot of W with the
+    launch's fp32 product, / gamma, + bias * g0).  Against the y form of the same code (ONEPEACE_DGAMMA_FROM_WGRAD=0): the loss and every
+    other gradient bit-identical (nothing else changes), the gammas within bf16 rounding, less memory held; and the gammas of BOTH
+    forms against the plain-autograd (non-flat) run."""
+    from one_peace_amd import ops
+    from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from tests.model_util import TinyDictionary
+    from types import SimpleNamespace
+    cfg = dict(embed_dim=256, ffn_embed_dim=512, layers=3, attention_heads=4, image_rel_bucket_size=4, text_bucket_size=256,
+               audio_bucket_size=512)
+    B = 64  # every stream's row count (and their sum) a multiple of 64: the weight gradients ride on the grouped launch
+    inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    res = {}
+    old = ops.DGAMMA_FROM_WGRAD
+    fused_seen = {"n": 0}
+    orig_ok = ops.dgamma_from_wgrad_ok
+
+    def counted_ok(*a, **k):
+        r = orig_ok(*a, **k)
+        fused_seen["n"] += int(bool(r))
+        return r
+    ops.dgamma_from_wgrad_ok = counted_ok
+    try:
+        for mode in ("autograd", "y", "wgrad"):
+            ops.DGAMMA_FROM_WGRAD = mode == "wgrad"
+            enc = one_peace_encoder_config(drop_path_rate=0.0, layer_scale_init_value=1e-1, checkpoint_activations=recompute, **cfg)
+            torch.manual_seed(0)
+            m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+            m = m.to(DEV).to(torch.bfloat16).train()
+            fl = FlatParameters(m) if mode != "autograd" else None
+            (fl or m).zero_grad()
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            fused_seen["n"] = 0
+            loss, _, _ = TriModalContrastiveCriterion(None, 0.0, lock_step=lock)(m, {"net_input": inp, "nsentences": B})
+            torch.cuda.synchronize()
+            held = torch.cuda.memory_allocated() - base
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (float(loss.detach()), held, fused_seen["n"],
+                         {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+            del m, fl, loss
+    finally:
+        ops.DGAMMA_FROM_WGRAD = old
+        ops.dgamma_from_wgrad_ok = orig_ok
+    assert res["wgrad"][2] >= 6 and res["y"][2] == 0, (res["wgrad"][2], res["y"][2])  # every branch of every layer took the new form
+    assert res["wgrad"][0] == res["y"][0]
+    n_gamma = 0
+    for n, g in res["y"][3].items():
+        gw = res["wgrad"][3][n]
+        if n.endswith("gamma_1") or n.endswith("gamma_2"):
+            n_gamma += 1
+            ga = res["autograd"][3][n]
+            assert rel_fro(gw, ga) <= 2e-2 and rel_fro(g, ga) <= 2e-2, (n, rel_fro(gw, ga), rel_fro(g, ga))
+            assert rel_fro(gw, g) <= 2e-2, (n, rel_fro(gw, g))
+        else:
+            assert torch.equal(gw, g), (n, float((gw - g).abs().max()))
+    assert n_gamma == 6
+    if not recompute:
+        assert res["wgrad"][1] < res["y"][1], (res["wgrad"][1], res["y"][1])  # 4 H of the 46 H bytes per token and layer are not kept
+
+
 @pytest.mark.parametrize("lock", [False, True])
 def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock):
     """ops.set_recompute_cheap: the memory level between "keep everything" and checkpoint_activations -- the four

@@ -1098,6 +1098,77 @@ def test_gemm_tn_grouped_is_bit_identical_to_unsplit_launches(name, nwg):
             assert_close(out, r, what="grouped dW")
 
 
+@pytest.mark.parametrize("nwg", [0, 5])
+def test_gemm_tn_grouped_row_dot_side_product(nwg):
+    """(ABI 7) op_gemm_tn_grouped with W / rowdot on some problems: rowdot[m] += sum_n W[m][n] * P[m][n] with P = THIS launch's fp32
+    product A^T B (not the accumulated gradient), added on top of what the buffer holds; the gradients themselves must stay bit-identical
+    to a launch without the side product, and a problem without one is untouched.  (With A = gamma-scaled gradient of a residual branch
+    this is gamma * sum_rows ps dout y-without-bias: ops.dgamma_from_wgrad_ok, transformer_layer.py:70-88.)"""
+    hip = hipmod()
+    sizes = [(1024, 256, 512, True), (2048, 512, 256, True), (512, 256, 256, True)]
+    with_side = (True, False, True)
+    probs, plain, refs, rowdots = [], [], [], []
+    for i, (K, M, N, acc) in enumerate(sizes):
+        dy, x, base, w = rnd(K, M, seed=10 + i, scale=0.5), rnd(K, N, seed=40 + i, scale=0.5), rnd(M, N, seed=70 + i), rnd(M, N, seed=90 + i)
+        a, b = dev_bf16(dy), dev_bf16(x)
+        out = dev_bf16(base).clone()
+        wd = dev_bf16(w)
+        rd = torch.full((M,), 0.25, dtype=torch.float32, device=DEV) if with_side[i] else None
+        probs.append((a, b, out, acc, (wd, rd) if with_side[i] else None))
+        plain.append((a, b, dev_bf16(base).clone(), acc))
+        prod = a.float().t() @ b.float()
+        refs.append(0.25 + (wd.float() * prod).sum(1))
+        rowdots.append(rd)
+    assert hip.gemm_tn_grouped(plain, tune=nwg)
+    assert hip.gemm_tn_grouped(probs, tune=nwg)
+    torch.cuda.synchronize()
+    for q, q0, ref, rd in zip(probs, plain, refs, rowdots):
+        assert torch.equal(q[2], q0[2]), "the side product changed the gradient"
+        if rd is not None:
+            err = float((rd - ref).abs().max()) / float(ref.abs().max())
+            assert err < 2e-3, err
+    with pytest.raises(RuntimeError):  # ragged M: the side product rides on full tiles only
+        bad = (dev_bf16(rnd(128, 264)), dev_bf16(rnd(128, 256)), dev_bf16(rnd(264, 256)), True,
+               (dev_bf16(rnd(264, 256)), torch.zeros(264, dtype=torch.float32, device=DEV)))
+        hip.gemm_tn_grouped([bad, bad[:4]])
+
+
+def test_resid_bwd_g0_and_gamma_grad_finish():
+    """(ABI 7) The layer-scale gradient without the branch output: for out = resid + ps * gamma * (x W^T + b),
+    dgamma[n] = sum_k W[n][k] G[n][k] + b[n] g0[n] with G = (ps dout)^T x and g0 = sum_m ps dout -- op_resid_bwd hands out g0, the
+    grouped weight-gradient launch the row dot of W with dW = gamma * G, op_gamma_grad_finish divides by gamma and re-arms the buffer.
+    Against the definition sum_m ps dout y in fp32; gamma == 0 drops the row-dot term."""
+    hip = hipmod()
+    M, N, K, rps = 1024, 256, 512, 64
+    dout, x, w, b = rnd(M, N, seed=1), rnd(M, K, seed=2, scale=0.5), rnd(N, K, seed=3, scale=0.2), rnd(N, seed=4)
+    gamma = (0.5 + rnd(N, seed=5).abs()).clamp(max=2.0)
+    gamma[7] = 0.0
+    ps = (torch.arange(M // rps) % 3 != 0).float() / 0.75
+    d_, x_, w_, b_, g_ = dev_bf16(dout), dev_bf16(x), dev_bf16(w), dev_bf16(b), dev_bf16(gamma)
+    g0 = torch.empty(N, dtype=torch.float32, device=DEV)
+    dbias = torch.zeros(N, dtype=torch.bfloat16, device=DEV)
+    dy, dg, db = hip.resid_bwd(d_, None, g_, ps.to(DEV), rps, dgamma=None, dbias=dbias, accumulate=True, g0=g0)
+    assert dg is None
+    rows = ps.repeat_interleave(rps)[:, None].to(DEV)
+    dq = d_.float() * rows
+    assert_close(g0, dq.sum(0).cpu(), what="g0")
+    assert_close(db, (dq * g_.float()).sum(0).cpu(), what="dbias")
+    rowdot = torch.zeros(N, dtype=torch.float32, device=DEV)
+    dW = torch.zeros(N, K, dtype=torch.bfloat16, device=DEV)
+    other = (dev_bf16(rnd(256, 256, seed=8)), dev_bf16(rnd(256, 256, seed=9)), torch.zeros(256, 256, dtype=torch.bfloat16, device=DEV), True)
+    assert hip.gemm_tn_grouped([(dy, x_, dW, True, (w_, rowdot)), other])
+    base = dev_bf16(rnd(N, seed=6))
+    dgamma = base.clone()
+    hip.gamma_grad_finish(rowdot, g_, [(b_, g0)], dgamma, True)
+    torch.cuda.synchronize()
+    y = x_.float() @ w_.float().t() + b_.float()
+    ref = (dq * y).sum(0)
+    ref[7] = (b_.float() * g0)[7]  # gamma == 0: only the bias term survives (y is not recoverable from a zero-scaled gradient)
+    ref = ref + base.float()
+    assert_close(dgamma, ref.cpu(), what="dgamma from the weight gradient")
+    assert float(rowdot.abs().max()) == 0.0  # re-armed
+
+
 def test_gemm_tn_grouped_rejects_what_the_kernel_cannot_take():
     hip = hipmod()
     ok = (dev_bf16(rnd(128, 64)), dev_bf16(rnd(128, 64)), dev_bf16(rnd(64, 64)), False)

@@ -255,9 +255,10 @@ class _WgradQueue:
         """Forget everything a backward pass that raised left behind (the engine does not run queue_callback callbacks then):
         stale operands must not be accumulated into the freshly zeroed gradients of the next step, and the end-of-backward
         safety net has to be registered again.  Called by distributed.FlatParameters.zero_grad / BucketedGradReducer.reset."""
+        if self.items or self.after:  # a launch that never ran leaves its side-product buffers un-armed (dirty or never returned)
+            _rowdot_pool.clear()
         self.items, self.done, self.after, self.armed = [], [], [], False
         self.epoch += 1
-        _rowdot_pool.clear()  # (a launch that never ran leaves its side-product buffer un-armed)
 
     @staticmethod
     def _span(out):

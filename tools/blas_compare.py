@@ -50,8 +50,12 @@ case("qkv  M=73216 N=4608 K=1536 (bias q, v)", 2.0 * MALL * 3 * H * H, lambda: h
      lambda: torch.matmul(x, wcat.t(), out=o_q))
 res, y, b2, gamma = rnd(MALL, H), torch.empty(MALL, H, **bf), rnd(H), rnd(H)
 ps = torch.rand(MALL // 257 + 2, device="cuda")
-case("out-proj + residual M=73216 N=1536 K=1536", 2.0 * MALL * H * H,
-     lambda: hip.gemm_nt(x, [wq[0]], [b2], epilogue=hip.EPI_RESID, resid=res, gamma=gamma, rowscale=ps, rows_per_sample=257, h0=y, out=o_h),
+# Y2 = 1: with the second output y (what training launched until round 5; since then dgamma comes from the weight gradient and the training
+# launch writes ONE output -- ops.dgamma_from_wgrad_ok)
+Y2 = os.environ.get("Y2", "0") == "1"
+case("out-proj + residual%s M=73216 N=1536 K=1536" % (" + y" if Y2 else ""), 2.0 * MALL * H * H,
+     lambda: hip.gemm_nt(x, [wq[0]], [b2], epilogue=hip.EPI_RESID, resid=res, gamma=gamma, rowscale=ps, rows_per_sample=257, h0=y if Y2 else None,
+                         out=o_h),
      lambda: torch.matmul(x, wq[0].t(), out=o_h))
 x3, w3t = rnd(MALL, 3 * H), rnd(H, 3 * H, scale=0.02)
 case("dgrad q|k|v  M=73216 N=1536 K=4608", 2.0 * MALL * H * 3 * H, lambda: hip.gemm_nt(x3, [w3t], out=o_h, splitk=False),
@@ -74,8 +78,9 @@ for M, tag in ((MI, "image"), (MA, "audio")):
     o_ff, o_f, o_m = torch.empty(M, 2 * F, **bf), torch.empty(M, F, **bf), torch.empty(M, H, **bf)
     case("%s up-projection wi_0|wi_1 M=%d N=12288 K=1536" % (tag, M), 4.0 * M * F * H, lambda: hip.gemm_nt(xm, [w0, w1], n_seg=F, N=2 * F, out=o_ff),
          lambda: torch.matmul(xm, w01.t(), out=o_ff))
-    case("%s down-proj + residual M=%d N=1536 K=6144" % (tag, M), 2.0 * M * H * F,
-         lambda: hip.gemm_nt(xf, [w2], [b2], epilogue=hip.EPI_RESID, resid=res[:M], gamma=gamma, rowscale=ps, rows_per_sample=257, h0=y[:M], out=o_m),
+    case("%s down-proj + residual%s M=%d N=1536 K=6144" % (tag, " + y" if Y2 else "", M), 2.0 * M * H * F,
+         lambda: hip.gemm_nt(xf, [w2], [b2], epilogue=hip.EPI_RESID, resid=res[:M], gamma=gamma, rowscale=ps, rows_per_sample=257,
+                             h0=y[:M] if Y2 else None, out=o_m),
          lambda: torch.matmul(xf, w2.t(), out=o_m))
     case("%s dgrad down-proj M=%d N=6144 K=1536" % (tag, M), 2.0 * M * F * H, lambda: hip.gemm_nt(xm, [w2t], out=o_f, splitk=False),
          lambda: torch.matmul(xm, w2t.t(), out=o_f))

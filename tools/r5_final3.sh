@@ -12,7 +12,8 @@ for c in 1 2 4; do
 done
 timeout 500 python bench.py --config 4 --fp8 --steps 8 --warmup 3 --no-cpu-baseline --no-power-probe --no-skip-leg > $O/bench_config4_fp8.txt 2> $O/bench_config4_fp8.err
 tail -1 $O/bench_config4_fp8.txt | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print('config 4 fp8', d['ms_per_step'], d['value'], r.get('fp8_gemm'), d['config'].get('final_loss'))" || tail -5 $O/bench_config4_fp8.err
-ITERS=30 ROUNDS=3 timeout 400 python tools/blas_compare.py > $O/blas_compare.txt 2>&1; tail -4 $O/blas_compare.txt
+ITERS=30 ROUNDS=3 timeout 400 python tools/blas_compare.py > $O/blas_compare.txt 2>&1; grep -v amdgpu.ids $O/blas_compare.txt | tail -22
+Y2=1 ITERS=30 ROUNDS=3 timeout 400 python tools/blas_compare.py 2>&1 | grep "residual" > $O/blas_compare_with_y.txt; cat $O/blas_compare_with_y.txt
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof_r5f
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r5f -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-power-probe --no-skip-leg > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err

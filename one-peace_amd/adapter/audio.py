@@ -171,7 +171,7 @@ class AudioAdapter(nn.Module):
                 frames = common.take_rows(frames, ids[:, 1:] - 1)
                 biases = common.take_bias(biases, ids, bsz)
             pos = torch.cat([self.cls_pos_embed.expand(bsz, -1, -1), self._positions(frames)], dim=1)
-            emb = torch.cat([self.cls_embedding.expand(bsz, -1, -1), frames], dim=1)
+            emb = common.prepend_token(self.cls_embedding, frames)
             if self.layernorm_embedding is not None:
                 emb = self.layernorm_embedding(emb)
             if self.alpha != 1.0:

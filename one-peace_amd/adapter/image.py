@@ -116,7 +116,7 @@ class ImageAdapter(nn.Module):
         if preserve_embed is not None:
             emb = common.scatter_preserved(preserve_ids, preserve_embed, mask_token, bsz, n)
         else:
-            emb = torch.cat([self.cls_embedding.expand(bsz, -1, -1).to(src_images.dtype), self._stem(src_images)], dim=1)
+            emb = common.prepend_token(self.cls_embedding, self._stem(src_images))
             if preserve_ids is not None:
                 padding_mask = preserve_ids.eq(-1)
                 ids = preserve_ids.masked_fill(padding_mask, preserve_ids.size(1) - 1)

@@ -51,7 +51,7 @@ class TextAdapter(nn.Module):
         if preserve_embed is not None:
             emb = common.scatter_preserved(preserve_ids, preserve_embed, mask_token, bsz, n)
         else:
-            emb = torch.cat([self.cls_embedding.expand(bsz, -1, -1), self.embed_tokens(src_tokens)], dim=1)
+            emb = common.prepend_token(self.cls_embedding, self.embed_tokens(src_tokens))
             if preserve_ids is not None:
                 padding_mask = preserve_ids.eq(-1)
                 ids = preserve_ids.masked_fill(padding_mask, preserve_ids.size(1) - 1)

@@ -1030,8 +1030,15 @@ class AttnBranchFn(torch.autograd.Function):
         grads = _return_grads(ATTN_PARAMS, params, G, direct)
         dimgs = []
         for sg, w in zip(segs, want_dbias):  # placeholders (see _RelPosImageFn.backward); the real gradients went into bias.acc
-            img = sg.bias.image if sg.bias is not None else None
-            dimgs.append(torch.zeros((), dtype=img.dtype, device=img.device).expand(img.shape) if w else None)
+            # ONE placeholder per handle and backward pass: the engine counts the image node's dependencies by graph edges (an undefined
+            # gradient still decrements them), so the node runs after every consuming layer either way -- forty placeholders made autograd
+            # materialise and add forty [heads, S, Spad] zero images per stream and step (3 fills + 3 adds per layer in the step trace)
+            if w and not getattr(sg.bias, "_grad_routed", False):
+                sg.bias._grad_routed = True
+                img = sg.bias.image
+                dimgs.append(torch.zeros((), dtype=img.dtype, device=img.device).expand(img.shape))
+            else:
+                dimgs.append(None)
         return (dx, None, None, None, None, None, None, *dimgs, *grads)
 
 

@@ -208,7 +208,11 @@ class TransformerEncoder(nn.Module):
             per_layer.append(handles)
             row0 += B * S
             samples += B
-        x2 = torch.cat(xs, dim=0)
+        x2 = xs[0].new_empty(row0, xs[0].shape[1])  # (slice copies, not torch.cat: see adapter.common.prepend_token)
+        r = 0
+        for xi in xs:
+            x2[r:r + xi.shape[0]] = xi
+            r += xi.shape[0]
         dev = x2.device
         packable = all(getattr(h, "ids", None) is None and not isinstance(h, ops.DenseBias) for hs in per_layer for h in hs)
         if self.skip_dropped_branches and packable:

@@ -1096,6 +1096,8 @@ def test_layer_scale_gradient_from_the_weight_gradient_matches_the_branch_output
             ga = res["autograd"][3][n]
             assert rel_fro(gw, ga) <= 2e-2 and rel_fro(g, ga) <= 2e-2, (n, rel_fro(gw, ga), rel_fro(g, ga))
             assert rel_fro(gw, g) <= 2e-2, (n, rel_fro(gw, g))
+        elif "rel_pos_table" in n:  # (their fold adds ten million bias-gradient entries onto a few thousand table rows with fp32 atomics:
+            assert rel_fro(gw, g) <= 1e-3, (n, rel_fro(gw, g))  # the last bit of an entry can differ from run to run)
         else:
             assert torch.equal(gw, g), (n, float((gw - g).abs().max()))
     assert n_gamma == 6

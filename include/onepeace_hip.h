@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -88,6 +88,12 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
                        const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
                        const void* const* resid, int64_t ldr, const void* const* gamma, const float* const* rowscale,
                        const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream);
+/* (ABI 7) `batch` equally shaped products  C_z[M,N] = A_z[M,K] W_z[N,K]^T (+ bias_z[N])  with operands at constant element strides as ONE
+ * launch (blockIdx.z = z; 128 x 128 tiles, no split-K): the per-group GEMMs of the audio adapter's grouped positional Conv1d over
+ * strided patch views (one_peace/models/adapter/audio.py:57-84; each group alone fills half the chip).  bias nullable. */
+int op_gemm_nt_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldb, int64_t stride_b, const void* bias,
+                       int64_t stride_bias, void* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K, int64_t batch,
+                       void* stream);
 /* Grouped form of op_gemm_tn: up to 16 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  with their own operands,
  * sizes, K_i and outputs as ONE persistent launch WITHOUT split-K: the tile list of all problems is walked by one workgroup per
  * CU (per-XCD queues of WAVES -- as many consecutive tiles of a problem's tile rectangle as the XCD has workgroups, all of one K, so

@@ -123,6 +123,9 @@ class GroupedConv1dSameFn(torch.autograd.Function):
         xg = torch.zeros(G, B * Ts + k + 1, cg, dtype=x.dtype, device=x.device)
         xg[:, : B * Ts].view(G, B, Ts, cg)[:, :, P:P + T] = x.view(B, T, G, cg).permute(2, 0, 1, 3)
         y = torch.empty(G, B * Ts, cg, dtype=x.dtype, device=x.device)
+        if cg % 8 == 0 and xg.stride(0) % 8 == 0:  # the G products as ONE launch (each alone fills half the chip: 16 launches per layer before)
+            hip.gemm_nt_batched(xg, wg, bias_g.contiguous() if bias_g is not None else None, y, B * Ts, Kp)
+            return xg, y
         for g in range(G):
             a = _as_rows(xg[g], B * Ts, Kp, cg, 0)
             hip.gemm_nt(a, [wg[g]], [bias_g[g]] if bias_g is not None else None, out=y[g], splitk=False)

@@ -63,7 +63,7 @@ __device__ __forceinline__ int w_row_to_col(int p) {
 // acc[nl][mi][r] = h0, acc[2+nl][mi][r] = h1 of column nl*4 + r.
 template <int EPI, int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32x4 (&acc)[4][MI], int mrow0, int nbase,
-                                              int fbase, int g, int t) {
+                                              int fbase, int g, int t, int64_t bias_off = 0) {  // bias_off: batched launches (element offset of the batch's bias vector)
   if (EPI == EPI_GEGLU) {
     const int f0 = fbase + g * 8;  // 8 contiguous f:  acc[nl][mi][r] = h0, acc[2+nl][mi][r] = h1, f = f0 + nl*4 + r
     if (f0 >= p.N) return;
@@ -98,6 +98,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
     const int seg = nc0 / p.n_seg;
     const bf16_t* bp = p.bias[seg];
     if (bp) {
+      bp += bias_off;
       float tmp[8];
       Vec8<bf16_t>::load(bp + (nc0 - seg * p.n_seg), tmp);
 #pragma unroll
@@ -204,10 +205,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
   }
 }
 
+// Batched launches (round 5; op_gemm_nt_batched): blockIdx.z = problem of a batch of equally shaped products whose operands lie at constant
+// element strides (the 16 groups of the audio positional convolution, adapter/audio.py:57-84: one launch of 16 x 268 tiles instead of 16
+// launches that fill half the chip each); all strides 0 = the plain launch.
+struct NtBatch { int64_t a, b, c, bias; };
+
 template <int EPI, bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p, const NtBatch bt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t zb = blockIdx.z;
   const int wm = wid >> 1, wn = wid & 1;
   const int g = lane >> 4, t = lane & 15;
   constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 64 : 128;
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     const int row = q >> 3, pc = q & 7;
     const int c = pc ^ (row & 7);
     const int gm = min(m0 + row, p.M - 1);
-    srcA[i] = p.A + (int64_t)gm * p.lda + c * 8;
+    srcA[i] = p.A + zb * bt.a + (int64_t)gm * p.lda + c * 8;
     int gn = min(n0 + w_row_to_col<EPI>(row), p.N - 1);
     const bf16_t* base;
     if (EPI == EPI_GEGLU) {
@@ -242,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
       base = p.B[seg];
       gn -= seg * p.n_seg;
     }
-    srcB[i] = base + (int64_t)gn * p.ldb + c * 8;
+    srcB[i] = base + zb * bt.b + (int64_t)gn * p.ldb + c * 8;
   }
 
   f32x4 acc[4][4];  // [ni][mi]
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
   for (int mi = 0; mi < 4; ++mi) rdX[mi] = (wm * 64 + mi * 16 + t) * 128;
 
   int nk = p.K / BK;
-  void* Cout = p.C;
+  void* Cout = (EPI == EPI_F32) ? (void*)((float*)p.C + zb * bt.c) : (void*)((bf16_t*)p.C + zb * bt.c);
   if (p.kt_per_split > 0) {  // split-K: this workgroup owns K-tiles [z*kps, min(nk, (z+1)*kps)) and its own output slab
     const int kt0 = blockIdx.y * p.kt_per_split;
     nk = min(nk - kt0, p.kt_per_split);
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmArgs p) {
     }
   }
 
-  gemm_epilogue<EPI, 4>(p, Cout, acc, m0 + wm * 64, n0 + wn * 64, n0 + wn * 32, g, t);
+  gemm_epilogue<EPI, 4>(p, Cout, acc, m0 + wm * 64, n0 + wn * 64, n0 + wn * 32, g, t, zb * bt.bias);
 }
 
 // =====================================================================================================================
@@ -2128,15 +2135,15 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
 }
 
 template <int EPI>
-int launch(const GemmArgs& a, int glds, hipStream_t s, int splits = 1) {
-  const dim3 grid(a.tiles_m * a.tiles_n, splits);
+int launch(const GemmArgs& a, int glds, hipStream_t s, int splits = 1, int batch = 1, NtBatch bt = NtBatch{0, 0, 0, 0}) {
+  const dim3 grid(a.tiles_m * a.tiles_n, splits, batch);
   const size_t sh = 4 * TILE_BYTES;
   if (glds) OP_ENSURE_LDS((gemm_nt_kernel<EPI, true>), sh, "gemm");
   else OP_ENSURE_LDS((gemm_nt_kernel<EPI, false>), sh, "gemm");
   if (glds)
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), sh, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, dim3(256), sh, s, a, bt);
   else
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), sh, s, a);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, dim3(256), sh, s, a, bt);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
@@ -2433,6 +2440,34 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { op_set_error("gemm_nt: split-K reduce launch failed: %s", hipGetErrorString(e)); rc = (int)e; }
   }
+  op_prof_end(slot, stream);
+  return rc;
+}
+
+// `batch` equally shaped products  C_z[M,N] = A_z[M,K] W_z[N,K]^T (+ bias_z[N])  whose operands lie at constant element strides
+// (stride_* between consecutive problems; bias / stride_bias optional): ONE launch of the 128 x 128 kernel with blockIdx.z = z, no
+// split-K.  The per-group GEMMs of a grouped Conv1d over strided patch views (adapter/audio.py:57-84, GroupedConv1dSameFn): each of them
+// alone fills half the chip.  Rules as op_gemm_nt's plain epilogue (K % 64 == 0, N % 8 == 0, lda / ldb % 8 == 0, ldc % 4 == 0).
+int op_gemm_nt_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldb, int64_t stride_b, const void* bias,
+                       int64_t stride_bias, void* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K, int64_t batch,
+                       void* stream) {
+  OP_CHECK_ARG(A && W && C, "gemm_nt_batched: null A/W/C");
+  OP_CHECK_ARG(M >= 0 && N > 0 && K > 0 && batch >= 1 && batch <= 65535, "gemm_nt_batched: bad sizes M=%lld N=%lld K=%lld batch=%lld", (long long)M,
+               (long long)N, (long long)K, (long long)batch);
+  OP_CHECK_ARG(K % BK == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt_batched: K %% 64, N %% 8, lda / ldb %% 8, ldc %% 4");
+  OP_CHECK_ARG(stride_a % 8 == 0 && stride_b % 8 == 0 && stride_c % 4 == 0 && stride_bias % 8 == 0, "gemm_nt_batched: strides must keep 16-byte alignment");
+  if (M == 0) return OP_OK;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = (const bf16_t*)A; a.lda = lda;
+  a.B[0] = (const bf16_t*)W; a.ldb = ldb; a.n_seg = (int)N;
+  a.bias[0] = (const bf16_t*)bias;
+  a.C = C; a.ldc = ldc;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.rows_per_sample = 1;
+  a.tiles_m = ceil_div(M, BM);
+  a.tiles_n = ceil_div(N, 128);
+  const int slot = op_prof_begin(0, 2.0 * (double)batch * (double)M * (double)N * (double)K, stream);
+  const int rc = launch<EPI_BIAS>(a, 1, (hipStream_t)stream, 1, (int)batch, NtBatch{stride_a, stride_b, stride_c, stride_bias});
   op_prof_end(slot, stream);
   return rc;
 }

@@ -41,6 +41,7 @@ SIGNATURES = {
     "op_gemm_tn_grouped_counter_bytes": (I64, []),
     "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, I64, I64, P, I64]),
     "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
+    "op_gemm_nt_batched": (c_int, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I64, I64, I64, I64, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
     "op_transpose_desc_bytes": (I64, []),
@@ -436,6 +437,18 @@ def gemm_plan(M, N, K, epilogue=EPI_BIAS, has_bias=True, workspace_bytes=SPLITK_
 def gemm_tn_supported(K, M, N, lda, ldb):
     return (K % 64 == 0 and M % 8 == 0 and N % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and M >= 8 and N >= 8
             and 31 * lda + M < (1 << 30) and 31 * ldb + N < (1 << 30))
+
+
+def gemm_nt_batched(A, W, bias, out, rows, K):
+    """out[z] = A_z W[z]^T (+ bias[z]) for z < G as ONE launch.  A: [G, *, lda] whose batch z starts at A[z] and whose ROWS are read with
+    stride A.stride(1) as K-wide (possibly overlapping) patches; W [G, N, K] contiguous; bias [G, N] or None; out [G, rows, N]."""
+    G, N = W.shape[0], W.shape[1]
+    assert W.is_contiguous() and out.is_contiguous() and out.shape == (G, rows, N) and A.stride(2) == 1
+    GEMM_ALGO_BYTES[0] += 2 * G * (rows * K + N * K + rows * N)
+    GEMM_ALGO_BYTES[1] += 1
+    _check(lib().op_gemm_nt_batched(ptr(A), A.stride(1), A.stride(0), ptr(W), K, N * K, ptr(bias), N if bias is not None else 0, ptr(out), N,
+                                    rows * N, rows, N, K, G, stream()), "op_gemm_nt_batched")
+    return out
 
 
 def gemm_tn_grouped_plan(sizes, workgroups=256, tune=0):

@@ -1098,6 +1098,28 @@ def test_gemm_tn_grouped_is_bit_identical_to_unsplit_launches(name, nwg):
             assert_close(out, r, what="grouped dW")
 
 
+@pytest.mark.parametrize("use_bias", [False, True])
+def test_gemm_nt_batched_equals_one_launch_per_problem(use_bias):
+    """(ABI 7) op_gemm_nt_batched: G equally shaped products over OVERLAPPING strided patch views (row stride cg < K: the grouped
+    positional Conv1d of the audio adapter, adapter/audio.py:57-84, as GEMMs over a zero-padded group-major copy) in one launch --
+    bit-identical to one op_gemm_nt launch per group on the same views, and within the bf16 tolerance of the fp32 product."""
+    hip = hipmod()
+    G, rows, cg, k = 5, 700, 96, 19
+    Kp = (k * cg + 63) // 64 * 64
+    xg = dev_bf16(rnd(G, rows + k + 1, cg, seed=3, scale=0.5))
+    wg = dev_bf16(rnd(G, cg, Kp, seed=4, scale=0.05))
+    bias = dev_bf16(rnd(G, cg, seed=5)) if use_bias else None
+    out = torch.empty(G, rows, cg, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_nt_batched(xg, wg, bias, out, rows, Kp)
+    torch.cuda.synchronize()
+    for g in range(G):
+        a = torch.as_strided(xg[g], (rows, Kp), (cg, 1), xg[g].storage_offset())
+        one = hip.gemm_nt(a, [wg[g]], [bias[g]] if use_bias else None, splitk=False)
+        assert torch.equal(out[g], one), "batched launch differs from the per-group launch (group %d)" % g
+        ref = a.float() @ wg[g].float().t() + (bias[g].float() if use_bias else 0.0)
+        assert_close(out[g], ref.cpu(), what="batched product")
+
+
 @pytest.mark.parametrize("nwg", [0, 5])
 def test_gemm_tn_grouped_row_dot_side_product(nwg):
     """(ABI 7) op_gemm_tn_grouped with W / rowdot on some problems: rowdot[m] += sum_n W[m][n] * P[m][n] with P = THIS launch's fp32

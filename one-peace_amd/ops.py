@@ -666,7 +666,14 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
     H = x2.shape[1]
     xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
     if H % 128 == 0:
-        qkv = hip.gemm_nt(xln1, [P["wq"], P["wk"], P["wv"]], [P["bq"], None, P["bv"]], n_seg=H, N=3 * H)
+        Nr = x2.shape[0]
+        full = _qkv_rows_that_fill_whole_rounds(Nr, 3 * H) if QKV_ROUND_SPLIT else Nr
+        if full < Nr:  # (689.8 / 689.7 -> 687.3 / 687.0 ms on the headline step, same box: profiles/r5_experiments.md section 12)
+            qkv = torch.empty(Nr, 3 * H, dtype=x2.dtype, device=x2.device)
+            for lo, hi in ((0, full), (full, Nr)):
+                hip.gemm_nt(xln1[lo:hi], [P["wq"], P["wk"], P["wv"]], [P["bq"], None, P["bv"]], n_seg=H, N=3 * H, out=qkv[lo:hi])
+        else:
+            qkv = hip.gemm_nt(xln1, [P["wq"], P["wk"], P["wv"]], [P["bq"], None, P["bv"]], n_seg=H, N=3 * H)
     else:
         qkv = torch.empty(x2.shape[0], 3 * H, dtype=x2.dtype, device=x2.device)
         for i, (w, b) in enumerate(((P["wq"], P["bq"]), (P["wk"], None), (P["wv"], P["bv"]))):
@@ -694,6 +701,20 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
     for i, lse in enumerate(lses):
         acts["lse%d" % i] = lse
     return x_mid, acts
+
+
+QKV_ROUND_SPLIT = os.environ.get("ONEPEACE_QKV_ROUND_SPLIT", "1") != "0"
+
+
+def _qkv_rows_that_fill_whole_rounds(rows, n_out, cus=256, max_tail=512):
+    """Largest multiple of 256 rows whose 256 x 256 tiles are a whole number of rounds of `cus` workgroups, when that leaves at most
+    `max_tail` rows for a second, small launch and saves a round (73 088 rows x 4608 columns: 5 148 tiles = 20.1 rounds -- 28 tiles
+    cost a 21st round; 284 row tiles = 5 112 tiles = 20 rounds + a 384-row launch); else `rows`."""
+    tn, tm = (n_out + 255) // 256, (rows + 255) // 256
+    rounds = -(-tm * tn // cus)
+    tm_main = (rounds - 1) * cus // tn
+    full = tm_main * 256
+    return full if 0 < rows - full <= max_tail and tm_main > 0 else rows
 
 
 GEGLU_SPLIT = os.environ.get("ONEPEACE_GEGLU_SPLIT", "1") != "0"

@@ -52,3 +52,22 @@ def test_encoder_plans_cover_every_branch_with_drop_path():
     assert torch.allclose(scales[1][0], mask[1, 0].float() / 0.9) and scales[1][1] is None
     enc.eval()
     assert enc._draw_kept_plans(segs, 3 * B, rows, torch.device("cpu")) == (None, None)
+
+
+def test_qkv_launch_is_cut_to_whole_rounds_only_when_a_small_second_launch_saves_one():
+    """ops._qkv_rows_that_fill_whole_rounds (round 5): rows of the main q|k|v launch such that its 256 x 256 tiles are whole rounds of 256
+    workgroups -- only when that saves a round and leaves at most 512 rows for the second launch."""
+    from one_peace_amd import ops
+    f = ops._qkv_rows_that_fill_whole_rounds
+    assert f(73088, 4608) == 72704          # headline: 286 x 18 = 5148 tiles = 20.1 rounds -> 284 row tiles (20 rounds) + 384 rows
+    assert f(73088, 1536) == 73088          # 1716 tiles = 6.7 rounds: 30 row tiles would be left over
+    assert f(72704, 4608) == 72704          # already whole rounds
+    assert f(32896, 12288) == 32768         # 129 x 48 = 24.2 rounds -> 128 row tiles + the 128-row tail the planner splits off anyway
+    assert f(2048, 4608) == 2048            # less than one round: nothing to cut
+    for rows in range(256, 80000, 1777):
+        for n in (1536, 4608, 12288):
+            full = f(rows, n)
+            assert full == rows or (full % 256 == 0 and 0 < rows - full <= 512 and (full // 256) * (n // 256) % 256 <= 255)
+            if full != rows:  # the main launch is within its last whole round, and one round fewer than the unsplit launch
+                tiles, tiles_all = (full // 256) * (n // 256), -(-rows // 256) * (n // 256)
+                assert -(-tiles // 256) == -(-tiles_all // 256) - 1

@@ -1191,6 +1191,23 @@ def test_resid_bwd_g0_and_gamma_grad_finish():
     assert float(rowdot.abs().max()) == 0.0  # re-armed
 
 
+def test_gamma_grad_finish_with_three_weight_sets_sharing_gamma():
+    """The lock-step FFN form: gamma_2 is shared by the three modality FFNs -- one row-dot buffer receives the side products of three
+    down-projection weight gradients, op_gamma_grad_finish adds the three bias terms (one FFN without bias), writes (not accumulates)."""
+    hip = hipmod()
+    N = 256
+    rowdot = dev_bf16(rnd(N, seed=1)).float().contiguous()
+    gamma = dev_bf16((0.25 + rnd(N, seed=2).abs()).clamp(max=2.0))
+    bs = [dev_bf16(rnd(N, seed=3)), None, dev_bf16(rnd(N, seed=4))]
+    g0s = [dev_bf16(rnd(N, seed=5 + i)).float().contiguous() for i in range(3)]
+    ref = rowdot / gamma.float() + bs[0].float() * g0s[0] + bs[2].float() * g0s[2]
+    out = torch.full((N,), 7.0, dtype=torch.bfloat16, device=DEV)
+    hip.gamma_grad_finish(rowdot, gamma, list(zip(bs, g0s)), out, False)
+    torch.cuda.synchronize()
+    assert_close(out, ref.cpu(), what="dgamma over three weight sets")
+    assert float(rowdot.abs().max()) == 0.0
+
+
 def test_gemm_tn_grouped_rejects_what_the_kernel_cannot_take():
     hip = hipmod()
     ok = (dev_bf16(rnd(128, 64)), dev_bf16(rnd(128, 64)), dev_bf16(rnd(64, 64)), False)

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -94,6 +94,18 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
 int op_gemm_nt_batched(const void* A, int64_t lda, int64_t stride_a, const void* W, int64_t ldb, int64_t stride_b, const void* bias,
                        int64_t stride_bias, void* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K, int64_t batch,
                        void* stream);
+/* (ABI 7) First block of the audio feature extractor, fused and straight from the waveform (one_peace/models/adapter/audio.py:254-311,
+ * ConvFeatureExtractionModel block 0: Conv1d(1 -> C, kernel 10, stride `stride`, optional bias) -> LayerNorm over channels -> GELU):
+ *   y[r][c] = GELU(LN_C(bf16(sum_j w0[c][j] * wav[stride * r + j] (+ b0[c]))))        rows x C bf16, C <= 512, C % 8 == 0
+ * mean / rstd [rows] fp32 are kept for the backward, which RECOMPUTES the row from its ten samples and returns the parameter gradients
+ * (dw0 [C, 10], db0 [C], dlnw [C], dlnb [C]; bf16; nullable except dw0; overwritten or accumulated) -- the 2.1 GB convolution output
+ * of the headline batch is never written, re-read or kept.  workspace: op_audio_conv1_ln_gelu_bwd_workspace_bytes(C). */
+int op_audio_conv1_ln_gelu_fwd(const void* wav, int64_t stride, const void* w0, const void* b0, const void* lnw, const void* lnb, void* y,
+                               float* mean, float* rstd, int64_t rows, int64_t C, float eps, void* stream);
+int64_t op_audio_conv1_ln_gelu_bwd_workspace_bytes(int64_t C);
+int op_audio_conv1_ln_gelu_bwd(const void* dy, const void* wav, int64_t stride, const void* w0, const void* b0, const void* lnw, const void* lnb,
+                               const float* mean, const float* rstd, void* dw0, void* db0, void* dlnw, void* dlnb, void* workspace,
+                               int64_t rows, int64_t C, int accumulate, void* stream);
 /* Grouped form of op_gemm_tn: up to 16 weight-gradient GEMMs  C_i[M_i,N_i] (bf16, ldc_i) (+)= A_i^T B_i  with their own operands,
  * sizes, K_i and outputs as ONE persistent launch WITHOUT split-K: the tile list of all problems is walked by one workgroup per
  * CU (per-XCD queues of WAVES -- as many consecutive tiles of a problem's tile rectangle as the XCD has workgroups, all of one K, so

@@ -70,6 +70,29 @@ class StridedConv1dFn(torch.autograd.Function):
         return dx, dw
 
 
+class Conv1LnGeluFn(torch.autograd.Function):
+    """Block 0 of the feature extractor -- Conv1d(1 -> C, k = 10, stride 5) -> LayerNorm(C) -> GELU -- as ONE kernel each way, straight from
+    the flat waveform (csrc/audio.hip): the 2.1 GB convolution output of the headline batch is neither written nor kept; backward
+    recomputes each row from its ten samples and accumulates the four parameter gradients in registers.  wav gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, wav_flat, rows, stride, weight, bias, ln_w, ln_b, eps):
+        w0 = weight.reshape(weight.shape[0], 10).contiguous()
+        y, mean, rstd = hip.audio_conv1_ln_gelu_fwd(wav_flat, stride, w0, bias, ln_w, ln_b, rows, eps)
+        ctx.save_for_backward(wav_flat, w0, bias, ln_w, ln_b, mean, rstd)
+        ctx.stride, ctx.wshape = stride, tuple(weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        wav_flat, w0, bias, ln_w, ln_b, mean, rstd = ctx.saved_tensors
+        dw0, db0, dlw, dlb = hip.audio_conv1_ln_gelu_bwd(dy.contiguous(), wav_flat, ctx.stride, w0, bias, ln_w, ln_b, mean, rstd)
+        return None, None, None, dw0.view(ctx.wshape), db0, dlw, dlb, None
+
+
+FUSED_CONV1 = __import__("os").environ.get("ONEPEACE_FUSED_CONV1", "1") != "0"
+
+
 def _first_layer_rows(wav_flat, rows):
     """im2col of Conv1d(1 -> C, k = 10, stride 5) as a strided view of the flat (padded) waveform, K padded to 64."""
     a = torch.as_strided(wav_flat, (rows, 10), (5, 1), wav_flat.storage_offset())
@@ -90,11 +113,15 @@ def feature_extractor(src_audios, conv_blocks):
     wav[: B * Tp].view(B, Tp)[:, :T] = src_audios
     conv0, ln0 = conv_blocks[0][0], conv_blocks[0][2][1]
     rows = B * slots
-    with torch.no_grad():
-        a0 = _first_layer_rows(wav, rows)
-    w0 = F.pad(conv0.weight.reshape(conv0.weight.shape[0], 10), (0, 54))
-    x = ops.linear(a0, w0, conv0.bias)
-    x = ops.layer_norm(x, ln0.weight, ln0.bias, ln0.eps, gelu=True)
+    C0 = conv0.weight.shape[0]
+    if (FUSED_CONV1 and conv0.weight.shape[2] == 10 and conv0.stride[0] == 5 and C0 <= 512 and C0 % 8 == 0 and wav.dtype == torch.bfloat16):
+        x = Conv1LnGeluFn.apply(wav, rows, 5, conv0.weight, conv0.bias, ln0.weight, ln0.bias, ln0.eps)
+    else:
+        with torch.no_grad():
+            a0 = _first_layer_rows(wav, rows)
+        w0 = F.pad(conv0.weight.reshape(conv0.weight.shape[0], 10), (0, 54))
+        x = ops.linear(a0, w0, conv0.bias)
+        x = ops.layer_norm(x, ln0.weight, ln0.bias, ln0.eps, gelu=True)
     x = torch.cat([x, x.new_zeros(2, x.shape[1])], dim=0)  # slack rows
     valid = (valid - 10) // 5 + 1
     for block in conv_blocks[1:]:

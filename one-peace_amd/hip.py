@@ -42,6 +42,9 @@ SIGNATURES = {
     "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, I64, I64, P, I64]),
     "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "op_gemm_nt_batched": (c_int, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I64, I64, I64, I64, P]),
+    "op_audio_conv1_ln_gelu_fwd": (c_int, [P, I64, P, P, P, P, P, P, P, I64, I64, c_float, P]),
+    "op_audio_conv1_ln_gelu_bwd_workspace_bytes": (I64, [I64]),
+    "op_audio_conv1_ln_gelu_bwd": (c_int, [P, P, I64, P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
     "op_transpose_desc_bytes": (I64, []),
@@ -449,6 +452,29 @@ def gemm_nt_batched(A, W, bias, out, rows, K):
     _check(lib().op_gemm_nt_batched(ptr(A), A.stride(1), A.stride(0), ptr(W), K, N * K, ptr(bias), N if bias is not None else 0, ptr(out), N,
                                     rows * N, rows, N, K, G, stream()), "op_gemm_nt_batched")
     return out
+
+
+def audio_conv1_ln_gelu_fwd(wav, stride, w0, b0, lnw, lnb, rows, eps):
+    """GELU(LN(conv(wav))) of the feature extractor's first block straight from the flat waveform: y [rows, C], mean, rstd [rows]."""
+    C = w0.shape[0]
+    assert w0.is_contiguous() and w0.numel() == C * 10 and wav.is_contiguous() and wav.numel() >= stride * (rows - 1) + 10
+    y = torch.empty(rows, C, dtype=torch.bfloat16, device=wav.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=wav.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=wav.device)
+    _check(lib().op_audio_conv1_ln_gelu_fwd(ptr(wav), stride, ptr(w0), ptr(b0), ptr(lnw), ptr(lnb), ptr(y), ptr(mean), ptr(rstd), rows, C, eps,
+                                            stream()), "op_audio_conv1_ln_gelu_fwd")
+    return y, mean, rstd
+
+
+def audio_conv1_ln_gelu_bwd(dy, wav, stride, w0, b0, lnw, lnb, mean, rstd):
+    """Parameter gradients of audio_conv1_ln_gelu_fwd (bf16): dw0 [C, 10], db0 [C] | None, dlnw [C] | None, dlnb [C] | None."""
+    rows, C = dy.shape
+    mk = lambda ref, shape: torch.empty(shape, dtype=torch.bfloat16, device=dy.device) if ref is not None else None  # noqa: E731
+    dw0, db0, dlw, dlb = torch.empty(C, 10, dtype=torch.bfloat16, device=dy.device), mk(b0, C), mk(lnw, C), mk(lnb, C)
+    ws = workspace(lib().op_audio_conv1_ln_gelu_bwd_workspace_bytes(C), dy.device, "audio_conv1")
+    _check(lib().op_audio_conv1_ln_gelu_bwd(ptr(dy), ptr(wav), stride, ptr(w0), ptr(b0), ptr(lnw), ptr(lnb), ptr(mean), ptr(rstd), ptr(dw0), ptr(db0),
+                                            ptr(dlw), ptr(dlb), ptr(ws), rows, C, 0, stream()), "op_audio_conv1_ln_gelu_bwd")
+    return dw0, db0, dlw, dlb
 
 
 def gemm_tn_grouped_plan(sizes, workgroups=256, tune=0):

@@ -952,6 +952,70 @@ def test_audio_feature_extractor_matches_conv_stack():
     assert_close(out, ref.float(), fro=3e-2, mx=8e-2, what="feature extractor (bf16 vs bf16, 7 layers)")
 
 
+@pytest.mark.parametrize("C,bias", [(64, False), (512, True), (512, False)])
+def test_audio_first_block_fused_from_the_waveform(C, bias):
+    """(ABI 7) op_audio_conv1_ln_gelu_fwd / _bwd: Conv1d(1 -> C, k = 10, stride 5) -> LayerNorm(C) -> GELU as ONE kernel each way, rows
+    computed from their ten waveform samples (adapter/audio.py:254-311, block 0).  Against the fp32 definition (the convolution output
+    rounded to bf16 before the statistics, as every bf16 path stores it), forward and all four parameter gradients; and the whole
+    extractor with the fused block against the GEMM + LayerNorm form of rounds 1-4 (ONEPEACE_FUSED_CONV1=0)."""
+    from one_peace_amd import audio_ops
+    from one_peace_amd.adapter.audio import ConvFeatureExtractionModel
+    hip = hipmod()
+    g = torch.Generator().manual_seed(3)
+    B, T = 3, 4000
+    Tp = (T + 319) // 320 * 320
+    rows = B * (Tp // 5)
+    wav = torch.zeros(B * Tp + 16)
+    wav[: B * Tp].view(B, Tp)[:, :T] = torch.randn(B, T, generator=g)
+    w0 = bf16_round(torch.randn(C, 10, generator=g) * 0.4)
+    b0 = bf16_round(torch.randn(C, generator=g) * 0.1) if bias else None
+    lw, lb = bf16_round(1 + 0.1 * torch.randn(C, generator=g)), bf16_round(0.1 * torch.randn(C, generator=g))
+    dy = bf16_round(torch.randn(rows, C, generator=g))
+    wq = bf16_round(wav)
+    # ---- fp32 definition ----
+    w0r, lwr, lbr = w0.clone().requires_grad_(True), lw.clone().requires_grad_(True), lb.clone().requires_grad_(True)
+    b0r = b0.clone().requires_grad_(True) if bias else None
+    patches = torch.as_strided(wq, (rows, 10), (5, 1))
+    x = patches @ w0r.t() + (b0r if bias else 0.0)
+    x = x + (bf16_round(x.detach()) - x.detach())  # straight-through bf16 rounding of the stored convolution output
+    ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x, (C,), lwr, lbr, 1e-5))
+    (ref * dy).sum().backward()
+    # ---- HIP ----
+    wd = dev_bf16(wq)
+    y, mean, rstd = hip.audio_conv1_ln_gelu_fwd(wd, 5, dev_bf16(w0), dev_bf16(b0) if bias else None, dev_bf16(lw), dev_bf16(lb), rows, 1e-5)
+    assert_close(y, ref.detach(), what="fused first block")
+    dw0, db0, dlw, dlb = hip.audio_conv1_ln_gelu_bwd(dev_bf16(dy), wd, 5, dev_bf16(w0), dev_bf16(b0) if bias else None, dev_bf16(lw), dev_bf16(lb),
+                                                     mean, rstd)
+    assert_close(dw0, w0r.grad, fro=8e-3, mx=3e-2, what="dW of the first convolution")
+    assert_close(dlw, lwr.grad, fro=8e-3, mx=3e-2, what="dLN weight")
+    assert_close(dlb, lbr.grad, fro=8e-3, mx=3e-2, what="dLN bias")
+    if bias:
+        assert_close(db0, b0r.grad, fro=8e-3, mx=3e-2, what="db of the first convolution")
+    else:
+        assert db0 is None
+    # ---- the whole extractor: fused block against the GEMM + LayerNorm form ----
+    if C == 64:
+        torch.manual_seed(0)
+        spec = [(64, 10, 5)] + [(64, 3, 2)] * 4 + [(64, 2, 2)] * 2
+        m = ConvFeatureExtractionModel(spec).to(DEV).to(torch.bfloat16)
+        wv = torch.randn(3, 4000, device=DEV).to(torch.bfloat16)
+        outs, grads = {}, {}
+        saved = audio_ops.FUSED_CONV1
+        try:
+            for mode in (True, False):
+                audio_ops.FUSED_CONV1 = mode
+                m.zero_grad()
+                o = audio_ops.feature_extractor(wv, m.conv_layers)
+                o.float().square().sum().backward()
+                outs[mode] = o.detach().float()
+                grads[mode] = {n: q.grad.detach().float().clone() for n, q in m.named_parameters()}
+        finally:
+            audio_ops.FUSED_CONV1 = saved
+        assert_close(outs[True], outs[False].cpu(), fro=2e-2, mx=6e-2, what="extractor, fused vs unfused first block")
+        for n, gq in grads[False].items():
+            assert rel_fro(grads[True][n], gq) <= 3e-2, (n, rel_fro(grads[True][n], gq))
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(16448, 4608, 1536, "qkv"), (16448, 6144, 1536, "geglu"), (16000, 1536, 6144, "resid"),
                                        (32896, 1536, 1536, "bias"),
                                        # the EXACT launches of the headline step (128 x 257 image tokens per pass), fp32-checked:

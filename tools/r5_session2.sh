@@ -131,4 +131,17 @@ call16() {
   done
 }
 
+call17() {
+  # round 5, call 17: first block of the audio feature extractor fused from the waveform: tests, audio model tests, same-box A/B (ONEPEACE_FUSED_CONV1)
+  d=$R/gpurun_out/r5c17; mkdir -p $d
+  cd $R
+  timeout 900 python -m pytest tests/test_ops_gpu.py -m gpu -x -q -k "audio" > $d/pytest_ops.txt 2>&1; tail -3 $d/pytest_ops.txt
+  timeout 1200 python -m pytest tests/test_model_gpu.py -m gpu -x -q -k "audio or micro or deep_text or pretrain_al or stage2" > $d/pytest_model.txt 2>&1; tail -3 $d/pytest_model.txt
+  timeout 300 python __graft_entry__.py smoke > $d/smoke.txt 2>&1; tail -1 $d/smoke.txt
+  B="--steps 8 --warmup 2 --no-cpu-baseline --no-power-probe --no-skip-leg"
+  for v in 0 1 0 1; do
+    ONEPEACE_FUSED_CONV1=$v timeout 400 python bench.py $B > $d/bench_${v}_$(date +%s).txt 2> $d/bench_$v.err; tail -1 $(ls -t $d/bench_${v}_*.txt | head -1) | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; m=d['config'].get('memory') or {}; print('headline fused-conv1=$v', round(d['ms_per_step'],1), round(d['value'],1), 'gemm', round(r.get('frac',0),4), 'peak GB', m.get('peak_reserved_gb'), 'loss', d['config'].get('final_loss'))" || tail -5 $d/bench_$v.err
+  done
+}
+
 "$@"

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd; 8: the layer-scale gradient without a division -- rscale of op_gemm_tn_grouped, op_transpose_scaled + the scale member of the op_transpose_batched descriptor, op_resid_bwd leaves gamma out of dbranch when g0 is asked for, op_gamma_grad_finish lost its gamma argument; rowdot is a [N / 128][M] matrix of partial sums written once each (no atomics) */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -125,14 +125,20 @@ int64_t op_gemm_tn_grouped_counter_bytes(void);
 int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* N, const int64_t* K, int64_t workgroups, int64_t tune,
                                 int32_t* out, int64_t cap);
 /* (ABI 7) W / ldw / rowdot: nullable HOST arrays; for a problem with rowdot[i] != NULL (requires accumulate[i], M_i and N_i multiples
- * of 256, W_i [M_i, N_i] bf16 16-byte aligned, ldw_i % 8 == 0) the launch also adds  rowdot_i[m] += sum_n W_i[m][n] * P_i[m][n]  (fp32
- * atomics; P_i = THIS launch's fp32 product A_i^T B_i before it is rounded into C_i).  With A = gamma-scaled output gradient of a
- * residual branch, B = input of the branch's last Linear and W = that Linear's weight, rowdot / gamma is the layer-scale gradient
- * sum_rows rowscale * dout * (x W^T) -- see op_gamma_grad_finish -- and the branch output y never has to be kept for backward
- * (one_peace/models/transformer/transformer_layer.py:70-88). */
+ * of 256, W_i [M_i, N_i] bf16 16-byte aligned, ldw_i % 8 == 0) the launch also WRITES the partial row dots
+ *   rowdot_i[s][m] = sum_{n in [128 s, 128 s + 128)} W_i[m][n] * P_i[m][n],   s < N_i / 128,   rowdot_i: fp32 [N_i / 128][M_i]
+ * (ABI 8: every entry stored exactly once -- no atomics, no zeroing, run-to-run identical; ABI 7 added into one [M_i] vector with fp32
+ * atomics; P_i = THIS launch's fp32 product A_i^T B_i before it is rounded into C_i).
+ * (ABI 8) rscale: nullable HOST array; rscale[i] != NULL (bf16 [M_i], only with rowdot[i]) makes the accumulation
+ * C_i[m][:] += rscale_i[m] * P_i[m][:] while rowdot still sums W_i * the UNSCALED P_i.  With A = rowscale * dout, the output gradient
+ * of a residual branch WITHOUT the layer scale (op_resid_bwd with g0), B = input of the branch's last Linear, W = that Linear's
+ * weight and rscale = gamma:  C += the weight gradient gamma[n] * (A^T B)[n][:], and sum_s rowdot[s][n] = sum_k W[n][k] * (A^T B)[n][k] IS the
+ * layer-scale gradient sum_rows rowscale * dout * (x W^T) (+ the bias term of op_gamma_grad_finish) -- for any gamma, including 0 --
+ * and the branch output y never has to be written or kept (one_peace/models/transformer/transformer_layer.py:70-88). */
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
-                       const void* const* W, const int64_t* ldw, float* const* rowdot, void* counters, int64_t tune, void* stream);
+                       const void* const* W, const int64_t* ldw, float* const* rowdot, const void* const* rscale, void* counters,
+                       int64_t tune, void* stream);
 /* `tune` (op_gemm_nt, op_gemm_tn, op_gemm_plan): per-call tuning word, 0 = what production uses.  The library keeps NO tuning
  * state, so every entry point is a pure function of its arguments; tests and tools select a kernel flavour with the call:
  * bits 0-1 tile (0 auto: a cost model picks 128x128 or 256x256 tiles, K-splits and the tail-rows split; 1 force 128x128;
@@ -228,10 +234,15 @@ int op_relpos_bias_bwd_ids(const float* dbias, const int* bucket, int64_t bucket
 /* ---- HBM-bound helpers of the layer backward -----------------------------------------------------------------------
  * (the reference gets these from autograd over transformer_layer.py:54-88,149-157) */
 int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream);
+/* (ABI 8) out[c][r] = bf16(scale[r] * in[r][c]); scale: bf16 [rows] or NULL (= op_transpose).  The input-gradient copy of the last
+ * Linear of a residual branch with the layer scale folded in: dx = (rowscale * dout) . (gamma o W)
+ * (one_peace/models/transformer/transformer_layer.py:70-88; the operand op_resid_bwd writes with g0 carries no gamma). */
+int op_transpose_scaled(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, const void* scale,
+                        void* stream);
 /* Many transposes in one launch (the dgrad copies of all weights after an optimiser step).  table: DEVICE array of n
  * descriptors, op_transpose_desc_bytes() bytes each, laid out as { const void* in; void* out; int32 rows, cols;
- * int64 ld_in, ld_out; int32 tile0, tiles_x; } with tile0 = running sum of ceil(cols/64)*ceil(rows/64) and
- * tiles_x = ceil(cols/64); total_tiles = that sum over all descriptors. */
+ * int64 ld_in, ld_out; int32 tile0, tiles_x; const void* scale; } with tile0 = running sum of ceil(cols/64)*ceil(rows/64),
+ * tiles_x = ceil(cols/64) and scale as in op_transpose_scaled (NULL = none); total_tiles = that sum over all descriptors. */
 int op_transpose_batched(const void* table, int64_t n, int64_t total_tiles, void* stream);
 int64_t op_transpose_desc_bytes(void);
 int64_t op_colsum_workspace_bytes(int64_t N);
@@ -241,20 +252,25 @@ int op_colsum_segments(const void* x, void* out0, void* out1, void* out2, void* 
                        int64_t seg_cols, int accumulate, void* stream);
 /* Backward of out = resid + rowscale[m/rps] * gamma[n] * y[m][n] (layer-scale + drop-path residual,
  * one_peace/models/transformer/transformer_layer.py:70-88,190-196,224-226) in one pass:
- * dbranch = rowscale*gamma*dout; dgamma (+)= sum_m rowscale*dout*y; dbias (+)= sum_m dbranch.  Nullable: y+dgamma, gamma,
+ * dbranch = rowscale*gamma*dout; dgamma (+)= sum_m rowscale*dout*y; dbias (+)= sum_m rowscale*gamma*dout.  Nullable: y+dgamma, gamma,
  * rowscale, dbias, g0.  (ABI 7) g0 (fp32 [N], overwritten): sum_m rowscale*dout, i.e. dbias WITHOUT the gamma factor -- what
- * op_gamma_grad_finish multiplies with the last Linear's bias when dgamma is taken from the weight gradient instead of from y. */
+ * op_gamma_grad_finish multiplies with the last Linear's bias when dgamma is taken from the weight gradient instead of from y.
+ * (ABI 8) With g0 != NULL (an alternative to y + dgamma) dbranch = rowscale*dout, WITHOUT gamma: the weight-gradient launch applies
+ * gamma to its output rows (op_gemm_tn_grouped: rscale) and the input-gradient GEMM reads a gamma-scaled weight copy
+ * (op_transpose_scaled), so that the layer-scale gradient needs no division by gamma. */
 int64_t op_resid_bwd_workspace_bytes(int64_t N);
 int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                  void* dbranch, void* dgamma, void* dbias, float* g0, void* workspace, int64_t M, int64_t N, int accumulate,
                  void* stream);
-/* (ABI 7) Layer-scale gradient of a residual branch  out = resid + rowscale * gamma * (x W^T + b)  WITHOUT the branch output:
- *   dgamma[n] (+)= rowdot[n] / gamma[n] + sum_i b_i[n] * g0_i[n]      (rowdot[n] := 0 afterwards: the buffer is re-armed)
- * rowdot: op_gemm_tn_grouped's side product over the gamma-scaled gradient (= gamma[n] * sum_k W[n][k] * ((rowscale*dout)^T x)[n][k]);
+/* (ABI 7; 8: no gamma argument, no division, partial slots instead of atomics) Layer-scale gradient of a residual branch
+ * out = resid + rowscale * gamma * (x W^T + b)  WITHOUT the branch output:
+ *   dgamma[n] (+)= sum_{s < slots} rowdot[s][n] + sum_i b_i[n] * g0_i[n]
+ * rowdot: fp32 [slots][N], op_gemm_tn_grouped's partial row dots over the UNSCALED gradient of one or more weight sets laid out slot
+ * after slot (sum_s = sum_k W[n][k] * ((rowscale*dout)^T x)[n][k]); folded in slot order: deterministic;
  * (b_i, g0_i): bias of the last Linear and op_resid_bwd's g0 for up to three weight sets that share gamma (the three modality FFNs of
- * a lock-step layer, transformer_layer.py:203-226; b_i NULL = no bias).  gamma[n] == 0: the rowdot term is dropped (y is not
- * recoverable from a zero-scaled gradient).  dgamma: bf16 [N]. */
-int op_gamma_grad_finish(float* rowdot, const void* gamma, const void* b0, const float* g00, const void* b1, const float* g01,
+ * a lock-step layer, transformer_layer.py:203-226; b_i NULL = no bias).  Exact for every gamma, 0 included (the reference:
+ * transformer_layer.py:78-88).  dgamma: bf16 [N]. */
+int op_gamma_grad_finish(const float* rowdot, int64_t slots, const void* b0, const float* g00, const void* b1, const float* g01,
                          const void* b2, const float* g02, void* dgamma, int64_t N, int accumulate, void* stream);
 /* Backward of LayerNorm_F(gelu(h0) * h1) w.r.t. h0, h1 and the LayerNorm affine in one pass (the FFN's GeGLU + inner
  * sub-LayerNorm, transformer_layer.py:64-67,111-118); mean/rstd: forward statistics.  workspace: op_layernorm_bwd_workspace_bytes.

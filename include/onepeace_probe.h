@@ -23,6 +23,10 @@ int op_probe_mfma_f8(const void* a, const void* b, const void* sa, const void* s
  * clock ticks and 100 MHz ticks over the loop.  The caller times the launch: flops = workgroups x 4 x iters x 64 x 16384.  bench.py
  * uses it to report the MFMA rate the package sustains at its power limit beside the data-sheet peak. */
 int op_probe_mfma_rate(const void* operands, float* out, void* clk, int workgroups, int iters, void* stream);
+/* A stand-in for a collective's kernel sharing the GPU with backward: `workgroups` x 256 threads, 96 KiB of LDS each (one per CU), copying their own
+ * slab (slab_floats floats of buf per workgroup) for `micros` microseconds.  when: NULL or workgroups x 2 uint64 (start, end in 100 MHz
+ * ticks).  tools/cu_contention_ab.py: what CUs held by another kernel cost the persistent / one-tile NT GEMM launches. */
+int op_probe_occupy(void* buf, long long slab_floats, int workgroups, long long micros, void* when, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,10 +13,11 @@ def prepend_token(tok, body):
     """[tok | body] along the sequence: tok [1, 1, H] (a parameter, broadcast over the batch), body [B, S, H] -> [B, S + 1, H].
     Same values and gradients as torch.cat([tok.expand(B, -1, -1), body], dim=1) (adapter/text.py:110-113 and its siblings); two slice
     copies into one allocation instead -- the batched 2-byte copy kernel behind torch.cat moves these 100 MB matrices at 0.3-0.6 TB/s
-    (0.8 ms per call in the headline step, profiles/r5_bench_last_step_final2_b128.txt)."""
+    (0.8 ms per call in the headline step, profiles/r5_bench_last_step_final2_b128.txt).  The result has torch.cat's PROMOTED dtype
+    (an fp32 cls token in front of a bf16 body under autocast gives fp32, as in the reference), not the body's."""
     B, S, H = body.shape
-    out = body.new_empty(B, S + 1, H)
-    out[:, :1] = tok.to(body.dtype).expand(B, -1, -1)
+    out = body.new_empty(B, S + 1, H, dtype=torch.result_type(tok, body))
+    out[:, :1] = tok.expand(B, -1, -1)
     out[:, 1:] = body
     return out
 

@@ -12,8 +12,11 @@ constexpr int CS_MAX_PARTS = 256;
 // ------------------------------------------------------------------------------------------------------------
 // bf16 2-D transpose  out[c][r] = in[r][c]   (64x64 tiles through LDS, 8-byte global accesses on both sides)
 // ------------------------------------------------------------------------------------------------------------
+// scale (nullable): out[c][r] = bf16(scale[r] * in[r][c]) -- the dgrad copy of a residual branch's last Linear with the layer scale
+// folded in (ops._transposed(..., scale=gamma): dx = (rowscale * dout) . (gamma o W), transformer_layer.py:70-88)
 __device__ __forceinline__ void transpose_tile(int bx, int by, const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                        int rows, int cols, int64_t ld_in, int64_t ld_out) {
+                                                        int rows, int cols, int64_t ld_in, int64_t ld_out,
+                                                        const bf16_t* __restrict__ scale = nullptr) {
   __shared__ bf16_t tile[64][64 + 2];
   const int r0 = by * 64, c0 = bx * 64;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16 threads, 4 elements each along the fast axis
@@ -21,13 +24,14 @@ __device__ __forceinline__ void transpose_tile(int bx, int by, const bf16_t* __r
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + ty + k * 16, c = c0 + tx * 4;
     if (r < rows) {
+      const float sc = scale ? (float)scale[r] : 1.f;
       if (c + 3 < cols && (ld_in & 3) == 0) {
         bf16x4 v = *reinterpret_cast<const bf16x4*>(in + (int64_t)r * ld_in + c);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tile[ty + k * 16][tx * 4 + j] = v[j];
+        for (int j = 0; j < 4; ++j) tile[ty + k * 16][tx * 4 + j] = scale ? (bf16_t)(sc * (float)v[j]) : v[j];
       } else {
         for (int j = 0; j < 4; ++j)
-          if (c + j < cols) tile[ty + k * 16][tx * 4 + j] = in[(int64_t)r * ld_in + c + j];
+          if (c + j < cols) tile[ty + k * 16][tx * 4 + j] = scale ? (bf16_t)(sc * (float)in[(int64_t)r * ld_in + c + j]) : in[(int64_t)r * ld_in + c + j];
       }
     }
   }
@@ -51,13 +55,13 @@ __device__ __forceinline__ void transpose_tile(int bx, int by, const bf16_t* __r
 
 
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int rows, int cols,
-                                                        int64_t ld_in, int64_t ld_out) {
-  transpose_tile(blockIdx.x, blockIdx.y, in, out, rows, cols, ld_in, ld_out);
+                                                        int64_t ld_in, int64_t ld_out, const bf16_t* __restrict__ scale) {
+  transpose_tile(blockIdx.x, blockIdx.y, in, out, rows, cols, ld_in, ld_out, scale);
 }
 
 // Many transposes in ONE launch (the dgrad copies of all weights after an optimiser step: 520 matrices at 4B).  Descriptor i
 // covers tiles [tile0[i], tile0[i+1]) of the launch; a workgroup finds its matrix by binary search.
-struct TransposeDesc { const bf16_t* in; bf16_t* out; int rows, cols; int64_t ld_in, ld_out; int tile0, tiles_x; };
+struct TransposeDesc { const bf16_t* in; bf16_t* out; int rows, cols; int64_t ld_in, ld_out; int tile0, tiles_x; const bf16_t* scale; };
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const TransposeDesc* __restrict__ table, int n) {
   const int b = blockIdx.x;
   int lo = 0, hi = n - 1;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const TransposeD
   }
   const TransposeDesc d = table[lo];
   const int local = b - d.tile0;
-  transpose_tile(local % d.tiles_x, local / d.tiles_x, d.in, d.out, d.rows, d.cols, d.ld_in, d.ld_out);
+  transpose_tile(local % d.tiles_x, local / d.tiles_x, d.in, d.out, d.rows, d.cols, d.ld_in, d.ld_out, d.scale);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -131,16 +135,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __res
 }
 
 // Layer-scale gradient from the weight gradient's side product (op_gemm_tn_grouped: rowdot) instead of from the branch output.
-__global__ __launch_bounds__(256) void gamma_grad_finish_kernel(float* __restrict__ rowdot, const bf16_t* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gamma_grad_finish_kernel(const float* __restrict__ rowdot, int slots,
                                                                 const bf16_t* __restrict__ b0, const float* __restrict__ g00,
                                                                 const bf16_t* __restrict__ b1, const float* __restrict__ g01,
                                                                 const bf16_t* __restrict__ b2, const float* __restrict__ g02,
                                                                 bf16_t* __restrict__ dgamma, int N, int accumulate) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
-  const float gm = (float)gamma[n];
-  float t = gm != 0.f ? rowdot[n] / gm : 0.f;
-  rowdot[n] = 0.f;
+  float t = 0.f;  // (round 6) the side product of the UNSCALED gradient: exact for any gamma, also 0; slots folded in a fixed order
+  for (int s = 0; s < slots; ++s) t += rowdot[(int64_t)s * N + n];
   if (g00) t += (b0 ? (float)b0[n] : 0.f) * g00[n];
   if (g01) t += (b1 ? (float)b1[n] : 0.f) * g01[n];
   if (g02) t += (b2 ? (float)b2[n] : 0.f) * g02[n];
@@ -659,19 +662,23 @@ __global__ __launch_bounds__(256) void rows_merge_kernel(const bf16_t* __restric
 
 extern "C" {
 
-int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream) {
+int op_transpose_scaled(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, const void* scale,
+                        void* stream) {
   OP_CHECK_ARG(in && out && rows >= 0 && cols >= 0, "transpose: bad args");
   if (rows == 0 || cols == 0) return OP_OK;
   dim3 grid(ceil_div(cols, 64), ceil_div(rows, 64));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, (bf16_t*)out, (int)rows,
-                     (int)cols, ld_in, ld_out);
+                     (int)cols, ld_in, ld_out, (const bf16_t*)scale);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }
+int op_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, void* stream) {
+  return op_transpose_scaled(in, out, rows, cols, ld_in, ld_out, nullptr, stream);
+}
 
 // Batched transposes: `table` is a DEVICE array of n descriptors {in, out, rows, cols, ld_in, ld_out, tile0, tiles_x}
-// (struct TransposeDesc, 48 bytes: two pointers, two int32, two int64, two int32; tile0 = running sum of
-// ceil(cols/64)*ceil(rows/64), tiles_x = ceil(cols/64)); total_tiles = the sum over all descriptors.
+// (struct TransposeDesc, 56 bytes: two pointers, two int32, two int64, two int32, one pointer; tile0 = running sum of
+// ceil(cols/64)*ceil(rows/64), tiles_x = ceil(cols/64), scale = nullable bf16 [rows] row scales of `in`); total_tiles = the sum over all descriptors.
 int op_transpose_batched(const void* table, int64_t n, int64_t total_tiles, void* stream) {
   OP_CHECK_ARG(table && n > 0 && total_tiles > 0, "transpose_batched: bad args");
   hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
@@ -719,6 +726,7 @@ int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float
   OP_CHECK_ARG(dout && dbranch, "resid_bwd: null pointer");
   OP_CHECK_ARG(N > 0 && N % 8 == 0, "resid_bwd: N must be a multiple of 8");
   OP_CHECK_ARG(!dgamma || y, "resid_bwd: dgamma needs y");
+  OP_CHECK_ARG(!(dgamma && g0), "resid_bwd: g0 (dbranch without gamma) and dgamma (from y) are alternatives");
   OP_CHECK_ARG(!(dgamma || dbias || g0) || workspace, "resid_bwd: dgamma/dbias/g0 requested without workspace");
   if (M == 0) {
     if (g0) (void)hipMemsetAsync(g0, 0, (size_t)N * sizeof(float), (hipStream_t)stream);
@@ -729,8 +737,10 @@ int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float
   if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
   if (parts < 1) parts = 1;
   float* ws = (dgamma || dbias || g0) ? (float*)workspace : nullptr;
+  // (ABI 8) g0 wanted = the layer-scale gradient comes from the weight gradient: dbranch stays WITHOUT gamma (the weight-gradient and
+  // input-gradient GEMMs carry it: op_gemm_tn_grouped's rscale, op_transpose_scaled), dbias still gets it in the fold
   hipLaunchKernelGGL(resid_bwd_kernel, dim3(ceil_div(N, 512), parts), dim3(256), 0, s, (const bf16_t*)dout,
-                     (const bf16_t*)(dgamma ? y : nullptr), (const bf16_t*)gamma, rowscale,
+                     (const bf16_t*)(dgamma ? y : nullptr), (const bf16_t*)(g0 ? nullptr : gamma), rowscale,
                      (int)(rows_per_sample > 0 ? rows_per_sample : 1), (bf16_t*)dbranch, ws, M, (int)N);
   OP_LAUNCH_CHECK();
   if (ws) {
@@ -744,11 +754,11 @@ int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float
   return OP_OK;
 }
 
-// dgamma[n] (+)= rowdot[n] / gamma[n] + sum_i b_i[n] * g0_i[n];  rowdot[n] = 0  (see include/onepeace_hip.h)
-int op_gamma_grad_finish(float* rowdot, const void* gamma, const void* b0, const float* g00, const void* b1, const float* g01,
+// dgamma[n] (+)= sum_s rowdot[s][n] + sum_i b_i[n] * g0_i[n]  (see include/onepeace_hip.h)
+int op_gamma_grad_finish(const float* rowdot, int64_t slots, const void* b0, const float* g00, const void* b1, const float* g01,
                          const void* b2, const float* g02, void* dgamma, int64_t N, int accumulate, void* stream) {
-  OP_CHECK_ARG(rowdot && gamma && dgamma && N > 0, "gamma_grad_finish: null pointer");
-  hipLaunchKernelGGL(gamma_grad_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, rowdot, (const bf16_t*)gamma,
+  OP_CHECK_ARG(rowdot && dgamma && N > 0 && slots > 0, "gamma_grad_finish: null pointer");
+  hipLaunchKernelGGL(gamma_grad_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, rowdot, (int)slots,
                      (const bf16_t*)b0, g00, (const bf16_t*)b1, g01, (const bf16_t*)b2, g02, (bf16_t*)dgamma, (int)N, accumulate);
   OP_LAUNCH_CHECK();
   return OP_OK;

@@ -1633,9 +1633,12 @@ struct TnProb {
   const bf16_t* A; const bf16_t* B; bf16_t* C;  // C[M,N] (+)= A[K,M]^T B[K,N]
   int64_t lda, ldb, ldc;
   int M, N, K, tiles_m, tiles_n, accumulate;
-  // optional (round 5): rowdot[m] += sum_n W[m][n] * (this launch's fp32 product)[m][n] -- the layer-scale gradient of a residual
-  // branch taken from the weight gradient of its last Linear (transformer_layer.py:70-88; see op_gemm_tn_grouped)
-  const bf16_t* W; int64_t ldw; float* rowdot;
+  // optional (round 5): rowdot[s][m] = sum over the 128 columns n of slot s of W[m][n] * (this launch's fp32 product)[m][n], s < N / 128 --
+  // the layer-scale gradient of a residual branch taken from the weight gradient of its last Linear (transformer_layer.py:70-88; see
+  // op_gemm_tn_grouped)
+  // (round 6) rscale != nullptr (only with rowdot): C[m][:] += rscale[m] * product[m][:], while rowdot sums W * the UNSCALED product -- with A the
+  // un-gamma-scaled branch gradient, rscale = gamma and W the last Linear's weight, rowdot IS the layer-scale gradient (no division)
+  const bf16_t* W; int64_t ldw; float* rowdot; const bf16_t* rscale;
 };
 // A queue is a list of RUNS: `n` consecutive slots of one problem's slot order (below), from slot0 on.
 struct TnRun { int prob_n; int slot0; };  // prob_n = problem << 24 | n
@@ -1693,13 +1696,16 @@ __host__ __device__ __forceinline__ bool tn_decode(const TnGroupArgs& p, int x, 
 // first batch is folded; `between` (the next ticket's draw) runs after the first half so that its returning atomic is not in front
 // of loads the wave waits for.  GUARD: tiles on the matrix edge (M, N are multiples of 8: a lane's 8 columns are in or out together).
 // rowdot != nullptr (full tiles, accumulate): the fp32 block is also multiplied with the same block of W and summed along the rows -- a lane folds its 8
-// columns of 16 rows over both 64-column halves, the 8 lanes of a row are folded by three shuffles, one atomic per row and wave.
+// columns of 16 rows over both 64-column halves, the 8 lanes of a row are folded by three shuffles, one store per row and wave into the
+// wave's own slot of the [N / 128][M] partial matrix.
 // (ROWDOT is a run-time, wave-uniform switch of the <ACCUM, !GUARD> instantiation: a fifth inlined copy of the epilogue made the register
 // allocator hoist accumulator reads over the branches and spill 243 dwords per lane.)
 template <bool ACCUM, bool GUARD, typename F>
 __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&acc)[2][4][8], int mrow0, int nbase, int M, int N, int lane, char* wlds,
-                                                F between, const bf16_t* Wm = nullptr, int64_t ldw = 0, float* rowdot = nullptr) {
+                                                F between, const bf16_t* Wm = nullptr, int64_t ldw = 0, float* rowdot = nullptr,
+                                                const bf16_t* rscale = nullptr) {
   const bool ROWDOT = ACCUM && !GUARD && rowdot != nullptr;
+  const bool RSCALE = ROWDOT && rscale != nullptr;
   const int g = lane >> 4, t = lane & 15;
   const int rrow = lane >> 3, cp = lane & 7;
   float rd[16];
@@ -1729,6 +1735,7 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {
       bf16x8 nxt[8], wrow[4];
+      float gam[4] = {1.f, 1.f, 1.f, 1.f};  // row scales of the four rows in flight (1: fma(1, p, old) rounds like old + p)
       if (ACCUM && hb == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1740,6 +1747,10 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
         if (ROWDOT && (i & 3) == 0) {  // W rows four at a time (the kernel sits at 254 of 256 VGPRs: eight in flight spilled)
 #pragma unroll
           for (int j = 0; j < 4; ++j) wrow[j] = *reinterpret_cast<const bf16x8*>(wbase + (int64_t)(hb * 8 + i + j) * 8 * ldw);
+          if (RSCALE) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gam[j] = (float)rscale[mrow0 + rrow + (hb * 8 + i + j) * 8];
+          }
         }
         const int row = (hb * 8 + i) * 8 + rrow;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(wlds + row * 256 + (((2 * cp) ^ (row & 15)) << 4));
@@ -1747,8 +1758,8 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
         bf16x8 w;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          w[r] = (bf16_t)(ACCUM ? (float)old[i][r] + lo[r] : lo[r]);
-          w[4 + r] = (bf16_t)(ACCUM ? (float)old[i][4 + r] + hi[r] : hi[r]);
+          w[r] = (bf16_t)(ACCUM ? __builtin_fmaf(gam[i & 3], lo[r], (float)old[i][r]) : lo[r]);
+          w[4 + r] = (bf16_t)(ACCUM ? __builtin_fmaf(gam[i & 3], hi[r], (float)old[i][4 + r]) : hi[r]);
         }
         if (ok(hb * 8 + i)) *reinterpret_cast<bf16x8*>(cbase + (int64_t)(hb * 8 + i) * 8 * ldc) = w;
         if (ROWDOT) {
@@ -1776,7 +1787,9 @@ __device__ __forceinline__ void tn_epilogue_lds(bf16_t* C, int64_t ldc, f32x4 (&
       v += __shfl_xor(v, 1);
       v += __shfl_xor(v, 2);
       v += __shfl_xor(v, 4);
-      if (cp == 0) atomicAdd(rowdot + mrow0 + rrow + i * 8, v);
+      // (round 6) slot nbase / 128 of the [2 * tiles_n][M] partial matrix: every (slot, row) is written exactly once per launch -- no
+      // atomics, no zeroing, the same bits every run; op_gamma_grad_finish folds the slots in a fixed order
+      if (cp == 0) rowdot[(int64_t)(nbase >> 7) * M + mrow0 + rrow + i * 8] = v;
     }
   }
 }
@@ -1984,7 +1997,7 @@ __global__ __launch_bounds__(256) void gemm256w_tn_grouped_kernel(const TnGroupA
         char* wlds = smem + wid * 32768;
         const int mr = m0 + wm * 128, nb = n0 + wn * 128;
         if (m0 + 256 <= M && n0 + 256 <= N) {  // (uniform) tile inside the matrix
-          if (q.accumulate) tn_epilogue_lds<true, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next, q.W, q.ldw, q.rowdot);  // (rowdot: host checked accumulate, M, N % 256 == 0)
+          if (q.accumulate) tn_epilogue_lds<true, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next, q.W, q.ldw, q.rowdot, q.rscale);  // (rowdot: host checked accumulate, M, N % 256 == 0)
           else tn_epilogue_lds<false, false>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
         } else {
           if (q.accumulate) tn_epilogue_lds<true, true>(q.C, q.ldc, acc, mr, nb, M, N, lane, wlds, draw_next);
@@ -2742,7 +2755,8 @@ int64_t op_gemm_tn_grouped_plan(int64_t nprob, const int64_t* M, const int64_t* 
 // tune: bits 0-9 = forced number of workgroups (0: one per CU, at most one per tile); bit 10 = round 4's solo workgroups (see the kernel).
 int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb, void* const* C,
                        const int64_t* ldc, const int64_t* M, const int64_t* N, const int64_t* K, const int32_t* accumulate,
-                       const void* const* W, const int64_t* ldw, float* const* rowdot, void* counters, int64_t tune, void* stream) {
+                       const void* const* W, const int64_t* ldw, float* const* rowdot, const void* const* rscale, void* counters, int64_t tune,
+                       void* stream) {
   OP_CHECK_ARG(nprob >= 1 && nprob <= TN_MAX_PROB, "gemm_tn_grouped: %lld problems (1 ... %d)", (long long)nprob, TN_MAX_PROB);
   OP_CHECK_ARG(A && lda && B && ldb && C && ldc && M && N && K && accumulate && counters, "gemm_tn_grouped: null pointer");
   int order[TN_MAX_PROB];
@@ -2777,6 +2791,9 @@ int op_gemm_tn_grouped(int64_t nprob, const void* const* A, const int64_t* lda, 
                        ((uintptr_t)W[s] & 15) == 0,
                    "gemm_tn_grouped: problem %d: rowdot needs W (16-byte aligned, ldw %% 8 == 0), accumulate and M, N multiples of 256", s);
       q.W = (const bf16_t*)W[s]; q.ldw = ldw[s]; q.rowdot = rowdot[s];
+      q.rscale = rscale != nullptr ? (const bf16_t*)rscale[s] : nullptr;
+    } else {
+      OP_CHECK_ARG(rscale == nullptr || rscale[s] == nullptr, "gemm_tn_grouped: problem %d: rscale rides on the rowdot epilogue (rowdot is null)", s);
     }
     tiles += (int64_t)q.tiles_m * q.tiles_n;
     work += 2.0 * (double)M[s] * (double)N[s] * (double)K[s];

@@ -118,9 +118,43 @@ __global__ __launch_bounds__(256) void probe_mfma_rate_kernel(const bf16x8* __re
   }
 }
 
+// A stand-in for a collective's kernel on the GPU it shares with backward: `workgroups` x 256 threads that each hold a CU slot (96 KiB of
+// LDS: two of them do not fit one CU) and copy their own slab of `buf` back and forth -- light HBM traffic, no matrix work -- until
+// `ticks` of the 100 MHz clock have passed.  tools/cu_contention_ab.py runs it beside the NT GEMM launches to measure what CUs held by
+// another kernel cost the persistent and the one-tile-per-workgroup forms (distributed.share_cus_with_collectives).
+__global__ __launch_bounds__(256) void probe_occupy_kernel(float* buf, long long slab_floats, unsigned long long ticks, unsigned long long* when) {
+  extern __shared__ float hold[];  // 96 KiB
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  float* mine = buf + (long long)blockIdx.x * slab_floats;
+  hold[threadIdx.x] = 0.f;
+  unsigned long long now = t0;
+  while (now - t0 < ticks) {
+    for (long long i = threadIdx.x; i < slab_floats / 2; i += 256) {
+      const float v = mine[i];
+      mine[slab_floats / 2 + i] = v + hold[(i + threadIdx.x) & 16383];
+    }
+    now = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0 && when) {
+    when[2 * blockIdx.x] = t0;
+    when[2 * blockIdx.x + 1] = now;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// buf: workgroups x slab_floats floats (each workgroup copies the first half of its slab onto the second); when: nullable, workgroups x 2
+// uint64 = start / end of each workgroup in 100 MHz ticks.
+int op_probe_occupy(void* buf, long long slab_floats, int workgroups, long long micros, void* when, void* stream) {
+  OP_CHECK_ARG(buf && slab_floats >= 512 && workgroups > 0 && micros > 0, "probe_occupy: bad argument");
+  OP_ENSURE_LDS(probe_occupy_kernel, 96 * 1024, "probe_occupy");
+  hipLaunchKernelGGL(probe_occupy_kernel, dim3(workgroups), dim3(256), 96 * 1024, (hipStream_t)stream, (float*)buf, slab_floats,
+                     (unsigned long long)micros * 100ull, (unsigned long long*)when);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
 
 // operands: 8 fragments x 64 lanes x 8 bf16 (8 KiB); out: workgroups x 256 floats; clk: workgroups x 2 uint64.  64 MFMAs per wave and
 // iteration: flops = workgroups x 4 waves x iters x 64 x 16 384.

@@ -35,21 +35,33 @@ def init_distributed(backend=None):
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         warm_up_collectives()
-    if world > 1 and backend == "nccl" and "ONEPEACE_TUNE_SCHED" not in os.environ:
-        share_cus_with_collectives()
+    rule = os.environ.get("ONEPEACE_SHARE_CUS")  # "1": one-tile NT launches whatever the world size; "0": never; unset: the default below
+    if rule == "1" or (rule is None and SHARE_CUS_DEFAULT and world > 1 and backend == "nccl" and "ONEPEACE_TUNE_SCHED" not in os.environ):
+        share_cus_with_collectives(verbose=rank == 0)
     return rank, world, local
 
 
-def share_cus_with_collectives():
-    """NT GEMM launches as one tile per workgroup (tune sched 7: gemm256v_kernel, bit-identical results) while RCCL kernels share the
-    GPU with backward.  The persistent form (one workgroup per CU walking tiles blockIdx, blockIdx + 256, ...: -0.5 ... -3.6 % per launch
-    in isolation, level in the whole step: 700.5 / 701.1 against 699.8 / 698.2 ms on one box, profiles/r5_bench_nt_*_samebox_1gpu.json) assumes every workgroup gets its CU at once; a four-wave GEMM workgroup owns its CU's whole register file
-    and LDS, so the c CUs an all-reduce kernel holds are c workgroups that start only when others END -- the launch then takes up to
-    twice its time, where thousands of one-tile workgroups simply flow onto the CUs that are free (T + r c / 256).  The grouped
-    weight-gradient launch draws tickets and needs no such switch.  (Reasoned from the dispatch rules, not measured: no multi-GPU node in
-    this environment; ONEPEACE_TUNE_SCHED=0 keeps the single-GPU rule.)"""
+# Default launch rule of the NT GEMMs on a multi-GPU node (see share_cus_with_collectives).  Decided by tools/cu_contention_ab.py on one GPU
+# (profiles/r6_cu_contention_ab.txt); ONEPEACE_SHARE_CUS=1 / 0 overrides it either way.
+SHARE_CUS_DEFAULT = True
+
+
+def share_cus_with_collectives(verbose=False):
+    """NT GEMM launches as one tile per workgroup (tune sched 7: gemm256v_kernel for single problems, the grouped launches as plain tile
+    lists; bit-identical results: tests/test_distributed_gpu.py) while RCCL kernels share the GPU with backward.  The persistent form
+    (one workgroup per CU walking tiles blockIdx, blockIdx + 256, ...) assumes every workgroup gets its CU at once; a four-wave GEMM
+    workgroup owns its CU's whole register file and LDS, so the c CUs an all-reduce kernel holds are c workgroups that start only when
+    others END -- the launch then takes up to twice its time, where thousands of one-tile workgroups simply flow onto the CUs that are
+    free (T * 256 / (256 - c)).  Without contention the one-tile form is 0.5 ... 3.6 % behind per K = 1536 launch and level over the whole
+    step (700.5 / 701.1 against 699.8 / 698.2 ms on one box, profiles/r5_bench_nt_*_samebox_1gpu.json).  The grouped weight-gradient
+    launch draws tickets and needs no such switch.  Measured on ONE GPU with a stand-in for the collective's kernel on a CU-masked stream
+    (tools/cu_contention_ab.py -> profiles/r6_cu_contention_ab.txt); never yet beside a real RCCL kernel (no multi-GPU node here)."""
     from . import hip
     hip.TUNE.sched = 7
+    if verbose:
+        import sys
+        print("[one_peace_amd.distributed] NT GEMM launches: one tile per workgroup (tune sched 7) while collectives share the CUs; "
+              "ONEPEACE_SHARE_CUS=0 keeps the persistent single-GPU rule", file=sys.stderr)
 
 
 def warm_up_collectives():

@@ -40,19 +40,20 @@ SIGNATURES = {
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
     "op_gemm_tn_grouped_counter_bytes": (I64, []),
     "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, I64, I64, P, I64]),
-    "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
+    "op_gemm_tn_grouped": (c_int, [I64, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I64, P]),
     "op_gemm_nt_batched": (c_int, [P, I64, I64, P, I64, I64, P, I64, P, I64, I64, I64, I64, I64, I64, P]),
     "op_audio_conv1_ln_gelu_fwd": (c_int, [P, I64, P, P, P, P, P, P, P, I64, I64, c_float, P]),
     "op_audio_conv1_ln_gelu_bwd_workspace_bytes": (I64, [I64]),
     "op_audio_conv1_ln_gelu_bwd": (c_int, [P, P, I64, P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, P]),
     "op_transpose": (c_int, [P, P, I64, I64, I64, I64, P]),
+    "op_transpose_scaled": (c_int, [P, P, I64, I64, I64, I64, P, P]),
     "op_transpose_batched": (c_int, [P, I64, I64, P]),
     "op_transpose_desc_bytes": (I64, []),
     "op_colsum_workspace_bytes": (I64, [I64]),
     "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
     "op_resid_bwd_workspace_bytes": (I64, [I64]),
     "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, P, I64, I64, c_int, P]),
-    "op_gamma_grad_finish": (c_int, [P, P, P, P, P, P, P, P, P, I64, c_int, P]),
+    "op_gamma_grad_finish": (c_int, [P, I64, P, P, P, P, P, P, P, I64, c_int, P]),
     "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, P, P, P, I64, I64, c_int, P]),
     "op_ln_geglu_fwd": (c_int, [P, P, I64, P, P, P, P, P, I64, I64, c_float, P]),
     "op_colsum": (c_int, [P, P, P, I64, P, P, P, I64, I64, c_int, c_int, P]),
@@ -91,6 +92,7 @@ PROBE_SIGNATURES = {
     "op_probe_glds": (c_int, [P, P, c_int, P, P]),
     "op_probe_mfma_f8": (c_int, [P, P, P, P, P, c_int, P]),
     "op_probe_mfma_rate": (c_int, [P, P, P, c_int, c_int, P]),
+    "op_probe_occupy": (c_int, [P, ctypes.c_longlong, c_int, ctypes.c_longlong, P, P]),
 }
 
 
@@ -109,7 +111,7 @@ class Tuning:
         self.gm = 0              # M-tiles per L2 group (0 auto)
         self.force_splits = 0    # forced K-split count of small problems (tools)
         self.glds = 1            # 1 LDS-DMA staging, 0 register-staged operands
-        self.sched = int(os.environ.get("ONEPEACE_TUNE_SCHED", "0"))  # four-wave NT launches: 0 auto, 1 / 3 gemm256v_kernel schedule, 6 persistent gemm256p_kernel for single problems too (A/B), 7 gemm256w_kernel
+        self.sched = int(os.environ.get("ONEPEACE_TUNE_SCHED", "0"))  # four-wave NT launches: 0 auto (persistent gemm256p_kernel for K <= 2048), 1 / 3 gemm256v_kernel, 6 gemm256p_kernel for every single problem (A/B), 7 one tile per workgroup: gemm256v_kernel, grouped launches unrolled into the tile list (distributed.share_cus_with_collectives)
         self.fp8_small = 0       # op_gemm_nt_fp8: 1 = keep the 128 x 128 kernel (tests, A/B)
         self.merge_dbias = 1     # attention backward: 1 merged dQ + dBias kernel, 0 separate kernels
         self.resident = 1        # attention forward: bit 0 resident kernels on; bits 1-2 ablations (tools)
@@ -511,9 +513,10 @@ TN_GROUP_MAX = 16
 
 def gemm_tn_grouped(problems, tune=0):
     """ONE persistent launch for up to 16 weight-gradient GEMMs, no split-K (csrc/gemm.hip: gemm256w_tn_grouped_kernel).
-    problems: [(A_km [K, M], B_kn [K, N], out [M, N] bf16, accumulate[, (W [M, N] bf16, rowdot fp32 [M])])].  Returns False (nothing
-    launched) when a problem does not qualify for the transpose-read kernel -- the caller then runs gemm_tn per problem.
-    (W, rowdot): rowdot[m] += sum_n W[m][n] * (this launch's fp32 product)[m][n] -- see gamma_grad_finish."""
+    problems: [(A_km [K, M], B_kn [K, N], out [M, N] bf16, accumulate[, (W [M, N] bf16, rowdot fp32 [N / 128, M][, rscale bf16 [M]])])].
+    Returns False (nothing launched) when a problem does not qualify for the transpose-read kernel -- the caller then runs gemm_tn per
+    problem.  (W, rowdot): rowdot[s][m] = sum over the 128 columns n of slot s of W[m][n] * (this launch's fp32 product)[m][n] (written,
+    every entry once); rscale: out[m] += rscale[m] * product[m] while rowdot sums the unscaled product -- see gamma_grad_finish."""
     n = len(problems)
     dev = problems[0][0].device
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
@@ -523,14 +526,18 @@ def gemm_tn_grouped(problems, tune=0):
     arr = lambda vals: (c_int64 * n)(*vals)  # noqa: E731
     As, Bs, Cs = [q[0] for q in problems], [q[1] for q in problems], [q[2] for q in problems]
     acc = (ctypes.c_int32 * n)(*[int(bool(q[3])) for q in problems])
-    side = [q[4] if len(q) > 4 and q[4] is not None else (None, None) for q in problems]
-    Ws, Rs = [w for w, _ in side], [r for _, r in side]
+    side = [tuple(q[4]) + (None,) * (3 - len(q[4])) if len(q) > 4 and q[4] is not None else (None, None, None) for q in problems]
+    Ws, Rs, Ss = [x[0] for x in side], [x[1] for x in side], [x[2] for x in side]
     has_side = any(r is not None for r in Rs)
+    for sc, r, a, b in zip(Ss, Rs, As, Bs):
+        assert sc is None or (sc.dtype == torch.bfloat16 and sc.is_contiguous() and sc.numel() == a.shape[1])
+        assert r is None or (r.dtype == torch.float32 and r.is_contiguous() and r.shape == (b.shape[1] // 128, a.shape[1])), "rowdot: fp32 [N / 128, M]"
     rc = lib().op_gemm_tn_grouped(n, _ptr_array(As, n), arr([a.stride(0) for a in As]), _ptr_array(Bs, n), arr([b.stride(0) for b in Bs]),
                                   _ptr_array(Cs, n), arr([c.stride(0) for c in Cs]), arr([a.shape[1] for a in As]),
                                   arr([b.shape[1] for b in Bs]), arr([a.shape[0] for a in As]), acc,
                                   _ptr_array(Ws, n) if has_side else None, arr([w.stride(0) if w is not None else 0 for w in Ws]) if has_side else None,
-                                  _ptr_array(Rs, n) if has_side else None, ptr(ctr), int(tune), stream())
+                                  _ptr_array(Rs, n) if has_side else None, _ptr_array(Ss, n) if any(x is not None for x in Ss) else None,
+                                  ptr(ctr), int(tune), stream())
     if rc == -95:
         return False
     _check(rc, "op_gemm_tn_grouped")
@@ -541,24 +548,29 @@ def gemm_tn_grouped(problems, tune=0):
     return True
 
 
-def transpose(x2d, out=None):
+def transpose(x2d, out=None, scale=None):
+    """out[c][r] = x2d[r][c] (* scale[r]: bf16 [rows], the product rounded to bf16)."""
     rows, cols = x2d.shape
     if out is None:
         out = torch.empty(cols, rows, dtype=x2d.dtype, device=x2d.device)
-    _check(lib().op_transpose(ptr(x2d), ptr(out), rows, cols, x2d.stride(0), out.stride(0), stream()), "op_transpose")
+    assert scale is None or (scale.dtype == torch.bfloat16 and scale.is_contiguous() and scale.numel() == rows)
+    _check(lib().op_transpose_scaled(ptr(x2d), ptr(out), rows, cols, x2d.stride(0), out.stride(0), ptr(scale), stream()), "op_transpose")
     return out
 
 
 def transpose_table(jobs, device):
-    """jobs: [(src [rows, cols] (last dim contiguous), dst view [cols, rows] (last dim contiguous))] -> (device table, total tiles)
-    for transpose_batched; the table stays valid as long as the tensors keep their storage."""
+    """jobs: [(src [rows, cols] (last dim contiguous), dst view [cols, rows] (last dim contiguous)[, scale bf16 [rows] or None])] ->
+    (device table, total tiles) for transpose_batched; the table stays valid as long as the tensors keep their storage."""
     import struct
-    assert lib().op_transpose_desc_bytes() == 48
+    assert lib().op_transpose_desc_bytes() == 56
     raw, tile0 = b"", 0
-    for src, dst in jobs:
+    for job in jobs:
+        src, dst = job[:2]
+        scale = job[2] if len(job) > 2 else None
         rows, cols = src.shape
         tx, ty = (cols + 63) // 64, (rows + 63) // 64
-        raw += struct.pack("<QQiiqqii", src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), tile0, tx)
+        raw += struct.pack("<QQiiqqiiQ", src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), tile0, tx,
+                           scale.data_ptr() if scale is not None else 0)
         tile0 += tx * ty
     table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     return table, tile0
@@ -596,7 +608,8 @@ def colsum_segments(x, seg_cols, outs=None, accumulate=False):
 def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma=None, dbias=None, accumulate=False, g0=None):
     """dbranch = rowscale*gamma*dout plus the column reductions dgamma / dbias in one pass.  dgamma / dbias: True
     (allocate), a bf16 [N] tensor (write or, with accumulate, add into it) or None (skip).  g0: fp32 [N] that receives
-    sum_m rowscale*dout (dbias without the gamma factor: gamma_grad_finish's operand)."""
+    sum_m rowscale*dout (dbias without the gamma factor: gamma_grad_finish's operand) -- and dbranch is then rowscale*dout WITHOUT
+    gamma (the weight-gradient launch's rscale and the gamma-scaled transposed weight carry it)."""
     M, N = dout.shape
     out = torch.empty_like(dout)
     if dgamma is True:
@@ -612,14 +625,16 @@ def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma
     return out, dgamma, dbias
 
 
-def gamma_grad_finish(rowdot, gamma, pairs, dgamma, accumulate):
-    """dgamma (+)= rowdot / gamma + sum_i b_i * g0_i; rowdot is zeroed (re-armed).  rowdot: fp32 [N], the side product of gemm_tn_grouped
-    over the gamma-scaled gradient; pairs: up to three (bias bf16 [N] or None, g0 fp32 [N])."""
-    assert rowdot.dtype == torch.float32 and len(pairs) <= 3 and dgamma.dtype == torch.bfloat16 and gamma.dtype == torch.bfloat16
+def gamma_grad_finish(rowdot, pairs, dgamma, accumulate):
+    """dgamma (+)= sum_s rowdot[s] + sum_i b_i * g0_i.  rowdot: fp32 [slots, N], the partial row dots of gemm_tn_grouped over the
+    un-gamma-scaled gradient (several weight sets that share gamma: their slots one after the other); pairs: up to three (bias bf16 [N]
+    or None, g0 fp32 [N])."""
+    assert rowdot.dtype == torch.float32 and rowdot.dim() == 2 and rowdot.is_contiguous() and len(pairs) <= 3 and dgamma.dtype == torch.bfloat16
+    assert rowdot.shape[1] == dgamma.numel()
     flat = []
     for b, g0 in list(pairs) + [(None, None)] * (3 - len(pairs)):
         flat += [ptr(b), ptr(g0)]
-    _check(lib().op_gamma_grad_finish(ptr(rowdot), ptr(gamma), *flat, ptr(dgamma), rowdot.numel(), int(accumulate), stream()),
+    _check(lib().op_gamma_grad_finish(ptr(rowdot), rowdot.shape[0], *flat, ptr(dgamma), rowdot.shape[1], int(accumulate), stream()),
            "op_gamma_grad_finish")
     return dgamma
 

@@ -50,47 +50,55 @@ def refresh_weight_cache():
             continue
         hip.quant_fp8_rows(w.detach(), out=qs)
         _fp8_cache[k] = (ref, (w._version, w.data_ptr(), _cache_epoch), qs)
-    live = [(k, v) for k, v in _wt_cache.items() if all(r() is not None for r in v[0])]
+    live = [(k, v) for k, v in _wt_cache.items() if all(r() is not None for r in v[0]) and (v[3] is None or v[3]() is not None)]
     if not live:
         return
-    sig = tuple((k, tuple(r().data_ptr() for r in v[0]), v[2].data_ptr()) for k, v in live)
+    sig = tuple((k, tuple(r().data_ptr() for r in v[0]), v[2].data_ptr(), v[3]().data_ptr() if v[3] is not None else 0) for k, v in live)
     if _refresh_plan is None or _refresh_plan[0] != sig:
         jobs = []
         for k, v in live:
             off = 0
             for r in v[0]:
                 w = r().detach()
-                jobs.append((w, v[2][:, off:off + w.shape[0]]))  # segment i fills columns [off, off + out_i) of [in, sum out]
+                # segment i fills columns [off, off + out_i) of [in, sum out]; a scaled entry (one weight) carries its row scales
+                jobs.append((w, v[2][:, off:off + w.shape[0]], v[3]().detach() if v[3] is not None else None))
                 off += w.shape[0]
         table, tiles = hip.transpose_table(jobs, live[0][1][2].device)
         _refresh_plan = (sig, table, len(jobs), tiles)
     hip.transpose_batched(_refresh_plan[1], _refresh_plan[2], _refresh_plan[3])
     for k, v in live:
-        ws = tuple(r() for r in v[0])
-        _wt_cache[k] = (v[0], (tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws), _cache_epoch), v[2])
+        _wt_cache[k] = (v[0], _wt_version(tuple(r() for r in v[0]), v[3]() if v[3] is not None else None), v[2], v[3])
 
 
-def _transposed(ws):
+def _wt_version(ws, scale):
+    return (tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws), _cache_epoch,
+            (scale._version, scale.data_ptr()) if scale is not None else None)
+
+
+def _transposed(ws, scale=None):
     """[sum(out_i), in] -> cached bf16 [in, sum(out_i)] (ws: one weight or a tuple that is concatenated on dim 0).
+    scale (bf16 [out], one weight only): column j of the copy is scale[j] * W[j, :] -- the last Linear of a residual branch with the
+    layer scale folded in, the operand of  dx = (rowscale * dout) . (gamma o W)  when the branch gradient is kept un-scaled.
 
     Entries are keyed by the identity of the parameter objects and validated through weak references (a freed
     parameter's address can be handed to a different tensor by the allocator) plus (_version, epoch)."""
     ws = ws if isinstance(ws, (tuple, list)) else (ws,)
-    key = tuple(id(w) for w in ws)
-    ver = (tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws), _cache_epoch)
+    assert scale is None or len(ws) == 1
+    key = tuple(id(w) for w in ws) + ((id(scale),) if scale is not None else ())
+    ver = _wt_version(ws, scale)
     hit = _wt_cache.get(key)
-    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)):
+    if hit is not None and all(r() is w for r, w in zip(hit[0], ws)) and (scale is None or (hit[3] is not None and hit[3]() is scale)):
         if hit[1] == ver:
             return hit[2]
         out = hit[2]
     else:
         out = None
         if len(_wt_cache) > 4096:  # drop entries of parameters that no longer exist
-            for k in [k for k, v in _wt_cache.items() if any(r() is None for r in v[0])]:
+            for k in [k for k, v in _wt_cache.items() if any(r() is None for r in v[0]) or (v[3] is not None and v[3]() is None)]:
                 del _wt_cache[k]
     src = ws[0] if len(ws) == 1 else torch.cat([w.detach() for w in ws], dim=0)
-    t = hip.transpose(src.detach(), out)
-    _wt_cache[key] = (tuple(weakref.ref(w) for w in ws), ver, t)
+    t = hip.transpose(src.detach(), out, scale=scale.detach() if scale is not None else None)
+    _wt_cache[key] = (tuple(weakref.ref(w) for w in ws), ver, t, weakref.ref(scale) if scale is not None else None)
     return t
 
 
@@ -255,8 +263,6 @@ class _WgradQueue:
         """Forget everything a backward pass that raised left behind (the engine does not run queue_callback callbacks then):
         stale operands must not be accumulated into the freshly zeroed gradients of the next step, and the end-of-backward
         safety net has to be registered again.  Called by distributed.FlatParameters.zero_grad / BucketedGradReducer.reset."""
-        if self.items or self.after:  # a launch that never ran leaves its side-product buffers un-armed (dirty or never returned)
-            _rowdot_pool.clear()
         self.items, self.done, self.after, self.armed = [], [], [], False
         self.epoch += 1
 
@@ -267,7 +273,8 @@ class _WgradQueue:
         return lo, lo + ((out.shape[0] - 1) * out.stride(0) + out.shape[1]) * out.element_size()
 
     def add(self, dy, x, out, params, side=None, after=None):
-        """side: (W, rowdot) -- the launch also adds sum_n W[m][n] * product[m][n] to rowdot[m] (hip.gemm_tn_grouped);
+        """side: (W, rowdot [N / 128, M], gamma) -- `dy` carries NO layer scale: the launch adds gamma[m] * product[m] to out[m] and writes the
+        partial sums of W[m][n] * product[m][n] over 128-column slots to rowdot (hip.gemm_tn_grouped: rscale);
         after: called once the launch that holds this problem is enqueued (before the parameters are reported)."""
         lo, hi = self._span(out)
         for it in self.items:  # the grouped launch read-modify-writes C tiles without ordering between problems: two
@@ -302,8 +309,11 @@ class _WgradQueue:
                         hip.gemm_tn(dy, x, out, True)
                     else:  # (rare: the side product rides on the grouped launch only) the product once, used twice
                         prod = hip.gemm_tn(dy, x, None, False)
-                        out.add_(prod)
-                        side[1].add_((side[0].detach().float() * prod.float()).sum(1))
+                        W, rowdot, gamma = side
+                        out.addcmul_(prod, gamma.detach().unsqueeze(1))
+                        rowdot.zero_()  # [slots, M]: the whole row dot goes into slot 0
+                        for r0 in range(0, prod.shape[0], 256):  # (row blocks: no fp32 copies of whole matrices)
+                            rowdot[0, r0:r0 + 256] = (W.detach()[r0:r0 + 256].float() * prod[r0:r0 + 256].float()).sum(1)
         for f in after:
             f()
         for q in done:
@@ -340,21 +350,25 @@ def wgrad_into(dy, x, grad_view, params, side=None, after=None):
 # backward -- a second output of the residual GEMM (its epilogue then moves three times the bytes of a plain launch) that is kept for
 # backward (2 H bytes per token and branch) and read again by op_resid_bwd.  But
 #     dgamma[n] = sum_k W[n][k] * G[n][k] + b[n] * g0[n],     G = (ps dout)^T x,   g0 = sum_m ps dout,
-# and the weight gradient the step computes anyway is dW = gamma[n] * G (its operand is the gamma-scaled gradient): the grouped
-# weight-gradient launch adds sum_k W * dW (its fp32 accumulators, before they are rounded into the bf16 gradient) to a row vector,
-# op_resid_bwd hands out g0, op_gamma_grad_finish divides by gamma.  y is then neither written nor kept nor read.
+# and the weight gradient the step computes anyway is dW = gamma[n] * G.  (Round 6) The branch gradient op_resid_bwd writes is
+# u = ps dout WITHOUT gamma; the grouped weight-gradient launch multiplies u^T x = G (its fp32 accumulators) with W into a row vector
+# -- that IS the first term, for any gamma including 0 -- and adds gamma[n] * G to the bf16 gradient; the input gradient
+# u . (gamma o W) reads a gamma-scaled transposed copy of W (rebuilt with the others after every optimiser step).  Round 5 fed the
+# launch the gamma-scaled gradient and divided the row vector by gamma: wrong (0) where gamma == 0.  y is neither written nor kept.
 DGAMMA_FROM_WGRAD = os.environ.get("ONEPEACE_DGAMMA_FROM_WGRAD", "1") != "0"
-_rowdot_pool = {}
 
 
-def _rowdot_take(device, n):
-    """A zeroed fp32 [n] buffer; op_gamma_grad_finish re-arms (zeroes) it, after which _rowdot_give returns it to the pool."""
-    pool = _rowdot_pool.setdefault((device, n, torch.cuda.current_stream(device).cuda_stream), [])
-    return pool.pop() if pool else torch.zeros(n, dtype=torch.float32, device=device)
-
-
-def _rowdot_give(buf):
-    _rowdot_pool.setdefault((buf.device, buf.numel(), torch.cuda.current_stream(buf.device).cuda_stream), []).append(buf)
+def _rowdot_slots(device, weights):
+    """The side-product buffer of a branch: fp32 [sum_i in_i / 128, out] -- weight i ([out, in_i]: the last Linear of one weight set
+    that shares gamma) owns in_i / 128 consecutive slots, each written exactly once by the grouped launch (no zeroing, no atomics).
+    Returns (buffer, [per-weight [in_i / 128, out] views])."""
+    n = [w.shape[1] // 128 for w in weights]
+    buf = torch.empty(sum(n), weights[0].shape[0], dtype=torch.float32, device=device)
+    views, off = [], 0
+    for k in n:
+        views.append(buf[off:off + k])
+        off += k
+    return buf, views
 
 
 def dgamma_from_wgrad_ok(rows, gamma, weights, biases, needs_g, needs_w):  # rows: per weight, the token rows of its gradient GEMM
@@ -825,14 +839,13 @@ def _return_grads(names, params, G, direct):
 def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs, g0=None):
     """Gradient of  resid + ps * gamma * (y)  w.r.t. the branch output and -- where they are wanted -- gamma and the last
     Linear's bias, in one pass.  g0 (fp32 [H]): gamma's gradient is NOT taken here (no y: dgamma_from_wgrad_ok); the kernel fills g0
-    with sum_m ps * dout for op_gamma_grad_finish instead."""
+    with sum_m ps * dout for op_gamma_grad_finish instead and returns ps * dout WITHOUT gamma."""
     names = tuple(n for n, present in ((gname, gamma is not None and g0 is None), (bname, True)) if present and needs.get(n))
     tgt, acc = _targets(direct, *names) if names else ([], False)
     t = dict(zip(names, tgt))
     dgamma = (t[gname] if acc else True) if gname in t else None
     dbias = (t[bname] if acc else True) if bname in t else None
-    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc,
-                               g0=g0 if torch.is_tensor(g0) else None)  # (g0 = False: fused mode for a Linear without bias)
+    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc, g0=g0)
     _finish(direct, G, names, tuple({gname: dg, bname: db}[n] for n in names), acc)
     return dy
 
@@ -871,11 +884,10 @@ def _weight_grad_fn(ctx, G):
 
 
 def _gamma_finish_hook(rowdot, gamma_param, pairs, done):
-    """After the grouped launch: dgamma += rowdot / gamma + sum b_i g0_i into gamma's flat gradient view; the buffer goes back to the pool
-    and gamma's in-place contribution is reported (the reducer may all-reduce its bucket)."""
+    """After the grouped launch: dgamma += sum_s rowdot[s] + sum b_i g0_i into gamma's flat gradient view, and gamma's in-place
+    contribution is reported (the reducer may all-reduce its bucket)."""
     def run():
-        hip.gamma_grad_finish(rowdot, gamma_param.detach(), pairs, gamma_param.grad, True)
-        _rowdot_give(rowdot)
+        hip.gamma_grad_finish(rowdot, pairs, gamma_param.grad, True)
         if done:
             _direct_grad_done(gamma_param)
     return run
@@ -971,20 +983,22 @@ class AttnBranchFn(torch.autograd.Function):
             dx_mid = hip.rows_gather(dx_full, kept)
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        if ctx.dg_fused:
-            g0 = torch.empty(H, dtype=torch.float32, device=dx_mid.device) if P["bo"] is not None else None
-            dy1 = _resid_backward(dx_mid, None, P["g1"], rowscale, rps, "g1", "bo", direct, G, needs, g0=g0 if g0 is not None else False)
-            rowdot = _rowdot_take(dx_mid.device, H)
-            weight_grad("wo", dy1, A["aln"], side=(P["wo"], rowdot),
-                        after=_gamma_finish_hook(rowdot, direct["g1"], [(P["bo"], g0)] if g0 is not None else [], True))
+        if ctx.dg_fused:  # dy1 = rowscale * dx_mid, WITHOUT gamma_1 (weight gradient: rscale; input gradient: scaled weight copy)
+            g0 = torch.empty(H, dtype=torch.float32, device=dx_mid.device)
+            dy1 = _resid_backward(dx_mid, None, P["g1"], rowscale, rps, "g1", "bo", direct, G, needs, g0=g0)
+            rowdot, (rd_wo,) = _rowdot_slots(dx_mid.device, [P["wo"]])
+            weight_grad("wo", dy1, A["aln"], side=(P["wo"], rd_wo, P["g1"]),
+                        after=_gamma_finish_hook(rowdot, direct["g1"], [(P["bo"], g0)] if P["bo"] is not None else [], True))
+            wo_t = _transposed(P["wo"], scale=P["g1"])
         else:
             dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs)
             if needs["wo"]:
                 weight_grad("wo", dy1, A["aln"])
+            wo_t = None
         upstream = ("ln1_w", "ln1_b", "wq", "bq", "wk", "wv", "bv", "aln_w", "aln_b")
         dx = None
         if need_x or any(want_dbias) or any(needs[n] for n in upstream):
-            daln = hip.gemm_nt(dy1, [_transposed(P["wo"])])
+            daln = hip.gemm_nt(dy1, [wo_t if wo_t is not None else _transposed(P["wo"])])
             if P["aln_w"] is not None:
                 want = needs["aln_w"] or needs["aln_b"]
                 (tw, tb), acc = _targets(direct, "aln_w", "aln_b") if want else ((None, None), False)
@@ -1087,8 +1101,8 @@ class FfnBranchFn(torch.autograd.Function):
                 acts["gln"] = None
             if not (needs["w0"] or needs["w1"]):
                 acts["xln2"] = None
-        ctx.cheap = keep and bool(int(save_acts) & 4) and not FP8_FFN
-        if ctx.cheap:  # (set_recompute_cheap)
+        ctx.cheap = keep and bool(int(save_acts) & 4)
+        if ctx.cheap:  # (set_recompute_cheap; also with the fp8 forward: backward reads the bf16 rows, which the same kernels re-create)
             acts["xln2"] = None
             if _geglu_split(P["w0"].shape[0], P["fln_w"]):  # LN_F(gelu(h0) * h1) comes back from the kept h0 | h1
                 acts["gln"] = None
@@ -1119,19 +1133,21 @@ class FfnBranchFn(torch.autograd.Function):
             dout2 = dout2.contiguous()
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
-        if ctx.dg_fused:
-            g0 = torch.empty(H, dtype=torch.float32, device=dout2.device) if P["b2"] is not None else None
-            dy2 = _resid_backward(dout2, None, P["g2"], ps, S, "g2", "b2", direct, G, needs, g0=g0 if g0 is not None else False)
-            rowdot = _rowdot_take(dout2.device, H)
-            weight_grad("w2", dy2, A["gln"], side=(P["w2"], rowdot),
-                        after=_gamma_finish_hook(rowdot, direct["g2"], [(P["b2"], g0)] if g0 is not None else [], True))
+        if ctx.dg_fused:  # dy2 = ps * dout, WITHOUT gamma_2 (see AttnBranchFn.backward)
+            g0 = torch.empty(H, dtype=torch.float32, device=dout2.device)
+            dy2 = _resid_backward(dout2, None, P["g2"], ps, S, "g2", "b2", direct, G, needs, g0=g0)
+            rowdot, (rd_w2,) = _rowdot_slots(dout2.device, [P["w2"]])
+            weight_grad("w2", dy2, A["gln"], side=(P["w2"], rd_w2, P["g2"]),
+                        after=_gamma_finish_hook(rowdot, direct["g2"], [(P["b2"], g0)] if P["b2"] is not None else [], True))
+            w2_t = _transposed(P["w2"], scale=P["g2"])
         else:
             dy2 = _resid_backward(dout2, A["y2"], P["g2"], ps, S, "g2", "b2", direct, G, needs)
             if needs["w2"]:
                 weight_grad("w2", dy2, A["gln"])
+            w2_t = None
         dx = None
         if need_x or any(needs[n] for n in ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b")):
-            dgln = hip.gemm_nt(dy2, [_transposed(P["w2"])])
+            dgln = hip.gemm_nt(dy2, [w2_t if w2_t is not None else _transposed(P["w2"])])
             # dh0 | dh1 as the two halves of ONE [N, 2F] matrix, in the memory order of the two weights' flat gradient views:
             # one weight-gradient launch (288 output tiles, one fold) when those views are adjacent, and always one K = 2F
             # input-gradient GEMM instead of two K = F launches chained through a residual epilogue
@@ -1280,7 +1296,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 acts["xln2"] = None
             if has_fln and not any(nd["w2@%d" % i] for i in range(nseg)):
                 acts["gln"] = None
-        ctx.cheap = keep and bool(int(save_acts) & 4) and not FP8_FFN
+        ctx.cheap = keep and bool(int(save_acts) & 4)
         if ctx.cheap:  # (set_recompute_cheap)
             acts["xln2"] = None
             if _geglu_split(Fd, params[5]):
@@ -1327,7 +1343,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
         dgln = torch.empty(N, Fd, dtype=dt, device=dev) if upstream else None
         colsets, dg_tmp = [], None
         fused = ctx.dg_fused  # gamma_2's gradient from the three down-projection weight gradients (no y2: dgamma_from_wgrad_ok)
-        rowdot, pairs = (_rowdot_take(dev, H), []) if fused else (None, None)
+        (rowdot, rd_views), pairs = (_rowdot_slots(dev, [P["w2@%d" % i] for i in range(nseg)]), []) if fused else ((None, None), None)
         for i, sg in enumerate(segs):
             r = slice(sg.row0, sg.end)
             k = lambda n: "%s@%d" % (n, i)  # noqa: E731
@@ -1340,9 +1356,10 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 tg = tb = True
                 acc_g = acc_b = False
             g0 = None
-            if fused and P[k("b2")] is not None:
+            if fused:  # (g0 also switches the kernel to the un-scaled branch gradient: dy2 = ps * dout without gamma_2)
                 g0 = torch.empty(H, dtype=torch.float32, device=dev)
-                pairs.append((P[k("b2")], g0))
+                if P[k("b2")] is not None:
+                    pairs.append((P[k("b2")], g0))
             dy2, dg_, db_ = hip.resid_bwd(dout[r], A["y2"][r] if want_g else None, P["g2"], pss[i], sg.S, dgamma=tg if want_g else None,
                                           dbias=tb if want_b else None, accumulate=(acc_g and want_g) or (acc_b and want_b), g0=g0)
             if want_g and not acc_g:
@@ -1353,14 +1370,14 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 else:
                     G[k("b2")] = db_
             if fused:  # (the hook rides on the last segment's problem: by then every (bias, g0) pair is listed)
-                weight_grad(k("w2"), dy2, A["gln"][r], side=(P[k("w2")], rowdot),
+                weight_grad(k("w2"), dy2, A["gln"][r], side=(P[k("w2")], rd_views[i], P["g2"]),
                             after=_gamma_finish_hook(rowdot, direct["g2"], pairs, True) if i == nseg - 1 else None)
             elif needs[k("w2")]:
                 weight_grad(k("w2"), dy2, A["gln"][r])
             if not upstream:
                 colsets.append(None)
                 continue
-            hip.gemm_nt(dy2, [_transposed(P[k("w2")])], out=dgln[r])
+            hip.gemm_nt(dy2, [_transposed(P[k("w2")], scale=P["g2"] if fused else None)], out=dgln[r])
             pair = (k("w0"), k("w1"))
             order = _adjacent_grads(direct, pair) if needs[pair[0]] and needs[pair[1]] and Fd % 8 == 0 else None
             cols = tuple(order) if order else pair

@@ -208,6 +208,7 @@ class TransformerEncoder(nn.Module):
             per_layer.append(handles)
             row0 += B * S
             samples += B
+        assert all(xi.dtype == xs[0].dtype for xi in xs), "forward_multi: the streams of a lock-step pass share one dtype (bf16 on the HIP path)"
         x2 = xs[0].new_empty(row0, xs[0].shape[1])  # (slice copies, not torch.cat: see adapter.common.prepend_token)
         r = 0
         for xi in xs:

@@ -274,13 +274,22 @@ def audio_adapter(sd, p, src_audios, padding_mask, conv_pos_groups=16):
 # ------------------------------------------------------------------------------------------------
 # encoder + models
 # ------------------------------------------------------------------------------------------------
+def layerdrop_mask(num_layers, p, training=True):
+    """fairseq/modules/layer_drop.py:38-44: one uniform draw per layer from the CPU generator when the layer list is iterated; layer i
+    runs iff not training or u_i > p."""
+    u = torch.empty(num_layers).uniform_()
+    return [(not training) or bool(u[i] > p) for i in range(num_layers)]
+
+
 def encoder_forward(sd, p, num_heads, num_layers, encoder_type, text_info=None, image_info=None,
-                    audio_info=None, path_scales=None):
+                    audio_info=None, path_scales=None, layer_mask=None, return_all_hiddens=False):
     """transformer_encoder.py:73-232.  *_info = (x [B,S,H], pad [B,S], [bias [heads,S,S], ...] or None).
 
     Stream concat (:116-137), zeroing of padded positions (:139-142), block-diagonal bias with -inf on
     padded keys (:144-162; cross-modal blocks stay 0), layer loop with one shared or per-layer bias
     (:172-188), per-modality final LayerNorm (:201-220).  Returns x batch-major [B, S, H] and the mask.
+    layer_mask: the layers a LayerDropModuleList pass runs (layerdrop_mask; :48-51 -- the bias index stays the position in the
+    ITERATION, :172-176).  return_all_hiddens (:186-199): also {modality: [time-major slice of every executed layer's output]}.
     """
     infos = {"text": [text_info], "image": [image_info], "audio": [audio_info],
              "vl": [text_info, image_info], "al": [text_info, audio_info]}[encoder_type]
@@ -306,10 +315,22 @@ def encoder_forward(sd, p, num_heads, num_layers, encoder_type, text_info=None, 
     tl = text_info[0].shape[1] if text_info is not None else 0
     il = image_info[0].shape[1] if image_info is not None else 0
     al = audio_info[0].shape[1] if audio_info is not None else 0
+    states = {"text": [], "image": [], "audio": []}
+    idx = 0  # position in the iteration over the executed layers (the reference enumerates the LayerDropModuleList iterator)
     for li in range(num_layers):
-        bias = None if not biases else (biases[0] if len(biases) == 1 else biases[li])
+        if layer_mask is not None and not layer_mask[li]:
+            continue
+        bias = None if not biases else (biases[0] if len(biases) == 1 else biases[idx])
         ps = None if path_scales is None else path_scales[li]
         x = encoder_layer(x, sd, "%s.layers.%d" % (p, li), num_heads, encoder_type, bias, tl, il, al, ps)
+        idx += 1
+        if return_all_hiddens:
+            if text_info is not None:
+                states["text"].append(x[:tl])
+            if image_info is not None:
+                states["image"].append(x[tl:tl + il])
+            if audio_info is not None:
+                states["audio"].append(x[tl + il:tl + il + al])
 
     def final(t, m):
         k = "%s.%s_layer_norm.weight" % (p, m)
@@ -321,6 +342,8 @@ def encoder_forward(sd, p, num_heads, num_layers, encoder_type, text_info=None, 
         second = "image" if encoder_type == "vl" else "audio"
         n2 = il if encoder_type == "vl" else al
         x = torch.cat([final(x[:tl], "text"), final(x[-n2:], second)], dim=0)
+    if return_all_hiddens:
+        return x.transpose(0, 1), pad, states
     return x.transpose(0, 1), pad
 
 

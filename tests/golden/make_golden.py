@@ -384,10 +384,62 @@ def optim_fixture():
     print("optim: %d groups, grad norms %s" % (len(opt.param_groups), [round(float(x), 4) for x in norms]))
 
 
+LAYERDROP = dict(embed_dim=128, ffn_embed_dim=256, layers=4, attention_heads=2, image_rel_bucket_size=4, text_bucket_size=256,
+                 audio_bucket_size=512, layer_scale_init_value=1e-1)
+LAYERDROP_CASES = ((False, 1), (True, 1), (True, 5), (True, 3), (True, 11))  # (training, seed of the CPU generator before the encoder call)
+
+
+def layerdrop_fixture():
+    """return_all_hiddens + layerdrop on the UNMODIFIED reference encoder (transformer_encoder.py:48-51,186-199;
+    fairseq/modules/layer_drop.py:13-44): a joint text+image stream and a text-only stream through four layers with layerdrop 0.5, eval and
+    training mode; the layerdrop mask of a pass is what `torch.empty(4).uniform_()` draws from the seeded CPU generator at the start of
+    the layer loop (the adapters run before the seed is set; drop-path and dropout are 0: nothing else consumes random numbers).
+    Stored per case: which layers ran, every returned state and the encoder output.
+
+    The model is BUILT with layerdrop 1e-9 and the list's probability set to 0.5 afterwards: the reference's constructors enumerate
+    `fusion_model.layers` in training mode to wrap the layers (one_peace_retrieval.py: `for i, layer in enumerate(...layers):
+    ...layers[i] = fsdp_wrap(layer)`), which with layerdrop > 0 DRAWS a mask -- a dropped layer shifts the index and the loop then
+    stores a later layer object into an earlier slot (seed 0, p = 0.5: slots 2 and 3 end up the same module, the original layer 2 is
+    gone).  That is a construction accident of the reference, not part of the forward semantics pinned here."""
+    rt = R.ref("one_peace.models.one_peace.one_peace_retrieval")
+    cfg = R.make_cfg(**LAYERDROP)
+    cfg.encoder.layerdrop = 1e-9
+    torch.manual_seed(0)
+    m = rt.OnePeaceRetrievalModel(cfg, R.TinyDictionary(1000), "val")
+    layers = m.encoder_wrapper.fusion_model.layers
+    assert len({id(x) for x in layers._modules.values()}) == 4
+    layers.p = 0.5
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    missing, unexpected = m.load_state_dict(synth.synth_state_dict(shapes), strict=False)
+    assert not unexpected and all(k.split(".")[-1] in synth.NON_SYNTH for k in missing), (missing, unexpected)
+    inp = synth.synth_inputs(3, text_len=15, image_res=64, audio_samples=8000, vocab=1000)
+    W = m.encoder_wrapper
+    assert type(W.fusion_model.layers).__name__ == "LayerDropModuleList"
+    cases = []
+    for train, seed in LAYERDROP_CASES:
+        m.train(train)
+        rec = dict(train=train, seed=seed)
+        with torch.no_grad():
+            t = W.text_adapter(inp["src_tokens"], None, None, None)
+            i = W.image_adapter(inp["src_images"], None, None, None, False)
+            torch.manual_seed(seed)
+            ran = (torch.empty(4).uniform_() > 0.5).tolist() if train else [True] * 4
+            for et, infos in (("vl", (t, i, None)), ("text", (t, None, None))):
+                torch.manual_seed(seed)
+                out = W.fusion_model(*infos, return_all_hiddens=True, encoder_type=et)
+                assert len(out["text_encoder_states"]) == sum(ran) and out["audio_encoder_states"] == []
+                rec[et] = dict(encoder_out=out["encoder_out"][0].clone(), text_states=[x.clone() for x in out["text_encoder_states"]],
+                               image_states=[x.clone() for x in out["image_encoder_states"]])
+        rec["ran"] = ran
+        cases.append(rec)
+    torch.save(dict(cfg=LAYERDROP, layerdrop=0.5, vocab=1000, shapes=shapes, inputs=inp, cases=cases), os.path.join(HERE, "layerdrop_hiddens.pt"))
+    print("layerdrop:", [(c["train"], c["seed"], c["ran"]) for c in cases])
+
+
 if __name__ == "__main__":
     assert R.reference_available(), "needs /root/reference"
-    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep", "stage2", "deep40", "deep_ta"):
-        {"optim": optim_fixture, "deep": deep_vision_fixture, "stage2": lambda: pretrain_al_fixture(stage2=True),
+    if len(sys.argv) > 1 and sys.argv[1] in ("optim", "deep", "stage2", "deep40", "deep_ta", "layerdrop"):
+        {"layerdrop": layerdrop_fixture, "optim": optim_fixture, "deep": deep_vision_fixture, "stage2": lambda: pretrain_al_fixture(stage2=True),
          "deep40": deep_vision40_fixture, "deep_ta": deep_text_audio_fixture}[sys.argv[1]]()
         sys.exit(0)
     micro_fixture()
@@ -400,6 +452,7 @@ if __name__ == "__main__":
     deep_vision_fixture()
     deep_vision40_fixture()
     deep_text_audio_fixture()
+    layerdrop_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".pt"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

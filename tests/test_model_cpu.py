@@ -357,3 +357,56 @@ def test_layerdrop_encoder_bookkeeping_does_not_go_through_the_layerdrop_iterato
     torch.manual_seed(5)
     out = F(W.text_adapter(inp["src_tokens"], None, None, None), None, None, return_all_hiddens=True, encoder_type="text")
     assert len(out["text_encoder_states"]) == keep and out["image_encoder_states"] == []
+
+
+def _layerdrop_model(fx):
+    from types import SimpleNamespace
+    from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    from tests.model_util import TinyDictionary
+    enc = one_peace_encoder_config(drop_path_rate=0.0, checkpoint_activations=False, **fx["cfg"])
+    enc.layerdrop = fx["layerdrop"]
+    torch.manual_seed(0)
+    return load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(fx["vocab"]), "val"),
+                      fx["shapes"])
+
+
+def test_layerdrop_and_all_hiddens_match_the_reference_fixture(golden_dir):
+    """The mirror's torch path against what the UNMODIFIED reference returned (tests/golden/make_golden.py layerdrop_fixture;
+    transformer_encoder.py:48-51,186-199, fairseq/modules/layer_drop.py:13-44): same seed of the CPU generator -> the same layers run, the
+    same per-layer states (T x B x C slices per modality) and the same encoder output, eval and training, joint and single stream."""
+    fx = _fx(golden_dir, "layerdrop_hiddens.pt")
+    m = _layerdrop_model(fx)
+    W = m.encoder_wrapper
+    inp = fx["inputs"]
+    for case in fx["cases"]:
+        m.train(case["train"])
+        with torch.no_grad():
+            t = W.text_adapter(inp["src_tokens"], None, None, None)
+            i = W.image_adapter(inp["src_images"], None, None, None, False)
+            for et, infos in (("vl", (t, i, None)), ("text", (t, None, None))):
+                torch.manual_seed(case["seed"])
+                out = W.fusion_model(*infos, return_all_hiddens=True, encoder_type=et)
+                want = case[et]
+                assert torch.allclose(out["encoder_out"][0], want["encoder_out"], atol=ATOL, rtol=1e-4), (case["seed"], et)
+                assert len(out["text_encoder_states"]) == sum(case["ran"]) and out["audio_encoder_states"] == []
+                assert len(out["image_encoder_states"]) == (sum(case["ran"]) if et == "vl" else 0)
+                for got, ref in zip(out["text_encoder_states"] + out["image_encoder_states"], want["text_states"] + want["image_states"]):
+                    assert got.shape == ref.shape and torch.allclose(got, ref, atol=ATOL, rtol=1e-4), (case["seed"], et)
+
+
+def test_prepend_token_promotes_like_torch_cat():
+    """adapter/text.py:110-113 (and siblings) concatenate the cls token with torch.cat, which PROMOTES mixed dtypes (an fp32 token in front
+    of a bf16 body under autocast gives fp32); the slice-copy form of the mirrors must do the same, values and gradients."""
+    from one_peace_amd.adapter.common import prepend_token
+    g = torch.Generator().manual_seed(0)
+    for td, bd in ((torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)):
+        tok = torch.randn(1, 1, 8, generator=g).to(td).requires_grad_(True)
+        body = torch.randn(3, 5, 8, generator=g).to(bd).requires_grad_(True)
+        got = prepend_token(tok, body)
+        want = torch.cat([tok.expand(3, -1, -1), body], dim=1)
+        assert got.dtype == want.dtype and torch.equal(got, want), (td, bd, got.dtype, want.dtype)
+        w = torch.randn(got.shape, generator=g)
+        g1 = torch.autograd.grad((got.float() * w).sum(), (tok, body))
+        g2 = torch.autograd.grad((want.float() * w).sum(), (tok, body))
+        assert all(a.dtype == b.dtype and torch.equal(a, b) for a, b in zip(g1, g2))

@@ -397,12 +397,15 @@ def test_full_size_layer_4b_dimensions():
     yb, dxb, dtb, gb = run(torch.bfloat16, False, x)     # yardstick: the reference algorithm op by op in bf16
     yh, dxh, dth, gh = run(torch.bfloat16, True, x)
     report = []
-    _check("4B-dim layer out", yh.cpu(), yb.cpu(), y32, 1.5e-2, report)
-    _check("4B-dim layer dx", dxh.cpu(), dxb.cpu(), dx32, 5e-2, report)
-    _check("4B-dim layer dtable", dth.cpu(), dtb.cpu(), dt32, 5e-2, report)
+    # (round 6) bounds = 2.5 x what these tensors measure (profiles/r5_layer_4b_parity_report.txt: out 3.0e-3, dx 3.3e-3, table
+    # 8.4e-3, parameter gradients 2.7e-3 ... 9.9e-3): a numerical regression of 3 x in any of them fails, the micro-model bounds stay
+    # where the micro model measures (up to 4e-2)
+    _check("4B-dim layer out", yh.cpu(), yb.cpu(), y32, 7.5e-3, report)
+    _check("4B-dim layer dx", dxh.cpu(), dxb.cpu(), dx32, 8.5e-3, report)
+    _check("4B-dim layer dtable", dth.cpu(), dtb.cpu(), dt32, 2.1e-2, report)
     for n, ref in g32.items():
         if n in gh and float(ref.norm()) > 1e-7:
-            _check("4B-dim grad " + n, gh[n].cpu(), gb[n].cpu(), ref, 5e-2, report)
+            _check("4B-dim grad " + n, gh[n].cpu(), gb[n].cpu(), ref, 2.5e-2, report)
     assert len([n for n in g32 if n in gh]) >= 20  # attention + image-FFN parameters (the text / audio FFNs take no part)
     # property 1: permuting the samples permutes the outputs, bit for bit
     perm = torch.tensor([3, 0, 5, 1, 4, 2])
@@ -489,17 +492,267 @@ def test_lock_step_layer_4b_dimensions_against_the_fp32_oracle():
         m, (b, s) = sg.name, shapes[sg.name]
         rows = slice(sg.row0, sg.end)
         live = (~pads[m]) if m in pads else torch.ones(b, s, dtype=torch.bool)
-        check("lock-step 4B layer out " + m, y2[rows].view(b, s, H)[live.to(DEV)], ref_out[m][live], 1.5e-2)
-        check("lock-step 4B layer dx " + m, x2d.grad[rows].view(b, s, H), ref_dx[m], 5e-2)
-        check("lock-step 4B layer dtable " + m, tabs[m].grad, ref_dt[m], 5e-2)  # (audio: 8.3e-3 measured at this size)
+        # (round 6) bounds = 2.5 x measured (profiles/r5_lock_step_layer_4b_parity_report.txt: 3.0e-3 / 3.3e-3 / 8.4e-3, gradients <= 9.9e-3)
+        check("lock-step 4B layer out " + m, y2[rows].view(b, s, H)[live.to(DEV)], ref_out[m][live], 7.5e-3)
+        check("lock-step 4B layer dx " + m, x2d.grad[rows].view(b, s, H), ref_dx[m], 8.5e-3)
+        check("lock-step 4B layer dtable " + m, tabs[m].grad, ref_dt[m], 2.1e-2)
     n = 0
     for name, q in mdev.named_parameters():
         if name in g32 and float(g32[name].norm()) > 1e-7:
             assert q.grad is not None, name
-            check("lock-step 4B layer grad " + name, q.grad, g32[name], 5e-2)
+            check("lock-step 4B layer grad " + name, q.grad, g32[name], 2.5e-2)
             n += 1
     assert n >= 30  # attention branch (12) + three FFN sets (6 each) + final LayerNorm, layer-scale vectors
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "lock_step_layer_4b_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")
+
+
+_FLAT_ORACLE = {}
+
+
+def _flat_layers_case(gamma_scale):
+    """Weights, inputs, masks and the fp32 oracle's results of test_lock_step_layers_4b_under_flat_parameters... (cached per layer-scale
+    magnitude: the oracle does not depend on the recompute level)."""
+    if gamma_scale in _FLAT_ORACLE:
+        return _FLAT_ORACLE[gamma_scale]
+    from one_peace_amd.relpos import add_cls_buckets, make_image_bucket_position, make_token_bucket_position
+    from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    H, heads, L = 1536, 24, 2
+    cfg = one_peace_encoder_config(embed_dim=H, ffn_embed_dim=6144, layers=L, attention_heads=heads, drop_path_rate=0.4)
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([TransformerEncoderLayer(cfg, drop_path_rate=0.4) for _ in range(L)])
+    g = torch.Generator().manual_seed(5)
+    for n, q in layers.named_parameters():
+        if n.endswith("gamma_1") or n.endswith("gamma_2"):  # the layer scale AROUND gamma_scale, one entry exactly 0 and one tiny
+            q.data.copy_(gamma_scale * (1.0 + 0.3 * torch.randn(q.shape, generator=g)))
+            q.data[5], q.data[6] = 0.0, gamma_scale * 1e-3
+        elif q.dim() == 1:
+            q.data.add_(0.1 * torch.randn(q.shape, generator=g))
+    layers = layers.to(torch.bfloat16)  # the weights the device sees, exactly
+    shapes = {"text": (8, 64), "image": (64, 257), "audio": (32, 250)}  # row counts that are multiples of 64, like the headline's
+    nrel_img = (2 * 16 - 1) ** 2 + 3
+    buckets = {"image": make_image_bucket_position(16, nrel_img),
+               "text": add_cls_buckets(make_token_bucket_position(256)[:64, :64].clone(), 2 * 256 - 1),
+               "audio": add_cls_buckets(make_token_bucket_position(512)[:250, :250].clone(), 2 * 512 - 1)}
+    tables = {m: (0.5 * torch.randn(int(buckets[m].max()) + 1, heads, generator=g)).to(torch.bfloat16).float() for m in shapes}
+    xs = {m: torch.randn(b, s, H, generator=g).to(torch.bfloat16).float() for m, (b, s) in shapes.items()}
+    dys = {m: torch.randn(b, s, H, generator=g).to(torch.bfloat16).float() for m, (b, s) in shapes.items()}
+    pads = {"audio": torch.zeros(32, 250, dtype=torch.bool)}
+    pads["audio"][1, 230:] = True
+    pads["audio"][7, 190:] = True
+    pads["audio"][20, 64:] = True
+    probs = [0.2, 0.4]  # drop-path rate of the two layers (linspace(0, 0.4, 40) ends there: transformer_encoder.py:53)
+    masks = {m: torch.bernoulli(torch.full((L, 2, b), 0.7), generator=g) for m, (b, s) in shapes.items()}  # host-drawn, shared with the oracle
+    for m in masks:
+        masks[m][:, :, 0] = 1.0
+    scales = {m: [(masks[m][i, 0] / (1 - probs[i]), masks[m][i, 1] / (1 - probs[i])) for i in range(L)] for m in shapes}
+    # ---- fp32 oracle: one pass per modality over the two layers, shared leaves ----
+    sdo = {"L." + k: v.detach().clone().float().requires_grad_(True) for k, v in layers.state_dict().items()}
+    ref_out, ref_dx, ref_dt = {}, {}, {}
+    for m, (b, s) in shapes.items():
+        xo, tabo = xs[m].clone().requires_grad_(True), tables[m].clone().requires_grad_(True)
+        bias_o = O.rel_pos_bias(tabo, buckets[m]).unsqueeze(0).expand(b, -1, -1, -1)
+        if m in pads:
+            bias_o = bias_o.masked_fill(pads[m][:, None, None, :], float("-inf"))
+        h = xo.transpose(0, 1)
+        for i in range(L):
+            h = O.encoder_layer(h, sdo, "L.%d" % i, heads, m, bias_o, path_scale=scales[m][i])
+        yo = h.transpose(0, 1)
+        live = (~pads[m]).unsqueeze(-1).float() if m in pads else 1.0
+        (yo * dys[m] * live).sum().backward()
+        ref_out[m], ref_dx[m], ref_dt[m] = yo.detach(), xo.grad, tabo.grad
+    g32 = {k[2:]: v.grad for k, v in sdo.items() if v.grad is not None}
+    case = dict(layers=layers, shapes=shapes, buckets=buckets, tables=tables, xs=xs, dys=dys, pads=pads, scales=scales, ref_out=ref_out,
+                ref_dx=ref_dx, ref_dt=ref_dt, g32=g32, H=H, heads=heads, L=L)
+    _FLAT_ORACLE[gamma_scale] = case
+    return case
+
+
+# bounds = 2.5 x the largest error measured per class of tensor (gpurun_out/flat_layers_4b_parity_report_*.txt -> profiles/r6_*)
+@pytest.mark.parametrize("gamma_scale,cheap", [(1e-6, False), (1e-6, True), (1e-1, False), (1e-1, True)])
+def test_lock_step_layers_4b_under_flat_parameters_against_the_fp32_oracle(gamma_scale, cheap):
+    """Round 6 (VERDICT r5 Weak #1): the gradient route bench.py TIMES, at the headline's dimensions, against the fp32 oracle.  Two
+    lock-step encoder layers (H = 1536, F = 6144, 24 heads; 8 x 64 text, 64 x 257 image, 32 x 250 audio tokens with padded keys) whose
+    parameters live in distributed.FlatParameters: every gradient is accumulated IN PLACE in the flat buffer by the kernel that
+    produces it, all weight gradients of a layer are ONE grouped launch, the residual GEMMs write no branch output and gamma_1 / gamma_2
+    take their gradient from the weight-gradient launch's row dot (ops.dgamma_from_wgrad_ok holds: asserted), stochastic depth with
+    host-drawn per-sample masks (rates 0.2 / 0.4) shared with the oracle, the layer scale drawn around 1e-6 (the reference's
+    layer_scale_init_value, pretrain_vl_3B.yaml) and around 1e-1 with one entry exactly 0.0 -- where round 5's rowdot / gamma form
+    returned 0 instead of the reference's sum_m ps dout y (transformer_layer.py:78-88) -- and the cheap recompute level on / off.
+    Compared: per-modality outputs, input gradients, the three bias-table gradients and EVERY flat-buffer gradient."""
+    import copy
+    from one_peace_amd import hip, ops
+    from one_peace_amd.distributed import FlatParameters
+    from one_peace_amd.relpos import RelPosSpec
+    c = _flat_layers_case(gamma_scale)
+    H, L, shapes, pads = c["H"], c["L"], c["shapes"], c["pads"]
+    mdev = copy.deepcopy(c["layers"]).to(DEV).train()
+    flat = FlatParameters(mdev)
+    flat.zero_grad()
+    old_cheap = ops.set_recompute_cheap(cheap)
+    try:
+        segs, x2, tabs, row0 = [], [], {}, 0
+        for m, (b, s) in shapes.items():
+            tabs[m] = c["tables"][m].to(DEV).to(torch.bfloat16).requires_grad_(True)
+            key_pad = None
+            if m in pads:
+                key_pad = torch.ones(b, hip.attn_spad(s), dtype=torch.uint8, device=DEV)
+                key_pad[:, :s] = pads[m].to(torch.uint8).to(DEV)
+            segs.append(ops.StreamSeg(m, b, s, row0, RelPosSpec(tabs[m], c["buckets"][m].to(DEV)).handle(), key_pad))
+            x2.append(c["xs"][m].reshape(b * s, H))
+            row0 += b * s
+        assert row0 % 64 == 0
+        x2d = torch.cat(x2).to(DEV).to(torch.bfloat16).requires_grad_(True)
+        h = x2d
+        fused_seen = []
+        orig_ok = ops.dgamma_from_wgrad_ok
+
+        def spy(*a, **k):
+            r = orig_ok(*a, **k)
+            fused_seen.append(r)
+            return r
+        ops.dgamma_from_wgrad_ok = spy
+        try:
+            for i, layer in enumerate(mdev):
+                ps1 = torch.cat([c["scales"][m][i][0].repeat_interleave(shapes[m][1]) for m in shapes]).to(DEV)
+                ps2s = [c["scales"][m][i][1].to(DEV) for m in shapes]
+                h = layer.forward_fused_multi(h, segs, ps1, ps2s)
+        finally:
+            ops.dgamma_from_wgrad_ok = orig_ok
+        assert fused_seen and all(fused_seen), "the layer-scale gradients did not take the weight-gradient route"
+        dy2 = torch.cat([(c["dys"][m] * ((~pads[m]).unsqueeze(-1).float() if m in pads else 1.0)).reshape(-1, H) for m in shapes]).to(DEV)
+        (h.float() * dy2).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_recompute_cheap(old_cheap)
+    report, worst = [], {}
+
+    def check(kind, name, got, ref, bound):
+        e = rel_fro(got.float().cpu(), ref)
+        report.append("%-70s hip %.3e (bound %.1e, |ref| %.3e)" % (name, e, bound, float(ref.norm())))
+        worst[kind] = max(worst.get(kind, 0.0), e)
+        assert e <= bound, "%s: %.3e > %.1e" % (name, e, bound)
+    for sg in segs:
+        m, (b, s) = sg.name, shapes[sg.name]
+        rows = slice(sg.row0, sg.end)
+        live = (~pads[m]) if m in pads else torch.ones(b, s, dtype=torch.bool)
+        check("out", "flat lock-step 2 x 4B layers out " + m, h[rows].view(b, s, H)[live.to(DEV)], c["ref_out"][m][live], FLAT_BOUNDS["out"])
+        check("dx", "flat lock-step 2 x 4B layers dx " + m, x2d.grad[rows].view(b, s, H), c["ref_dx"][m], FLAT_BOUNDS["dx"])
+        check("dtable", "flat lock-step 2 x 4B layers dtable " + m, tabs[m].grad, c["ref_dt"][m], FLAT_BOUNDS["dtable"])
+    n = 0
+    for name, q in mdev.named_parameters():
+        ref = c["g32"].get(name)
+        assert ref is not None and q.grad is not None and q.grad.data_ptr() >= flat.grads.data_ptr(), name
+        kind = "gamma" if "gamma" in name else "grad"
+        check(kind, "flat lock-step 2 x 4B layers grad " + name, q.grad, ref, FLAT_BOUNDS[kind])
+        if "gamma" in name:  # the zero and the tiny layer-scale entry, element by element: the reference's value, not 0
+            for col in (5, 6):
+                got, want = float(q.grad[col]), float(ref[col])
+                scale = float(ref.abs().median())
+                report.append("%-70s [%d] got %.4e want %.4e" % (name, col, got, want))
+                assert abs(got - want) <= 4e-2 * abs(want) + 2e-2 * scale, (name, col, got, want)
+        n += 1
+    assert n >= 2 * 40, n  # per layer: attention branch 12, three FFN sets 6 each, final LayerNorm 2, layer scales 2 ...
+    report.append("worst per class: " + "  ".join("%s %.3e" % kv for kv in sorted(worst.items())))
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out",
+                      "flat_layers_4b_parity_report_gamma%g_cheap%d.txt" % (gamma_scale, int(cheap))), "w").write("\n".join(report) + "\n")
+
+
+FLAT_BOUNDS = {"out": 1.5e-2, "dx": 5e-2, "dtable": 5e-2, "grad": 5e-2, "gamma": 5e-2}  # first run: the common bounds; tightened below
+
+
+LONG_AUDIO_BOUNDS = {"out": 1.5e-2, "dx": 5e-2, "dtable": 5e-2, "grad": 5e-2}  # first run: the common bounds; tightened below
+
+
+@pytest.mark.parametrize("stream", ["audio", "al"])
+def test_reference_audio_length_15s_4b_layer_against_the_fp32_oracle(stream):
+    """Round 6 (VERDICT r5 Missing #2): the reference's own audio length -- pretrain_al_3B.yaml:10 max_duration 15 s = 750 tokens, the
+    `al` joint stream 72 text + 750 audio = 822 tokens (transformer_encoder.py:144-162, transformer_layer.py:214-217) -- through one
+    encoder layer at the 4B dimensions with RAGGED key padding, forward and backward, against the fp32 oracle.  These lengths leave
+    the persistent attention kernels (193 ... 257 tokens) for the streaming ones; the joint stream reads the block-diagonal bias (text
+    table | audio table, zero across) and routes each row range through its own FFN."""
+    from one_peace_amd import hip
+    from one_peace_amd.relpos import RelPosSpec, add_cls_buckets, joint_handle, make_token_bucket_position
+    from one_peace_amd.transformer.transformer_layer import TransformerEncoderLayer
+    from one_peace_amd.unify_model_config import one_peace_encoder_config
+    H, heads = 1536, 24
+    cfg = one_peace_encoder_config(embed_dim=H, ffn_embed_dim=6144, layers=1, attention_heads=heads, drop_path_rate=0.0)
+    torch.manual_seed(0)
+    layer = TransformerEncoderLayer(cfg, drop_path_rate=0.0)
+    g = torch.Generator().manual_seed(9)
+    for n, q in layer.named_parameters():
+        if q.dim() == 1:
+            q.data.add_(0.1 * torch.randn(q.shape, generator=g))
+    layer = layer.to(torch.bfloat16)
+    Sa, St = 750, 72
+    bk_a = add_cls_buckets(make_token_bucket_position(512)[:Sa, :Sa].clone(), 2 * 512 - 1)
+    bk_t = add_cls_buckets(make_token_bucket_position(256)[:St, :St].clone(), 2 * 256 - 1)
+    tab_a = (0.5 * torch.randn(int(bk_a.max()) + 1, heads, generator=g)).to(torch.bfloat16).float()
+    tab_t = (0.5 * torch.randn(int(bk_t.max()) + 1, heads, generator=g)).to(torch.bfloat16).float()
+    if stream == "audio":
+        B, S = 4, Sa
+        lens = [750, 701, 333, 64]            # frames of each clip incl. CLS: the rest is padding
+        pad = torch.arange(S)[None, :] >= torch.tensor(lens)[:, None]
+    else:
+        B, S = 3, St + Sa
+        tl, al = [72, 40, 13], [750, 518, 97]  # text tokens / audio frames of each pair; padding sits at the end of EACH segment
+        pad = torch.cat([torch.arange(St)[None, :] >= torch.tensor(tl)[:, None], torch.arange(Sa)[None, :] >= torch.tensor(al)[:, None]], 1)
+    x = torch.randn(B, S, H, generator=g).to(torch.bfloat16).float()
+    dy = torch.randn(B, S, H, generator=g).to(torch.bfloat16).float() * (~pad).unsqueeze(-1).float()
+    # ---- fp32 oracle ----
+    sdo = {"L." + k: v.detach().clone().float().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xo, ta, tt = x.clone().requires_grad_(True), tab_a.clone().requires_grad_(True), tab_t.clone().requires_grad_(True)
+    if stream == "audio":
+        bias_o = O.rel_pos_bias(ta, bk_a).unsqueeze(0).expand(B, -1, -1, -1)
+        kw = {}
+    else:
+        blk = torch.zeros(heads, S, S)
+        bias_o = (torch.nn.functional.pad(O.rel_pos_bias(tt, bk_t), (0, Sa, 0, Sa)) + torch.nn.functional.pad(O.rel_pos_bias(ta, bk_a), (St, 0, St, 0))
+                  + blk).unsqueeze(0).expand(B, -1, -1, -1)
+        kw = dict(text_seq_len=St, audio_seq_len=Sa)
+    bias_o = bias_o.masked_fill(pad[:, None, None, :], float("-inf"))
+    yo = O.encoder_layer(xo.transpose(0, 1), sdo, "L", heads, stream, bias_o, **kw).transpose(0, 1)
+    (yo * dy).sum().backward()
+    g32 = {k[2:]: v.grad for k, v in sdo.items() if v.grad is not None}
+    # ---- HIP ----
+    m = layer.to(DEV)
+    m.zero_grad()
+    xd = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    tad, ttd = tab_a.to(DEV).to(torch.bfloat16).requires_grad_(True), tab_t.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    key_pad = torch.ones(B, hip.attn_spad(S), dtype=torch.uint8, device=DEV)
+    key_pad[:, :S] = pad.to(torch.uint8).to(DEV)
+    if stream == "audio":
+        y = m.forward_fused(xd, RelPosSpec(tad, bk_a.to(DEV)).handle(), key_pad, "audio")
+    else:
+        handle = joint_handle([RelPosSpec(ttd, bk_t.to(DEV)), RelPosSpec(tad, bk_a.to(DEV))], [St, Sa])
+        y = m.forward_fused(xd, handle, key_pad, "al", seg_lens=(St, Sa))
+    (y.float() * dy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    report, worst = [], {}
+
+    def check(kind, name, got, ref):
+        e = rel_fro(got.float().cpu(), ref)
+        bound = LONG_AUDIO_BOUNDS[kind]
+        report.append("%-70s hip %.3e (bound %.1e)" % (name, e, bound))
+        worst[kind] = max(worst.get(kind, 0.0), e)
+        assert e <= bound, "%s: %.3e > %.1e" % (name, e, bound)
+    live = ~pad
+    check("out", "%s 15 s 4B layer out" % stream, y[live.to(DEV)], yo.detach()[live])
+    check("dx", "%s 15 s 4B layer dx" % stream, xd.grad[live.to(DEV)], xo.grad[live])
+    check("dtable", "%s 15 s 4B layer dtable audio" % stream, tad.grad, ta.grad)
+    if stream == "al":
+        check("dtable", "al 15 s 4B layer dtable text", ttd.grad, tt.grad)
+    n = 0
+    for name, q in m.named_parameters():
+        ref = g32.get(name)
+        if ref is not None and float(ref.norm()) > 1e-7:
+            assert q.grad is not None, name
+            check("grad", "%s 15 s 4B layer grad %s" % (stream, name), q.grad, ref)
+            n += 1
+    assert n >= (26 if stream == "al" else 20), n
+    report.append("worst per class: " + "  ".join("%s %.3e" % kv for kv in sorted(worst.items())))
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "audio_15s_4b_parity_report_%s.txt" % stream), "w").write(
         "\n".join(report) + "\n")
 
 
@@ -684,12 +937,15 @@ def test_batched_weight_cache_refresh_after_optimizer_step():
                 out.append(float(loss.detach()))
                 if mode == "batched":
                     n = 0
-                    for key, (refs, ver, t) in ops._wt_cache.items():
+                    for key, (refs, ver, t, sref) in ops._wt_cache.items():
                         ws = [r() for r in refs]
                         if any(w is None for w in ws) or not any(w is p for w in ws for p in m.parameters()):
                             continue
                         assert ver[2] == ops._cache_epoch
-                        assert torch.equal(t, torch.cat([w.detach() for w in ws], 0).t()), key
+                        want = torch.cat([w.detach() for w in ws], 0)
+                        if sref is not None:  # the last Linear of a residual branch: the layer scale is folded into the copy
+                            want = (want.float() * sref().detach().float()[:, None]).to(torch.bfloat16)
+                        assert torch.equal(t, want.t()), key
                         n += 1
                     assert n >= 2 * 6  # per layer: q|k|v, out, 3 x (wi_0, wi_1, w2) of the modality actually used ...
         finally:
@@ -981,58 +1237,61 @@ def test_lock_step_pass_matches_one_forward_per_modality(flat, drop_path, recomp
     assert n_exact > 40 and n_close > 20
 
 
-def test_fused_encoder_returns_all_hiddens_and_honours_layerdrop():
+def test_fused_encoder_returns_all_hiddens_and_honours_layerdrop(golden_dir):
     """TransformerEncoder on the HIP path with the two switches that used to send a pass to the torch ops (VERDICT r4 missing #4):
-    return_all_hiddens (transformer_encoder.py:186-190: every layer's output per modality, T x B x C) and layerdrop in training
-    (fairseq/modules/layer_drop.py:13-44; transformer_encoder.py:48-49).  A joint text+image stream, same seed for the layerdrop draw:
-    the fused path must run the same layers as the torch-op path of the same mirror and return the same states within bf16 rounding."""
+    return_all_hiddens (transformer_encoder.py:186-199: every executed layer's output per modality, T x B x C) and layerdrop in training
+    (fairseq/modules/layer_drop.py:13-44; transformer_encoder.py:48-51).  (Round 6) Against what the UNMODIFIED REFERENCE returned for
+    the same weights, inputs and seed of the CPU generator (tests/golden/layerdrop_hiddens.pt, make_golden.py layerdrop_fixture): the
+    fused path must run exactly the layers the reference ran -- counted -- and return its states and encoder output within the
+    activation bound (1.5e-2), for a joint text+image stream and a text-only stream, eval and training."""
     from one_peace_amd.unify_model_config import one_peace_encoder_config
     from one_peace_amd.one_peace.one_peace_retrieval import OnePeaceRetrievalModel
     from one_peace_amd.transformer import transformer_layer as TL
     from tests.model_util import TinyDictionary
     from types import SimpleNamespace
-    enc = one_peace_encoder_config(embed_dim=128, ffn_embed_dim=256, layers=4, attention_heads=2, image_rel_bucket_size=4,
-                                   text_bucket_size=256, audio_bucket_size=512, drop_path_rate=0.0, layer_scale_init_value=1e-1,
-                                   checkpoint_activations=False)
-    enc.layerdrop = 0.5
+    fx = _fx(golden_dir, "layerdrop_hiddens.pt")
+    enc = one_peace_encoder_config(drop_path_rate=0.0, checkpoint_activations=False, **fx["cfg"])
+    enc.layerdrop = fx["layerdrop"]
     torch.manual_seed(0)
-    m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
+    m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(fx["vocab"]), "val"), fx["shapes"])
     m = m.to(DEV).to(torch.bfloat16)
     W = m.encoder_wrapper
-    inp = _to_dev(synth.synth_inputs(3, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
+    inp = _to_dev(fx["inputs"])
     fused_calls = {"n": 0}
     orig_fused = TL.TransformerEncoderLayer.forward_fused
 
     def counted(self, *a, **k):
         fused_calls["n"] += 1
         return orig_fused(self, *a, **k)
-
-    def run(train, seed):
-        m.train(train)
-        torch.manual_seed(seed)  # the layerdrop mask comes from the CPU generator, once per pass
-        t = W.text_adapter(inp["src_tokens"], None, None, None)
-        i = W.image_adapter(inp["src_images"], None, None, None, False)
-        return W.fusion_model(t, i, None, return_all_hiddens=True, encoder_type="vl")
     TL.TransformerEncoderLayer.forward_fused = counted
+    report = []
     try:
-        for train, seed, n_run in ((False, 1, 4), (True, 1, 2), (True, 5, 3), (True, 3, 0)):  # torch.manual_seed(s); uniform_(4) > 0.5
+        for case in fx["cases"]:
+            m.train(case["train"])
+            n_run = sum(case["ran"])
             with torch.no_grad():
-                fused_calls["n"] = 0
-                o_h = run(train, seed)
-                assert fused_calls["n"] == n_run, (train, seed, fused_calls["n"])
-                _force_torch_path(m, True)
-                o_t = run(train, seed)
-                _force_torch_path(m, False)
-            for key in ("text_encoder_states", "image_encoder_states"):
-                assert len(o_h[key]) == len(o_t[key]) == n_run, (key, len(o_h[key]), len(o_t[key]))
-                for a, b in zip(o_h[key], o_t[key]):
-                    assert a.shape == b.shape and a.shape[1] == 3
-                    # two bf16 paths against each other (each is held to 1.5e-2 of fp32 elsewhere): 1.5e-2 * sqrt(2) + margin
-                    assert rel_fro(a.float(), b.float()) <= 2.5e-2, (key, rel_fro(a.float(), b.float()))
-            assert o_h["audio_encoder_states"] == []
-            assert rel_fro(o_h["encoder_out"][0].float(), o_t["encoder_out"][0].float()) <= 2.5e-2
+                t = W.text_adapter(inp["src_tokens"], None, None, None)
+                i = W.image_adapter(inp["src_images"], None, None, None, False)
+                for et, infos in (("vl", (t, i, None)), ("text", (t, None, None))):
+                    fused_calls["n"] = 0
+                    torch.manual_seed(case["seed"])  # the layerdrop mask comes from the CPU generator, once per pass
+                    out = W.fusion_model(*infos, return_all_hiddens=True, encoder_type=et)
+                    assert fused_calls["n"] == n_run, (case["train"], case["seed"], et, fused_calls["n"], n_run)
+                    want = case[et]
+                    assert len(out["text_encoder_states"]) == n_run and out["audio_encoder_states"] == []
+                    assert len(out["image_encoder_states"]) == (n_run if et == "vl" else 0)
+                    pairs = [("out", out["encoder_out"][0], want["encoder_out"])]
+                    pairs += [("text state %d" % k, a, b) for k, (a, b) in enumerate(zip(out["text_encoder_states"], want["text_states"]))]
+                    pairs += [("image state %d" % k, a, b) for k, (a, b) in enumerate(zip(out["image_encoder_states"], want["image_states"]))]
+                    for what, got, ref in pairs:
+                        assert got.shape == ref.shape, (what, got.shape, ref.shape)
+                        e = rel_fro(got.float().cpu(), ref)
+                        report.append("train %d seed %2d %-4s %-14s %.3e" % (case["train"], case["seed"], et, what, e))
+                        assert e <= 1.5e-2, (case["seed"], et, what, e)
     finally:
         TL.TransformerEncoderLayer.forward_fused = orig_fused
+    open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "layerdrop_hiddens_parity_report.txt"), "w").write(
+        "\n".join(report) + "\n")
 
 
 @pytest.mark.parametrize("lock,recompute", [(False, False), (True, False), (True, True)])
@@ -1105,13 +1364,15 @@ def test_layer_scale_gradient_from_the_weight_gradient_matches_the_branch_output
         assert res["wgrad"][1] < res["y"][1], (res["wgrad"][1], res["y"][1])  # 4 H of the 46 H bytes per token and layer are not kept
 
 
-@pytest.mark.parametrize("lock", [False, True])
-def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock):
+@pytest.mark.parametrize("lock,fp8", [(False, False), (True, False), (False, True), (True, True)])
+def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock, fp8):
     """ops.set_recompute_cheap: the memory level between "keep everything" and checkpoint_activations -- the four
     LayerNorm-type outputs only weight gradients read (LN1(x), the attention sub-LayerNorm's output, LN2(x_mid), LN_F(gelu(h0) h1))
     are re-created in backward by the same kernels on the same kept rows.  Loss and EVERY gradient must be bit-identical to the
     keep-everything run, and less memory must be held between forward and backward.  lock: the lock-step pass (AttnBranchFn over all
-    rows + FfnBranchMultiFn) or one pass per modality (AttnBranchFn + FfnBranchFn)."""
+    rows + FfnBranchMultiFn) or one pass per modality (AttnBranchFn + FfnBranchFn).  fp8 (round 6): with the opt-in fp8
+    forward FFN the level used to be ignored silently for the FFN branch (bench.py's memory estimate assumed it); backward reads the
+    bf16 rows, which the plain kernels re-create bit for bit next to what the _q8 variants wrote in the forward."""
     from one_peace_amd import ops
     from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
     from one_peace_amd.distributed import FlatParameters
@@ -1125,6 +1386,7 @@ def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock):
     inp = _to_dev(synth.synth_inputs(B, text_len=15, image_res=64, audio_samples=8000, vocab=1000))
     res = {}
     old = ops.set_recompute_cheap(False)
+    old_fp8 = ops.set_fp8_ffn(fp8)
     try:
         for cheap in (False, True):
             ops.set_recompute_cheap(cheap)
@@ -1145,6 +1407,7 @@ def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock):
             del m, fl, loss
     finally:
         ops.set_recompute_cheap(old)
+        ops.set_fp8_ffn(old_fp8)
     assert res[True][0] == res[False][0]
     assert len(res[True][2]) == len(res[False][2]) > 60
     for n, g in res[False][2].items():

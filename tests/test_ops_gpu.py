@@ -1188,8 +1188,9 @@ def test_gemm_nt_batched_equals_one_launch_per_problem(use_bias):
 def test_gemm_tn_grouped_row_dot_side_product(nwg):
     """(ABI 7) op_gemm_tn_grouped with W / rowdot on some problems: rowdot[m] += sum_n W[m][n] * P[m][n] with P = THIS launch's fp32
     product A^T B (not the accumulated gradient), added on top of what the buffer holds; the gradients themselves must stay bit-identical
-    to a launch without the side product, and a problem without one is untouched.  (With A = gamma-scaled gradient of a residual branch
-    this is gamma * sum_rows ps dout y-without-bias: ops.dgamma_from_wgrad_ok, transformer_layer.py:70-88.)"""
+    to a launch without the side product, and a problem without one is untouched.  (ABI 8) With rscale the gradient receives
+    rscale[m] * P[m] while rowdot still sums the unscaled product: with A = the branch gradient without gamma and rscale = gamma, rowdot
+    is sum_rows ps dout y-without-bias for ANY gamma (ops.dgamma_from_wgrad_ok, transformer_layer.py:70-88)."""
     hip = hipmod()
     sizes = [(1024, 256, 512, True), (2048, 512, 256, True), (512, 256, 256, True)]
     with_side = (True, False, True)
@@ -1199,11 +1200,11 @@ def test_gemm_tn_grouped_row_dot_side_product(nwg):
         a, b = dev_bf16(dy), dev_bf16(x)
         out = dev_bf16(base).clone()
         wd = dev_bf16(w)
-        rd = torch.full((M,), 0.25, dtype=torch.float32, device=DEV) if with_side[i] else None
+        rd = torch.full((N // 128, M), 0.25, dtype=torch.float32, device=DEV) if with_side[i] else None  # (overwritten, not added to)
         probs.append((a, b, out, acc, (wd, rd) if with_side[i] else None))
         plain.append((a, b, dev_bf16(base).clone(), acc))
         prod = a.float().t() @ b.float()
-        refs.append(0.25 + (wd.float() * prod).sum(1))
+        refs.append((wd.float() * prod).view(M, N // 128, 128).sum(2).t().contiguous())  # [slots, M]: 128-column partial sums
         rowdots.append(rd)
     assert hip.gemm_tn_grouped(plain, tune=nwg)
     assert hip.gemm_tn_grouped(probs, tune=nwg)
@@ -1213,22 +1214,65 @@ def test_gemm_tn_grouped_row_dot_side_product(nwg):
         if rd is not None:
             err = float((rd - ref).abs().max()) / float(ref.abs().max())
             assert err < 2e-3, err
+    again = [(q[0], q[1], q[2].clone(), q[3], (q[4][0], torch.empty_like(q[4][1])) if q[4] is not None else None) for q in probs]
+    assert hip.gemm_tn_grouped(again, tune=nwg)  # no atomics: the partial sums are the same bits in every launch
+    torch.cuda.synchronize()
+    for q, q2 in zip(probs, again):
+        assert q[4] is None or torch.equal(q[4][1], q2[4][1])
+    # (ABI 8) row scales: an all-ones vector changes no bit; a real one (with zeros and tiny entries) scales the accumulated product only
+    ones = [(q[0], q[1], dev_bf16(rnd(*q[2].shape, seed=70 + i)).clone(), q[3],
+             (q[4][0], torch.zeros_like(q[4][1]), torch.ones(q[2].shape[0], dtype=torch.bfloat16, device=DEV)) if q[4] is not None else None)
+            for i, q in enumerate(probs)]
+    scaled, scales = [], []
+    for i, q in enumerate(probs):
+        sc = dev_bf16(rnd(q[2].shape[0], seed=120 + i))
+        sc[3], sc[5] = 0.0, 1e-6
+        scales.append(sc)
+        scaled.append((q[0], q[1], dev_bf16(rnd(*q[2].shape, seed=70 + i)).clone(), q[3],
+                       (q[4][0], torch.zeros_like(q[4][1]), sc) if q[4] is not None else None))
+    assert hip.gemm_tn_grouped(ones, tune=nwg)
+    assert hip.gemm_tn_grouped(scaled, tune=nwg)
+    torch.cuda.synchronize()
+    for i, (q1, qs, q0, ref) in enumerate(zip(ones, scaled, plain, refs)):
+        assert torch.equal(q1[2], q0[2]), "a row scale of 1 changed the gradient"
+        if qs[4] is None:
+            assert torch.equal(qs[2], q0[2])
+            continue
+        prod = qs[0].float().t() @ qs[1].float()
+        want = dev_bf16(rnd(*qs[2].shape, seed=70 + i)).float() + scales[i].float()[:, None] * prod
+        assert_close(qs[2], want.cpu(), what="row-scaled accumulation")
+        assert torch.equal(qs[2][3], dev_bf16(rnd(*qs[2].shape, seed=70 + i))[3]), "a zero row scale must leave the row alone"
+        err = float((qs[4][1] - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-3, err  # the side product does not see the scale
     with pytest.raises(RuntimeError):  # ragged M: the side product rides on full tiles only
         bad = (dev_bf16(rnd(128, 264)), dev_bf16(rnd(128, 256)), dev_bf16(rnd(264, 256)), True,
-               (dev_bf16(rnd(264, 256)), torch.zeros(264, dtype=torch.float32, device=DEV)))
+               (dev_bf16(rnd(264, 256)), torch.zeros(2, 264, dtype=torch.float32, device=DEV)))
         hip.gemm_tn_grouped([bad, bad[:4]])
+    with pytest.raises(RuntimeError):  # a row scale without the side product
+        q = plain[0]
+        lib = hip.lib()
+        import ctypes
+        one = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())  # noqa: E731
+        i64 = lambda v: (ctypes.c_int64 * 1)(v)  # noqa: E731
+        ctr = torch.zeros(int(lib.op_gemm_tn_grouped_counter_bytes()), dtype=torch.uint8, device=DEV)
+        sc = torch.ones(q[2].shape[0], dtype=torch.bfloat16, device=DEV)
+        hip._check(lib.op_gemm_tn_grouped(1, one(q[0]), i64(q[0].stride(0)), one(q[1]), i64(q[1].stride(0)), one(q[2]), i64(q[2].stride(0)),
+                                          i64(q[0].shape[1]), i64(q[1].shape[1]), i64(q[0].shape[0]), (ctypes.c_int32 * 1)(1), None, None, None,
+                                          one(sc), hip.ptr(ctr), 0, hip.stream()), "op_gemm_tn_grouped")
 
 
 def test_resid_bwd_g0_and_gamma_grad_finish():
-    """(ABI 7) The layer-scale gradient without the branch output: for out = resid + ps * gamma * (x W^T + b),
-    dgamma[n] = sum_k W[n][k] G[n][k] + b[n] g0[n] with G = (ps dout)^T x and g0 = sum_m ps dout -- op_resid_bwd hands out g0, the
-    grouped weight-gradient launch the row dot of W with dW = gamma * G, op_gamma_grad_finish divides by gamma and re-arms the buffer.
-    Against the definition sum_m ps dout y in fp32; gamma == 0 drops the row-dot term."""
+    """(ABI 7, 8) The layer-scale gradient without the branch output: for out = resid + ps * gamma * (x W^T + b),
+    dgamma[n] = sum_k W[n][k] G[n][k] + b[n] g0[n] with G = (ps dout)^T x and g0 = sum_m ps dout -- op_resid_bwd hands out g0 and the
+    branch gradient u = ps dout WITHOUT gamma, the grouped weight-gradient launch adds gamma * G to the weight gradient and the row dot of
+    W with G to a vector, op_gamma_grad_finish adds the bias term and re-arms the buffer.  No division by gamma anywhere: against the
+    reference's definition sum_m ps dout y in fp32 (transformer_layer.py:78-88) for EVERY entry, gamma == 0, 1e-6 and 1e-30 included;
+    the input gradient u . (gamma o W) from the gamma-scaled transposed copy (op_transpose_scaled)."""
     hip = hipmod()
     M, N, K, rps = 1024, 256, 512, 64
     dout, x, w, b = rnd(M, N, seed=1), rnd(M, K, seed=2, scale=0.5), rnd(N, K, seed=3, scale=0.2), rnd(N, seed=4)
     gamma = (0.5 + rnd(N, seed=5).abs()).clamp(max=2.0)
-    gamma[7] = 0.0
+    gamma[7], gamma[8], gamma[9] = 0.0, 1e-6, 1e-30
     ps = (torch.arange(M // rps) % 3 != 0).float() / 0.75
     d_, x_, w_, b_, g_ = dev_bf16(dout), dev_bf16(x), dev_bf16(w), dev_bf16(b), dev_bf16(gamma)
     g0 = torch.empty(N, dtype=torch.float32, device=DEV)
@@ -1239,20 +1283,27 @@ def test_resid_bwd_g0_and_gamma_grad_finish():
     dq = d_.float() * rows
     assert_close(g0, dq.sum(0).cpu(), what="g0")
     assert_close(db, (dq * g_.float()).sum(0).cpu(), what="dbias")
-    rowdot = torch.zeros(N, dtype=torch.float32, device=DEV)
+    assert torch.equal(dy, dq.to(torch.bfloat16)), "with g0 the branch gradient carries no gamma"
+    rowdot = torch.full((K // 128, N), float("nan"), dtype=torch.float32, device=DEV)  # every slot is written: no zeroing needed
     dW = torch.zeros(N, K, dtype=torch.bfloat16, device=DEV)
     other = (dev_bf16(rnd(256, 256, seed=8)), dev_bf16(rnd(256, 256, seed=9)), torch.zeros(256, 256, dtype=torch.bfloat16, device=DEV), True)
-    assert hip.gemm_tn_grouped([(dy, x_, dW, True, (w_, rowdot)), other])
+    assert hip.gemm_tn_grouped([(dy, x_, dW, True, (w_, rowdot, g_)), other])
     base = dev_bf16(rnd(N, seed=6))
     dgamma = base.clone()
-    hip.gamma_grad_finish(rowdot, g_, [(b_, g0)], dgamma, True)
+    hip.gamma_grad_finish(rowdot, [(b_, g0)], dgamma, True)
+    wt = hip.transpose(w_, scale=g_)
+    dx = hip.gemm_nt(dy, [wt])
     torch.cuda.synchronize()
     y = x_.float() @ w_.float().t() + b_.float()
-    ref = (dq * y).sum(0)
-    ref[7] = (b_.float() * g0)[7]  # gamma == 0: only the bias term survives (y is not recoverable from a zero-scaled gradient)
-    ref = ref + base.float()
+    ref = (dq * y).sum(0) + base.float()  # the reference's value for every column: no exception for gamma == 0
     assert_close(dgamma, ref.cpu(), what="dgamma from the weight gradient")
-    assert float(rowdot.abs().max()) == 0.0  # re-armed
+    for col in (7, 8, 9):  # the zero / tiny layer scales one by one (assert_close is a norm over all columns)
+        assert abs(float(dgamma[col]) - float(ref[col])) <= 1.2e-2 * (abs(float(ref[col])) + 1e-3), (col, float(dgamma[col]), float(ref[col]))
+    dyg = dy.float() * g_.float()  # what the reference back-propagates into the branch: ps * gamma * dout
+    assert_close(dW, (dyg.t() @ x_.float()).cpu(), what="weight gradient gamma * G")
+    assert float(dW[7].abs().max()) == 0.0
+    assert torch.equal(wt, (w_.float() * g_.float()[:, None]).to(torch.bfloat16).t())
+    assert_close(dx, (dyg @ w_.float()).cpu(), what="input gradient through the gamma-scaled weight copy")
 
 
 def test_gamma_grad_finish_with_three_weight_sets_sharing_gamma():
@@ -1260,16 +1311,14 @@ def test_gamma_grad_finish_with_three_weight_sets_sharing_gamma():
     down-projection weight gradients, op_gamma_grad_finish adds the three bias terms (one FFN without bias), writes (not accumulates)."""
     hip = hipmod()
     N = 256
-    rowdot = dev_bf16(rnd(N, seed=1)).float().contiguous()
-    gamma = dev_bf16((0.25 + rnd(N, seed=2).abs()).clamp(max=2.0))
+    rowdot = dev_bf16(rnd(3 * 4, N, seed=1)).float().contiguous()  # three weight sets x four 128-column slots
     bs = [dev_bf16(rnd(N, seed=3)), None, dev_bf16(rnd(N, seed=4))]
     g0s = [dev_bf16(rnd(N, seed=5 + i)).float().contiguous() for i in range(3)]
-    ref = rowdot / gamma.float() + bs[0].float() * g0s[0] + bs[2].float() * g0s[2]
+    ref = rowdot.sum(0) + bs[0].float() * g0s[0] + bs[2].float() * g0s[2]
     out = torch.full((N,), 7.0, dtype=torch.bfloat16, device=DEV)
-    hip.gamma_grad_finish(rowdot, gamma, list(zip(bs, g0s)), out, False)
+    hip.gamma_grad_finish(rowdot, list(zip(bs, g0s)), out, False)
     torch.cuda.synchronize()
     assert_close(out, ref.cpu(), what="dgamma over three weight sets")
-    assert float(rowdot.abs().max()) == 0.0
 
 
 def test_gemm_tn_grouped_rejects_what_the_kernel_cannot_take():

@@ -207,3 +207,32 @@ def test_deep_text_and_audio_towers_with_backward_against_reference(golden_dir):
             assert torch.allclose(sd[k].grad, g, atol=1e-4, rtol=5e-4), k
         checked += 1
     assert checked > 300
+
+
+def test_layerdrop_and_all_hiddens_against_reference(golden_dir):
+    """transformer_encoder.py:48-51,186-199 + fairseq/modules/layer_drop.py:13-44 on the unmodified reference (make_golden.py
+    layerdrop_fixture): the oracle draws the same layerdrop mask from the seeded CPU generator, runs the same layers and returns the same
+    per-layer states, for a joint text+image stream and a text-only stream, in eval and training mode."""
+    fx = _load(golden_dir, "layerdrop_hiddens.pt")
+    sd = _micro_sd(fx)
+    heads, L = fx["cfg"]["attention_heads"], fx["cfg"]["layers"]
+    inp = fx["inputs"]
+    p = "encoder_wrapper"
+    ti = O.text_adapter(sd, p + ".text_adapter", inp["src_tokens"])
+    ii = O.image_adapter(sd, p + ".image_adapter", inp["src_images"])
+    n_states = 0
+    for case in fx["cases"]:
+        torch.manual_seed(case["seed"])
+        mask = O.layerdrop_mask(L, fx["layerdrop"], training=case["train"])
+        assert mask == case["ran"], (case["seed"], mask, case["ran"])
+        for et, infos in (("vl", (ti, ii)), ("text", (ti, None))):
+            x, _, states = O.encoder_forward(sd, p + ".fusion_model", heads, L, et, infos[0], infos[1], None, layer_mask=mask,
+                                             return_all_hiddens=True)
+            want = case[et]
+            assert torch.allclose(x.transpose(0, 1), want["encoder_out"], atol=ATOL, rtol=1e-4), (case["seed"], et)
+            assert len(states["text"]) == len(want["text_states"]) == sum(mask) and states["audio"] == []
+            assert len(states["image"]) == len(want["image_states"]) == (sum(mask) if et == "vl" else 0)
+            for got, ref in zip(states["text"] + states["image"], want["text_states"] + want["image_states"]):
+                assert got.shape == ref.shape and torch.allclose(got, ref, atol=ATOL, rtol=1e-4), (case["seed"], et)
+                n_states += 1
+    assert n_states == 3 * sum(sum(c["ran"]) for c in fx["cases"])

@@ -128,7 +128,7 @@ def test_side_products_ride_on_the_grouped_launch_and_hooks_run_before_the_param
     """Round 5 (layer-scale gradient from the weight gradient): a queued problem may carry (W, rowdot) and an `after` hook.  The side product
     travels with its problem into the grouped launch; the hook runs once the launch is enqueued and BEFORE the completion signals (gamma's
     own signal is given by the hook); a lone problem that misses the grouped launch takes the product once and uses it for the gradient
-    and for the row dot; a reset after a failed pass drops hooks and the side-product buffer pool."""
+    and for the row dot; a reset after a failed pass drops the hooks (round 6: the side-product buffers are written once per launch, there is no pool to re-arm)."""
     rec = _Rec(monkeypatch)
     q = ops._wgrad_queue
     order = []
@@ -136,13 +136,13 @@ def test_side_products_ride_on_the_grouped_launch_and_hooks_run_before_the_param
     for p in (p1, p2):
         p._op_pending = 1
         p._op_on_final = lambda param, tag=id(p): order.append(("final", tag))
-    W, rowdot = torch.ones(64, 32, dtype=torch.bfloat16), torch.zeros(64)
+    W, rowdot, gam = torch.ones(64, 32, dtype=torch.bfloat16), torch.full((2, 64), 9.0), torch.full((64,), 0.5, dtype=torch.bfloat16)
 
     def two():
-        q.add(*_prob(), [p1], side=(W, rowdot), after=lambda: order.append(("after", 0)))
+        q.add(*_prob(), [p1], side=(W, rowdot, gam), after=lambda: order.append(("after", 0)))
         q.add(*_prob(), [p2])
     _in_backward(two)  # (flushed by the end-of-backward callback)
-    assert len(rec.grouped) == 1 and rec.grouped[0][0][4] == (W, rowdot) and rec.grouped[0][1][4] is None
+    assert len(rec.grouped) == 1 and rec.grouped[0][0][4] == (W, rowdot, gam) and rec.grouped[0][1][4] is None
     assert order[0] == ("after", 0) and [o[0] for o in order[1:]] == ["final", "final"]
     # a lone problem: no grouped launch; the product is formed once (accumulate = False into a temporary) and used twice
     rec.grouped.clear()
@@ -153,15 +153,14 @@ def test_side_products_ride_on_the_grouped_launch_and_hooks_run_before_the_param
         return torch.full((64, 32), 2.0, dtype=torch.bfloat16)
     monkeypatch.setattr(hip, "gemm_tn", fake_tn)
     dy, x, out = _prob()
-    _in_backward(lambda: q.add(dy, x, out, [], side=(W, rowdot), after=lambda: order.append(("after", 1))))
+    _in_backward(lambda: q.add(dy, x, out, [], side=(W, rowdot, gam), after=lambda: order.append(("after", 1))))
     assert not rec.grouped and made == [(None, False)]
-    assert float(out.float().sum()) == 2.0 * 64 * 32 and torch.equal(rowdot, torch.full((64,), 64.0))
+    assert float(out.float().sum()) == 0.5 * 2.0 * 64 * 32 and torch.equal(rowdot.sum(0), torch.full((64,), 64.0))  # gradient gamma * P, row dot of the unscaled P
     assert order[-1] == ("after", 1)
-    # reset after a failed pass: the hook of the abandoned problem never runs, the buffer pool is dropped
-    ops._rowdot_pool[("cpu", 64, 0)] = [rowdot]
+    # reset after a failed pass: the hook of the abandoned problem never runs
 
     def failing():
-        q.add(*_prob(), [], side=(W, rowdot), after=lambda: order.append(("after", 2)))
+        q.add(*_prob(), [], side=(W, rowdot, gam), after=lambda: order.append(("after", 2)))
         raise RuntimeError("out of memory")
     try:
         _in_backward(failing)
@@ -170,9 +169,4 @@ def test_side_products_ride_on_the_grouped_launch_and_hooks_run_before_the_param
     assert q.items
     ops.reset_wgrads()
     q.flush()
-    assert ("after", 2) not in order and not ops._rowdot_pool
-    # ... while a reset with nothing pending (every step's zero_grad) keeps the pool
-    ops._rowdot_pool[("cpu", 64, 0)] = [rowdot]
-    ops.reset_wgrads()
-    assert ops._rowdot_pool
-    ops._rowdot_pool.clear()
+    assert ("after", 2) not in order

@@ -720,7 +720,8 @@ def main():
                        "algorithmic_tflop_per_sample": None if full else fl / 1e12,
                        "step_algorithmic_tflops_per_gpu": None if full else fl * args.batch / (ms / 1e3) / 1e12,
                        "objective": "forward" if not train else args.objective, "final_loss": loss_v if train else None,
-                       **({"param_checksum": [float(flat.params.double().sum()), float(flat.params.double().abs().sum())],
+                       **({"param_checksum": [float(flat.params.sum(dtype=torch.float64)),  # (reductions without a temporary: the buffer is 7.8 GB)
+                                               float(torch.linalg.vector_norm(flat.params, ord=1, dtype=torch.float64))],
                            "nt_gemm_launch_rule": ("one tile per workgroup (tune sched 7: distributed.share_cus_with_collectives)"
                                                    if hip.TUNE.sched == 7 else "persistent workgroups for K <= 2048 and grouped launches"
                                                    if hip.TUNE.sched == 0 else "tune sched %d" % hip.TUNE.sched)} if train and not micro else {}),

@@ -653,7 +653,7 @@ def test_lock_step_layers_4b_under_flat_parameters_against_the_fp32_oracle(gamma
                 report.append("%-70s [%d] got %.4e want %.4e" % (name, col, got, want))
                 assert abs(got - want) <= 4e-2 * abs(want) + 2e-2 * scale, (name, col, got, want)
         n += 1
-    assert n >= 2 * 40, n  # per layer: attention branch 12, three FFN sets 6 each, final LayerNorm 2, layer scales 2 ...
+    assert n == 2 * 33, n  # per layer: attention branch 12 (incl. gamma_1), three FFN sets 6 each, final LayerNorm 2, gamma_2
     report.append("worst per class: " + "  ".join("%s %.3e" % kv for kv in sorted(worst.items())))
     open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out",
                       "flat_layers_4b_parity_report_gamma%g_cheap%d.txt" % (gamma_scale, int(cheap))), "w").write("\n".join(report) + "\n")
@@ -1298,9 +1298,11 @@ def test_fused_encoder_returns_all_hiddens_and_honours_layerdrop(golden_dir):
 def test_layer_scale_gradient_from_the_weight_gradient_matches_the_branch_output_form(lock, recompute):
     """ops.dgamma_from_wgrad_ok (round 5): with flat gradients and whole 256 x 256 weight-gradient tiles the residual GEMMs write no
     branch output y; gamma_1 / gamma_2 get their gradient from the out-proj / down-projection weight gradients (row dot of W with the
-    launch's fp32 product, / gamma, + bias * g0).  Against the y form of the same code (ONEPEACE_DGAMMA_FROM_WGRAD=0): the loss and every
-    other gradient bit-identical (nothing else changes), the gammas within bf16 rounding, less memory held; and the gammas of BOTH
-    forms against the plain-autograd (non-flat) run."""
+    launch's UNSCALED fp32 product, + bias * g0; round 6: no division).  Against the y form of the same code
+    (ONEPEACE_DGAMMA_FROM_WGRAD=0): the same loss; every gradient within bf16 rounding of the y form AND of the plain-autograd
+    (non-flat) run -- since round 6 the branch gradient travels without gamma (gamma sits in the weight-gradient epilogue and in the
+    transposed weight copy of the input gradient), so the two forms round at different places and are no longer bit-identical
+    upstream of the residual; less memory held."""
     from one_peace_amd import ops
     from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
     from one_peace_amd.distributed import FlatParameters
@@ -1355,10 +1357,10 @@ def test_layer_scale_gradient_from_the_weight_gradient_matches_the_branch_output
             ga = res["autograd"][3][n]
             assert rel_fro(gw, ga) <= 2e-2 and rel_fro(g, ga) <= 2e-2, (n, rel_fro(gw, ga), rel_fro(g, ga))
             assert rel_fro(gw, g) <= 2e-2, (n, rel_fro(gw, g))
-        elif "rel_pos_table" in n:  # (their fold adds ten million bias-gradient entries onto a few thousand table rows with fp32 atomics:
-            assert rel_fro(gw, g) <= 1e-3, (n, rel_fro(gw, g))  # the last bit of an entry can differ from run to run)
-        else:
-            assert torch.equal(gw, g), (n, float((gw - g).abs().max()))
+        else:  # gamma * (u^T x) against (gamma u)^T x, u (gamma W)^T against (gamma u) W^T: one bf16 rounding placed differently
+            ga = res["autograd"][3][n]
+            assert rel_fro(gw, g) <= 1.2e-2, (n, rel_fro(gw, g))
+            assert rel_fro(gw, ga) <= max(1.2e-2, 1.5 * rel_fro(g, ga)), (n, rel_fro(gw, ga), rel_fro(g, ga))
     assert n_gamma == 6
     if not recompute:
         assert res["wgrad"][1] < res["y"][1], (res["wgrad"][1], res["y"][1])  # 4 H of the 46 H bytes per token and layer are not kept
@@ -1411,6 +1413,9 @@ def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock, f
     assert res[True][0] == res[False][0]
     assert len(res[True][2]) == len(res[False][2]) > 60
     for n, g in res[False][2].items():
+        if "rel_pos_table" in n:  # (their fold scatters the bias gradient with fp32 atomics: the last bit can differ from run to run)
+            assert rel_fro(res[True][2][n].float(), g.float()) <= 1e-3, n
+            continue
         assert torch.equal(res[True][2][n], g), (n, float((res[True][2][n].float() - g.float()).abs().max()))
     # per token and layer LN1(x), the sub-LayerNorm output, LN2(x) (2 H bytes each) and LN_F(GeGLU) (2 F = 4 H bytes here) are not kept:
     # 10 H bytes x layers x rows (text 16 + image 17 tokens per sample, + the audio frames) -- at the 4B dimensions (F = 4 H) 14 of 46 H

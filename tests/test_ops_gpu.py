@@ -1297,8 +1297,14 @@ def test_resid_bwd_g0_and_gamma_grad_finish():
     y = x_.float() @ w_.float().t() + b_.float()
     ref = (dq * y).sum(0) + base.float()  # the reference's value for every column: no exception for gamma == 0
     assert_close(dgamma, ref.cpu(), what="dgamma from the weight gradient")
-    for col in (7, 8, 9):  # the zero / tiny layer scales one by one (assert_close is a norm over all columns)
-        assert abs(float(dgamma[col]) - float(ref[col])) <= 1.2e-2 * (abs(float(ref[col])) + 1e-3), (col, float(dgamma[col]), float(ref[col]))
+    # the zero / tiny layer scales one by one (assert_close is a norm over all columns): the reference's value within the bf16 noise of
+    # a column (sum over 1024 rows of bf16-rounded ps * dout times y: measured 2e-3 ... 4e-3 of the largest column), and NOT the
+    # bias-only value round 5 returned for gamma == 0
+    scale = float(ref.abs().max())
+    for col in (7, 8, 9):
+        assert abs(float(dgamma[col]) - float(ref[col])) <= 1e-2 * scale, (col, float(dgamma[col]), float(ref[col]), scale)
+    bias_only = float((b_.float() * g0)[7] + base.float()[7])
+    assert abs(float(ref[7]) - bias_only) > 5e-2 * scale and abs(float(dgamma[7]) - bias_only) > 4e-2 * scale, (float(dgamma[7]), bias_only)
     dyg = dy.float() * g_.float()  # what the reference back-propagates into the branch: ps * gamma * dout
     assert_close(dW, (dyg.t() @ x_.float()).cpu(), what="weight gradient gamma * G")
     assert float(dW[7].abs().max()) == 0.0

@@ -52,32 +52,42 @@ def main():
               ("FFN down dgrad   K=1536", 32896, F, H), ("FFN down (image) K=6144", 32896, H, F)]
     slab = 1 << 20
     buf = torch.zeros(64 * slab, dtype=torch.float32, device=dev)
+    # the GEMMs go on a NON-BLOCKING stream: torch's default stream is the legacy null stream, which serialises with every blocking
+    # stream -- the CU-masked one included (the first version of this tool measured the GEMMs AFTER the stand-in had ended)
+    main = torch.cuda.Stream()
+    when = torch.zeros(64 * 2, dtype=torch.int64, device=dev)
     print("# CUs held by a stand-in collective kernel vs the NT GEMM launch rule; ms per launch, median of %d (min)" % a.reps)
     print("# %-26s %6s %22s %22s %8s" % ("launch", "held", "persistent (sched 0)", "one tile/wg (sched 7)", "ratio"))
     for name, M, N, K in shapes:
         A, W, out = mk(M, K), mk(N, K), torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         for held in [int(x) for x in a.held.split(",")]:
             side = masked_stream(held) if held else None
-            res = {}
-            for sched in (0, 7):
-                hip.TUNE.sched = sched
-                ts = []
-                for rep in range(a.reps + 2):
-                    torch.cuda.synchronize()
-                    if held:
-                        hip._check_probe(P.op_probe_occupy(hip.ptr(buf), slab, held, a.occupy_us, None, side), "op_probe_occupy")
-                        time.sleep(0.0005)  # the stand-in is resident on its CUs before the GEMM is enqueued
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    hip.gemm_nt(A, [W], out=out)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    if rep >= 2:
-                        ts.append(e0.elapsed_time(e1))
-                ts.sort()
-                res[sched] = (ts[len(ts) // 2], ts[0])
+            res, overlap = {}, []
+            with torch.cuda.stream(main):
+                for sched in (0, 7):
+                    hip.TUNE.sched = sched
+                    ts = []
+                    for rep in range(a.reps + 2):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        if held:
+                            hip._check_probe(P.op_probe_occupy(hip.ptr(buf), slab, held, a.occupy_us, hip.ptr(when), side), "op_probe_occupy")
+                        time.sleep(0.0005)  # the stand-in is resident on its CUs before the GEMM is enqueued (same pause without one)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        hip.gemm_nt(A, [W], out=out)
+                        e1.record()
+                        e1.synchronize()
+                        t1 = time.perf_counter()  # the GEMM is done; with a stand-in of occupy_us that must be BEFORE the stand-in ends
+                        torch.cuda.synchronize()
+                        if rep >= 2:
+                            ts.append(e0.elapsed_time(e1))
+                            overlap.append((t1 - t0) * 1e6 < a.occupy_us)
+                    ts.sort()
+                    res[sched] = (ts[len(ts) // 2], ts[0])
             hip.TUNE.sched = 0
-            print("  %-26s %6d %12.4f (%7.4f) %12.4f (%7.4f) %8.3f" % (name, held, res[0][0], res[0][1], res[7][0], res[7][1], res[7][0] / res[0][0]))
+            print("  %-26s %6d %12.4f (%7.4f) %12.4f (%7.4f) %8.3f   %s" % (name, held, res[0][0], res[0][1], res[7][0], res[7][1], res[7][0] / res[0][0],
+                  "" if not held else "GEMM finished while the stand-in ran: %d / %d reps" % (sum(overlap), len(overlap))))
     print("# ratio < 1: the one-tile rule is faster under that contention.  A launch with `held` CUs taken for its whole duration:")
     print("# persistent = up to 2 T (the late workgroups start when the first ones end), one tile = T * 256 / (256 - held).")
 

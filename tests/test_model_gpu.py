@@ -569,7 +569,6 @@ def _flat_layers_case(gamma_scale):
     return case
 
 
-# bounds = 2.5 x the largest error measured per class of tensor (gpurun_out/flat_layers_4b_parity_report_*.txt -> profiles/r6_*)
 @pytest.mark.parametrize("gamma_scale,cheap", [(1e-6, False), (1e-6, True), (1e-1, False), (1e-1, True)])
 def test_lock_step_layers_4b_under_flat_parameters_against_the_fp32_oracle(gamma_scale, cheap):
     """Round 6 (VERDICT r5 Weak #1): the gradient route bench.py TIMES, at the headline's dimensions, against the fp32 oracle.  Two
@@ -659,10 +658,14 @@ def test_lock_step_layers_4b_under_flat_parameters_against_the_fp32_oracle(gamma
                       "flat_layers_4b_parity_report_gamma%g_cheap%d.txt" % (gamma_scale, int(cheap))), "w").write("\n".join(report) + "\n")
 
 
-FLAT_BOUNDS = {"out": 1.5e-2, "dx": 5e-2, "dtable": 5e-2, "grad": 5e-2, "gamma": 5e-2}  # first run: the common bounds; tightened below
+# 2.5 x the largest error measured per class over the four cases (profiles/r6_flat_layers_4b_parity_report_*.txt: out 3.3e-3, dx 3.8e-3,
+# bias tables 6.5e-3, parameter gradients 8.1e-3, layer scales 5.9e-3)
+FLAT_BOUNDS = {"out": 8.2e-3, "dx": 9.5e-3, "dtable": 1.6e-2, "grad": 2.0e-2, "gamma": 1.5e-2}
 
 
-LONG_AUDIO_BOUNDS = {"out": 1.5e-2, "dx": 5e-2, "dtable": 5e-2, "grad": 5e-2}  # first run: the common bounds; tightened below
+# 2.5 x the largest error measured per class (profiles/r6_audio_15s_4b_parity_report_{audio,al}.txt: out 2.4e-3, dx 2.5e-3, bias tables
+# 5.7e-3, parameter gradients 6.7e-3)
+LONG_AUDIO_BOUNDS = {"out": 6.1e-3, "dx": 6.4e-3, "dtable": 1.4e-2, "grad": 1.7e-2}
 
 
 @pytest.mark.parametrize("stream", ["audio", "al"])
@@ -1358,7 +1361,10 @@ def test_layer_scale_gradient_from_the_weight_gradient_matches_the_branch_output
             assert rel_fro(gw, ga) <= 2e-2 and rel_fro(g, ga) <= 2e-2, (n, rel_fro(gw, ga), rel_fro(g, ga))
             assert rel_fro(gw, g) <= 2e-2, (n, rel_fro(gw, g))
         else:  # gamma * (u^T x) against (gamma u)^T x, u (gamma W)^T against (gamma u) W^T: one bf16 rounding placed differently
-            ga = res["autograd"][3][n]
+            ga = res["autograd"][3].get(n)
+            if ga is None:  # a parameter the step does not use (mask embeddings): no gradient under autograd, zeros in the flat buffer
+                assert float(g.abs().max()) == 0.0 and float(gw.abs().max()) == 0.0, n
+                continue
             assert rel_fro(gw, g) <= 1.2e-2, (n, rel_fro(gw, g))
             assert rel_fro(gw, ga) <= max(1.2e-2, 1.5 * rel_fro(g, ga)), (n, rel_fro(gw, ga), rel_fro(g, ga))
     assert n_gamma == 6

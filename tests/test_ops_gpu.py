@@ -1303,8 +1303,8 @@ def test_resid_bwd_g0_and_gamma_grad_finish():
     scale = float(ref.abs().max())
     for col in (7, 8, 9):
         assert abs(float(dgamma[col]) - float(ref[col])) <= 1e-2 * scale, (col, float(dgamma[col]), float(ref[col]), scale)
-    bias_only = float((b_.float() * g0)[7] + base.float()[7])
-    assert abs(float(ref[7]) - bias_only) > 5e-2 * scale and abs(float(dgamma[7]) - bias_only) > 4e-2 * scale, (float(dgamma[7]), bias_only)
+    bias_only = float((b_.float() * g0)[7] + base.float()[7])  # what round 5 returned for the gamma == 0 column: the row-dot term missing
+    assert abs(float(dgamma[7]) - float(ref[7])) < 0.25 * abs(float(ref[7]) - bias_only), (float(dgamma[7]), float(ref[7]), bias_only)
     dyg = dy.float() * g_.float()  # what the reference back-propagates into the branch: ps * gamma * dout
     assert_close(dW, (dyg.t() @ x_.float()).cpu(), what="weight gradient gamma * G")
     assert float(dW[7].abs().max()) == 0.0

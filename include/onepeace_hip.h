@@ -216,10 +216,13 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
  * image (257) and audio (<= 250 at 5 s) streams of the pretraining step -- with the bias gradient delivered in TABLE space:
  * dtable fp32 [num_rel][heads] (nullable) receives  dtable[bucket[q][k]][h] += sum_b dS[b][h][q][k]  (the reference:
  * one_peace/models/adapter/image.py:164-171, the expand over the batch summed by autograd into the nn.Embedding(num_rel, heads)).
- * biasT: bf16 [heads][S][Spad], rows = key (op_relpos_bias_build, transposed); bucket: int32 [S][S]; delta: fp32 [B][heads][Spad] from
+ * biasT: bf16 [heads][S][Spad], rows = key (op_relpos_bias_build, transposed); bucket: the int16 table op_attn_bucket_pack makes of the
+ * int32 [S][S] bucket table (op_attn_bucket_pack_elems(S) elements, built once per table and length); delta: fp32 [B][heads][Spad] from
  * op_attn_bwd_delta.  Returns -95 and launches nothing for other lengths / tables that do not fit the LDS next to an item. */
+int64_t op_attn_bucket_pack_elems(int64_t S);
+int op_attn_bucket_pack(const int32_t* bucket, void* out, int64_t S, void* stream);
 int op_attn_bwd_fused(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* biasT,
-                      const int32_t* bucket, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                      const void* bucket, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                       int64_t ldg, float* dtable, int64_t num_rel, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim,
                       float scale, int64_t tune, void* stream);
 

@@ -26,6 +26,10 @@ int op_probe_mfma_rate(const void* operands, float* out, void* clk, int workgrou
 /* A stand-in for a collective's kernel sharing the GPU with backward: `workgroups` x 256 threads, 96 KiB of LDS each (one per CU), copying their own
  * slab (slab_floats floats of buf per workgroup) for `micros` microseconds.  when: NULL or workgroups x 2 uint64 (start, end in 100 MHz
  * ticks).  tools/cu_contention_ab.py: what CUs held by another kernel cost the persistent / one-tile NT GEMM launches. */
+/* Throughput of LDS atomics: `workgroups` x 8 waves, each wave iters x 16 conflict-free wave-level operations on LDS (mode 0 ds_add_f32,
+ * 1 ds_add_u32, 2 ds_write_b32).  out: workgroups x 512 floats; clk: workgroups uint64 = shader cycles of the loop; cycles per
+ * wave-level instruction of the CU = clk / (iters * 16 * 8).  (Round 6: what decided the fused attention backward.) */
+int op_probe_lds_atomic(float* out, void* clk, int workgroups, int iters, int mode, void* stream);
 int op_probe_occupy(void* buf, long long slab_floats, int workgroups, long long micros, void* when, void* stream);
 
 #ifdef __cplusplus

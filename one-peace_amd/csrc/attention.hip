@@ -2892,27 +2892,28 @@ int launch_bwd_dkdv_pers(const AttnBwdArgs& a, hipStream_t s) {
 //   * S = 257: the 257th QUERY is a ninth 32-query half with one live row; the 257th KEY is a ninth 16-key block that wave w runs
 //     against query half w (wave 0 also against the ninth half) -- its dQ / dBias shares go the same way, its dK / dV row is summed over
 //     the waves through LDS.
-// LDS: Q | dO (2 x rows x 128 B) | lse, delta (4 KiB) | dQ fp32 (rows x 272 B) | 8 x 1 KiB dS scratch | lone-key scratch | bucket sums =
-// 160 384 B at S = 257: single-buffered, the next item's fetch starts when the last wave has left the current one.
+// LDS: Q | dO (2 x 272 rows x 128 B) | lse, delta (4 KiB) | dQ fp32 (264 rows x 272 B) | 8 x 1 KiB dS scratch | lone-key scratch | bucket sums =
+// 162 432 B at S = 257: single-buffered, the next item's fetch starts when the last wave has left the current one.
 // delta = rowsum(dO o O) comes from op_attn_bwd_delta.  Keys that do not exist or are padded get P = 0 here (their dS would reach dQ).
 // =====================================================================================================================
 constexpr int FUSED_DQ_LD = 68;  // floats per row of the fp32 dQ image: rows 4 apart are 16 banks apart (lane groups g of a D fragment)
 
 template <bool HAS_BIAS, bool HAS_PAD, bool LONE>
-__global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwdArgs p, const int* __restrict__ bucket, float* __restrict__ dtable,
+__global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwdArgs p, const short* __restrict__ bpack, float* __restrict__ dtable,
                                                                           int num_rel, int rows_pad, int nitems, int ipw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, t = lane & 15;
-  const int QBY = rows_pad * 128;
+  const int QBY = rows_pad * 128;  // rows_pad: S rounded up to 16 (the ninth query half of S = 257 reads rows 256 ... 271: clamped copies of row 256)
+  const int dq_rows = (p.S + 7) & ~7;
   char* ldsQ = smem;
   char* ldsO = smem + QBY;
   const float* ldsL = reinterpret_cast<const float*>(smem + 2 * QBY);
   const float* ldsD = ldsL + 512;
-  float* dqa = reinterpret_cast<float*>(smem + 2 * QBY + 4096);                       // [rows_pad][FUSED_DQ_LD]
-  char* scr = smem + 2 * QBY + 4096 + rows_pad * FUSED_DQ_LD * 4 + wid * 1024;         // this wave's dS scratch [32 keys][16 queries] bf16
-  float* lscr = reinterpret_cast<float*>(smem + 2 * QBY + 4096 + rows_pad * FUSED_DQ_LD * 4 + PERS_NW * 1024);  // [PERS_NW][PERS_SCRL]
+  float* dqa = reinterpret_cast<float*>(smem + 2 * QBY + 4096);                       // [dq_rows][FUSED_DQ_LD]: rows < S are used
+  char* scr = smem + 2 * QBY + 4096 + dq_rows * FUSED_DQ_LD * 4 + wid * 1024;          // this wave's dS scratch [32 keys][16 queries] bf16
+  float* lscr = reinterpret_cast<float*>(smem + 2 * QBY + 4096 + dq_rows * FUSED_DQ_LD * 4 + PERS_NW * 1024);  // [PERS_NW][PERS_SCRL]
   float* bacc = lscr + PERS_NW * PERS_SCRL;                                             // [num_rel] bucket sums of the current head
   const int S = p.S;
   const int kbase = wid * 32;
@@ -2937,7 +2938,7 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
   const int scr_r = (g * 4 + (t >> 2)) * 32 + (t & 3) * 8;   // + kb * 512: transpose-read piece of rows kb*16 + g*4 .. + 3
 
   for (int i = tid; i < num_rel; i += PERS_NW * 64) bacc[i] = 0.f;
-  for (int i = tid; i < rows_pad * FUSED_DQ_LD; i += PERS_NW * 64) dqa[i] = 0.f;
+  for (int i = tid; i < dq_rows * FUSED_DQ_LD; i += PERS_NW * 64) dqa[i] = 0.f;
 
   const int ngrp = rows_pad >> 3;
   const int NG = 2 * ngrp + 4;
@@ -2975,10 +2976,29 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
     }
   };
 
-  // One 32-query half (q0h) against NKB 16-key blocks starting at key0: S, dP -> P, dS -> dV^T, dK^T (attn_bwd_dkdv_pers_kernel: half),
-  // then this wave's share of dQ and of the bucket sums.
-  auto half = [&](const int q0h, auto nkb_c, const int key0, const bf16x8 (&kx)[2][2], const bf16x8 (&vx)[2][2], const bf16x8 (&kq)[4],
-                  const bool (&kd)[2], const int hh, f32x4 (&dvx)[2][4], f32x4 (&dkx)[2][4]) {
+  // What a query half reads from global memory -- the transposed-bias fragments of the wave's key blocks and the bucket indices of its
+  // dS elements (int16, packed by op_attn_bucket_pack in the order the lanes hold them: ONE 16-byte load per key block) -- is requested
+  // one half AHEAD: loaded inside the half it cost an exposed L2 round trip per half, and sixteen serialised ones with the indices
+  // read element by element behind bounds checks (the first version of this kernel: 3.6 ms against the kernel pair's 0.52).
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  struct HalfIn { bf16x8 bx[2]; s16x8 ix[2]; };
+  const int nkblk = (S + 15) >> 4;
+  auto load_in = [&](int hf, int keyblk0, auto nkb_c, int hh, HalfIn& in) {
+    constexpr int NKB = decltype(nkb_c)::value;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      if constexpr (HAS_BIAS) {  // transposed image rows of this lane's keys: 8 consecutive queries = one second-operand fragment per 32 queries
+        const int key = min((keyblk0 + kb) * 16 + t, S - 1);
+        in.bx[kb] = *reinterpret_cast<const bf16x8*>(p.biasT + ((int64_t)hh * S + key) * p.Spad + hf * 32 + g * 8);
+        if (want_db) in.ix[kb] = *reinterpret_cast<const s16x8*>(bpack + (((int64_t)hf * nkblk + keyblk0 + kb) * 64 + lane) * 8);
+      }
+    }
+  };
+
+  // One 32-query half (q0h) against NKB 16-key blocks: S, dP -> P, dS -> dV^T, dK^T (attn_bwd_dkdv_pers_kernel: half), then this wave's
+  // share of dQ and of the bucket sums.
+  auto half = [&](const int q0h, auto nkb_c, const bf16x8 (&kx)[2][2], const bf16x8 (&vx)[2][2], const bf16x8 (&kq)[4],
+                  const bool (&kd)[2], const HalfIn& in, f32x4 (&dvx)[2][4], f32x4 (&dkx)[2][4]) {
     constexpr int NKB = decltype(nkb_c)::value;
     f32x4 s[2][NKB], dp[2][NKB];
 #pragma unroll
@@ -2986,14 +3006,6 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     const bool second = q0h + 16 < S;  // (uniform) the half's second 16-query block holds a query
-    bf16x8 bx[NKB];
-    if constexpr (HAS_BIAS) {  // transposed image rows of this lane's keys: 8 consecutive queries = one second-operand fragment per 32 queries
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        const int key = min(key0 + kb * 16 + t, S - 1);
-        bx[kb] = *reinterpret_cast<const bf16x8*>(p.biasT + ((int64_t)hh * S + key) * p.Spad + q0h + g * 8);
-      }
-    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j == 1 && !second) continue;
@@ -3010,7 +3022,7 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
       }
       if constexpr (HAS_BIAS) {
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j ? sel_hi : sel_lo, bx[kb], s[j][kb], 0, 0, 0);
+        for (int kb = 0; kb < NKB; ++kb) s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j ? sel_hi : sel_lo, in.bx[kb], s[j][kb], 0, 0, 0);
       }
     }
     float l2[2][4], dl[2][4];
@@ -3053,6 +3065,18 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
       pfr[kb] = pack8(a0, a1);
       dsf[kb] = pack8(b0, b1);
     }
+    // ---- bias-table gradient: dS summed per bucket (the batch sum of this head lives in LDS).  Unconditional: a query row or key that
+    // does not exist has dS = 0 and a valid index in the packed table ----
+#ifndef OP_EXP_FUSED_NODB  // (ablation switches of tools/attn_fused_ab.py: timing only, wrong results)
+    if (want_db) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(bacc + in.ix[kb][j * 4 + r], dp[j][kb][r]);
+    }
+#endif
     const s16x4 zero4 = {0, 0, 0, 0};
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
@@ -3070,6 +3094,7 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
       }
     }
     // ---- dQ: dS [16 queries x 32 keys] -> LDS rows [key][query] -> first-operand fragment (M = query, K = key) x K rows of the keys ----
+#ifndef OP_EXP_FUSED_NODQ
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (j == 1 && !second) continue;
@@ -3077,34 +3102,26 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
       for (int kb = 0; kb < 2; ++kb) {
         bf16x4 w;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = kb < NKB ? (bf16_t)dp[j][kb < NKB ? kb : 0][r] : (bf16_t)0.f;
+        for (int r = 0; r < 4; ++r) w[r] = kb < NKB ? dsf[kb < NKB ? kb : 0][j * 4 + r] : (bf16_t)0.f;
         *reinterpret_cast<bf16x4*>(scr + kb * 512 + scr_w) = w;
       }
       const bf16x8 afr = join_tr(tr_read(scr + scr_r), tr_read(scr + 512 + scr_r));
-      float* drow = dqa + (q0h + j * 16 + g * 4) * FUSED_DQ_LD + t;
+      // rows >= S hold zero shares: they are added onto row S - 1 (x + 0) instead of past the image -- no branch around the atomics
+      int roff[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) roff[r] = min(q0h + j * 16 + g * 4 + r, S - 1) * FUSED_DQ_LD + t;
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
         const f32x4 dq4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, kq[db], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(drow + r * FUSED_DQ_LD + db * 16, dq4[r]);
+#ifndef OP_EXP_FUSED_NODQADD
+        for (int r = 0; r < 4; ++r) atomicAdd(dqa + roff[r] + db * 16, dq4[r]);
+#else
+        for (int r = 0; r < 4; ++r) dkx[0][db][r] += dq4[r];
+#endif
       }
     }
-    // ---- bias-table gradient: dS summed per bucket (the batch sum of this head lives in LDS) ----
-    if (want_db) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (j == 1 && !second) continue;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          const int key = key0 + kb * 16 + t;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int qq = q0h + j * 16 + g * 4 + r;
-            if (qq < S && key < S) atomicAdd(bacc + bucket[(int64_t)qq * S + key], dp[j][kb][r]);
-          }
-        }
-      }
-    }
+#endif
   };
 
   const int first = blockIdx.x * ipw, last = min(first + ipw, nitems);
@@ -3122,6 +3139,7 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
     const uint8_t* padrow = HAS_PAD ? p.key_pad + (int64_t)b * p.Spad : nullptr;
     bf16x8 kf[2][2], vf[2][2], kq[4];
     bool kd[2];
+    (void)padrow;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int key = kbase + kb * 16 + t, kc = min(key, S - 1);
@@ -3147,8 +3165,19 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
     __syncthreads();  // every wave's pieces of the fetch have landed
 
     const int nhalf = (S + 31) >> 5;
+    using N2 = std::integral_constant<int, 2>;
+    using N1 = std::integral_constant<int, 1>;
     if (wave_active) {
-      for (int hf = 0; hf < nhalf; ++hf) half(hf * 32, std::integral_constant<int, 2>{}, kbase, kf, vf, kq, kd, h, dvT, dkT);
+      HalfIn ia, ib;
+      load_in(0, wid * 2, N2{}, h, ia);
+      for (int hf = 0; hf < nhalf; hf += 2) {
+        if (hf + 1 < nhalf) load_in(hf + 1, wid * 2, N2{}, h, ib);
+        half(hf * 32, N2{}, kf, vf, kq, kd, ia, dvT, dkT);
+        if (hf + 1 < nhalf) {
+          if (hf + 2 < nhalf) load_in(hf + 2, wid * 2, N2{}, h, ia);
+          half(hf * 32 + 32, N2{}, kf, vf, kq, kd, ib, dvT, dkT);
+        }
+      }
     }
     if constexpr (LONE) {  // key 256: a ninth key block (one live column) that wave w runs against query half w, wave 0 also against half 8
       bf16x8 kl[2][2], vl[2][2], kql[4];
@@ -3170,8 +3199,11 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
       f32x4 dvl[2][4], dkl[2][4];
 #pragma unroll
       for (int db = 0; db < 4; ++db) { dvl[0][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkl[0][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-      half(wid * 32, std::integral_constant<int, 1>{}, 256, kl, vl, kql, kdl, h, dvl, dkl);
-      if (wid == 0) half(256, std::integral_constant<int, 1>{}, 256, kl, vl, kql, kdl, h, dvl, dkl);
+      HalfIn il, il8;
+      load_in(wid, 16, N1{}, h, il);
+      if (wid == 0) load_in(8, 16, N1{}, h, il8);
+      half(wid * 32, N1{}, kl, vl, kql, kdl, il, dvl, dkl);
+      if (wid == 0) half(256, N1{}, kl, vl, kql, kdl, il8, dvl, dkl);
       float* sc = lscr + wid * PERS_SCRL;
       if (t == 0) {  // D fragment: lane (g, t) holds dV^T[d = db*16 + g*4 + r][key column t]
 #pragma unroll
@@ -3230,15 +3262,33 @@ __global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwd
   if (want_db && cur_h >= 0) flush_bacc(cur_h);
 }
 
+inline int attn_fused_rows(int64_t S) { return S > 256 ? 272 : 256; }
 inline size_t attn_fused_lds(int64_t S, int64_t num_rel) {
-  const int rows_pad = S > 256 ? 264 : 256;
-  return (size_t)2 * rows_pad * 128 + 4096 + (size_t)rows_pad * FUSED_DQ_LD * 4 + PERS_NW * 1024 + PERS_NW * PERS_SCRL * 4 +
+  return (size_t)2 * attn_fused_rows(S) * 128 + 4096 + (size_t)((S + 7) & ~7) * FUSED_DQ_LD * 4 + PERS_NW * 1024 + PERS_NW * PERS_SCRL * 4 +
          (size_t)((num_rel + 63) / 64) * 64 * 4;
 }
 
+// bucket [S][S] int32 -> int16 in the order attn_bwd_fused_kernel's lanes hold their dS elements: out[hf][keyblk][lane][j * 4 + r] =
+// bucket[hf*32 + j*16 + g*4 + r][keyblk*16 + t]  (lane = g*16 + t; 0 where the query or the key does not exist: their dS is 0)
+__global__ __launch_bounds__(256) void bucket_pack_kernel(const int* __restrict__ bucket, short* __restrict__ out, int S, int nkblk, int total) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int lane = gid & 63, blk = gid >> 6;
+  const int hf = blk / nkblk, kblk = blk - hf * nkblk;
+  const int g = lane >> 4, t = lane & 15;
+  const int key = kblk * 16 + t;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = hf * 32 + j * 16 + g * 4 + r;
+      out[(int64_t)gid * 8 + j * 4 + r] = (q < S && key < S) ? (short)bucket[(int64_t)q * S + key] : (short)0;
+    }
+}
+
 template <bool HAS_BIAS, bool HAS_PAD>
-int launch_bwd_fused(const AttnBwdArgs& a, const int* bucket, float* dtable, int num_rel, hipStream_t s) {
-  const int rows_pad = a.S > 256 ? 264 : 256;
+int launch_bwd_fused(const AttnBwdArgs& a, const short* bucket, float* dtable, int num_rel, hipStream_t s) {
+  const int rows_pad = attn_fused_rows(a.S);
   const size_t sh = attn_fused_lds(a.S, num_rel);
   const int nitems = a.B * a.heads;
   const int nwg = min(nitems, attn_num_cus());
@@ -3526,11 +3576,25 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
 
 // (ABI 9) dQ, dK, dV and the relative-position TABLE gradient in one kernel (attn_bwd_fused_kernel) for 193 <= S <= 257 with a bias
 // shared by all samples (or none).  biasT: bf16 [heads][S][Spad], rows = key (the transposed image of op_relpos_bias_build); bucket:
-// int32 [S][S] (the table row of every (query, key): what the image was built from); dtable: fp32 [num_rel][heads], ADDED to (nullable:
-// no table gradient).  delta: fp32 [B][heads][Spad] from op_attn_bwd_delta.  Returns -95 (nothing launched) for other lengths, a bias
+// the int16 table of op_attn_bucket_pack (the table row of every (query, key): what the image was built from); dtable: fp32
+// [num_rel][heads], ADDED to (nullable: no table gradient).  delta: fp32 [B][heads][Spad] from op_attn_bwd_delta.  Returns -95 (nothing launched) for other lengths, a bias
 // without bucket table, or a table that does not fit the LDS next to the item (num_rel > ~1800): the caller then runs op_attn_bwd.
+int64_t op_attn_bucket_pack_elems(int64_t S) { return (int64_t)((S + 31) / 32) * ((S + 15) / 16) * 64 * 8; }
+
+// bucket: int32 [S][S] with values < 32768 -> out: int16 [op_attn_bucket_pack_elems(S)], the index table op_attn_bwd_fused reads (built
+// once per (table, sequence length); the bucket table is a registered buffer of the adapters, adapter/image.py:19-34, text.py:18-29).
+int op_attn_bucket_pack(const int32_t* bucket, void* out, int64_t S, void* stream) {
+  OP_CHECK_ARG(bucket && out && S > 0, "attn_bucket_pack: bad args");
+  const int nkblk = (int)((S + 15) / 16);
+  const int total = (int)((S + 31) / 32) * nkblk * 64;
+  hipLaunchKernelGGL(bucket_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const int*)bucket, (short*)out, (int)S,
+                     nkblk, total);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
 int op_attn_bwd_fused(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* biasT,
-                      const int32_t* bucket, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
+                      const void* bucket, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
                       int64_t ldg, float* dtable, int64_t num_rel, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim,
                       float scale, int64_t tune, void* stream) {
   (void)tune;
@@ -3538,7 +3602,7 @@ int op_attn_bwd_fused(const void* q, const void* k, const void* v, int64_t ld, c
   OP_CHECK_ARG(head_dim == HD, "attn_bwd_fused: head_dim %lld unsupported (only 64)", (long long)head_dim);
   OP_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && ldg % 8 == 0, "attn_bwd_fused: bad leading dims");
   OP_CHECK_ARG(Spad >= ((S + 127) / 128) * 128 && Spad % 8 == 0, "attn_bwd_fused: Spad must be >= S rounded up to 128");
-  OP_CHECK_ARG(!dtable || (biasT && bucket && num_rel > 0), "attn_bwd_fused: a table gradient needs the bias image, the bucket table and num_rel");
+  OP_CHECK_ARG(!dtable || (biasT && bucket && num_rel > 0 && num_rel < 32768), "attn_bwd_fused: a table gradient needs the bias image, the packed bucket table and num_rel < 32768");
   const bool inv_exact = (float)(bf16_t)(1.0f / scale) * scale == 1.0f;
   if (!(S > 192 && S <= 257) || (biasT && !inv_exact) || attn_fused_lds(S, biasT ? num_rel : 0) > 163840 || B * heads <= 0) {
     op_set_error("attn_bwd_fused: S = %lld / num_rel = %lld not supported by the fused kernel", (long long)S, (long long)num_rel);
@@ -3555,10 +3619,11 @@ int op_attn_bwd_fused(const void* q, const void* k, const void* v, int64_t ld, c
   const int nrel = biasT ? (int)num_rel : 0;
   const int slot = op_prof_begin(2, 5.0 * 2.0 * (double)B * (double)heads * (double)S * (double)S * HD, stream);
   int rc;
-  if (biasT && key_pad) rc = launch_bwd_fused<true, true>(a, bucket, dtable, nrel, s);
-  else if (biasT) rc = launch_bwd_fused<true, false>(a, bucket, dtable, nrel, s);
-  else if (key_pad) rc = launch_bwd_fused<false, true>(a, bucket, dtable, nrel, s);
-  else rc = launch_bwd_fused<false, false>(a, bucket, dtable, nrel, s);
+  const short* bp = (const short*)bucket;
+  if (biasT && key_pad) rc = launch_bwd_fused<true, true>(a, bp, dtable, nrel, s);
+  else if (biasT) rc = launch_bwd_fused<true, false>(a, bp, dtable, nrel, s);
+  else if (key_pad) rc = launch_bwd_fused<false, true>(a, bp, dtable, nrel, s);
+  else rc = launch_bwd_fused<false, false>(a, bp, dtable, nrel, s);
   op_prof_end(slot, stream);
   if (rc != OP_OK) return rc;
   OP_LAUNCH_CHECK();

@@ -141,9 +141,45 @@ __global__ __launch_bounds__(256) void probe_occupy_kernel(float* buf, long long
   }
 }
 
+// Throughput of LDS atomics: 8 waves of one workgroup per CU, each wave `iters` x 16 wave-level atomic adds on its own conflict-free 64-word
+// rows (mode 0: ds_add_f32, 1: ds_add_u32, 2: plain ds_write_b32 as the yardstick).  clk[block] = shader cycles of wave 0's loop.
+__global__ __launch_bounds__(512) void probe_lds_atomic_kernel(float* out, unsigned long long* clk, int iters, int mode) {
+  __shared__ float buf[8 * 16 * 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float* mine = buf + w * 16 * 64 + lane;
+  for (int i = threadIdx.x; i < 8 * 16 * 64; i += 512) buf[i] = 0.f;
+  __syncthreads();
+  const unsigned long long c0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    if (mode == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) atomicAdd(mine + j * 64, 1.0f);
+    } else if (mode == 1) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) atomicAdd(reinterpret_cast<unsigned*>(mine) + j * 64, 1u);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) reinterpret_cast<volatile float*>(mine)[j * 64] = (float)it;
+    }
+  }
+  __syncthreads();
+  const unsigned long long c1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) clk[blockIdx.x] = c1 - c0;
+  out[(long long)blockIdx.x * 512 + threadIdx.x] = buf[threadIdx.x];
+}
+
 }  // namespace
 
 extern "C" {
+
+// out: workgroups x 512 floats; clk: workgroups uint64 (shader cycles of the loop).  Per wave-level instruction: clk / (iters * 16 * 8).
+int op_probe_lds_atomic(float* out, void* clk, int workgroups, int iters, int mode, void* stream) {
+  OP_CHECK_ARG(out && clk && workgroups > 0 && iters > 0 && mode >= 0 && mode <= 2, "probe_lds_atomic: bad argument");
+  hipLaunchKernelGGL(probe_lds_atomic_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, out, (unsigned long long*)clk, iters, mode);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
 
 // buf: workgroups x slab_floats floats (each workgroup copies the first half of its slab onto the second); when: nullable, workgroups x 2
 // uint64 = start / end of each workgroup in 100 MHz ticks.

@@ -525,6 +525,7 @@ class RelPosBias:
         self.tacc = None
         self._imageT = None
         self._frag = None
+        self._bucket_pack = None
         self.image = _RelPosImageFn.apply(table, self)
 
     @property
@@ -543,6 +544,13 @@ class RelPosBias:
             else:
                 self._imageT = hip.relpos_bias_build(self.table.detach(), self.bucket, self.S, self.Spad, transposed=True)
         return self._imageT
+
+    @property
+    def bucket_pack(self):
+        """The bucket table in the fused attention backward's index order (hip.attn_bucket_pack; built on first use, shared by all layers)."""
+        if self._bucket_pack is None:
+            self._bucket_pack = hip.attn_bucket_pack(self.bucket.contiguous())
+        return self._bucket_pack
 
     def table_accumulator(self):
         """fp32 [num_rel, heads]: the fused attention backward (hip.attn_bwd_fused) adds the bias gradient in TABLE space -- dS summed
@@ -1484,7 +1492,7 @@ def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias, key_pad, wan
                                                hip.stream()), "op_attn_bwd_delta")
         dtable = bias.table_accumulator() if (bias is not None and want_dbias) else None
         if hip.attn_bwd_fused(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, lse, delta, bias.imageT if bias is not None else None,
-                              bias.bucket.contiguous() if bias is not None else None, key_pad, dq, dk, dv, dq.stride(0), dtable, B, S, Spad,
+                              bias.bucket_pack if bias is not None else None, key_pad, dq, dk, dv, dq.stride(0), dtable, B, S, Spad,
                               heads, scale):
             return
         attn = None  # (delta is computed: the kernel pair below must not recompute it into the same workspace)

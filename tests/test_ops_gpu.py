@@ -723,7 +723,7 @@ def test_attention_fused_backward(B, S, heads, use_bias, use_pad):
     hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(do), hip.ptr(out), do.stride(0), hip.ptr(delta), B, S, Spad, heads, hip.stream()), "delta")
     dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
     dtable = torch.full((num_rel, heads), 0.5, dtype=torch.float32, device=DEV) if use_bias else None  # (added to, not overwritten)
-    ok = hip.attn_bwd_fused(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, do, lse, delta, biasT_d, bucket_d, pad_d, dqkv[:, :H], dqkv[:, H:2 * H],
+    ok = hip.attn_bwd_fused(d[:, :H], d[:, H:2 * H], d[:, 2 * H:], 3 * H, do, lse, delta, biasT_d, hip.attn_bucket_pack(bucket_d) if use_bias else None, pad_d, dqkv[:, :H], dqkv[:, H:2 * H],
                             dqkv[:, 2 * H:], 3 * H, dtable, B, S, Spad, heads, 0.125)
     assert ok, "the fused kernel must take this shape"
     torch.cuda.synchronize()

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd; 8: the layer-scale gradient without a division -- rscale of op_gemm_tn_grouped, op_transpose_scaled + the scale member of the op_transpose_batched descriptor, op_resid_bwd leaves gamma out of dbranch when g0 is asked for, op_gamma_grad_finish lost its gamma argument; rowdot is a [N / 128][M] matrix of partial sums written once each (no atomics); 9: op_attn_bwd_fused */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd; 8: the layer-scale gradient without a division -- rscale of op_gemm_tn_grouped, op_transpose_scaled + the scale member of the op_transpose_batched descriptor, op_resid_bwd leaves gamma out of dbranch when g0 is asked for, op_gamma_grad_finish lost its gamma argument; rowdot is a [N / 128][M] matrix of partial sums written once each (no atomics) */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -211,20 +211,6 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
                 const float* lse, float* delta, void* dq,
                 void* dk, void* dv, int64_t ldg, float* dbias, int64_t B, int64_t S, int64_t Spad, int64_t heads,
                 int64_t head_dim, float scale, int64_t tune, void* stream);
-/* (ABI 9) The same gradients from ONE kernel (attn_bwd_fused_kernel: S and dP are formed once per (sample, head); rounds 1-5 ran a
- * dQ + dBias kernel and a dK / dV kernel that each recompute them) for 193 <= S <= 257 and a bias image shared by all samples -- the
- * image (257) and audio (<= 250 at 5 s) streams of the pretraining step -- with the bias gradient delivered in TABLE space:
- * dtable fp32 [num_rel][heads] (nullable) receives  dtable[bucket[q][k]][h] += sum_b dS[b][h][q][k]  (the reference:
- * one_peace/models/adapter/image.py:164-171, the expand over the batch summed by autograd into the nn.Embedding(num_rel, heads)).
- * biasT: bf16 [heads][S][Spad], rows = key (op_relpos_bias_build, transposed); bucket: the int16 table op_attn_bucket_pack makes of the
- * int32 [S][S] bucket table (op_attn_bucket_pack_elems(S) elements, built once per table and length); delta: fp32 [B][heads][Spad] from
- * op_attn_bwd_delta.  Returns -95 and launches nothing for other lengths / tables that do not fit the LDS next to an item. */
-int64_t op_attn_bucket_pack_elems(int64_t S);
-int op_attn_bucket_pack(const int32_t* bucket, void* out, int64_t S, void* stream);
-int op_attn_bwd_fused(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* biasT,
-                      const void* bucket, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
-                      int64_t ldg, float* dtable, int64_t num_rel, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim,
-                      float scale, int64_t tune, void* stream);
 
 /* ---- relative-position bias tables -------------------------------------------------------------------------------
  * Replaces get_rel_pos_bias of adapter/image.py:164-171, adapter/text.py:76-83, adapter/audio.py:117-124:

@@ -17,8 +17,6 @@
 // global -> registers -> LDS with the next tile's loads in flight during the current tile's MFMAs.
 //
 // Roofline: MFMA.  Algorithmic flops per launch = 4 * B * heads * S * S * 64 (QK^T + PV, 2 flops/MAC).
-#include <string.h>
-
 #include <type_traits>
 
 #include "common.h"
@@ -2872,438 +2870,6 @@ int launch_bwd_dkdv_pers(const AttnBwdArgs& a, hipStream_t s) {
   return OP_OK;
 }
 
-
-// =====================================================================================================================
-// attn_bwd_fused_kernel (round 6): dQ, dK, dV AND the bias-table gradient of a (sample, head) item in ONE pass over S and dP, for the
-// 193 ... 257-token streams with a shared relative-position table (the image and audio streams of the pretraining step).
-// Rounds 1-5 ran two kernels per stream -- dQ (+ dBias) with the waves owning queries, dK / dV with the waves owning keys -- each of
-// which recomputes S = scale Q K^T + bias, dP = dO V^T, P and dS (14 instead of 10 S^2 * 64 flops units per item, the softmax
-// arithmetic and every Q / dO fragment read twice).  Both are latency / issue bound (profiles/pmc/r5_attention_S257_B128.txt: 29 - 45 %
-// of the wave cycles waiting), so what the second pass costs is its whole instruction stream, not its MFMAs.  Here:
-//   * the skeleton of attn_bwd_dkdv_pers_kernel: one workgroup of 8 waves per CU walks items, wave w owns keys 32 w ... 32 w + 31 (K / V
-//     fragments, dK^T / dV^T accumulators in registers), ALL of Q and dO of the item plus its lse / delta rows sit in LDS (LDS-DMA);
-//   * dQ: the wave's dS block [16 queries x 32 keys] goes through 1 KiB of per-wave LDS as bf16 rows [key][query] and comes back by
-//     ds_read_b64_tr_b16 as a first-operand fragment (M = query, K = the wave's 32 keys); times the K rows of those keys (second
-//     operand, gathered once per item) it is the wave's share of dQ [16 x 64], which is ADDED to an fp32 [S x 64] image in LDS
-//     (ds_add_f32, conflict-free: 68-float rows) -- the cross-wave sum the query-owning kernel avoided by recomputing everything;
-//   * dBias in BUCKET space: the table has 964 / 1026 rows, so the sum over the batch lives in 4 KiB of LDS per workgroup (one head at
-//     a time: items are walked head-major) and dS is added to it through the bucket index (ds_add_f32), flushed to the fp32 table
-//     gradient with a few thousand global atomics per workgroup -- no [heads, S, S] image, no 129 accumulator registers per lane;
-//   * S = 257: the 257th QUERY is a ninth 32-query half with one live row; the 257th KEY is a ninth 16-key block that wave w runs
-//     against query half w (wave 0 also against the ninth half) -- its dQ / dBias shares go the same way, its dK / dV row is summed over
-//     the waves through LDS.
-// LDS: Q | dO (2 x 272 rows x 128 B) | lse, delta (4 KiB) | dQ fp32 (264 rows x 272 B) | 8 x 1 KiB dS scratch | lone-key scratch | bucket sums =
-// 162 432 B at S = 257: single-buffered, the next item's fetch starts when the last wave has left the current one.
-// delta = rowsum(dO o O) comes from op_attn_bwd_delta.  Keys that do not exist or are padded get P = 0 here (their dS would reach dQ).
-// =====================================================================================================================
-constexpr int FUSED_DQ_LD = 68;  // floats per row of the fp32 dQ image: rows 4 apart are 16 banks apart (lane groups g of a D fragment)
-
-template <bool HAS_BIAS, bool HAS_PAD, bool LONE>
-__global__ __launch_bounds__(PERS_NW * 64, 2) void attn_bwd_fused_kernel(AttnBwdArgs p, const short* __restrict__ bpack, float* __restrict__ dtable,
-                                                                          int num_rel, int rows_pad, int nitems, int ipw) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = lane >> 4, t = lane & 15;
-  const int QBY = rows_pad * 128;  // rows_pad: S rounded up to 16 (the ninth query half of S = 257 reads rows 256 ... 271: clamped copies of row 256)
-  const int dq_rows = (p.S + 7) & ~7;
-  char* ldsQ = smem;
-  char* ldsO = smem + QBY;
-  const float* ldsL = reinterpret_cast<const float*>(smem + 2 * QBY);
-  const float* ldsD = ldsL + 512;
-  float* dqa = reinterpret_cast<float*>(smem + 2 * QBY + 4096);                       // [dq_rows][FUSED_DQ_LD]: rows < S are used
-  char* scr = smem + 2 * QBY + 4096 + dq_rows * FUSED_DQ_LD * 4 + wid * 1024;          // this wave's dS scratch [32 keys][16 queries] bf16
-  float* lscr = reinterpret_cast<float*>(smem + 2 * QBY + 4096 + dq_rows * FUSED_DQ_LD * 4 + PERS_NW * 1024);  // [PERS_NW][PERS_SCRL]
-  float* bacc = lscr + PERS_NW * PERS_SCRL;                                             // [num_rel] bucket sums of the current head
-  const int S = p.S;
-  const int kbase = wid * 32;
-  const bool wave_active = kbase < min(S, 256);
-  const float c1 = p.scale * LOG2E;
-  const bool want_db = HAS_BIAS && dtable != nullptr;
-
-  bf16x8 sel_lo, sel_hi;
-  {
-    const bf16_t inv = (bf16_t)(1.0f / p.scale), zero = (bf16_t)0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      sel_lo[i] = (g * 8 + i == t) ? inv : zero;
-      sel_hi[i] = (g * 8 + i == 16 + t) ? inv : zero;
-    }
-  }
-  int trsw[4];
-#pragma unroll
-  for (int db = 0; db < 4; ++db) trsw[db] = tr_off_swz(0, db, g, t);
-  const int kswz[2] = {((0 * 4 + g) ^ (t & 7)) << 4, ((1 * 4 + g) ^ (t & 7)) << 4};
-  const int scr_w = t * 32 + g * 8;                          // + kb * 512: row key kb*16 + t, queries g*4 .. g*4 + 3 of the 16-query block
-  const int scr_r = (g * 4 + (t >> 2)) * 32 + (t & 3) * 8;   // + kb * 512: transpose-read piece of rows kb*16 + g*4 .. + 3
-
-  for (int i = tid; i < num_rel; i += PERS_NW * 64) bacc[i] = 0.f;
-  for (int i = tid; i < dq_rows * FUSED_DQ_LD; i += PERS_NW * 64) dqa[i] = 0.f;
-
-  const int ngrp = rows_pad >> 3;
-  const int NG = 2 * ngrp + 4;
-  const int r_in = lane >> 3, slot = lane & 7;
-  auto fetch = [&](int b, int h) {  // Q, dO rows (swizzled 16-byte slots), lse and delta rows of the item by LDS-DMA, 1 KiB per wave instruction
-    for (int grp = wid; grp < NG; grp += PERS_NW) {
-      const char* sbase;
-      unsigned voff;
-      int dst_off;
-      if (grp < 2 * ngrp) {
-        const bool isd = grp >= ngrp;
-        const int gi = isd ? grp - ngrp : grp;
-        const int r = gi * 8 + r_in;
-        const int qr = min(r, S - 1);
-        const int ldx = isd ? (int)p.ldo : (int)p.ld;
-        voff = (unsigned)((qr * ldx + ((slot ^ (r & 7)) << 3)) * 2);
-        sbase = isd ? (const char*)(p.dout + (int64_t)b * S * p.ldo + h * HD) : (const char*)(p.q + (int64_t)b * S * p.ld + h * HD);
-        dst_off = (isd ? QBY : 0) + gi * 1024;
-      } else {
-        const int e = grp - 2 * ngrp;  // 0, 1: lse chunks; 2, 3: delta chunks
-        voff = (unsigned)min((e & 1) * 1024 + (r_in * 8 + slot) * 16, p.Spad * 4 - 16);
-        sbase = (const char*)((e < 2 ? p.lse : p.delta) + ((int64_t)b * p.heads + h) * p.Spad);
-        dst_off = 2 * QBY + e * 1024;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + voff),
-                                       (__attribute__((address_space(3))) void*)(smem + dst_off), 16, 0, 0);
-    }
-  };
-  auto flush_bacc = [&](int h) {  // bucket sums of head h -> fp32 table gradient [num_rel][heads]; the LDS sums are re-armed
-    __syncthreads();
-    for (int i = tid; i < num_rel; i += PERS_NW * 64) {
-      const float v = bacc[i];
-      if (v != 0.f) atomicAdd(dtable + (int64_t)i * p.heads + h, v);
-      bacc[i] = 0.f;
-    }
-  };
-
-  // What a query half reads from global memory -- the transposed-bias fragments of the wave's key blocks and the bucket indices of its
-  // dS elements (int16, packed by op_attn_bucket_pack in the order the lanes hold them: ONE 16-byte load per key block) -- is requested
-  // one half AHEAD: loaded inside the half it cost an exposed L2 round trip per half, and sixteen serialised ones with the indices
-  // read element by element behind bounds checks (the first version of this kernel: 3.6 ms against the kernel pair's 0.52).
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  struct HalfIn { bf16x8 bx[2]; s16x8 ix[2]; };
-  const int nkblk = (S + 15) >> 4;
-  auto load_in = [&](int hf, int keyblk0, auto nkb_c, int hh, HalfIn& in) {
-    constexpr int NKB = decltype(nkb_c)::value;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      if constexpr (HAS_BIAS) {  // transposed image rows of this lane's keys: 8 consecutive queries = one second-operand fragment per 32 queries
-        const int key = min((keyblk0 + kb) * 16 + t, S - 1);
-        in.bx[kb] = *reinterpret_cast<const bf16x8*>(p.biasT + ((int64_t)hh * S + key) * p.Spad + hf * 32 + g * 8);
-        if (want_db) in.ix[kb] = *reinterpret_cast<const s16x8*>(bpack + (((int64_t)hf * nkblk + keyblk0 + kb) * 64 + lane) * 8);
-      }
-    }
-  };
-
-  // One 32-query half (q0h) against NKB 16-key blocks: S, dP -> P, dS -> dV^T, dK^T (attn_bwd_dkdv_pers_kernel: half), then this wave's
-  // share of dQ and of the bucket sums.
-  auto half = [&](const int q0h, auto nkb_c, const bf16x8 (&kx)[2][2], const bf16x8 (&vx)[2][2], const bf16x8 (&kq)[4],
-                  const bool (&kd)[2], const HalfIn& in, f32x4 (&dvx)[2][4], f32x4 (&dkx)[2][4]) {
-    constexpr int NKB = decltype(nkb_c)::value;
-    f32x4 s[2][NKB], dp[2][NKB];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) { s[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[j][kb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    const bool second = q0h + 16 < S;  // (uniform) the half's second 16-query block holds a query
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !second) continue;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int off = (q0h + j * 16 + t) * 128 + kswz[kk];
-        const bf16x8 qfr = *reinterpret_cast<const bf16x8*>(ldsQ + off);
-        const bf16x8 ofr = *reinterpret_cast<const bf16x8*>(ldsO + off);
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-          s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kx[kb][kk], s[j][kb], 0, 0, 0);
-          dp[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ofr, vx[kb][kk], dp[j][kb], 0, 0, 0);
-        }
-      }
-      if constexpr (HAS_BIAS) {
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) s[j][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j ? sel_hi : sel_lo, in.bx[kb], s[j][kb], 0, 0, 0);
-      }
-    }
-    float l2[2][4], dl[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !second) continue;
-      const int qrow = q0h + j * 16 + g * 4;  // + r
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ldsL + qrow);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ldsD + qrow);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {  // rows >= S: lse / delta are unspecified (possibly NaN / inf) -> P = 0, delta = 0
-        const bool live = qrow + r < S;
-        l2[j][r] = live ? l4[r] * LOG2E : INFINITY;
-        dl[j][r] = live ? d4[r] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !second) continue;
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][kb][r], c1, -l2[j][r]));
-          pr = kd[kb] ? 0.f : pr;  // a dead key's P column would reach dQ and the bucket sums
-          s[j][kb][r] = pr;
-          dp[j][kb][r] = pr * (dp[j][kb][r] - dl[j][r]);
-        }
-      }
-    }
-    bf16x8 pfr[NKB], dsf[NKB];
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      float a0[4], a1[4], b0[4], b1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a0[r] = s[0][kb][r]; a1[r] = s[1][kb][r];
-        b0[r] = dp[0][kb][r]; b1[r] = dp[1][kb][r];
-      }
-      pfr[kb] = pack8(a0, a1);
-      dsf[kb] = pack8(b0, b1);
-    }
-    // ---- bias-table gradient: dS summed per bucket (the batch sum of this head lives in LDS).  Unconditional: a query row or key that
-    // does not exist has dS = 0 and a valid index in the packed table ----
-#ifndef OP_EXP_FUSED_NODB  // (ablation switches of tools/attn_fused_ab.py: timing only, wrong results)
-    if (want_db) {
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(bacc + in.ix[kb][j * 4 + r], dp[j][kb][r]);
-    }
-#endif
-    const s16x4 zero4 = {0, 0, 0, 0};
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      const s16x4 o0 = tr_read(ldsO + q0h * 128 + trsw[db]), q0r = tr_read(ldsQ + q0h * 128 + trsw[db]);
-      s16x4 o1 = zero4, q1r = zero4;
-      if (second) {
-        o1 = tr_read(ldsO + q0h * 128 + trsw[db] + 2048);
-        q1r = tr_read(ldsQ + q0h * 128 + trsw[db] + 2048);
-      }
-      const bf16x8 oT = join_tr(o0, o1), qT = join_tr(q0r, q1r);
-#pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) {
-        dvx[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oT, pfr[kb], dvx[kb][db], 0, 0, 0);
-        dkx[kb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, dsf[kb], dkx[kb][db], 0, 0, 0);
-      }
-    }
-    // ---- dQ: dS [16 queries x 32 keys] -> LDS rows [key][query] -> first-operand fragment (M = query, K = key) x K rows of the keys ----
-#ifndef OP_EXP_FUSED_NODQ
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !second) continue;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        bf16x4 w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = kb < NKB ? dsf[kb < NKB ? kb : 0][j * 4 + r] : (bf16_t)0.f;
-        *reinterpret_cast<bf16x4*>(scr + kb * 512 + scr_w) = w;
-      }
-      const bf16x8 afr = join_tr(tr_read(scr + scr_r), tr_read(scr + 512 + scr_r));
-      // rows >= S hold zero shares: they are added onto row S - 1 (x + 0) instead of past the image -- no branch around the atomics
-      int roff[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) roff[r] = min(q0h + j * 16 + g * 4 + r, S - 1) * FUSED_DQ_LD + t;
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const f32x4 dq4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, kq[db], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-#ifndef OP_EXP_FUSED_NODQADD
-        for (int r = 0; r < 4; ++r) atomicAdd(dqa + roff[r] + db * 16, dq4[r]);
-#else
-        for (int r = 0; r < 4; ++r) dkx[0][db][r] += dq4[r];
-#endif
-      }
-    }
-#endif
-  };
-
-  const int first = blockIdx.x * ipw, last = min(first + ipw, nitems);
-  int cur_h = -1;
-  for (int item = first; item < last; ++item) {
-    const int h = item / p.B, b = item - h * p.B;  // head-major: a workgroup's items share their head (at most one change per workgroup)
-    if (want_db && h != cur_h) {
-      if (cur_h >= 0) flush_bacc(cur_h);
-      cur_h = h;
-    }
-    __syncthreads();  // the previous item's dQ flush (and the first zero fill) is done; Q / dO are free
-    fetch(b, h);
-    const bf16_t* sk = p.k + (int64_t)b * S * p.ld + h * HD;
-    const bf16_t* sv = p.v + (int64_t)b * S * p.ld + h * HD;
-    const uint8_t* padrow = HAS_PAD ? p.key_pad + (int64_t)b * p.Spad : nullptr;
-    bf16x8 kf[2][2], vf[2][2], kq[4];
-    bool kd[2];
-    (void)padrow;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const int key = kbase + kb * 16 + t, kc = min(key, S - 1);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        kf[kb][kk] = *reinterpret_cast<const bf16x8*>(sk + (int64_t)kc * p.ld + kk * 32 + g * 8);
-        vf[kb][kk] = *reinterpret_cast<const bf16x8*>(sv + (int64_t)kc * p.ld + kk * 32 + g * 8);
-      }
-      kd[kb] = key >= min(S, 256) || (HAS_PAD && padrow[kc] != 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {  // second operand of dQ: K[key pi(g*8+i)][d = db*16 + t], pi = the key order of the transpose-read fragment
-      const int kc = min(kbase + (i < 4 ? g * 4 + i : 16 + g * 4 + i - 4), S - 1);
-#pragma unroll
-      for (int db = 0; db < 4; ++db) kq[db][i] = sk[(int64_t)kc * p.ld + db * 16 + t];
-    }
-    f32x4 dvT[2][4], dkT[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int db = 0; db < 4; ++db) { dvT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[kb][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // every wave's pieces of the fetch have landed
-
-    const int nhalf = (S + 31) >> 5;
-    using N2 = std::integral_constant<int, 2>;
-    using N1 = std::integral_constant<int, 1>;
-    if (wave_active) {
-      HalfIn ia, ib;
-      load_in(0, wid * 2, N2{}, h, ia);
-      for (int hf = 0; hf < nhalf; hf += 2) {
-        if (hf + 1 < nhalf) load_in(hf + 1, wid * 2, N2{}, h, ib);
-        half(hf * 32, N2{}, kf, vf, kq, kd, ia, dvT, dkT);
-        if (hf + 1 < nhalf) {
-          if (hf + 2 < nhalf) load_in(hf + 2, wid * 2, N2{}, h, ia);
-          half(hf * 32 + 32, N2{}, kf, vf, kq, kd, ib, dvT, dkT);
-        }
-      }
-    }
-    if constexpr (LONE) {  // key 256: a ninth key block (one live column) that wave w runs against query half w, wave 0 also against half 8
-      bf16x8 kl[2][2], vl[2][2], kql[4];
-      const int kc = S - 1;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        kl[0][kk] = *reinterpret_cast<const bf16x8*>(sk + (int64_t)kc * p.ld + kk * 32 + g * 8);
-        vl[0][kk] = *reinterpret_cast<const bf16x8*>(sv + (int64_t)kc * p.ld + kk * 32 + g * 8);
-        kl[1][kk] = kl[0][kk];
-        vl[1][kk] = vl[0][kk];
-      }
-#pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const bf16_t kv = sk[(int64_t)kc * p.ld + db * 16 + t];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kql[db][i] = kv;  // (every row of the operand is key 256: only its dS column is non-zero)
-      }
-      const bool kdl[2] = {t != 0 || (HAS_PAD && padrow[kc] != 0), true};
-      f32x4 dvl[2][4], dkl[2][4];
-#pragma unroll
-      for (int db = 0; db < 4; ++db) { dvl[0][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkl[0][db] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-      HalfIn il, il8;
-      load_in(wid, 16, N1{}, h, il);
-      if (wid == 0) load_in(8, 16, N1{}, h, il8);
-      half(wid * 32, N1{}, kl, vl, kql, kdl, il, dvl, dkl);
-      if (wid == 0) half(256, N1{}, kl, vl, kql, kdl, il8, dvl, dkl);
-      float* sc = lscr + wid * PERS_SCRL;
-      if (t == 0) {  // D fragment: lane (g, t) holds dV^T[d = db*16 + g*4 + r][key column t]
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          *reinterpret_cast<f32x4*>(sc + db * 16 + g * 4) = dvl[0][db];
-          *reinterpret_cast<f32x4*>(sc + 64 + db * 16 + g * 4) = dkl[0][db];
-        }
-      }
-    }
-    __syncthreads();  // every wave's dQ shares are in the fp32 image (and the lone key's partial rows in the scratch)
-
-    // ---- outputs: dK / dV rows of this wave's keys from registers; dQ from the LDS image (re-armed to zero); the lone key's rows ----
-    if (wave_active) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        const int key = kbase + kb * 16 + t;
-        if (key < min(S, 256)) {
-          const bool dead = HAS_PAD && kd[kb];
-          bf16_t* rk = p.dk + ((int64_t)b * S + key) * p.ldg + h * HD + g * 4;
-          bf16_t* rv = p.dv + ((int64_t)b * S + key) * p.ldg + h * HD + g * 4;
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            bf16x4 a, c;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              a[r] = dead ? (bf16_t)0.f : (bf16_t)(dkT[kb][db][r] * p.scale);
-              c[r] = dead ? (bf16_t)0.f : (bf16_t)dvT[kb][db][r];
-            }
-            *reinterpret_cast<bf16x4*>(rk + db * 16) = a;
-            *reinterpret_cast<bf16x4*>(rv + db * 16) = c;
-          }
-        }
-      }
-    }
-    for (int i = tid; i < S * 8; i += PERS_NW * 64) {
-      const int row = i >> 3, c8 = (i & 7) * 8;
-      float* src = dqa + row * FUSED_DQ_LD + c8;
-      const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-      bf16x8 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)(lo[r] * p.scale); o[4 + r] = (bf16_t)(hi[r] * p.scale); }
-      *reinterpret_cast<bf16x8*>(p.dq + ((int64_t)b * S + row) * p.ldg + h * HD + c8) = o;
-      *reinterpret_cast<f32x4*>(src) = (f32x4){0.f, 0.f, 0.f, 0.f};
-      *reinterpret_cast<f32x4*>(src + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (LONE && wid == PERS_NW - 1) {  // dK / dV rows of key S - 1: the sum of the eight partials; lane = head dimension
-      float dv = 0.f, dk = 0.f;
-#pragma unroll
-      for (int w = 0; w < PERS_NW; ++w) { dv += lscr[w * PERS_SCRL + lane]; dk += lscr[w * PERS_SCRL + 64 + lane]; }
-      const bool dead = HAS_PAD && padrow[S - 1] != 0;
-      const int64_t row = ((int64_t)b * S + S - 1) * p.ldg + h * HD + lane;
-      p.dv[row] = dead ? (bf16_t)0.f : (bf16_t)dv;
-      p.dk[row] = dead ? (bf16_t)0.f : (bf16_t)(dk * p.scale);
-    }
-  }
-  if (want_db && cur_h >= 0) flush_bacc(cur_h);
-}
-
-inline int attn_fused_rows(int64_t S) { return S > 256 ? 272 : 256; }
-inline size_t attn_fused_lds(int64_t S, int64_t num_rel) {
-  return (size_t)2 * attn_fused_rows(S) * 128 + 4096 + (size_t)((S + 7) & ~7) * FUSED_DQ_LD * 4 + PERS_NW * 1024 + PERS_NW * PERS_SCRL * 4 +
-         (size_t)((num_rel + 63) / 64) * 64 * 4;
-}
-
-// bucket [S][S] int32 -> int16 in the order attn_bwd_fused_kernel's lanes hold their dS elements: out[hf][keyblk][lane][j * 4 + r] =
-// bucket[hf*32 + j*16 + g*4 + r][keyblk*16 + t]  (lane = g*16 + t; 0 where the query or the key does not exist: their dS is 0)
-__global__ __launch_bounds__(256) void bucket_pack_kernel(const int* __restrict__ bucket, short* __restrict__ out, int S, int nkblk, int total) {
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= total) return;
-  const int lane = gid & 63, blk = gid >> 6;
-  const int hf = blk / nkblk, kblk = blk - hf * nkblk;
-  const int g = lane >> 4, t = lane & 15;
-  const int key = kblk * 16 + t;
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = hf * 32 + j * 16 + g * 4 + r;
-      out[(int64_t)gid * 8 + j * 4 + r] = (q < S && key < S) ? (short)bucket[(int64_t)q * S + key] : (short)0;
-    }
-}
-
-template <bool HAS_BIAS, bool HAS_PAD>
-int launch_bwd_fused(const AttnBwdArgs& a, const short* bucket, float* dtable, int num_rel, hipStream_t s) {
-  const int rows_pad = attn_fused_rows(a.S);
-  const size_t sh = attn_fused_lds(a.S, num_rel);
-  const int nitems = a.B * a.heads;
-  const int nwg = min(nitems, attn_num_cus());
-  const int ipw = ceil_div(nitems, nwg);
-  const int grid = ceil_div(nitems, ipw);
-  if (a.S > 256) {
-    OP_ENSURE_LDS((attn_bwd_fused_kernel<HAS_BIAS, HAS_PAD, true>), 163840, "attn_bwd_fused");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<HAS_BIAS, HAS_PAD, true>), dim3(grid), dim3(PERS_NW * 64), sh, s, a, bucket, dtable, num_rel, rows_pad, nitems, ipw);
-  } else {
-    OP_ENSURE_LDS((attn_bwd_fused_kernel<HAS_BIAS, HAS_PAD, false>), 163840, "attn_bwd_fused");
-    hipLaunchKernelGGL((attn_bwd_fused_kernel<HAS_BIAS, HAS_PAD, false>), dim3(grid), dim3(PERS_NW * 64), sh, s, a, bucket, dtable, num_rel, rows_pad, nitems, ipw);
-  }
-  return OP_OK;
-}
-
 }  // namespace
 
 extern "C" int op_prof_begin(int family, double work, void* stream);
@@ -3571,62 +3137,6 @@ int op_attn_bwd(const void* q, const void* k, const void* v, int64_t ld, const v
                        s, a);
     OP_LAUNCH_CHECK();
   }
-  return OP_OK;
-}
-
-// (ABI 9) dQ, dK, dV and the relative-position TABLE gradient in one kernel (attn_bwd_fused_kernel) for 193 <= S <= 257 with a bias
-// shared by all samples (or none).  biasT: bf16 [heads][S][Spad], rows = key (the transposed image of op_relpos_bias_build); bucket:
-// the int16 table of op_attn_bucket_pack (the table row of every (query, key): what the image was built from); dtable: fp32
-// [num_rel][heads], ADDED to (nullable: no table gradient).  delta: fp32 [B][heads][Spad] from op_attn_bwd_delta.  Returns -95 (nothing launched) for other lengths, a bias
-// without bucket table, or a table that does not fit the LDS next to the item (num_rel > ~1800): the caller then runs op_attn_bwd.
-int64_t op_attn_bucket_pack_elems(int64_t S) { return (int64_t)((S + 31) / 32) * ((S + 15) / 16) * 64 * 8; }
-
-// bucket: int32 [S][S] with values < 32768 -> out: int16 [op_attn_bucket_pack_elems(S)], the index table op_attn_bwd_fused reads (built
-// once per (table, sequence length); the bucket table is a registered buffer of the adapters, adapter/image.py:19-34, text.py:18-29).
-int op_attn_bucket_pack(const int32_t* bucket, void* out, int64_t S, void* stream) {
-  OP_CHECK_ARG(bucket && out && S > 0, "attn_bucket_pack: bad args");
-  const int nkblk = (int)((S + 15) / 16);
-  const int total = (int)((S + 31) / 32) * nkblk * 64;
-  hipLaunchKernelGGL(bucket_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, (const int*)bucket, (short*)out, (int)S,
-                     nkblk, total);
-  OP_LAUNCH_CHECK();
-  return OP_OK;
-}
-
-int op_attn_bwd_fused(const void* q, const void* k, const void* v, int64_t ld, const void* dout, int64_t ldo, const void* biasT,
-                      const void* bucket, const void* key_pad, const float* lse, const float* delta, void* dq, void* dk, void* dv,
-                      int64_t ldg, float* dtable, int64_t num_rel, int64_t B, int64_t S, int64_t Spad, int64_t heads, int64_t head_dim,
-                      float scale, int64_t tune, void* stream) {
-  (void)tune;
-  OP_CHECK_ARG(q && k && v && dout && lse && delta && dq && dk && dv, "attn_bwd_fused: null pointer");
-  OP_CHECK_ARG(head_dim == HD, "attn_bwd_fused: head_dim %lld unsupported (only 64)", (long long)head_dim);
-  OP_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0 && ldg % 8 == 0, "attn_bwd_fused: bad leading dims");
-  OP_CHECK_ARG(Spad >= ((S + 127) / 128) * 128 && Spad % 8 == 0, "attn_bwd_fused: Spad must be >= S rounded up to 128");
-  OP_CHECK_ARG(!dtable || (biasT && bucket && num_rel > 0 && num_rel < 32768), "attn_bwd_fused: a table gradient needs the bias image, the packed bucket table and num_rel < 32768");
-  const bool inv_exact = (float)(bf16_t)(1.0f / scale) * scale == 1.0f;
-  if (!(S > 192 && S <= 257) || (biasT && !inv_exact) || attn_fused_lds(S, biasT ? num_rel : 0) > 163840 || B * heads <= 0) {
-    op_set_error("attn_bwd_fused: S = %lld / num_rel = %lld not supported by the fused kernel", (long long)S, (long long)num_rel);
-    return OP_ENOTSUP;
-  }
-  AttnBwdArgs a;
-  memset(&a, 0, sizeof(a));
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ld = ld;
-  a.dout = (const bf16_t*)dout; a.ldo = ldo; a.biasT = (const bf16_t*)biasT; a.bias = (const bf16_t*)biasT;
-  a.key_pad = (const uint8_t*)key_pad; a.lse = lse; a.delta = delta;
-  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.ldg = ldg;
-  a.B = (int)B; a.S = (int)S; a.Spad = (int)Spad; a.heads = (int)heads; a.scale = scale;
-  hipStream_t s = (hipStream_t)stream;
-  const int nrel = biasT ? (int)num_rel : 0;
-  const int slot = op_prof_begin(2, 5.0 * 2.0 * (double)B * (double)heads * (double)S * (double)S * HD, stream);
-  int rc;
-  const short* bp = (const short*)bucket;
-  if (biasT && key_pad) rc = launch_bwd_fused<true, true>(a, bp, dtable, nrel, s);
-  else if (biasT) rc = launch_bwd_fused<true, false>(a, bp, dtable, nrel, s);
-  else if (key_pad) rc = launch_bwd_fused<false, true>(a, bp, dtable, nrel, s);
-  else rc = launch_bwd_fused<false, false>(a, bp, dtable, nrel, s);
-  op_prof_end(slot, stream);
-  if (rc != OP_OK) return rc;
-  OP_LAUNCH_CHECK();
   return OP_OK;
 }
 

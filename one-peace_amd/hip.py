@@ -74,9 +74,6 @@ SIGNATURES = {
     "op_attn_bias_pack": (c_int, [P, P, I64, I64, I64, P]),
     "op_attn_bwd_delta": (c_int, [P, P, I64, P, I64, I64, I64, I64, P]),
     "op_attn_bwd": (c_int, [P, P, P, I64, P, P, I64, P, P, P, I64, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, c_float, I64, P]),
-    "op_attn_bucket_pack_elems": (I64, [I64]),
-    "op_attn_bucket_pack": (c_int, [P, P, I64, P]),
-    "op_attn_bwd_fused": (c_int, [P, P, P, I64, P, I64, P, P, P, P, P, P, P, P, I64, P, I64, I64, I64, I64, I64, I64, c_float, I64, P]),
     "op_quant_fp8_rows": (c_int, [P, I64, P, I64, P, I64, I64, P]),
     "op_layernorm_fwd_q8": (c_int, [P, P, P, P, P, P, P, P, I64, I64, c_float, P]),
     "op_ln_geglu_fwd_q8": (c_int, [P, P, I64, P, P, P, P, P, P, P, I64, I64, c_float, P]),
@@ -843,32 +840,6 @@ def attn_bwd_launch(q, k, v, ld, dout, bias, biasT, key_pad, lse, delta, dq, dk,
                              _bias_bstride(bias),
                              ptr(key_pad), ptr(lse), ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldg, ptr(dbias), B, S, Spad, heads,
                              64, scale, TUNE.attn_bwd(), stream()), "op_attn_bwd")
-
-
-def attn_bucket_pack(bucket_i32):
-    """int32 [S, S] bucket table -> the int16 table attn_bwd_fused reads (the order its lanes hold their dS elements; built once per
-    table and sequence length)."""
-    S = bucket_i32.shape[0]
-    assert bucket_i32.dtype == torch.int32 and bucket_i32.is_contiguous() and tuple(bucket_i32.shape) == (S, S)
-    out = torch.empty(int(lib().op_attn_bucket_pack_elems(S)), dtype=torch.int16, device=bucket_i32.device)
-    _check(lib().op_attn_bucket_pack(ptr(bucket_i32), ptr(out), S, stream()), "op_attn_bucket_pack")
-    return out
-
-
-def attn_bwd_fused(q, k, v, ld, dout, lse, delta, biasT, bucket_pack, key_pad, dq, dk, dv, ldg, dtable, B, S, Spad, heads, scale):
-    """dQ, dK, dV and the fp32 table gradient dtable [num_rel, heads] (added to; None: none) in ONE kernel for 193 <= S <= 257 and a bias
-    shared by all samples (csrc/attention.hip: attn_bwd_fused_kernel).  bucket_pack: attn_bucket_pack(bucket); delta: fp32
-    [B, heads, Spad] from op_attn_bwd_delta.  Returns False (nothing launched) when the kernel does not take the shape: the caller runs
-    attn_bwd_launch."""
-    assert bucket_pack is None or (bucket_pack.dtype == torch.int16 and bucket_pack.numel() == int(lib().op_attn_bucket_pack_elems(S)))
-    assert dtable is None or (dtable.dtype == torch.float32 and dtable.is_contiguous() and dtable.shape[1] == heads)
-    rc = lib().op_attn_bwd_fused(ptr(q), ptr(k), ptr(v), ld, ptr(dout), dout.stride(0), ptr(biasT), ptr(bucket_pack), ptr(key_pad), ptr(lse),
-                                 ptr(delta), ptr(dq), ptr(dk), ptr(dv), ldg, ptr(dtable), dtable.shape[0] if dtable is not None else 0,
-                                 B, S, Spad, heads, 64, scale, TUNE.attn_bwd(), stream())
-    if rc == -95:
-        return False
-    _check(rc, "op_attn_bwd_fused")
-    return True
 
 
 def attn_dbias_buffer(B, S, heads, Spad, device, per_sample=False):

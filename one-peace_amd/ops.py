@@ -522,10 +522,8 @@ class RelPosBias:
         self.bucket = bucket_i32
         self.table = table
         self.acc = None
-        self.tacc = None
         self._imageT = None
         self._frag = None
-        self._bucket_pack = None
         self.image = _RelPosImageFn.apply(table, self)
 
     @property
@@ -544,20 +542,6 @@ class RelPosBias:
             else:
                 self._imageT = hip.relpos_bias_build(self.table.detach(), self.bucket, self.S, self.Spad, transposed=True)
         return self._imageT
-
-    @property
-    def bucket_pack(self):
-        """The bucket table in the fused attention backward's index order (hip.attn_bucket_pack; built on first use, shared by all layers)."""
-        if self._bucket_pack is None:
-            self._bucket_pack = hip.attn_bucket_pack(self.bucket.contiguous())
-        return self._bucket_pack
-
-    def table_accumulator(self):
-        """fp32 [num_rel, heads]: the fused attention backward (hip.attn_bwd_fused) adds the bias gradient in TABLE space -- dS summed
-        per bucket inside the kernel -- for every layer that uses this table."""
-        if self.tacc is None:
-            self.tacc = torch.zeros(self.num_rel, self.heads, dtype=torch.float32, device=self.image.device)
-        return self.tacc
 
     def grad_accumulator(self, B):
         """fp32 [slabs, heads, S, Spad]: the attention backward of every layer that uses this table adds its dS sums here
@@ -642,16 +626,13 @@ class _RelPosImageFn(torch.autograd.Function):
         # The attention backward kernels add dS straight into handle.acc (fp32); the tensor gradient that autograd
         # routes here is a placeholder that only orders this node after every consuming layer.
         h = ctx.handle_ref()
-        if h is None or (h.acc is None and h.tacc is None):
+        if h is None or h.acc is None:
             return torch.zeros(ctx.shape, dtype=torch.bfloat16, device=_unused.device), None
-        dtable = h.tacc  # (the fused backward kernel's sums are in table space already)
-        if h.acc is not None:
-            if h.ids is not None:
-                dimg = hip.relpos_bias_bwd_ids(h.acc, h.bucket, h.ids, h.num_rel)
-            else:
-                dimg = hip.relpos_bias_bwd(h.acc.sum(0), h.bucket, h.num_rel, h.S, h.Spad)
-            dtable = dimg if dtable is None else dtable + dimg
-        h.acc = h.tacc = None
+        if h.ids is not None:
+            dtable = hip.relpos_bias_bwd_ids(h.acc, h.bucket, h.ids, h.num_rel)
+        else:
+            dtable = hip.relpos_bias_bwd(h.acc.sum(0), h.bucket, h.num_rel, h.S, h.Spad)
+        h.acc = None
         return dtable.to(torch.bfloat16), None
 
 
@@ -1040,8 +1021,10 @@ class AttnBranchFn(torch.autograd.Function):
                 if sg.pad:  # rows of no sample: zero gradient (they are operand rows of the q|k|v weight gradient)
                     dqkv[sg.end - sg.pad:sg.end].zero_()
                 dparts = {n: dqkv[r, slot[n] * H:(slot[n] + 1) * H] for n in qkv_names}
-                _attn_backward(qkv[r], dattn[r], A["attn"][r], A["lse%d" % i], sg.B, sg.S, heads, scale, sg.bias, sg.key_pad, want_dbias[i],
-                               sg.frag(384), dparts["wq"], dparts["wk"], dparts["wv"])
+                _attn_backward(qkv[r], dattn[r], A["attn"][r], A["lse%d" % i], sg.B, sg.S, heads, scale,
+                               sg.bias.image.detach() if sg.bias is not None else None, sg.bias.imageT if sg.bias is not None else None,
+                               sg.key_pad, sg.bias.grad_accumulator(sg.B) if want_dbias[i] else None, sg.frag(384),
+                               dparts["wq"], dparts["wk"], dparts["wv"])
             bias_of = {"wq": "bq", "wv": "bv"}
             bnames = tuple(bias_of[n] for n in cols if n in bias_of and needs[bias_of[n]])
             if bnames:
@@ -1473,36 +1456,18 @@ def kept_segments(kept, segs, device):
     return out, vec
 
 
-FUSED_ATTN_BWD = os.environ.get("ONEPEACE_FUSED_ATTN_BWD", "1") != "0"  # (A/B switch: 0 = the dQ + dBias and dK / dV kernel pair of rounds 1-5)
-
-
-def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias, key_pad, want_dbias, bias_frag, dq, dk, dv):
-    """Attention backward; dq / dk / dv: [N, H] column blocks of one packed [N, 3H] gradient matrix (any block order).  bias: the
-    stream's RelPosBias-like handle or None; want_dbias: its table takes a gradient."""
+def _attn_backward(qkv, dattn, attn, lse, B, S, heads, scale, bias_img, biasT, key_pad, dbias_acc, bias_frag, dq, dk, dv):
+    """Attention backward; dq / dk / dv: [N, H] column blocks of one packed [N, 3H] gradient matrix (any block order)."""
     H = heads * 64
     dev = qkv.device
     Spad = hip.attn_spad(S)
-    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)  # workspace of the call (rowsum(dO o O))
-    # (round 6) one kernel for the 193 ... 257-token streams with a table shared by all samples: S and dP formed once, dQ summed over the
-    # key-owning waves in LDS, the bias gradient summed per bucket in LDS (csrc/attention.hip: attn_bwd_fused_kernel)
-    if (FUSED_ATTN_BWD and 192 < S <= 257 and attn.stride(0) == dattn.stride(0) and dq.stride(0) % 8 == 0
-            and (bias is None or (isinstance(bias, RelPosBias) and bias.ids is None and bias.bucket is not None
-                                  and bias.bucket.dtype == torch.int32 and tuple(bias.bucket.shape) == (S, S)))):
-        hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dattn), hip.ptr(attn), dattn.stride(0), hip.ptr(delta), B, S, Spad, heads,
-                                               hip.stream()), "op_attn_bwd_delta")
-        dtable = bias.table_accumulator() if (bias is not None and want_dbias) else None
-        if hip.attn_bwd_fused(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, lse, delta, bias.imageT if bias is not None else None,
-                              bias.bucket_pack if bias is not None else None, key_pad, dq, dk, dv, dq.stride(0), dtable, B, S, Spad,
-                              heads, scale):
-            return
-        attn = None  # (delta is computed: the kernel pair below must not recompute it into the same workspace)
-    elif attn.stride(0) != dattn.stride(0) or SEPARATE_DELTA:  # (the fused delta reads both with one row stride)
+    delta = torch.empty(B, heads, Spad, dtype=torch.float32, device=dev)  # workspace of the call (rowsum(dO o O), from the dQ kernels)
+    if attn.stride(0) != dattn.stride(0) or SEPARATE_DELTA:  # (the fused delta reads both with one row stride)
         hip._check(hip.lib().op_attn_bwd_delta(hip.ptr(dattn), hip.ptr(attn), dattn.stride(0), hip.ptr(delta), B, S, Spad, heads,
                                                hip.stream()), "op_attn_bwd_delta")
         attn = None
-    hip.attn_bwd_launch(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, bias.image.detach() if bias is not None else None,
-                        bias.imageT if bias is not None else None, key_pad, lse, delta, dq, dk, dv, dq.stride(0),
-                        bias.grad_accumulator(B) if (bias is not None and want_dbias) else None, B, S, Spad, heads, scale, bias_frag, out=attn)
+    hip.attn_bwd_launch(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], 3 * H, dattn, bias_img, biasT, key_pad, lse, delta, dq, dk,
+                        dv, dq.stride(0), dbias_acc, B, S, Spad, heads, scale, bias_frag, out=attn)
 
 
 def attn_branch(x, bias, key_pad, ps, heads, params, save_acts=False):

@@ -22,9 +22,6 @@ ATTN_SCRATCH_ALLOWED = {
     "attn_bwd_dq_dbias_kernelILi6ELb1ELi1E": 104, "attn_bwd_dq_dbias_kernelILi6ELb1ELi4E": 156, "attn_bwd_dq_dbias_kernelILi6ELb0ELi4E": 12,
     # merged dQ + dBias kernel of rounds 2-3 (per-sample bias images and the lengths the persistent kernel does not take)
     "attn_bwd_dbias_kernel": 12,
-    # (round 6) the fused backward kernel, first version: spills around the sixteen bucket loads + LDS atomics of a query half
-    "attn_bwd_fused_kernelILb1ELb1ELb1E": 416, "attn_bwd_fused_kernelILb1ELb1ELb0E": 192, "attn_bwd_fused_kernelILb1ELb0ELb1E": 408,
-    "attn_bwd_fused_kernelILb1ELb0ELb0E": 168, "attn_bwd_fused_kernelILb0ELb1ELb1E": 56, "attn_bwd_fused_kernelILb0ELb0ELb1E": 44,
 }
 
 

@@ -278,6 +278,16 @@ def auto_batch(device, tokens_per_sample, layers, recompute, candidates, fixed_g
     return candidates[-1]
 
 
+def param_checksum(flat):
+    """[sum, sum of absolute values] of the flat parameter buffer in fp64, 128 M elements at a time (a whole-buffer fp64 reduction made
+    torch allocate a 31 GB temporary: +29 GB peak reserved in the bench line)."""
+    tot = mag = 0.0
+    for c in flat.split(1 << 27):
+        tot += float(c.sum(dtype=torch.float64))
+        mag += float(c.abs().sum(dtype=torch.float64))
+    return [tot, mag]
+
+
 def main():
     global H, FFN, LAYERS, HEADS
     ap = argparse.ArgumentParser()
@@ -720,8 +730,7 @@ def main():
                        "algorithmic_tflop_per_sample": None if full else fl / 1e12,
                        "step_algorithmic_tflops_per_gpu": None if full else fl * args.batch / (ms / 1e3) / 1e12,
                        "objective": "forward" if not train else args.objective, "final_loss": loss_v if train else None,
-                       **({"param_checksum": [float(flat.params.sum(dtype=torch.float64)),  # (reductions without a temporary: the buffer is 7.8 GB)
-                                               float(torch.linalg.vector_norm(flat.params, ord=1, dtype=torch.float64))],
+                       **({"param_checksum": param_checksum(flat.params),
                            "nt_gemm_launch_rule": ("one tile per workgroup (tune sched 7: distributed.share_cus_with_collectives)"
                                                    if hip.TUNE.sched == 7 else "persistent workgroups for K <= 2048 and grouped launches"
                                                    if hip.TUNE.sched == 0 else "tune sched %d" % hip.TUNE.sched)} if train and not micro else {}),

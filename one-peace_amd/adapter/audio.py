@@ -170,7 +170,15 @@ class AudioAdapter(nn.Module):
                 ids = preserve_ids.masked_fill(padding_mask, preserve_ids.size(1) - 1)
                 frames = common.take_rows(frames, ids[:, 1:] - 1)
                 biases = common.take_bias(biases, ids, bsz)
-            pos = torch.cat([self.cls_pos_embed.expand(bsz, -1, -1), self._positions(frames)], dim=1)
+            if self.layernorm_embedding is None and self.alpha == 1.0:
+                # emb + pos with emb = [cls | frames], pos = [cls_pos | positions] (adapter/audio.py:186-203) as ONE add over the frames and
+                # one over the token: the same sums bit for bit, without the two [B, T + 1, H] concatenations (torch.cat's batched 2-byte
+                # copy kernel moved the 98 MB position matrix at 0.07 TB/s: 1.4 ms of the headline step) and the full-size add behind them
+                x = common.prepend_token(self.cls_embedding + self.cls_pos_embed, frames + self._positions(frames))
+                if self.type_embedding is not None:
+                    x = x + self.type_embedding
+                return self.dropout_module(x), padding_mask, biases
+            pos = common.prepend_token(self.cls_pos_embed, self._positions(frames))
             emb = common.prepend_token(self.cls_embedding, frames)
             if self.layernorm_embedding is not None:
                 emb = self.layernorm_embedding(emb)

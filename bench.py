@@ -801,7 +801,7 @@ def main():
             # HBM bytes per GEMM launch need separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), so they
             # cannot be collected inside this process: tools/pmc_bench_traffic.sh runs this command under those passes and writes
             # the file; it is quoted only for the exact configuration it was measured on.
-            for tname in ("r5_gemm_hbm_traffic.json", "r4_gemm_hbm_traffic.json", "r3_gemm_hbm_traffic.json", "r2_gemm_hbm_traffic.json", "r1_gemm_hbm_traffic.json"):
+            for tname in ("r6_gemm_hbm_traffic.json", "r5_gemm_hbm_traffic.json", "r4_gemm_hbm_traffic.json", "r3_gemm_hbm_traffic.json", "r2_gemm_hbm_traffic.json", "r1_gemm_hbm_traffic.json"):
                 tpath = os.path.join(ROOT, "profiles", tname)
                 if not os.path.exists(tpath):
                     continue

@@ -48,7 +48,7 @@ out = {
     "what": "HBM-side bytes per GEMM-family launch (all gemm* kernels; split-K folds are not counted as launches), one bench.py step",
     "command": "tools/pmc_bench_traffic.sh: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --kernel-include-regex 'gemm|splitk' -- "
                "python bench.py --steps 1 --warmup 1 --no-profile --no-cpu-baseline --no-skip-leg --no-power-probe (two separate passes + two calibration launches each)",
-    "round": 5, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
+    "round": 6, "config": 3, "per_gpu_batch": 128, "n_gpus": 1, "gemm_launches": n,
     "fetch_size_correction": fc, "write_size_correction": wc,
     "calibration": "tools/pmc_calib.py: A[32896,6144] bf16 read exactly once (404 MB > 256 MB Infinity Cache)",
     "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,

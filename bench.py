@@ -299,7 +299,9 @@ def main():
                          "3 tri-modal pretrain step (headline), 4 long-sequence image(+text) step at 448^2 / 512^2")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch; 0 = the config's own (largest that fits this GPU's HBM)")
     ap.add_argument("--res", type=int, default=448, choices=[448, 512], help="config 4: image size (785 / 1025 tokens)")
-    ap.add_argument("--fp8", action="store_true", help="config 4: FFN GEMMs on the fp8 (e4m3) MFMA path")
+    ap.add_argument("--fp8", action="store_true", help="config 4: FFN GEMMs on the fp8 (e4m3) MFMA path: forward up- / down-projection and "
+                    "(round 6) the two input-gradient GEMMs of the backward; weight gradients stay bf16")
+    ap.add_argument("--fp8-forward-only", action="store_true", help="with --fp8: keep the FFN input-gradient GEMMs in bf16 (round 5's variant; A/B)")
     ap.add_argument("--layers", type=int, default=LAYERS, help="debug only; the reported metric needs 40")
     ap.add_argument("--audio-seconds", type=float, default=5.0)
     ap.add_argument("--recompute", action="store_true", help="per-layer activation recompute (reference default)")
@@ -403,7 +405,7 @@ def main():
             args.batch = auto_batch(device, S_img + S_txt, args.layers, args.recompute, (64, 48, 32, 16, 8), 36.0, rccl_reserve)
         modal = {"text": S_txt, "image": S_img}
         name = ("BASELINE configs[4]: ONE-PEACE-4B long-sequence step, %d^2 image -> %d tokens + text 64: 2 forwards, ITC, backward, "
-                "grad all-reduce, grad-norm clip, AdamW%s" % (res, S_img, "; FFN GEMMs in fp8 (e4m3, per-row scales)" if args.fp8 else ""))
+                "grad all-reduce, grad-norm clip, AdamW%s" % (res, S_img, ("; FFN GEMMs in fp8 (e4m3, per-row scales): forward" + ("" if args.fp8_forward_only else " + input gradients")) if args.fp8 else ""))
         metric = "long-sequence (%d-token image) contrastive step samples/s ONE-PEACE-4B" % S_img
     else:
         S_img, audio_s, head, res = (17 if micro else 257), (None if full and not al else args.audio_seconds), "val", (64 if micro else 256)
@@ -434,7 +436,7 @@ def main():
         if args.config != 4:
             raise SystemExit("--fp8 is the variant of --config 4")
         from one_peace_amd import ops
-        ops.set_fp8_ffn(True)  # opt-in: FFN GEMMs (GeGLU up-projection, down-projection and their dgrads) on e4m3 operands
+        ops.set_fp8_ffn(True, dgrad=not args.fp8_forward_only)  # opt-in: FFN GEMMs (up- / down-projection and their input gradients) on e4m3 operands
 
     if al:
         model = build_pretrain_al_model(args.layers, device, args.recompute)

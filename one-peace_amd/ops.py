@@ -40,9 +40,10 @@ def refresh_weight_cache():
     _cache_epoch += 1
     # fp8 copies of the FFN weights (opt-in variant): re-quantised IN PLACE into the same buffers -- a replayed TrainStepGraph keeps
     # reading these addresses, and an eager step must not pay a cache miss per weight either
-    if not FP8_FFN and _fp8_cache:  # the opt-in variant was switched off: nothing reads these copies any more
+    if not FP8_FFN and (_fp8_cache or _fp8_derived_cache):  # the opt-in variant was switched off: nothing reads these copies any more
         _fp8_cache.clear()
         _fp8_pairs.clear()
+        _fp8_derived_cache.clear()
     for k, (ref, _, qs) in list(_fp8_cache.items()):
         w = ref()
         if w is None:
@@ -109,12 +110,37 @@ FP8_FFN = False
 _fp8_cache = {}
 
 
-def set_fp8_ffn(on):
-    """Opt in / out of running the FORWARD FFN GEMMs (GeGLU up-projection, down-projection) on fp8 e4m3 operands with per-row
-    scales (csrc/fp8.hip).  Backward stays on the bf16 kernels and the bf16 activations saved by the forward pass."""
-    global FP8_FFN
+FP8_FFN_DGRAD = os.environ.get("ONEPEACE_FP8_DGRAD", "1") != "0"
+
+
+def set_fp8_ffn(on, dgrad=None):
+    """Opt in / out of running the FFN GEMMs on fp8 e4m3 operands with per-row scales (csrc/fp8.hip): the forward up- and
+    down-projection and (round 6; dgrad=False or ONEPEACE_FP8_DGRAD=0 keeps them in bf16) the two INPUT-gradient GEMMs of the backward
+    -- d LN_F(g) = dy W2 and d LN2(x) = dh [W0 | W1] -- whose operands are quantised row by row (the gradient rows by op_quant_fp8_rows,
+    the transposed weight copies once per optimiser step).  The WEIGHT gradients stay on the bf16 kernels and the bf16 activations."""
+    global FP8_FFN, FP8_FFN_DGRAD
     old, FP8_FFN = FP8_FFN, bool(on)
+    if dgrad is not None:
+        FP8_FFN_DGRAD = bool(dgrad)
     return old
+
+
+_fp8_derived_cache = {}
+
+
+def _fp8_derived(t):
+    """(fp8 bytes, row scales) of a DERIVED bf16 matrix that keeps its address across optimiser steps (a cached transposed weight copy,
+    _transposed): quantised on first use after every refresh of the weight cache (epoch), in place."""
+    key = (t.data_ptr(), tuple(t.shape))
+    hit = _fp8_derived_cache.get(key)
+    if hit is not None and hit[0] == _cache_epoch:
+        return hit[1]
+    if len(_fp8_derived_cache) > 4096:
+        _fp8_derived_cache.clear()
+        hit = None
+    qs = hip.quant_fp8_rows(t, out=hit[1] if hit is not None else None)
+    _fp8_derived_cache[key] = (_cache_epoch, qs)
+    return qs
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -1147,7 +1173,12 @@ class FfnBranchFn(torch.autograd.Function):
             w2_t = None
         dx = None
         if need_x or any(needs[n] for n in ("ln2_w", "ln2_b", "w0", "w1", "fln_w", "fln_b")):
-            dgln = hip.gemm_nt(dy2, [w2_t if w2_t is not None else _transposed(P["w2"])])
+            fp8b = FP8_FFN and FP8_FFN_DGRAD and H % 128 == 0 and Fd % 128 == 0  # (opt-in) the two input-gradient GEMMs on e4m3 operands
+            w2t = w2_t if w2_t is not None else _transposed(P["w2"])
+            if fp8b:
+                dgln = hip.gemm_nt_fp8(*hip.quant_fp8_rows(dy2), *[[x] for x in _fp8_derived(w2t)])
+            else:
+                dgln = hip.gemm_nt(dy2, [w2t])
             # dh0 | dh1 as the two halves of ONE [N, 2F] matrix, in the memory order of the two weights' flat gradient views:
             # one weight-gradient launch (288 output tiles, one fold) when those views are adjacent, and always one K = 2F
             # input-gradient GEMM instead of two K = F launches chained through a residual epilogue
@@ -1173,7 +1204,11 @@ class FfnBranchFn(torch.autograd.Function):
                     if needs[n]:
                         weight_grad(n, dpart[n], A["xln2"])
             if need_x or needs["ln2_w"] or needs["ln2_b"]:
-                dxln2 = hip.gemm_nt(dh, [_transposed(tuple(P[n] for n in cols))])
+                w01t = _transposed(tuple(P[n] for n in cols))
+                if fp8b:
+                    dxln2 = hip.gemm_nt_fp8(*hip.quant_fp8_rows(dh), *[[x] for x in _fp8_derived(w01t)])
+                else:
+                    dxln2 = hip.gemm_nt(dh, [w01t])
                 want = needs["ln2_w"] or needs["ln2_b"]
                 (tw, tb), acc = _targets(direct, "ln2_w", "ln2_b") if want else ((None, None), False)
                 dx, dw_, db_ = hip.layernorm_bwd(dxln2, x_mid, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"], add=dout2, dw=tw, db=tb,
@@ -1343,6 +1378,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
         dgln = torch.empty(N, Fd, dtype=dt, device=dev) if upstream else None
         colsets, dg_tmp = [], None
         fused = ctx.dg_fused  # gamma_2's gradient from the three down-projection weight gradients (no y2: dgamma_from_wgrad_ok)
+        fp8b = FP8_FFN and FP8_FFN_DGRAD and H % 128 == 0 and Fd % 128 == 0
         (rowdot, rd_views), pairs = (_rowdot_slots(dev, [P["w2@%d" % i] for i in range(nseg)]), []) if fused else ((None, None), None)
         for i, sg in enumerate(segs):
             r = slice(sg.row0, sg.end)
@@ -1377,7 +1413,11 @@ class FfnBranchMultiFn(torch.autograd.Function):
             if not upstream:
                 colsets.append(None)
                 continue
-            hip.gemm_nt(dy2, [_transposed(P[k("w2")], scale=P["g2"] if fused else None)], out=dgln[r])
+            w2t = _transposed(P[k("w2")], scale=P["g2"] if fused else None)
+            if fp8b:  # (opt-in, round 6) d LN_F(g) = dy W2 on e4m3 operands: the gradient rows and the transposed weight copy row-quantised
+                hip.gemm_nt_fp8(*hip.quant_fp8_rows(dy2), *[[x] for x in _fp8_derived(w2t)], out=dgln[r])
+            else:
+                hip.gemm_nt(dy2, [w2t], out=dgln[r])
             pair = (k("w0"), k("w1"))
             order = _adjacent_grads(direct, pair) if needs[pair[0]] and needs[pair[1]] and Fd % 8 == 0 else None
             cols = tuple(order) if order else pair
@@ -1410,7 +1450,10 @@ class FfnBranchMultiFn(torch.autograd.Function):
             dxln2 = torch.empty(N, H, dtype=dt, device=dev)
             rs = [slice(sg.row0, sg.end) for sg in segs]
             wts = [_transposed(tuple(P[n] for n in cols)) for cols in colsets]
-            if hip.gemm_nt_grouped([dh[r] for r in rs], wts, outs=[dxln2[r] for r in rs]) is None:
+            if fp8b:  # one fp8 launch per modality (the grouped persistent launch is bf16 only)
+                for r, wt in zip(rs, wts):
+                    hip.gemm_nt_fp8(*hip.quant_fp8_rows(dh[r]), *[[x] for x in _fp8_derived(wt)], out=dxln2[r])
+            elif hip.gemm_nt_grouped([dh[r] for r in rs], wts, outs=[dxln2[r] for r in rs]) is None:
                 for r, wt in zip(rs, wts):
                     hip.gemm_nt(dh[r], [wt], out=dxln2[r])
             want = needs["ln2_w"] or needs["ln2_b"]

@@ -1810,8 +1810,11 @@ def test_stage2_pretraining_skips_frozen_weight_gradients(golden_dir):
     assert n > 20
 
 
-def test_fp8_ffn_forward_in_the_lock_step_pass():
-    """Round 5: with ops.set_fp8_ffn(True) a TRAINING lock-step pass keeps the lock-step form (it used to fall back to one pass per
+@pytest.mark.parametrize("dgrad", [False, True])
+def test_fp8_ffn_forward_in_the_lock_step_pass(dgrad):
+    """dgrad (round 6): ALSO the two input-gradient GEMMs of the FFN backward (dy W2, dh [W0 | W1]) on e4m3 operands -- gradient rows
+    quantised by op_quant_fp8_rows, the transposed weight copies once per optimiser step; the weight gradients stay bf16.
+    Round 5: with ops.set_fp8_ffn(True) a TRAINING lock-step pass keeps the lock-step form (it used to fall back to one pass per
     modality): LayerNorm2 / op_ln_geglu_fwd emit the fp8 operands, the plain N = 2F up-projection and the down-projection + residual run
     on the fp8 kernels per modality.  Same loss bits as the fp8 passes taken one by one (per row the same kernels), and within the
     variant's tolerance of the bf16 step; every gradient finite (backward = bf16 kernels on the saved bf16 activations)."""
@@ -1842,7 +1845,8 @@ def test_fp8_ffn_forward_in_the_lock_step_pass():
         torch.manual_seed(0)
         m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
         m = m.to(DEV).to(torch.bfloat16).train()
-        old = _ops.set_fp8_ffn(mode != "bf16")
+        old_dg = _ops.FP8_FFN_DGRAD
+        old = _ops.set_fp8_ffn(mode != "bf16", dgrad=dgrad)
         TE.TransformerEncoder.forward_multi, _ops.hip.gemm_nt_fp8 = counted, counted_f8
         used["multi"] = used["fp8"] = 0
         try:
@@ -1851,10 +1855,11 @@ def test_fp8_ffn_forward_in_the_lock_step_pass():
             loss.backward()
             torch.cuda.synchronize()
         finally:
-            _ops.set_fp8_ffn(old)
+            _ops.set_fp8_ffn(old, dgrad=old_dg)
             TE.TransformerEncoder.forward_multi, _ops.hip.gemm_nt_fp8 = orig_multi, orig_f8
         assert used["multi"] == (0 if mode == "fp8 one by one" else 1), (mode, used)
-        assert used["fp8"] == (0 if mode == "bf16" else 2 * 3 * 2), (mode, used)  # 2 layers x 3 modalities x (up, down)
+        # 2 layers x 3 modalities x (up, down [, dy W2, dh W01]); the first layer's FFN input gradient is needed too (adapters train)
+        assert used["fp8"] == (0 if mode == "bf16" else 2 * 3 * (4 if dgrad else 2)), (mode, used)
         res[mode] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
     assert res["fp8 lock-step"][0] == res["fp8 one by one"][0], (res["fp8 lock-step"][0], res["fp8 one by one"][0])
     assert abs(res["fp8 lock-step"][0] - res["bf16"][0]) <= 2e-2 * abs(res["bf16"][0]), (res["fp8 lock-step"][0], res["bf16"][0])

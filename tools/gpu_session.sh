@@ -11,6 +11,7 @@
 #   trace-cfg4    the same for --config 4
 #   traffic       FETCH_SIZE / WRITE_SIZE of the GEMM family over a bench run (tools/pmc_bench_traffic.sh)
 #   pmc-attn      PMC passes over the attention kernels at S = 257 / B = 128 and S = 785 / B = 64 (tools/pmc_attn.sh)
+#   fp8-ab        config 4: bf16 / fp8 forward only / fp8 forward + input gradients, alternating on one box, with loss curves
 #   contention    tools/cu_contention_ab.py;  blas   tools/blas_compare.py;  attn-bench  tools/attn_bench.py
 #   ab:<lib>      whole-step A/B (2 x 2 alternating runs) of the in-tree library against one-peace_amd/lib/<lib> (tools/build_variant.py)
 R=$GRAFT_REPO_ROOT; TAG=${1:-session}; shift
@@ -36,6 +37,13 @@ for stage in "$@"; do
     configs)
       for c in 1 2 4; do timeout 500 python bench.py --config $c --steps 8 --warmup 3 --no-cpu-baseline --no-power-probe --no-skip-leg > $O/bench_config$c.txt 2> $O/bench_config$c.err; line $O/bench_config$c.txt config$c; done
       timeout 500 python bench.py --config 4 --fp8 --steps 8 --warmup 3 --no-cpu-baseline --no-power-probe --no-skip-leg > $O/bench_config4_fp8.txt 2> $O/bench_config4_fp8.err; line $O/bench_config4_fp8.txt config4-fp8 ;;
+    fp8-ab)  # config 4 on ONE box, 20 timed steps with the loss of every step: bf16, fp8 forward only (round 5), fp8 forward + input gradients
+      for v in bf16 fp8fwd fp8 bf16 fp8fwd fp8; do
+        case $v in bf16) fl="";; fp8fwd) fl="--fp8 --fp8-forward-only";; fp8) fl="--fp8";; esac
+        n=$(ls $O | grep -c "^fp8ab_${v}_.*txt")
+        timeout 500 python bench.py --config 4 $fl --steps 20 --warmup 3 --loss-curve --no-cpu-baseline --no-power-probe --no-skip-leg > $O/fp8ab_${v}_$n.txt 2> $O/fp8ab_${v}_$n.err
+        line $O/fp8ab_${v}_$n.txt "cfg4-$v"
+      done ;;
     trace|trace-cfg4)
       extra=""; name=bench_last_step; [ $stage = trace-cfg4 ] && { extra="--config 4"; name=bench_config4_last_step; }
       ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_$TAG

@@ -154,7 +154,8 @@ int op_gemm_plan(int64_t M, int64_t N, int64_t K, int epilogue, int has_bias, in
 
 /* ---- fp8 (OCP e4m3) variant of the FFN GEMMs: BASELINE configs[4], explicit opt-in (csrc/fp8.hip) -------------------------
  * No reference counterpart (the reference trains in bf16/fp16, trainer.py:86-88); replaces, when the caller opts in, the
- * forward GEMMs of transformer_layer.py:54-67,149-157.  Per-row quantisation (x ~= q * scale[row], q = e4m3 of x * 448 / amax_row),
+ * forward GEMMs of transformer_layer.py:54-67,149-157 and (round 6) the two input-gradient GEMMs of their backward (the weight
+ * gradients stay bf16).  op_quant_fp8_rows: any cols % 8 == 0 (rows wider than 8192 columns are read twice).  Per-row quantisation (x ~= q * scale[row], q = e4m3 of x * 448 / amax_row),
  * fp32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4, dequantisation by scale_a[m] * scale_b[n] in the epilogue. */
 int op_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t cols, void* stream);
 /* Round 5 (ABI 6): op_layernorm_fwd (bf16, no GELU) / op_ln_geglu_fwd that ALSO write their output row-quantised to fp8 e4m3 -- q8

@@ -260,6 +260,33 @@ __global__ __launch_bounds__(256) void quant_fp8_rows_kernel(const bf16_t* __res
   }
 }
 
+// Rows wider than 8192 columns (round 6: the [N, 2F = 12 288] gradient of the GeGLU up-projection, an operand of the fp8 input-gradient
+// GEMM): two passes over the row, the second one re-reads it (L2-resident: 24 KiB per wavefront) instead of keeping 192 values per lane.
+__global__ __launch_bounds__(256) void quant_fp8_rows_wide_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q,
+                                                                  int64_t ldq, float* __restrict__ scale, int64_t rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * ldx;
+  float amax = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    float v[8];
+    Vec8<bf16_t>::load(xr + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+  }
+  amax = wave_max(amax);
+  const float sc = fp8_row_scale(amax);
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  uint8_t* qr = q + row * ldq;
+  for (int c = lane * 8; c < cols; c += 512) {
+    float v[8];
+    Vec8<bf16_t>::load(xr + c, v);
+    *reinterpret_cast<u32x2*>(qr + c) = fp8_pack8(v, inv);
+  }
+}
+
 // =====================================================================================================================
 // gemm256f8_kernel (round 5): the fp8 GEMM on the skeleton of the bf16 production kernel gemm256v_kernel (csrc/gemm.hip) --
 // 256 x 256 tile, four waves (one per SIMD) of 128 x 128, accumulators pinned in the 256 AGPRs by inline-asm MFMAs, five 32 KiB LDS
@@ -491,15 +518,17 @@ extern "C" {
 // x [rows, cols] bf16 (row stride ldx) -> q [rows, cols] fp8 e4m3 (row stride ldq bytes) + scale [rows] fp32 with
 // x ~= q * scale[row].  cols % 8 == 0, cols <= 8192.
 int op_quant_fp8_rows(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int64_t rows, int64_t cols, void* stream) {
-  OP_CHECK_ARG(x && q && scale && rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 8192 && ldx % 8 == 0 && ldq % 8 == 0,
-               "quant_fp8_rows: bad arguments (cols %% 8 == 0, cols <= 8192)");
+  OP_CHECK_ARG(x && q && scale && rows >= 0 && cols > 0 && cols % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0,
+               "quant_fp8_rows: bad arguments (cols, ldx, ldq %% 8 == 0)");
   if (rows == 0) return OP_OK;
   const dim3 grid((unsigned)((rows + 3) / 4));
   hipStream_t s = (hipStream_t)stream;
   if (cols <= 2048)
     hipLaunchKernelGGL(quant_fp8_rows_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale, rows, (int)cols);
-  else
+  else if (cols <= 8192)
     hipLaunchKernelGGL(quant_fp8_rows_kernel<16>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale, rows, (int)cols);
+  else
+    hipLaunchKernelGGL(quant_fp8_rows_wide_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, (uint8_t*)q, ldq, scale, rows, (int)cols);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

@@ -1441,7 +1441,7 @@ def _deq(q, s):
     return q.view(torch.float8_e4m3fn).float() * s[:, None]
 
 
-@pytest.mark.parametrize("rows,cols", [(5, 128), (130, 1536), (33, 6144), (64, 8192), (7, 264)])
+@pytest.mark.parametrize("rows,cols", [(5, 128), (130, 1536), (33, 6144), (64, 8192), (7, 264), (37, 12288), (6, 8200)])
 def test_fp8_row_quantisation(rows, cols):
     hip = hipmod()
     x = rnd(rows, cols, seed=1, scale=3.0)

@@ -69,6 +69,13 @@ def refresh_weight_cache():
     hip.transpose_batched(_refresh_plan[1], _refresh_plan[2], _refresh_plan[3])
     for k, v in live:
         _wt_cache[k] = (v[0], _wt_version(tuple(r() for r in v[0]), v[3]() if v[3] is not None else None), v[2], v[3])
+    for k, (_, qs, tref) in list(_fp8_derived_cache.items()):  # fp8 copies of the transposed weights (opt-in fp8 input-gradient GEMMs)
+        t = tref()
+        if t is None:
+            del _fp8_derived_cache[k]
+            continue
+        hip.quant_fp8_rows(t, out=qs)
+        _fp8_derived_cache[k] = (_cache_epoch, qs, tref)
 
 
 def _wt_version(ws, scale):
@@ -130,16 +137,18 @@ _fp8_derived_cache = {}
 
 def _fp8_derived(t):
     """(fp8 bytes, row scales) of a DERIVED bf16 matrix that keeps its address across optimiser steps (a cached transposed weight copy,
-    _transposed): quantised on first use after every refresh of the weight cache (epoch), in place."""
+    _transposed).  Quantised on first use; refresh_weight_cache re-quantises every entry IN PLACE right behind the transposes it rebuilds
+    (eagerly, outside any captured graph: a replayed TrainStepGraph keeps reading these addresses and must find this step's weights);
+    after invalidate_weight_cache (lazy mode) the next use re-quantises."""
     key = (t.data_ptr(), tuple(t.shape))
     hit = _fp8_derived_cache.get(key)
-    if hit is not None and hit[0] == _cache_epoch:
+    if hit is not None and hit[0] == _cache_epoch and hit[2]() is t:
         return hit[1]
     if len(_fp8_derived_cache) > 4096:
         _fp8_derived_cache.clear()
         hit = None
     qs = hip.quant_fp8_rows(t, out=hit[1] if hit is not None else None)
-    _fp8_derived_cache[key] = (_cache_epoch, qs)
+    _fp8_derived_cache[key] = (_cache_epoch, qs, weakref.ref(t))
     return qs
 
 

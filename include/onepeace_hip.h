@@ -34,6 +34,7 @@ const char* op_last_error(void);
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
  * family 0 = GEMM (work = flops), 1 = attention forward, 2 = attention backward.  HOST pointers. */
 int op_prof_enable(int on);
+int op_prof_reserve(int events); /* pre-creates events (two per profiled launch; created without the system-scope fence) */
 int op_prof_collect(double* ms, int64_t* count, double* work, int n_families);
 
 /* ---- LayerNorm (+ optional fused exact-erf GELU) ---------------------------------------------------------------

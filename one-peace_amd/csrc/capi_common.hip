@@ -26,7 +26,19 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int family; double work; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_prof_free;  // events of collected records, reused: a profiled step records ~6 000 of them
 int g_prof_on = 0;
+
+bool prof_event(hipEvent_t* e) {  // (under g_prof_mu)
+  if (!g_prof_free.empty()) {
+    *e = g_prof_free.back();
+    g_prof_free.pop_back();
+    return true;
+  }
+  // no system-scope fence at the event: the default flavour writes back / invalidates the caches at every record, which costs the
+  // FOLLOWING kernel (measured: a profiled headline step +28 ms with 1 700 default events).  Timing stays enabled.
+  return hipEventCreateWithFlags(e, hipEventDisableSystemFence) == hipSuccess;
+}
 }  // namespace
 
 extern "C" int op_prof_enable(int on) {
@@ -37,15 +49,34 @@ extern "C" int op_prof_enable(int on) {
 
 extern "C" int op_prof_active(void) { return g_prof_on; }
 
+// Pre-creates `events` events (two per profiled launch) so that the first profiled step does not pay for their creation.
+extern "C" int op_prof_reserve(int events) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  while ((int)g_prof_free.size() < events) {
+    hipEvent_t e;
+    hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
+    if (err != hipSuccess) {
+      op_set_error("op_prof_reserve: hipEventCreateWithFlags failed: %s", hipGetErrorString(err));
+      return (int)err;
+    }
+    g_prof_free.push_back(e);
+  }
+  return OP_OK;
+}
+
 // begin: records the start event, returns a slot (or -1 when profiling is off)
 extern "C" int op_prof_begin(int family, double work, void* stream) {
   if (!g_prof_on) return -1;
   ProfRec r;
   r.family = family;
   r.work = work;
-  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
-  hipEventRecord(r.a, (hipStream_t)stream);
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!prof_event(&r.a)) return -1;
+  if (!prof_event(&r.b)) {
+    g_prof_free.push_back(r.a);
+    return -1;
+  }
+  hipEventRecord(r.a, (hipStream_t)stream);
   g_prof.push_back(r);
   return (int)g_prof.size() - 1;
 }
@@ -69,8 +100,8 @@ extern "C" int op_prof_collect(double* ms, int64_t* count, double* work, int n_f
       count[r.family] += 1;
       work[r.family] += r.work;
     }
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+    g_prof_free.push_back(r.a);
+    g_prof_free.push_back(r.b);
   }
   g_prof.clear();
   return OP_OK;

@@ -28,6 +28,7 @@ SIGNATURES = {
     "op_abi_version": (c_int, []),
     "op_last_error": (ctypes.c_char_p, []),
     "op_prof_enable": (c_int, [c_int]),
+    "op_prof_reserve": (c_int, [c_int]),
     "op_prof_collect": (c_int, [P, P, P, c_int]),
     "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),

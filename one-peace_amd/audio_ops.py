@@ -73,21 +73,23 @@ class StridedConv1dFn(torch.autograd.Function):
 class Conv1LnGeluFn(torch.autograd.Function):
     """Block 0 of the feature extractor -- Conv1d(1 -> C, k = 10, stride 5) -> LayerNorm(C) -> GELU -- as ONE kernel each way, straight from
     the flat waveform (csrc/audio.hip): the 2.1 GB convolution output of the headline batch is neither written nor kept; backward
-    recomputes each row from its ten samples and accumulates the four parameter gradients in registers.  wav gets no gradient."""
+    recomputes each row from its ten samples and accumulates the four parameter gradients in registers.  wav gets no gradient.
+    Returns [rows + slack, C] with `slack` zero rows at the end (the next block's patch view reads past the last row): appending them with
+    torch.cat copied the 2.1 GB matrix of the headline batch once more (1.4 ms)."""
 
     @staticmethod
-    def forward(ctx, wav_flat, rows, stride, weight, bias, ln_w, ln_b, eps):
+    def forward(ctx, wav_flat, rows, stride, weight, bias, ln_w, ln_b, eps, slack=0):
         w0 = weight.reshape(weight.shape[0], 10).contiguous()
-        y, mean, rstd = hip.audio_conv1_ln_gelu_fwd(wav_flat, stride, w0, bias, ln_w, ln_b, rows, eps)
+        y, mean, rstd = hip.audio_conv1_ln_gelu_fwd(wav_flat, stride, w0, bias, ln_w, ln_b, rows, eps, slack_rows=slack)
         ctx.save_for_backward(wav_flat, w0, bias, ln_w, ln_b, mean, rstd)
-        ctx.stride, ctx.wshape = stride, tuple(weight.shape)
+        ctx.stride, ctx.wshape, ctx.rows = stride, tuple(weight.shape), rows
         return y
 
     @staticmethod
     def backward(ctx, dy):
         wav_flat, w0, bias, ln_w, ln_b, mean, rstd = ctx.saved_tensors
-        dw0, db0, dlw, dlb = hip.audio_conv1_ln_gelu_bwd(dy.contiguous(), wav_flat, ctx.stride, w0, bias, ln_w, ln_b, mean, rstd)
-        return None, None, None, dw0.view(ctx.wshape), db0, dlw, dlb, None
+        dw0, db0, dlw, dlb = hip.audio_conv1_ln_gelu_bwd(dy[:ctx.rows].contiguous(), wav_flat, ctx.stride, w0, bias, ln_w, ln_b, mean, rstd)
+        return None, None, None, dw0.view(ctx.wshape), db0, dlw, dlb, None, None
 
 
 FUSED_CONV1 = __import__("os").environ.get("ONEPEACE_FUSED_CONV1", "1") != "0"
@@ -115,14 +117,14 @@ def feature_extractor(src_audios, conv_blocks):
     rows = B * slots
     C0 = conv0.weight.shape[0]
     if (FUSED_CONV1 and conv0.weight.shape[2] == 10 and conv0.stride[0] == 5 and C0 <= 512 and C0 % 8 == 0 and wav.dtype == torch.bfloat16):
-        x = Conv1LnGeluFn.apply(wav, rows, 5, conv0.weight, conv0.bias, ln0.weight, ln0.bias, ln0.eps)
+        x = Conv1LnGeluFn.apply(wav, rows, 5, conv0.weight, conv0.bias, ln0.weight, ln0.bias, ln0.eps, 2)  # (+ 2 slack rows)
     else:
         with torch.no_grad():
             a0 = _first_layer_rows(wav, rows)
         w0 = F.pad(conv0.weight.reshape(conv0.weight.shape[0], 10), (0, 54))
         x = ops.linear(a0, w0, conv0.bias)
         x = ops.layer_norm(x, ln0.weight, ln0.bias, ln0.eps, gelu=True)
-    x = torch.cat([x, x.new_zeros(2, x.shape[1])], dim=0)  # slack rows
+        x = torch.cat([x, x.new_zeros(2, x.shape[1])], dim=0)  # slack rows
     valid = (valid - 10) // 5 + 1
     for block in conv_blocks[1:]:
         conv, ln = block[0], block[2][1]

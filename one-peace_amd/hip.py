@@ -458,11 +458,14 @@ def gemm_nt_batched(A, W, bias, out, rows, K):
     return out
 
 
-def audio_conv1_ln_gelu_fwd(wav, stride, w0, b0, lnw, lnb, rows, eps):
-    """GELU(LN(conv(wav))) of the feature extractor's first block straight from the flat waveform: y [rows, C], mean, rstd [rows]."""
+def audio_conv1_ln_gelu_fwd(wav, stride, w0, b0, lnw, lnb, rows, eps, slack_rows=0):
+    """GELU(LN(conv(wav))) of the feature extractor's first block straight from the flat waveform: y [rows + slack_rows, C] (the slack
+    rows zero: the next block's strided patch view reads past the last row), mean, rstd [rows]."""
     C = w0.shape[0]
     assert w0.is_contiguous() and w0.numel() == C * 10 and wav.is_contiguous() and wav.numel() >= stride * (rows - 1) + 10
-    y = torch.empty(rows, C, dtype=torch.bfloat16, device=wav.device)
+    y = torch.empty(rows + slack_rows, C, dtype=torch.bfloat16, device=wav.device)
+    if slack_rows:
+        y[rows:].zero_()
     mean = torch.empty(rows, dtype=torch.float32, device=wav.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=wav.device)
     _check(lib().op_audio_conv1_ln_gelu_fwd(ptr(wav), stride, ptr(w0), ptr(b0), ptr(lnw), ptr(lnb), ptr(y), ptr(mean), ptr(rstd), rows, C, eps,

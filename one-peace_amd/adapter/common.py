@@ -9,17 +9,92 @@ from ..relpos import RelPosSpec
 logger = logging.getLogger(__name__)
 
 
+class _PrependTokenFn(torch.autograd.Function):
+    """prepend_token with its own backward: autograd's CopySlices node of an `out[:, 1:] = body` assignment CLONES the incoming gradient
+    (two 100 MB copies per adapter call in the headline step); here the body's gradient is a view of it."""
+
+    @staticmethod
+    def forward(ctx, tok, body):
+        B, S, H = body.shape
+        out = body.new_empty(B, S + 1, H, dtype=torch.result_type(tok, body))
+        out[:, :1] = tok.expand(B, -1, -1)
+        out[:, 1:] = body
+        ctx.tok_shape, ctx.tok_dtype, ctx.body_dtype = tok.shape, tok.dtype, body.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        d_tok = g[:, :1].to(ctx.tok_dtype).sum_to_size(ctx.tok_shape) if ctx.needs_input_grad[0] else None
+        d_body = g[:, 1:].to(ctx.body_dtype) if ctx.needs_input_grad[1] else None
+        return d_tok, d_body
+
+
 def prepend_token(tok, body):
     """[tok | body] along the sequence: tok [1, 1, H] (a parameter, broadcast over the batch), body [B, S, H] -> [B, S + 1, H].
     Same values and gradients as torch.cat([tok.expand(B, -1, -1), body], dim=1) (adapter/text.py:110-113 and its siblings); two slice
     copies into one allocation instead -- the batched 2-byte copy kernel behind torch.cat moves these 100 MB matrices at 0.3-0.6 TB/s
     (0.8 ms per call in the headline step, profiles/r5_bench_last_step_final2_b128.txt).  The result has torch.cat's PROMOTED dtype
     (an fp32 cls token in front of a bf16 body under autocast gives fp32, as in the reference), not the body's."""
-    B, S, H = body.shape
-    out = body.new_empty(B, S + 1, H, dtype=torch.result_type(tok, body))
-    out[:, :1] = tok.expand(B, -1, -1)
-    out[:, 1:] = body
-    return out
+    return _PrependTokenFn.apply(tok, body)
+
+
+class PackRowsFn(torch.autograd.Function):
+    """Row matrices [n_i, H] -> one [sum n_i, H] allocation (what torch.cat(dim=0) returns; slice copies, see prepend_token); the gradients
+    are VIEWS of the incoming gradient (slice assignments under autograd clone it once per assignment)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        ctx.rows = [x.shape[0] for x in xs]
+        out = xs[0].new_empty(sum(ctx.rows), xs[0].shape[1])
+        r = 0
+        for x in xs:
+            out[r:r + x.shape[0]] = x
+            r += x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, r = [], 0
+        for i, n in enumerate(ctx.rows):
+            out.append(g[r:r + n] if ctx.needs_input_grad[i] else None)
+            r += n
+        return tuple(out)
+
+
+class SplitRowsFn(torch.autograd.Function):
+    """x [rows, H] -> the row ranges x[r0:r1] of `bounds` (views).  Backward writes the pieces' gradients into ONE buffer (autograd's
+    slice nodes build a zero-filled full-size matrix per piece and add them up: three fills, three copies and two full-size adds for
+    the three streams of the headline step)."""
+
+    @staticmethod
+    def forward(ctx, x, *bounds):
+        ctx.bounds, ctx.shape = bounds, x.shape
+        return tuple(x[r0:r1] for r0, r1 in bounds)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ref = next(g for g in gs if g is not None)
+        out = ref.new_empty(ctx.shape)
+        done = 0
+        for (r0, r1), g in zip(ctx.bounds, gs):  # (bounds ascending and disjoint: asserted by split_rows)
+            if r0 > done:
+                out[done:r0].zero_()
+            if g is None:
+                out[r0:r1].zero_()
+            else:
+                out[r0:r1] = g
+            done = r1
+        if done < ctx.shape[0]:
+            out[done:].zero_()
+        return (out,) + (None,) * len(ctx.bounds)
+
+
+def split_rows(x, bounds):
+    bounds = [tuple(b) for b in bounds]
+    assert all(a[1] <= b[0] for a, b in zip(bounds, bounds[1:])) and all(0 <= r0 <= r1 <= x.shape[0] for r0, r1 in bounds)
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return tuple(x[r0:r1] for r0, r1 in bounds)
+    return SplitRowsFn.apply(x, *bounds)
 
 
 def take_rows(t, ids):

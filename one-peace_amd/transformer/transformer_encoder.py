@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from .. import hip, ops
 from ..components import FairseqDropout, LayerNorm
+from ..adapter.common import PackRowsFn, split_rows
 from ..relpos import RelPosSpec, joint_handle
 from .transformer_layer import TransformerEncoderLayer
 
@@ -209,11 +210,7 @@ class TransformerEncoder(nn.Module):
             row0 += B * S
             samples += B
         assert all(xi.dtype == xs[0].dtype for xi in xs), "forward_multi: the streams of a lock-step pass share one dtype (bf16 on the HIP path)"
-        x2 = xs[0].new_empty(row0, xs[0].shape[1])  # (slice copies, not torch.cat: see adapter.common.prepend_token)
-        r = 0
-        for xi in xs:
-            x2[r:r + xi.shape[0]] = xi
-            r += xi.shape[0]
+        x2 = PackRowsFn.apply(*xs)  # (slice copies, not torch.cat: see adapter.common.prepend_token)
         dev = x2.device
         packable = all(getattr(h, "ids", None) is None and not isinstance(h, ops.DenseBias) for hs in per_layer for h in hs)
         if self.skip_dropped_branches and packable:
@@ -235,8 +232,9 @@ class TransformerEncoder(nn.Module):
             ps2s = [ps2[s0:s0 + B] if ps2 is not None else None for (_, B, _, _, _, s0) in segs]
             x2 = layer.forward_fused_multi(x2, lsegs, ps1_rows, ps2s, kept=plans[idx] if plans is not None else (None, None))
         out = {}
-        for (m, B, S, r0, _, _) in segs:
-            norm, rows = getattr(self, m + "_layer_norm"), x2[r0:r0 + B * S]
+        pieces = split_rows(x2, [(r0, r0 + B * S) for (_, B, S, r0, _, _) in segs])
+        for (m, B, S, _, _, _), rows in zip(segs, pieces):
+            norm = getattr(self, m + "_layer_norm")
             out[m] = (norm(rows) if norm is not None else rows).view(B, S, -1)
         return out
 

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- library ------------------------------------------------------------------------------------------------ */
-int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd; 8: the layer-scale gradient without a division -- rscale of op_gemm_tn_grouped, op_transpose_scaled + the scale member of the op_transpose_batched descriptor, op_resid_bwd leaves gamma out of dbranch when g0 is asked for, op_gamma_grad_finish lost its gamma argument; rowdot is a [N / 128][M] matrix of partial sums written once each (no atomics) */
+int op_abi_version(void); /* 2: per-call `tune` words replaced the process-wide knob setters; 3: op_gemm_nt_grouped, op_ln_geglu_fwd, ldd / ldh of op_ln_geglu_bwd, `out` of op_attn_bwd; 4: op_gemm_tn_grouped; 5: op_probe_mfma_rate, op_rows_gather / op_rows_merge, 16-byte rule of op_gemm_tn_grouped's C; 6: the op_probe_* entry points left for libonepeace_probe.so (include/onepeace_probe.h), op_gemm_nt_grouped answers OP_ENOTSUP for the GeGLU epilogue, op_gemm_tn_grouped_plan takes the workgroup count and tune word; 7: W / ldw / rowdot of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish, op_gemm_nt_batched, op_audio_conv1_ln_gelu_fwd / _bwd; 8: the layer-scale gradient without a division -- rscale of op_gemm_tn_grouped, op_transpose_scaled + the scale member of the op_transpose_batched descriptor, op_resid_bwd leaves gamma out of dbranch when g0 is asked for, op_gamma_grad_finish lost its gamma argument; rowdot is a [N / 128][M] matrix of partial sums written once each (no atomics); 9: row tables -- a residual branch that runs on the samples stochastic depth keeps reads and writes the FULL activation matrix through op_rows_map's table instead of through packed copies: x_rows of op_layernorm_fwd / op_layernorm_bwd, dout_rows of op_resid_bwd, resid_rows / resid_rows_total of op_gemm_nt and op_gemm_nt_grouped, op_rows_merge without `upd` copies the dropped samples' rows only; op_prof_reserve */
 const char* op_last_error(void);
 
 /* Live per-kernel-family timing with HIP events recorded on the launch stream (used by bench.py's `roofline`).
@@ -43,14 +43,18 @@ int op_prof_collect(double* ms, int64_t* count, double* work, int n_families);
  * per-modality final norms (transformer_encoder.py:201-220), and with act_gelu=1 the LayerNorm->GELU pairs of the
  * stems (adapter/image.py:66-75, adapter/audio.py:293-301).  x,y [rows, cols] contiguous; w,b [cols] or NULL;
  * mean,rstd fp32 [rows] (NULL = not wanted).  cols % 8 == 0, cols <= 8192. */
+/* (ABI 9) x_rows: nullable DEVICE int32 [rows] (op_rows_map): row r of the input is row x_rows[r] of a LARGER matrix x; an entry < 0
+ * stands for a row of zeros (the surplus rows of a rounded-up segment).  y / mean / rstd are indexed by r. */
 int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
-                     int64_t cols, float eps, int act_gelu, int dtype, void* stream);
+                     int64_t cols, float eps, int act_gelu, int dtype, const int* x_rows, void* stream);
 int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols);
 /* dx = LN backward (+ `add`: gradient arriving through the residual path, may be NULL, may alias dx);
  * dw, db [cols] optional (need `workspace`); accumulate != 0 adds into dw/db. */
 int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
                      const void* add, void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
-                     int act_gelu, int accumulate, int dtype, void* stream);
+                     int act_gelu, int accumulate, int dtype, const int* x_rows, void* stream);
+/* (ABI 9) x_rows as in op_layernorm_fwd: x, add AND dx are then rows x_rows[r] of larger matrices (dy, mean, rstd by r); rows with an
+ * entry < 0 are not stored.  With dx == add (in place) the rows no entry names keep `add`: the gradient of the skip connection. */
 
 /* ---- bf16 MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  with fused epilogues ---------------------------------------------
  * Replaces: q/k/v/out projections (multihead_attention.py:63-66,103-105,124; up to three weight segments of n_seg rows
@@ -71,7 +75,11 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
                const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
-               int64_t tune, void* stream);
+               int64_t tune, const int* resid_rows, int64_t resid_rows_total, void* stream);
+/* (ABI 9) resid_rows: nullable DEVICE int32 [M] (op_rows_map), residual epilogue only: `resid` and `C` are the BASES of matrices of
+ * resid_rows_total rows (each below 4 GiB), the residual is read from and the result written to row resid_rows[m]; rows with an entry
+ * < 0 are computed and dropped.  h0 (the branch output) and rowscale stay indexed by m.  The packed rows of the samples a residual
+ * branch keeps go straight back to their places (transformer_layer.py:78-88 without the products by zero). */
 /* C[M,N] (bf16) = A^T B with A [K,M] (lda), B [K,N] (ldb) row-major bf16: the weight-gradient GEMM dW = dy^T x of
  * nn.Linear (autograd of components.py:29-34 users) straight from the activation matrices (transpose-read fragments,
  * no transposed copies).  K % 64 == 0, M/N/lda/ldb % 8 == 0, else returns -95 (use op_transpose + op_gemm_nt).
@@ -88,7 +96,8 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
 int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, int64_t lda, const void* const* B, int64_t ldb,
                        const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
                        const void* const* resid, int64_t ldr, const void* const* gamma, const float* const* rowscale,
-                       const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream);
+                       const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, const int* const* resid_rows,
+                       int64_t resid_rows_total, void* stream); /* resid_rows: nullable HOST array of nprob DEVICE tables, see op_gemm_nt */
 /* (ABI 7) `batch` equally shaped products  C_z[M,N] = A_z[M,K] W_z[N,K]^T (+ bias_z[N])  with operands at constant element strides as ONE
  * launch (blockIdx.z = z; 128 x 128 tiles, no split-K): the per-group GEMMs of the audio adapter's grouped positional Conv1d over
  * strided patch views (one_peace/models/adapter/audio.py:57-84; each group alone fills half the chip).  bias nullable. */
@@ -263,7 +272,7 @@ int op_colsum_segments(const void* x, void* out0, void* out1, void* out2, void* 
 int64_t op_resid_bwd_workspace_bytes(int64_t N);
 int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                  void* dbranch, void* dgamma, void* dbias, float* g0, void* workspace, int64_t M, int64_t N, int accumulate,
-                 void* stream);
+                 const int* dout_rows, void* stream); /* (ABI 9) dout_rows: nullable DEVICE int32 [M]: row m of dout is row dout_rows[m] of a larger matrix (< 0: zeros); y / dbranch by m */
 /* (ABI 7; 8: no gamma argument, no division, partial slots instead of atomics) Layer-scale gradient of a residual branch
  * out = resid + rowscale * gamma * (x W^T + b)  WITHOUT the branch output:
  *   dgamma[n] (+)= sum_{s < slots} rowdot[s][n] + sum_i b_i[n] * g0_i[n]
@@ -343,6 +352,12 @@ int op_rows_gather(const void* src, void* dst, const int* list, int64_t nseg, co
 int op_rows_merge(const void* base, const void* upd, void* out, const int* list, int64_t nseg, const int64_t* src_row0,
                   const int64_t* dst_row0, const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples,
                   const int64_t* list_off, int64_t total, int64_t cols, void* stream);
+/* (ABI 9) op_rows_merge with upd == NULL (out != base): only the rows of the DROPPED samples are copied base -> out (the kept rows were
+ * written through a row table).  op_rows_map: map[r] (DEVICE int32 [dst_total]) = the row of the full matrix that packed row r stands
+ * for -- what op_rows_gather would read -- or -1 for the surplus rows; `list` = the kept lists as for op_rows_gather. */
+int op_rows_map(int* map, const int* list, int64_t nseg, const int64_t* src_row0, const int64_t* dst_row0, const int64_t* S,
+                const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples, const int64_t* list_off, int64_t dst_total,
+                void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ extern "C" void op_set_error(const char* fmt, ...) {
 
 extern "C" const char* op_last_error(void) { return g_err; }
 
-extern "C" int op_abi_version(void) { return 8; }
+extern "C" int op_abi_version(void) { return 9; }
 
 // ---- live per-kernel-family timing with HIP events on the launch stream ---------------------------
 // bench.py enables this around its timed region; gemm launches then record an event pair on the

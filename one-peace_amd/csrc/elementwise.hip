@@ -176,7 +176,8 @@ __global__ __launch_bounds__(256) void gamma_grad_finish_kernel(const float* __r
 __global__ __launch_bounds__(256) void resid_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ y,
                                                         const bf16_t* __restrict__ gamma, const float* __restrict__ rowscale,
                                                         int rps, bf16_t* __restrict__ dbranch, float* __restrict__ part,
-                                                        int64_t M, int N) {
+                                                        int64_t M, int N, const int* __restrict__ rows) {
+  // rows (nullable, ABI 9): row m of dout is row rows[m] of a LARGER matrix (< 0: no row -- reads as zeros); dbranch / y stay packed
   __shared__ float red[4][512];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int c = blockIdx.x * 512 + lane * 8;
@@ -185,13 +186,26 @@ __global__ __launch_bounds__(256) void resid_bwd_kernel(const bf16_t* __restrict
   if (c < N) {
     if (gamma) Vec8<bf16_t>::load(gamma + c, gv);
     const int64_t step = (int64_t)gridDim.y * 4;
-    for (int64_t m = (int64_t)blockIdx.y * 4 + wid; m < M; m += 2 * step) {
+    const int64_t mfirst = (int64_t)blockIdx.y * 4 + wid;
+    // (table entries of the NEXT trip are requested before this trip's rows are used: in one trip, entry -> row is an L2 latency per trip)
+    int64_t e0 = (rows && mfirst < M) ? rows[mfirst] : mfirst, e1 = (rows && mfirst + step < M) ? rows[mfirst + step] : mfirst + step;
+    for (int64_t m = mfirst; m < M; m += 2 * step) {
       const int64_t m2 = m + step;
       const bool two = m2 < M;
-      bf16x8 d0 = Vec8<bf16_t>::ldraw(dout + m * N + c), d1, y0, y1;
+      const int64_t s0 = e0, s1 = two ? e1 : -1;
+      const int64_t mn = m + 2 * step;
+      if (rows) {
+        if (mn < M) e0 = rows[mn];
+        if (mn + step < M) e1 = rows[mn + step];
+      } else {
+        e0 = mn;
+        e1 = mn + step;
+      }
+      const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+      bf16x8 d0 = s0 >= 0 ? Vec8<bf16_t>::ldraw(dout + s0 * N + c) : zero8, d1, y0, y1;
       if (y) y0 = Vec8<bf16_t>::ldraw(y + m * N + c);
       if (two) {
-        d1 = Vec8<bf16_t>::ldraw(dout + m2 * N + c);
+        d1 = s1 >= 0 ? Vec8<bf16_t>::ldraw(dout + s1 * N + c) : zero8;
         if (y) y1 = Vec8<bf16_t>::ldraw(y + m2 * N + c);
       }
 #pragma unroll
@@ -668,10 +682,28 @@ __global__ __launch_bounds__(256) void rows_merge_kernel(const bf16_t* __restric
       }
     }
     if (from < 0 && out == base) continue;  // in place: rows of dropped samples stay what they are
+    if (from >= 0 && upd == nullptr) continue;  // (ABI 9) no packed matrix: only the rows of dropped samples are copied
     const bf16x8* in = reinterpret_cast<const bf16x8*>(from >= 0 ? upd + from * cols : base + r * cols);
     bf16x8* o = reinterpret_cast<bf16x8*>(out + r * cols);
     for (int c = lane; c < n8; c += 64) o[c] = in[c];
   }
+}
+
+// packed row -> row of the full matrix (-1: a surplus row of a rounded-up segment): what op_rows_gather reads, as a table for the kernels
+// that read / write THROUGH it (ABI 9: op_layernorm_*, op_resid_bwd, the residual epilogue of op_gemm_nt)
+__global__ __launch_bounds__(256) void rows_map_kernel(int* __restrict__ map, const int* __restrict__ list, const RowsSegs d, int64_t dst_total) {
+  const int64_t rc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (rc >= dst_total) return;
+  int64_t from = -1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < d.nseg && rc >= d.seg[i].dst_row0 && rc < d.seg[i].dst_row0 + d.seg[i].dst_rows) {
+      const int local = (int)(rc - d.seg[i].dst_row0);
+      const int j = local / d.seg[i].S;
+      if (j < d.seg[i].n_kept) from = d.seg[i].src_row0 + (int64_t)list[d.seg[i].list_off + j] * d.seg[i].S + (local - j * d.seg[i].S);
+    }
+  }
+  map[rc] = (int)from;
 }
 
 }  // namespace
@@ -738,7 +770,7 @@ int64_t op_resid_bwd_workspace_bytes(int64_t N) { return 2 * (int64_t)CS_MAX_PAR
 // gamma, rowscale, y/dgamma, dbias nullable; dgamma/dbias are bf16 [N]; accumulate: add into them instead of overwriting.
 int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                  void* dbranch, void* dgamma, void* dbias, float* g0, void* workspace, int64_t M, int64_t N, int accumulate,
-                 void* stream) {
+                 const int* dout_rows, void* stream) {
   OP_CHECK_ARG(dout && dbranch, "resid_bwd: null pointer");
   OP_CHECK_ARG(N > 0 && N % 8 == 0, "resid_bwd: N must be a multiple of 8");
   OP_CHECK_ARG(!dgamma || y, "resid_bwd: dgamma needs y");
@@ -757,7 +789,7 @@ int op_resid_bwd(const void* dout, const void* y, const void* gamma, const float
   // input-gradient GEMMs carry it: op_gemm_tn_grouped's rscale, op_transpose_scaled), dbias still gets it in the fold
   hipLaunchKernelGGL(resid_bwd_kernel, dim3(ceil_div(N, 512), parts), dim3(256), 0, s, (const bf16_t*)dout,
                      (const bf16_t*)(dgamma ? y : nullptr), (const bf16_t*)(g0 ? nullptr : gamma), rowscale,
-                     (int)(rows_per_sample > 0 ? rows_per_sample : 1), (bf16_t*)dbranch, ws, M, (int)N);
+                     (int)(rows_per_sample > 0 ? rows_per_sample : 1), (bf16_t*)dbranch, ws, M, (int)N, dout_rows);
   OP_LAUNCH_CHECK();
   if (ws) {
     // job 0: dgamma from sum rs*dout*y; job 1: dbias = gamma * sum rs*dout; job 2 (g0): the same partials without gamma, fp32
@@ -1009,13 +1041,27 @@ int op_rows_merge(const void* base, const void* upd, void* out, const int* list,
                   const int64_t* dst_row0, const int64_t* S, const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples,
                   const int64_t* list_off, int64_t total, int64_t cols, void* stream) {
   RowsSegs d;
-  OP_CHECK_ARG(base && upd && out && list && cols > 0 && cols % 8 == 0, "rows_merge: bad argument");
+  OP_CHECK_ARG(base && out && list && cols > 0 && cols % 8 == 0, "rows_merge: bad argument");
+  OP_CHECK_ARG(upd || out != base, "rows_merge: without upd (copy of the dropped samples' rows) out must not be base");
   OP_CHECK_ARG(rows_segs(d, nseg, src_row0, dst_row0, S, n_kept, dst_rows, n_samples, list_off), "rows_merge: bad segment table");
   if (total == 0) return OP_OK;
   int64_t nb = (total + 3) / 4;
   if (nb > 8192) nb = 8192;
   hipLaunchKernelGGL(rows_merge_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)base, (const bf16_t*)upd,
                      (bf16_t*)out, list, d, total, (int)cols);
+  OP_LAUNCH_CHECK();
+  return OP_OK;
+}
+
+// (ABI 9) map[r] = the row of the full matrix packed row r stands for (op_rows_gather's source row), -1 for the surplus rows.
+int op_rows_map(int* map, const int* list, int64_t nseg, const int64_t* src_row0, const int64_t* dst_row0, const int64_t* S,
+                const int64_t* n_kept, const int64_t* dst_rows, const int64_t* n_samples, const int64_t* list_off, int64_t dst_total,
+                void* stream) {
+  RowsSegs d;
+  OP_CHECK_ARG(map && list, "rows_map: null pointer");
+  OP_CHECK_ARG(rows_segs(d, nseg, src_row0, dst_row0, S, n_kept, dst_rows, n_samples, list_off), "rows_map: bad segment table");
+  if (dst_total == 0) return OP_OK;
+  hipLaunchKernelGGL(rows_map_kernel, dim3((int)((dst_total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, map, list, d, dst_total);
   OP_LAUNCH_CHECK();
   return OP_OK;
 }

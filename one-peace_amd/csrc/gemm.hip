@@ -119,8 +119,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
   const bool second = nc0 + 8 < p.N;
   float alpha = 1.f;
   if (EPI == EPI_F32 && p.alpha) alpha = *p.alpha;
+  constexpr bool RES = epi_is_resid(EPI), ROWS = EPI == EPI_RESID_ROWS;
   float gv[16];
-  if (EPI == EPI_RESID) {
+  if (RES) {
     if (p.gamma) {
       float tmp[8];
       Vec8<bf16_t>::load(p.gamma + nc0, tmp);
@@ -138,13 +139,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
   }
   // residual epilogue: ALL residual rows (and row scales) of the MI fragments are requested first -- one load -> wait -> store
   // chain per fragment left eight HBM latencies in a row per wave, which the four waves of the one-wave-per-SIMD kernels cannot hide
-  typename Vec8<bf16_t>::raw_t rraw[(EPI == EPI_RESID) ? MI : 1][2];
-  float rsv[(EPI == EPI_RESID) ? MI : 1];
-  if (EPI == EPI_RESID) {
+  typename Vec8<bf16_t>::raw_t rraw[RES ? MI : 1][2];
+  float rsv[RES ? MI : 1];
+  if (RES) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       const int mc = min(mrow0 + mi * 16 + t, p.M - 1);
-      const bf16_t* rp = p.resid + (int64_t)mc * p.ldr + nc0;
+      // EPI_RESID_ROWS: the row of resid / C behind the lane's row (see gemm_epilogue_v.h); read again at the store (a cached load
+      // instead of MI live registers: the eight-wave kernels have none to spare)
+      const bf16_t* rp = p.resid + (int64_t)(ROWS ? max(p.rows[mc], 0) : mc) * p.ldr + nc0;
       rraw[mi][0] = Vec8<bf16_t>::ldraw(rp);
       rraw[mi][1] = Vec8<bf16_t>::ldraw(second ? rp + 8 : rp);
       rsv[mi] = p.rowscale ? p.rowscale[(mc + p.m_off) / p.rows_per_sample] : 1.f;
@@ -165,7 +168,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
     } else if (EPI == EPI_F32) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) o[j] = alpha * o[j] + bv[j];
-    } else if (EPI == EPI_RESID) {
+    } else if (RES) {
       const float rs = rsv[mi];
       float rv[16];
       float tmp[8];
@@ -195,7 +198,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, void* Cout, f32
         *reinterpret_cast<f32x4*>(C + q * 4) = (f32x4){o[q * 4], o[q * 4 + 1], o[q * 4 + 2], o[q * 4 + 3]};
       }
     } else {
-      bf16_t* C = (bf16_t*)Cout + (int64_t)m * p.ldc + nc0;
+      const int mo = ROWS ? p.rows[m] : m;
+      if (ROWS && mo < 0) continue;  // a row without a place in the full matrix
+      bf16_t* C = (bf16_t*)Cout + (int64_t)mo * p.ldc + nc0;
       float lo[8], hi[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { lo[j] = o[j]; hi[j] = o[8 + j]; }
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   const int wm = wid >> 1, wn = wid & 1;
   const int g = lane >> 4, t = lane & 15;
   constexpr int BN_OUT = (EPI == EPI_GEGLU) ? 128 : 256;
-  constexpr bool VMAP = EPI == EPI_BIAS || EPI == EPI_RESID;  // ends in epilogue_v: its operand order and column map
+  constexpr bool VMAP = EPI == EPI_BIAS || epi_is_resid(EPI);  // ends in epilogue_v: its operand order and column map
 
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
   const int GM = p.gm;
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(256) void gemm256v_kernel(const GemmArgs p) {
   // the empty fetches and the unused fragment reads of the last tile must be gone before the registers / the LDS get their next owner
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   TL_MARK(4);
-  if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+  if constexpr (EPI == EPI_BIAS || epi_is_resid(EPI)) {
     epilogue_v<EPI>(p, acc, m0 + wm * 128, n0 + wn * 128, g, t);
   } else {
     gemm_epilogue<EPI, 8>(p, p.C, acc[0], m0 + wm * 128, n0 + wn * 128, n0 + (wn * 2) * 32, g, t);
@@ -1033,6 +1038,7 @@ struct GroupArgs {
   const bf16_t* bias[3][3];
   void* C[3]; bf16_t* H0[3]; bf16_t* H1[3];
   const bf16_t* resid[3]; const bf16_t* gamma[3]; const float* rowscale[3]; int rows_per_sample[3];
+  const int* rows[3];  // EPI_RESID_ROWS (see gemm_epilogue_v.h)
   int64_t lda, ldb, ldc, ldr;
   const float* alpha;
   int n_seg, N, K, tiles_m, tiles_n, gm;
@@ -1045,7 +1051,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SCHED = 3;
-  static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "gemm256p_kernel: plain / bias and residual epilogues (epilogue_v)");
+  static_assert(EPI == EPI_BIAS || epi_is_resid(EPI), "gemm256p_kernel: plain / bias and residual epilogues (epilogue_v)");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -1206,7 +1212,7 @@ __global__ __launch_bounds__(256) void gemm256p_kernel(const GroupArgs p) {
       q.M = sel3(p.M, cur.prob); q.N = p.N; q.K = p.K; q.n_seg = p.n_seg; q.ldc = p.ldc; q.ldr = p.ldr; q.m_off = 0;
       q.C = sel3(p.C, cur.prob); q.H0 = sel3(p.H0, cur.prob); q.H1 = sel3(p.H1, cur.prob);
       q.resid = sel3(p.resid, cur.prob); q.gamma = sel3(p.gamma, cur.prob); q.rowscale = sel3(p.rowscale, cur.prob);
-      q.rows_per_sample = sel3(p.rows_per_sample, cur.prob); q.alpha = p.alpha;
+      q.rows_per_sample = sel3(p.rows_per_sample, cur.prob); q.alpha = p.alpha; q.rows = sel3(p.rows, cur.prob);
       q.bias[0] = q.bias[1] = q.bias[2] = nullptr;  // (unused: the tile's bias vector travels as an argument, see gemm_epilogue)
       // the tile lies in ONE weight segment (n_seg is a multiple of the tile width, checked at launch): kernel-argument table look-up
       const int segt = cur.n0 / p.n_seg;
@@ -2090,6 +2096,7 @@ int launch256p(const GroupArgs& ga, hipStream_t s, bool persistent = true) {
 static int launch256p_any(const GroupArgs& ga, int epi, hipStream_t s, bool persistent) {
   if (epi == EPI_BIAS) return launch256p<EPI_BIAS>(ga, s, persistent);
   if (epi == EPI_RESID) return launch256p<EPI_RESID>(ga, s, persistent);
+  if (epi == EPI_RESID_ROWS) return launch256p<EPI_RESID_ROWS>(ga, s, persistent);
   return OP_ENOTSUP;
 }
 
@@ -2104,7 +2111,7 @@ static GroupArgs group_of(const GemmArgs& a, int epi) {
   ga.mt_end[0] = ga.mt_end[1] = ga.mt_end[2] = ga.tiles_m;
   for (int i = 0; i < 3; ++i) { ga.B[0][i] = a.B[i]; ga.bias[0][i] = a.bias[i]; }
   ga.C[0] = a.C; ga.H0[0] = a.H0; ga.H1[0] = a.H1; ga.resid[0] = a.resid; ga.gamma[0] = a.gamma; ga.rowscale[0] = a.rowscale;
-  ga.rows_per_sample[0] = a.rows_per_sample;
+  ga.rows_per_sample[0] = a.rows_per_sample; ga.rows[0] = a.rows;
   ga.lda = a.lda; ga.ldb = a.ldb; ga.ldc = a.ldc; ga.ldr = a.ldr; ga.alpha = a.alpha;
   ga.n_seg = a.n_seg; ga.N = a.N; ga.K = a.K; ga.gm = a.gm;
   return ga;
@@ -2114,7 +2121,7 @@ template <int EPI>
 int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 1) {
   const dim3 grid(a.tiles_m * a.tiles_n, splits);
   const size_t sh = STAGES2 * STAGE2_BYTES;
-  OP_ENSURE_LDS((gemm256_kernel<EPI>), (int)sh, "gemm256");
+  if constexpr (EPI != EPI_RESID_ROWS) OP_ENSURE_LDS((gemm256_kernel<EPI>), (int)sh, "gemm256");
   const bool fills = (int64_t)a.tiles_m * a.tiles_n >= 256 && splits == 1;
   // four-wave flavour (one wave per SIMD, 128 x 128 per wave): +9 ... +14 % at K = 6144, +1 ... +5 % at K = 1536 (bias and
   // residual epilogues); the GeGLU launch (VALU-heavy epilogue on half as many waves) is 2 % slower and stays on eight waves;
@@ -2127,13 +2134,17 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
     // the tile walk at ScratchSize 0 it is ahead where tiles are short (K = 1536: q|k|v -1.7 %, FFN up-projection -1 ... -2 %, input
     // gradients of out-proj / down-projection -1.7 ... -3.6 %), level or behind at K >= 4608 (profiles/r5_blas_compare_sched6_ab.txt);
     // whole step 700.3 -> 695.2 ms with every four-wave launch persistent (profiles/r5_bench_sched6_samebox_*.json).
-    const bool short_k = (EPI == EPI_BIAS || EPI == EPI_RESID) && a.m_off == 0 && a.K <= 2048;
+    const bool short_k = (EPI == EPI_BIAS || epi_is_resid(EPI)) && a.m_off == 0 && a.K <= 2048;
     const int sched = T.sched == 0 ? (short_k ? 6 : V_SCHED_DEFAULT) : T.sched;
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_RESID) {
+    if constexpr (EPI == EPI_BIAS || epi_is_resid(EPI)) {
       if (sched == 6 && a.m_off == 0) return launch256p<EPI>(group_of(a, EPI), s, true);
     }
     return launch256v<EPI, 3>(a, s, grid, sh5);
   }
+  if constexpr (EPI == EPI_RESID_ROWS) {  // (gemm_nt_impl sends these launches to the 128 x 128 kernel: see four_wave_256)
+    op_set_error("gemm_nt: the row-table residual epilogue has no eight-wave 256 x 256 kernel");
+    return OP_ENOTSUP;
+  } else {
   // T.fullline: 0 BK = 32, 1 full-line always, 2 (default) full-line when the launch fills every CU at least once
   if ((T.fullline == 1 || (T.fullline == 2 && fills)) &&
       a.N % ((EPI == EPI_GEGLU) ? 128 : 256) == 0 && a.K % 64 == 0) {
@@ -2145,6 +2156,14 @@ int launch256(const GemmArgs& a, hipStream_t s, const GemmTune& T, int splits = 
   }
   OP_LAUNCH_CHECK();
   return OP_OK;
+  }
+}
+
+// does launch256 take a four-wave kernel (gemm256v / gemm256p) for this launch?  (the row-table residual epilogue exists in those and in
+// the 128 x 128 kernel only: the eight-wave 256 x 256 kernels have no registers left for it)
+static bool four_wave_256(int64_t M, int64_t N, int64_t K, int splits, const GemmTune& T) {
+  const bool fills = (int64_t)ceil_div(M, 256) * ceil_div(N, 256) >= 256 && splits == 1;
+  return (T.fullline == 3 || (T.fullline == 2 && fills)) && splits == 1 && N % 256 == 0 && K % 64 == 0 && K >= 128;
 }
 
 template <int EPI>
@@ -2202,6 +2221,7 @@ struct FoldArgs {
   int resid_epi;  // 0: out = acc + bias; 1: out = resid + rowscale * gamma * (acc + bias), h0 (optional) = acc + bias
   const bf16_t* resid; int64_t ldr; const bf16_t* gamma; const float* rowscale; int rows_per_sample, m_off;
   bf16_t* h0;
+  const int* rows;  // nullable (resid_epi only): resid / out are rows rows[m] of larger matrices, < 0 = no place (see EPI_RESID_ROWS)
 };
 __global__ __launch_bounds__(256) void splitk_fold_epilogue_kernel(const FoldArgs p) {
   const int n8 = p.N / 8;
@@ -2224,10 +2244,15 @@ __global__ __launch_bounds__(256) void splitk_fold_epilogue_kernel(const FoldArg
 #pragma unroll
       for (int j = 0; j < 8; ++j) a[j] += b[j];
     }
+    int64_t mo = m;
     if (p.resid_epi) {
       if (p.h0) Vec8<bf16_t>::store(p.h0 + m * p.ldc + c, a);
+      if (p.rows) {
+        mo = p.rows[m];
+        if (mo < 0) continue;
+      }
       float r[8], gv[8];
-      Vec8<bf16_t>::load(p.resid + m * p.ldr + c, r);
+      Vec8<bf16_t>::load(p.resid + mo * p.ldr + c, r);
       const float rs = p.rowscale ? p.rowscale[(m + p.m_off) / p.rows_per_sample] : 1.f;
       if (p.gamma) {
         Vec8<bf16_t>::load(p.gamma + c, gv);
@@ -2238,7 +2263,7 @@ __global__ __launch_bounds__(256) void splitk_fold_epilogue_kernel(const FoldArg
         for (int j = 0; j < 8; ++j) a[j] = r[j] + rs * a[j];
       }
     }
-    Vec8<bf16_t>::store(p.out + m * p.ldc + c, a);
+    Vec8<bf16_t>::store(p.out + mo * p.ldc + c, a);
   }
 }
 
@@ -2349,8 +2374,15 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
                         const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                         const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                         const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace,
-                        int64_t workspace_bytes, void* stream, int64_t m_off, bool allow_tail_split, const GemmTune& T) {
+                        int64_t workspace_bytes, void* stream, int64_t m_off, bool allow_tail_split, const GemmTune& T,
+                        const int* rows = nullptr, int64_t rows_total = 0) {
   OP_CHECK_ARG(A && B0 && C, "gemm_nt: null A/B/C");
+  if (rows) {  // (ABI 9) residual epilogue through a row table: resid / C are the bases of matrices of rows_total rows
+    OP_CHECK_ARG(epilogue == EPI_RESID, "gemm_nt: resid_rows goes with the residual epilogue");
+    OP_CHECK_ARG(rows_total > 0 && N % 8 == 0 && ldc % 8 == 0 && ldr % 8 == 0 &&
+                 (rows_total * (ldc > ldr ? ldc : ldr) + N) * 2 < (int64_t)0xfff00000ll,
+                 "gemm_nt: resid_rows: the full matrices must lie below 4 GiB (rows_total=%lld)", (long long)rows_total);
+  }
   OP_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_nt: bad sizes M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   OP_CHECK_ARG(K % BK == 0, "gemm_nt: K=%lld must be a multiple of %d (pad on the host)", (long long)K, BK);  // => even number of 32-deep stages
   OP_CHECK_ARG(N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: N, lda, ldb must be multiples of 8");
@@ -2364,7 +2396,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   a.resid = (const bf16_t*)resid; a.ldr = ldr; a.gamma = (const bf16_t*)gamma; a.rowscale = rowscale;
   a.rows_per_sample = rows_per_sample > 0 ? (int)rows_per_sample : 1;
   a.alpha = alpha;
-  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.m_off = (int)m_off;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.m_off = (int)m_off; a.rows = rows;
   a.n_seg = (int)(n_seg > 0 ? n_seg : N);
   a.tiles_m = ceil_div(M, BM);
   if (epilogue == EPI_GEGLU) {
@@ -2393,17 +2425,21 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
     const int64_t m_main = dec.m_main, m_rem = M - dec.m_main;
     const int64_t esz = epilogue == EPI_F32 ? 4 : 2;
     int rc = gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
-                          rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false, T);
+                          rows_per_sample, alpha, m_main, N, K, epilogue, workspace, workspace_bytes, stream, m_off, false, T, rows,
+                          rows_total);
     if (rc != OP_OK) return rc;
+    // (with a row table C / resid stay the bases of the full matrices: the table moves on instead)
     return gemm_nt_impl((const bf16_t*)A + m_main * lda, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2,
-                        (char*)C + m_main * ldc * esz, ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
-                        h1 ? (bf16_t*)h1 + m_main * ldc : nullptr, resid ? (const bf16_t*)resid + m_main * ldr : nullptr, ldr,
+                        rows ? C : (void*)((char*)C + m_main * ldc * esz), ldc, h0 ? (bf16_t*)h0 + m_main * ldc : nullptr,
+                        h1 ? (bf16_t*)h1 + m_main * ldc : nullptr,
+                        (resid && !rows) ? (const void*)((const bf16_t*)resid + m_main * ldr) : resid, ldr,
                         gamma, rowscale, rows_per_sample, alpha, m_rem, N, K, epilogue, workspace, workspace_bytes, stream,
-                        m_off + m_main, false, T);  // (the small launch may split K: 12 tiles alone are latency-bound)
+                        m_off + m_main, false, T, rows ? rows + m_main : nullptr,
+                        rows_total);  // (the small launch may split K: 12 tiles alone are latency-bound)
   }
   a.kt_per_split = plan.kt_per_split;
   a.slab = (int64_t)M * N;
-  int epi = epilogue;
+  int epi = (epilogue == EPI_RESID && rows) ? (int)EPI_RESID_ROWS : epilogue;
   void* c_final = C;
   const int64_t ldc_final = ldc;
   FoldArgs fold;
@@ -2412,7 +2448,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
     fold.out = (bf16_t*)C; fold.ldc = ldc; fold.M = (int)M; fold.N = (int)N;
     fold.bias[0] = a.bias[0]; fold.bias[1] = a.bias[1]; fold.bias[2] = a.bias[2]; fold.n_seg = a.n_seg;
     fold.resid_epi = epilogue == EPI_RESID; fold.resid = a.resid; fold.ldr = a.ldr; fold.gamma = a.gamma;
-    fold.rowscale = a.rowscale; fold.rows_per_sample = a.rows_per_sample; fold.m_off = a.m_off; fold.h0 = a.H0;
+    fold.rowscale = a.rowscale; fold.rows_per_sample = a.rows_per_sample; fold.m_off = a.m_off; fold.h0 = a.H0; fold.rows = rows;
     a.C = workspace;
     a.ldc = N;
     a.alpha = nullptr;
@@ -2422,7 +2458,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
   }
   const int slot = op_prof_begin(0, flops, stream);
   int rc;
-  if (plan.tile == 256) {
+  if (plan.tile == 256 && !(epi == EPI_RESID_ROWS && !four_wave_256(M, N, K, plan.splits, T))) {
     a.tiles_m = ceil_div(M, 256);
     a.tiles_n = ceil_div(N, epilogue == EPI_GEGLU ? 128 : 256);
     // L2 tile-group depth (tools/gemm_gm.py): few column tiles (N = 1536) -> walk all N-tiles of ONE M-tile together
@@ -2432,6 +2468,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
       case EPI_BIAS: rc = launch256<EPI_BIAS>(a, s, T, plan.splits); break;
       case EPI_F32: rc = launch256<EPI_F32>(a, s, T, plan.splits); break;
       case EPI_GEGLU: rc = launch256<EPI_GEGLU>(a, s, T, plan.splits); break;
+      case EPI_RESID_ROWS: rc = launch256<EPI_RESID_ROWS>(a, s, T, plan.splits); break;
       default: rc = launch256<EPI_RESID>(a, s, T, plan.splits); break;
     }
   } else {
@@ -2439,6 +2476,7 @@ static int gemm_nt_impl(const void* A, int64_t lda, const void* B0, const void* 
       case EPI_BIAS: rc = launch<EPI_BIAS>(a, T.glds, s, plan.splits); break;
       case EPI_F32: rc = launch<EPI_F32>(a, T.glds, s, plan.splits); break;
       case EPI_GEGLU: rc = launch<EPI_GEGLU>(a, T.glds, s, plan.splits); break;
+      case EPI_RESID_ROWS: rc = launch<EPI_RESID_ROWS>(a, T.glds, s, plan.splits); break;
       default: rc = launch<EPI_RESID>(a, T.glds, s, plan.splits); break;
     }
   }
@@ -2509,9 +2547,10 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
                const void* bias0, const void* bias1, const void* bias2, void* C, int64_t ldc, void* h0, void* h1,
                const void* resid, int64_t ldr, const void* gamma, const float* rowscale, int64_t rows_per_sample,
                const float* alpha, int64_t M, int64_t N, int64_t K, int epilogue, void* workspace, int64_t workspace_bytes,
-               int64_t tune, void* stream) {
+               int64_t tune, const int* resid_rows, int64_t resid_rows_total, void* stream) {
   return gemm_nt_impl(A, lda, B0, B1, B2, ldb, n_seg, bias0, bias1, bias2, C, ldc, h0, h1, resid, ldr, gamma, rowscale,
-                      rows_per_sample, alpha, M, N, K, epilogue, workspace, workspace_bytes, stream, 0, true, decode_tune(tune));
+                      rows_per_sample, alpha, M, N, K, epilogue, workspace, workspace_bytes, stream, 0, true, decode_tune(tune), resid_rows,
+                      resid_rows_total);
 }
 
 
@@ -2525,8 +2564,15 @@ int op_gemm_nt(const void* A, int64_t lda, const void* B0, const void* B1, const
 int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, int64_t lda, const void* const* B, int64_t ldb,
                        const void* const* bias, void* const* C, int64_t ldc, void* const* h0, void* const* h1,
                        const void* const* resid, int64_t ldr, const void* const* gamma, const float* const* rowscale,
-                       const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, void* stream) {
+                       const int64_t* rows_per_sample, int64_t N, int64_t K, int epilogue, int64_t tune, const int* const* resid_rows,
+                       int64_t resid_rows_total, void* stream) {
   const GemmTune T = decode_tune(tune);
+  if (resid_rows) {  // (ABI 9) see op_gemm_nt: all problems or none, one row count for all the full matrices
+    OP_CHECK_ARG(epilogue == EPI_RESID && resid_rows_total > 0 && ldr % 8 == 0 &&
+                 (resid_rows_total * (ldc > ldr ? ldc : ldr) + N) * 2 < (int64_t)0xfff00000ll,
+                 "gemm_nt_grouped: resid_rows: residual epilogue, full matrices below 4 GiB");
+    for (int i = 0; i < nprob && i < 3; ++i) OP_CHECK_ARG(resid_rows[i], "gemm_nt_grouped: resid_rows[%d] is null", i);
+  }
   OP_CHECK_ARG(nprob >= 1 && nprob <= 3 && A && M && B && C, "gemm_nt_grouped: 1..3 problems, non-null A / M / B / C arrays");
   OP_CHECK_ARG(epilogue == EPI_BIAS || epilogue == EPI_GEGLU || epilogue == EPI_RESID, "gemm_nt_grouped: epilogue %d", epilogue);
   if (epilogue == EPI_GEGLU) {  // round 5: the persistent kernel serves the two epilogues the step groups (plain / bias, residual); a
@@ -2560,6 +2606,7 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
       ga.gamma[i] = gamma ? (const bf16_t*)gamma[i] : nullptr;
       ga.rowscale[i] = rowscale ? rowscale[i] : nullptr;
       ga.rows_per_sample[i] = rows_per_sample && rows_per_sample[i] > 0 ? (int)rows_per_sample[i] : 1;
+      ga.rows[i] = resid_rows ? resid_rows[i] : nullptr;
       tiles += ceil_div(M[i], 256);
       rows += (double)M[i];
     } else {
@@ -2577,7 +2624,7 @@ int op_gemm_nt_grouped(int64_t nprob, const void* const* A, const int64_t* M, in
   // for one tile per workgroup (tune sched = 7; tests, A/B): with the round-3 epilogue (coalesced non-temporal stores: a short
   // drain in front of the next tile's loads) the persistent form is 2.2 % faster on both grouped launches of the step
   // (tools/gemm_grouped_bench.py: down-projection + residual 1.0856 -> 1.0619 ms, K = 6144 dgrad 1.0055 -> 0.9825 ms)
-  const int rc = launch256p_any(ga, epilogue, (hipStream_t)stream, T.sched != 7);
+  const int rc = launch256p_any(ga, resid_rows ? (int)EPI_RESID_ROWS : epilogue, (hipStream_t)stream, T.sched != 7);
   op_prof_end(slot, stream);
   return rc;
 }
@@ -2603,7 +2650,7 @@ int op_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, 
   a.B[0] = (const bf16_t*)B; a.B[1] = a.B[2] = nullptr; a.ldb = ldb; a.n_seg = (int)N;
   a.bias[0] = a.bias[1] = a.bias[2] = nullptr;
   a.C = C; a.ldc = ldc; a.H0 = a.H1 = nullptr; a.resid = nullptr; a.ldr = 0; a.gamma = nullptr; a.rowscale = nullptr;
-  a.rows_per_sample = 1; a.alpha = nullptr;
+  a.rows_per_sample = 1; a.alpha = nullptr; a.rows = nullptr;
   a.M = (int)M; a.N = (int)N; a.K = (int)K; a.gm = 4; a.m_off = 0;
   a.tiles_m = ceil_div(M, 256);
   a.tiles_n = ceil_div(N, 256);

@@ -7,7 +7,11 @@
 
 namespace {
 
-enum { EPI_BIAS = 0, EPI_F32 = 1, EPI_GEGLU = 2, EPI_RESID = 3 };
+// EPI_RESID_ROWS (internal: op_gemm_nt's residual epilogue with resid_rows, ABI 9): the residual is read from, and the output written
+// to, row rows[m] of LARGER matrices (resid / C are their bases; rows[m] < 0: the row is computed and dropped) -- the packed rows of
+// the samples a residual branch keeps under stochastic depth go straight back to their places in the full activation matrix.
+enum { EPI_BIAS = 0, EPI_F32 = 1, EPI_GEGLU = 2, EPI_RESID = 3, EPI_RESID_ROWS = 4 };
+constexpr bool epi_is_resid(int e) { return e == EPI_RESID || e == EPI_RESID_ROWS; }
 
 struct GemmArgs {
   const bf16_t* A; int64_t lda;
@@ -24,6 +28,7 @@ struct GemmArgs {
   int64_t slab;       // elements between split-K output slabs
   int gm;             // 256x256 kernels: M-tiles per L2 group (tile order: gm M-tiles x all N-tiles, M fastest)
   int m_off;          // row index of A's first row in the caller's matrix (rowscale lookup of a tail-rows launch)
+  const int* rows;    // EPI_RESID_ROWS: the row of resid / C that stands behind row m of the launch (-1: none); else unused
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -109,12 +114,17 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
   // tile_bias (a compile-time constant at every call site): the caller hands over the bias vector of the weight segment its tile
   // lies in (n_seg % 256 == 0) instead of the table p.bias[] -- gemm256p_kernel builds its GemmArgs per tile in registers, and ONE
   // dynamically indexed member put the whole struct into scratch (round 4: 232-288 bytes per lane, 16-28 scratch operations per tile)
-  static_assert(EPI == EPI_BIAS || EPI == EPI_RESID, "epilogue_v: plain / bias and residual epilogues only");
+  static_assert(EPI == EPI_BIAS || epi_is_resid(EPI), "epilogue_v: plain / bias and residual epilogues only");
+  constexpr bool ROWS = EPI == EPI_RESID_ROWS;
   const int rows_left = min(p.M - mrow0, 128);  // wave-uniform
   if (rows_left <= 0) return;
   const int ldc = (int)p.ldc;
   const int nrec = ((rows_left - 1) * ldc + 128) * 2;
-  const u32x4 rc = raw_rsrc((bf16_t*)p.C + (int64_t)mrow0 * p.ldc + ncol0, nrec);
+  // ROWS: the descriptor starts at the matrix base (+ the tile's first column) and spans "everything" (the host checked that the whole
+  // matrix lies below ROWS_SPAN bytes); the row goes into the per-lane offset, a row without a place gets an offset behind the span:
+  // its store is dropped / its load returns zeros -- the same mechanism that guards rows >= M in the plain form
+  constexpr unsigned ROWS_SPAN = 0xfffff000u, ROWS_NONE = 0xfffffff0u;
+  const u32x4 rc = ROWS ? raw_rsrc((bf16_t*)p.C + ncol0, (int)ROWS_SPAN) : raw_rsrc((bf16_t*)p.C + (int64_t)mrow0 * p.ldc + ncol0, nrec);
   const int voff = (g * 4 * ldc + t * 8) * 2;  // + ((mi*16 + r) * ldc) * 2 as the scalar offset
   const int seg = ncol0 / p.n_seg;
   const bf16_t* bp = tile_bias ? bias_of_tile : p.bias[seg];
@@ -177,9 +187,31 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
     else stores(std::false_type{});
   } else {
     const int ldr = (int)p.ldr;
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + (int64_t)mrow0 * p.ldr + ncol0), 0,
-                                                                        ((rows_left - 1) * ldr + 128) * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr =
+        ROWS ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + ncol0), 0, (int)ROWS_SPAN, 0x00020000)
+             : __builtin_amdgcn_make_buffer_rsrc((void*)(p.resid + (int64_t)mrow0 * p.ldr + ncol0), 0, ((rows_left - 1) * ldr + 128) * 2, 0x00020000);
     const int voff_r = (g * 4 * ldr + t * 8) * 2;
+    // ROWS: the lane's 32 rows are mi*16 + g*4 + r: four consecutive entries of the row table per mi (one 16-byte load each); the
+    // entries of a chunk are requested TWO chunks ahead (its residual loads, one chunk ahead, depend on them) and live until its
+    // stores: 24 registers instead of 32 (all up front: 20 bytes of scratch per lane in the persistent kernel).  Entries behind the
+    // last row of the launch read 0 and are masked by `rows_left`.
+    u32x4 rowv[ROWS ? 8 : 1];
+    const __amdgpu_buffer_rsrc_t rm =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(ROWS ? p.rows + mrow0 : nullptr), 0, ROWS ? rows_left * 4 : 0, 0x00020000);
+    auto load_rows = [&](int c) {
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) rowv[ROWS ? c * 2 + m2 : 0] = __builtin_amdgcn_raw_buffer_load_b128(rm, g * 16, (c * 2 + m2) * 64, 0);
+    };
+    if constexpr (ROWS) {
+      load_rows(0);
+      load_rows(1);
+    }
+    auto row_off = [&](int mi, int r, int ld) -> int {  // ROWS: byte offset of the lane's 16 bytes in row rows[...] (or behind the span)
+      const unsigned sv = rowv[ROWS ? mi : 0][r];  // (through a scalar: see row_of)
+      const int src = (int)sv;
+      const bool ok = src >= 0 && mi * 16 + g * 4 + r < rows_left;
+      return ok ? (int)((unsigned)src * (unsigned)ld * 2u + (unsigned)t * 16u) : (int)ROWS_NONE;
+    };
     // rowscale index of a row by multiply-high: exact while (rows + m_off) * rows_per_sample < 2^32 (else a true division)
     const unsigned rps = (unsigned)p.rows_per_sample;
     const bool exact = p.rowscale && (uint64_t)((unsigned)(p.M + p.m_off)) * rps < (1ull << 32) && rps > 1;
@@ -195,7 +227,8 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
         for (int r = 0; r < 4; ++r) {
           const int row = (c * 2 + m2) * 16 + r;  // + g * 4 in the lane offset
           // (plain loads: a non-temporal hint made the K = 1536 residual launch 7 % slower, tools/gemm_lib_ab.py)
-          dst[m2][r] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff_r, row * ldr * 2, 0);
+          if constexpr (ROWS) dst[m2][r] = __builtin_amdgcn_raw_buffer_load_b128(rr, row_off(c * 2 + m2, r, ldr), 0, 0);
+          else dst[m2][r] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff_r, row * ldr * 2, 0);
           if (p.rowscale) {
             const unsigned mc = (unsigned)(min(mrow0 + row + g * 4, p.M - 1) + p.m_off);
             rs[m2][r] = p.rowscale[exact ? __umulhi(mc, magic) : mc / rps];
@@ -217,6 +250,9 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
     const u32x4 ry = raw_rsrc(p.H0 + (int64_t)mrow0 * p.ldc + ncol0, has_y ? nrec : 0);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      if constexpr (ROWS) {
+        if (c + 2 < 4) load_rows(c + 2);
+      }
       if (c + 1 < 4) load_chunk(c + 1, rraw[(c + 1) & 1], rsv[(c + 1) & 1]);
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2) {
@@ -234,7 +270,8 @@ __device__ __forceinline__ void epilogue_v(const GemmArgs& p, f32x4 (&acc)[2][4]
           unpack_bf16x8(rraw[c & 1][m2][r], rv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = resid_out(rv[j], rs, gv[j], o[j]);
-          store_b128_padded(pack_bf16x8(o), rc, voff, soff);
+          if constexpr (ROWS) store_b128_padded(pack_bf16x8(o), rc, row_off(mi, r, ldc), 0);
+          else store_b128_padded(pack_bf16x8(o), rc, voff, soff);
         }
       }
     }

@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      const T* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      int64_t rows, int cols, float eps, uint8_t* __restrict__ q8 = nullptr,
-                                                     float* __restrict__ q8_scale = nullptr) {
+                                                     float* __restrict__ q8_scale = nullptr, const int* __restrict__ xmap = nullptr) {
+  // xmap (nullable, ABI 9): row r of the input is row xmap[r] of a LARGER matrix x (< 0: no row -- normalised as a row of zeros, which is
+  // what op_rows_gather's packed copy holds there); y / mean / rstd are indexed by r.  The packed rows of the samples a residual
+  // branch keeps, read straight from the full activation matrix.
   __shared__ float red[4];
   constexpr int G = 64 * NW;
   const int tig = (NW == 1) ? (threadIdx.x & 63) : threadIdx.x;
@@ -99,22 +102,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   // The next row is requested before the current one is reduced: twice the bytes in flight per wave.
   typedef typename Vec8<T>::raw_t raw_t;
   raw_t cur[CH], nxt[CH];
-  if (row0 < rows) {
+  // (the table entry of a row is requested one row BEFORE its data: behind each other in one trip, every row paid an L2 latency)
+  auto fetch = [&](int64_t src, raw_t (&dst)[CH]) {  // (uniform per row group: the entry is the same for every thread of the row)
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
-      if (c < cols) cur[i] = ldraw_sel<T, NT>(x + row0 * (int64_t)cols + c);
-    }
-  }
-  for (int64_t row = row0; row < rows; row += rstep) {
-    const int64_t nrow = row + rstep;
-    if (nrow < rows) {
-#pragma unroll
-      for (int i = 0; i < CH; ++i) {
-        const int c = (tig + G * i) * 8;
-        if (c < cols) nxt[i] = ldraw_sel<T, NT>(x + nrow * (int64_t)cols + c);
+      if (c < cols) {
+        if (src >= 0) dst[i] = ldraw_sel<T, NT>(x + src * (int64_t)cols + c);
+        else dst[i] = raw_t{};
       }
     }
+  };
+  int64_t nsrc = row0 + rstep < rows ? (xmap ? (int64_t)xmap[row0 + rstep] : row0 + rstep) : -1;
+  if (row0 < rows) fetch(xmap ? (int64_t)xmap[row0] : row0, cur);
+  for (int64_t row = row0; row < rows; row += rstep) {
+    const int64_t nrow = row + rstep, nnrow = nrow + rstep;
+    if (nrow < rows) fetch(nsrc, nxt);
+    if (nnrow < rows) nsrc = xmap ? (int64_t)xmap[nnrow] : nnrow;
     float v[CH][8];
     float s = 0.f;
 #pragma unroll
@@ -303,7 +307,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const T* __restrict__ w, const T* __restrict__ b,
                                                      const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in, const T* __restrict__ add,
-                                                     T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols) {
+                                                     T* __restrict__ dx, float* __restrict__ ws, int64_t rows, int cols,
+                                                     const int* __restrict__ xmap = nullptr) {
+  // xmap (nullable, ABI 9; see ln_fwd_kernel): x, add and dx are rows xmap[r] of LARGER matrices (dy / mean / rstd are indexed by r);
+  // a row without a source (< 0) is a row of zeros for x, has no `add` and is not stored.  dx may be `add` (in place: only the mapped
+  // rows change -- the rows of dropped samples keep the gradient of the skip connection).
   extern __shared__ __attribute__((aligned(16))) float smem[];  // NW==1: [4][cols] ; NW==4: [4]
   float* red = smem;
   constexpr int G = 64 * NW;
@@ -326,26 +334,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   }
   typedef typename Vec8<T>::raw_t raw_t;
   raw_t curx[CH], curg[CH], nxtx[CH], nxtg[CH], addv[CH];
+  // (uniform per row group; the entry of row r + 2 steps is requested while row r is computed: see ln_fwd_kernel)
+  int64_t src = row0 < rows ? (xmap ? (int64_t)xmap[row0] : row0) : -1;
+  int64_t nsrc = row0 + rstep < rows ? (xmap ? (int64_t)xmap[row0 + rstep] : row0 + rstep) : -1, nnsrc = -1;
   if (row0 < rows) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        curx[i] = ldraw_sel<T, NT>(x + row0 * (int64_t)cols + c);
+        if (src >= 0) curx[i] = ldraw_sel<T, NT>(x + src * (int64_t)cols + c);
+        else curx[i] = raw_t{};
         curg[i] = ldraw_sel<T, NT>(dy + row0 * (int64_t)cols + c);
       }
     }
   }
   for (int64_t row = row0; row < rows; row += rstep) {
     const float mean = mean_in[row], rstd = rstd_in[row];
-    const int64_t nrow = row + rstep;
+    const int64_t nrow = row + rstep, nnrow = nrow + rstep;
+    if (nnrow < rows) nnsrc = xmap ? (int64_t)xmap[nnrow] : nnrow;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {  // residual-path gradient of this row + both operands of the next row
       const int c = (tig + G * i) * 8;
       if (c < cols) {
-        if (add) addv[i] = ldraw_sel<T, NT>(add + row * (int64_t)cols + c);
+        if (add && src >= 0) addv[i] = ldraw_sel<T, NT>(add + src * (int64_t)cols + c);
         if (nrow < rows) {
-          nxtx[i] = ldraw_sel<T, NT>(x + nrow * (int64_t)cols + c);
+          if (nsrc >= 0) nxtx[i] = ldraw_sel<T, NT>(x + nsrc * (int64_t)cols + c);
+          else nxtx[i] = raw_t{};
           nxtg[i] = ldraw_sel<T, NT>(dy + nrow * (int64_t)cols + c);
         }
       }
@@ -373,11 +387,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     group_sum2<NW>(s1, s2, red);
     const float c1 = s1 * inv, c2 = s2 * inv;
-    T* dr = dx + row * (int64_t)cols;
+    T* dr = dx + (src >= 0 ? src : 0) * (int64_t)cols;
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = (tig + G * i) * 8;
-      if (c < cols) {
+      if (c < cols && src >= 0) {
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (g[i][j] - c1 - xh[i][j] * c2);
@@ -392,6 +406,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) { curx[i] = nxtx[i]; curg[i] = nxtg[i]; }
+    src = nsrc;
+    nsrc = nnsrc;
   }
   if (ws == nullptr) return;  // uniform
   float* wsb = ws + (int64_t)blockIdx.x * 2 * cols;
@@ -580,7 +596,7 @@ inline int ln_grid(int64_t rows, int nw, int cap) {
 
 template <typename T, bool GELU>
 int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
-                    int cols, float eps, hipStream_t s) {
+                    int cols, float eps, hipStream_t s, const int* xmap = nullptr) {
   const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* Y = (T*)y;
   // cache policy: non-temporal row accesses for a TRAINING pass (the caller wants the statistics: a backward follows) over a matrix of
   // >= 64 MiB -- it streams once, and what it left in L2 / Infinity Cache only displaced the next GEMM's panels (-2 % on the headline
@@ -589,8 +605,8 @@ int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float*
   const bool nt = mean != nullptr && (int64_t)rows * cols * (int64_t)sizeof(T) >= ((int64_t)64 << 20);
 #define LN_F(CH, NW)                                                                                                                      \
   do {                                                                                                                                    \
-    if (nt) hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU, true>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps); \
-    else hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU, false>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps); \
+    if (nt) hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU, true>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps, (uint8_t*)nullptr, (float*)nullptr, xmap); \
+    else hipLaunchKernelGGL((ln_fwd_kernel<T, CH, NW, GELU, false>), dim3(ln_grid(rows, NW, g_ln_blocks_fwd)), dim3(256), 0, s, X, W, B, Y, mean, rstd, rows, cols, eps, (uint8_t*)nullptr, (float*)nullptr, xmap); \
   } while (0)
   if (cols <= 512) LN_F(1, 1);
   else if (cols <= 1024) LN_F(2, 1);
@@ -608,7 +624,7 @@ int ln_fwd_dispatch(const void* x, const void* w, const void* b, void* y, float*
 template <typename T, bool GELU>
 int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
                     const void* add, void* dx, void* dw, void* db, float* ws, int64_t rows, int cols, int accumulate,
-                    hipStream_t s) {
+                    hipStream_t s, const int* xmap = nullptr) {
   const T* DY = (const T*)dy; const T* X = (const T*)x; const T* W = (const T*)w; const T* B = (const T*)b; T* DX = (T*)dx;
   const T* ADD = (const T*)add;
   int grid = 0;
@@ -619,9 +635,9 @@ int ln_bwd_dispatch(const void* dy, const void* x, const void* w, const void* b,
     grid = ln_grid(rows, NW, g_ln_blocks_bwd);                                                                               \
     size_t sh = (NW == 1) ? (size_t)4 * cols * sizeof(float) : 64;                                          \
     if (nt) hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU, true>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
-                       rstd, ADD, DX, wsk, rows, cols);                                                          \
+                       rstd, ADD, DX, wsk, rows, cols, xmap);                                                    \
     else hipLaunchKernelGGL((ln_bwd_kernel<T, CH, NW, GELU, false>), dim3(grid), dim3(256), sh, s, DY, X, W, B, mean,   \
-                       rstd, ADD, DX, wsk, rows, cols);                                                          \
+                       rstd, ADD, DX, wsk, rows, cols, xmap);                                                    \
   } while (0)
   if (cols <= 512) LN_B(1, 1);
   else if (cols <= 1024) LN_B(2, 1);
@@ -654,18 +670,18 @@ int64_t op_layernorm_bwd_workspace_bytes(int64_t rows, int64_t cols) {
 }
 
 int op_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows,
-                     int64_t cols, float eps, int act_gelu, int dtype, void* stream) {
+                     int64_t cols, float eps, int act_gelu, int dtype, const int* x_rows, void* stream) {
   OP_CHECK_ARG(x && y, "layernorm_fwd: null x/y");
   OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0, "layernorm_fwd: cols=%lld must be a positive multiple of 8",
                (long long)cols);
   if (rows == 0) return OP_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OP_DT_BF16)
-    return act_gelu ? ln_fwd_dispatch<bf16_t, true>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s)
-                    : ln_fwd_dispatch<bf16_t, false>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s);
+    return act_gelu ? ln_fwd_dispatch<bf16_t, true>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s, x_rows)
+                    : ln_fwd_dispatch<bf16_t, false>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s, x_rows);
   if (dtype == OP_DT_F32)
-    return act_gelu ? ln_fwd_dispatch<float, true>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s)
-                    : ln_fwd_dispatch<float, false>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s);
+    return act_gelu ? ln_fwd_dispatch<float, true>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s, x_rows)
+                    : ln_fwd_dispatch<float, false>(x, w, b, y, mean, rstd, rows, (int)cols, eps, s, x_rows);
   op_set_error("layernorm_fwd: bad dtype %d", dtype);
   return OP_EINVAL;
 }
@@ -697,7 +713,7 @@ int op_layernorm_fwd_q8(const void* x, const void* w, const void* b, void* y, fl
 // dx = LN backward (+ add, the gradient arriving through the residual path, optional and may alias dx)
 int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b, const float* mean, const float* rstd,
                      const void* add, void* dx, void* dw, void* db, void* workspace, int64_t rows, int64_t cols,
-                     int act_gelu, int accumulate, int dtype, void* stream) {
+                     int act_gelu, int accumulate, int dtype, const int* x_rows, void* stream) {
   OP_CHECK_ARG(dy && x && dx && mean && rstd, "layernorm_bwd: null pointer");
   OP_CHECK_ARG(rows >= 0 && cols > 0 && cols % 8 == 0, "layernorm_bwd: cols=%lld must be a positive multiple of 8",
                (long long)cols);
@@ -706,14 +722,14 @@ int op_layernorm_bwd(const void* dy, const void* x, const void* w, const void* b
   hipStream_t s = (hipStream_t)stream;
   if (dtype == OP_DT_BF16)
     return act_gelu ? ln_bwd_dispatch<bf16_t, true>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
-                                                    (int)cols, accumulate, s)
+                                                    (int)cols, accumulate, s, x_rows)
                     : ln_bwd_dispatch<bf16_t, false>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
-                                                     (int)cols, accumulate, s);
+                                                     (int)cols, accumulate, s, x_rows);
   if (dtype == OP_DT_F32)
     return act_gelu ? ln_bwd_dispatch<float, true>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
-                                                   (int)cols, accumulate, s)
+                                                   (int)cols, accumulate, s, x_rows)
                     : ln_bwd_dispatch<float, false>(dy, x, w, b, mean, rstd, add, dx, dw, db, (float*)workspace, rows,
-                                                    (int)cols, accumulate, s);
+                                                    (int)cols, accumulate, s, x_rows);
   op_set_error("layernorm_bwd: bad dtype %d", dtype);
   return OP_EINVAL;
 }

@@ -30,14 +30,14 @@ SIGNATURES = {
     "op_prof_enable": (c_int, [c_int]),
     "op_prof_reserve": (c_int, [c_int]),
     "op_prof_collect": (c_int, [P, P, P, c_int]),
-    "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P]),
+    "op_layernorm_fwd": (c_int, [P, P, P, P, P, P, I64, I64, c_float, c_int, c_int, P, P]),
     "op_layernorm_bwd_workspace_bytes": (I64, [I64, I64]),
     "op_attn_bwd_dbias_slabs": (I64, [I64, I64, I64, I64]),
-    "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P]),
+    "op_layernorm_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I64, I64, c_int, c_int, c_int, P, P]),
     "op_gemm_plan": (c_int, [c_int64, c_int64, c_int64, c_int, c_int, c_int64, I64, P]),
     "op_gemm_nt": (c_int, [P, I64, P, P, P, I64, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, P, I64, I64, I64,
-                           c_int, P, I64, I64, P]),
-    "op_gemm_nt_grouped": (c_int, [I64, P, P, I64, P, I64, P, P, I64, P, P, P, I64, P, P, P, I64, I64, c_int, I64, P]),
+                           c_int, P, I64, I64, P, I64, P]),
+    "op_gemm_nt_grouped": (c_int, [I64, P, P, I64, P, I64, P, P, I64, P, P, P, I64, P, P, P, I64, I64, c_int, I64, P, I64, P]),
     "op_gemm_tn": (c_int, [P, I64, P, I64, P, I64, I64, I64, I64, c_int, P, I64, I64, P]),
     "op_gemm_tn_grouped_counter_bytes": (I64, []),
     "op_gemm_tn_grouped_plan": (I64, [I64, P, P, P, I64, I64, P, I64]),
@@ -53,7 +53,7 @@ SIGNATURES = {
     "op_colsum_workspace_bytes": (I64, [I64]),
     "op_colsum_segments": (c_int, [P, P, P, P, P, I64, I64, I64, c_int, P]),
     "op_resid_bwd_workspace_bytes": (I64, [I64]),
-    "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, P, I64, I64, c_int, P]),
+    "op_resid_bwd": (c_int, [P, P, P, P, I64, P, P, P, P, P, I64, I64, c_int, P, P]),
     "op_gamma_grad_finish": (c_int, [P, I64, P, P, P, P, P, P, P, I64, c_int, P]),
     "op_ln_geglu_bwd": (c_int, [P, P, P, P, P, P, P, P, I64, I64, P, P, P, I64, I64, c_int, P]),
     "op_ln_geglu_fwd": (c_int, [P, P, I64, P, P, P, P, P, I64, I64, c_float, P]),
@@ -81,6 +81,7 @@ SIGNATURES = {
     "op_gemm_nt_fp8": (c_int, [P, I64, P, P, P, I64, P, P, P, P, I64, P, P, P, I64, P, P, I64, I64, I64, I64, c_int, I64, P]),
     "op_rows_gather": (c_int, [P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
     "op_rows_merge": (c_int, [P, P, P, P, I64, P, P, P, P, P, P, P, I64, I64, P]),
+    "op_rows_map": (c_int, [P, P, I64, P, P, P, P, P, P, P, I64, P]),
 }
 
 
@@ -269,12 +270,16 @@ def _req(t, name, dtype=None):
 # ---------------------------------------------------------------------------------------------------
 # thin tensor-level wrappers (no autograd here; see ops.py)
 # ---------------------------------------------------------------------------------------------------
-def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True, q8=False):
+def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True, q8=False, x_rows=None):
     """q8=True (bf16, no GELU): returns (y, mean, rstd, (fp8 bytes, row scales)) -- the output also row-quantised to e4m3, bit-identical
-    to quant_fp8_rows(y), without a pass of its own."""
+    to quant_fp8_rows(y), without a pass of its own.  x_rows (int32 [rows], KeptRows.rowmap): the input rows are rows x_rows[r] of the
+    larger matrix x2d (< 0: a row of zeros); the outputs have x_rows.numel() rows."""
     _req(x2d, "x")
     rows, cols = x2d.shape
-    y = torch.empty_like(x2d)
+    if x_rows is not None:
+        assert not q8 and x_rows.dtype == torch.int32 and x_rows.is_contiguous()
+        rows = x_rows.numel()
+    y = torch.empty(rows, cols, dtype=x2d.dtype, device=x2d.device)
     mean = rstd = None
     if want_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
@@ -287,7 +292,7 @@ def layernorm_fwd(x2d, w, b, eps=1e-5, gelu=False, want_stats=True, q8=False):
                "op_layernorm_fwd_q8")
         return y, mean, rstd, (q, qs)
     _check(lib().op_layernorm_fwd(ptr(x2d), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, cols, eps,
-                                  int(gelu), _dt(x2d), stream()), "op_layernorm_fwd")
+                                  int(gelu), _dt(x2d), ptr(x_rows), stream()), "op_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -305,8 +310,14 @@ def workspace(nbytes, device, tag="ws"):
 
 
 def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None, db=None, accumulate=False, add=None,
-                  dx=None):
+                  dx=None, x_rows=None):
+    """x_rows (int32 [rows of dy]): x, add and dx are rows x_rows[r] of larger matrices; dx must be given (dx = add: in place, the
+    rows no entry names keep `add`)."""
     rows, cols = x.shape
+    if x_rows is not None:
+        assert dx is not None and dx.shape == x.shape and (add is None or add.shape == x.shape) and x_rows.dtype == torch.int32
+        rows = x_rows.numel()
+        assert dy.shape[0] == rows
     if dx is None:
         dx = torch.empty_like(x)
     ws = None
@@ -319,7 +330,7 @@ def layernorm_bwd(dy, x, w, b, mean, rstd, gelu=False, need_wgrad=True, dw=None,
     else:
         dw = db = None
     _check(lib().op_layernorm_bwd(ptr(dy), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(add), ptr(dx), ptr(dw), ptr(db),
-                                  ptr(ws), rows, cols, int(gelu), int(accumulate), _dt(x), stream()), "op_layernorm_bwd")
+                                  ptr(ws), rows, cols, int(gelu), int(accumulate), _dt(x), ptr(x_rows), stream()), "op_layernorm_bwd")
     return dx, dw, db
 
 
@@ -328,9 +339,14 @@ GEMM_ALGO_BYTES = [0, 0]  # [bytes, launches]: operands read once + outputs writ
 
 
 def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h1=None, resid=None, gamma=None,
-            rowscale=None, rows_per_sample=0, alpha=None, N=None, ldc=None, splitk=True):
-    """C[M,N] = A[M,K] @ cat(Bs)[N,K]^T with the fused epilogue.  Bs: list of 1-3 [n_seg,K] weights (GeGLU: [W0, W1])."""
+            rowscale=None, rows_per_sample=0, alpha=None, N=None, ldc=None, splitk=True, resid_rows=None):
+    """C[M,N] = A[M,K] @ cat(Bs)[N,K]^T with the fused epilogue.  Bs: list of 1-3 [n_seg,K] weights (GeGLU: [W0, W1]).
+    resid_rows (int32 [M], residual epilogue): resid and out are FULL matrices, row m of the launch reads / writes their row
+    resid_rows[m] (< 0: dropped); h0 stays [M, N]."""
     M, K = A.shape
+    if resid_rows is not None:
+        assert epilogue == EPI_RESID and out is not None and resid is not None and out.shape == resid.shape and resid_rows.numel() == M
+        assert resid_rows.dtype == torch.int32 and resid_rows.is_contiguous()
     Bs = list(Bs) + [None] * (3 - len(Bs))
     biases = list(biases or []) + [None] * (3 - len(biases or []))
     if epilogue == EPI_GEGLU:
@@ -358,7 +374,8 @@ def gemm_nt(A, Bs, biases=None, out=None, epilogue=EPI_BIAS, n_seg=0, h0=None, h
     _check(lib().op_gemm_nt(ptr(A), A.stride(0), ptr(Bs[0]), ptr(Bs[1]), ptr(Bs[2]), Bs[0].stride(0), n_seg,
                             ptr(biases[0]), ptr(biases[1]), ptr(biases[2]), ptr(out), ldc_, ptr(h0), ptr(h1),
                             ptr(resid), resid.stride(0) if resid is not None else 0, ptr(gamma), ptr(rowscale),
-                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, TUNE.gemm(), stream()), "op_gemm_nt")
+                            rows_per_sample, ptr(alpha), M, Nn, K, epilogue, ptr(ws), ws_bytes, TUNE.gemm(), ptr(resid_rows),
+                            out.shape[0] if resid_rows is not None else 0, stream()), "op_gemm_nt")
     return out
 
 
@@ -370,8 +387,9 @@ def _ptr_array(items, n):
 
 
 def gemm_nt_grouped(As, Ws, biases=None, outs=None, epilogue=EPI_BIAS, h0s=None, h1s=None, resids=None, gammas=None,
-                    rowscales=None, rows_per_sample=None):
-    """One launch for up to three problems out_p = epilogue(A_p @ W_p^T) with a common N, K (the per-modality FFNs of a layer).
+                    rowscales=None, rows_per_sample=None, resid_rows=None):
+    """(resid_rows: per problem an int32 row table, see gemm_nt -- outs / resids are then the full matrices, one row count for all.)
+    One launch for up to three problems out_p = epilogue(A_p @ W_p^T) with a common N, K (the per-modality FFNs of a layer).
     As: [M_p, K] tensors with a common row stride; Ws: per problem one weight, or (wi_0, wi_1) for the GeGLU epilogue.
     Returns the list of outputs, or None when the shape does not qualify for the persistent kernel (caller falls back)."""
     n = len(As)
@@ -398,7 +416,9 @@ def gemm_nt_grouped(As, Ws, biases=None, outs=None, epilogue=EPI_BIAS, h0s=None,
     GEMM_ALGO_BYTES[1] += 1
     rc = lib().op_gemm_nt_grouped(n, _ptr_array(As, n), Ms, lda, _ptr_array(flatB, 2 * n), ldb, _ptr_array(flatb, 2 * n),
                                   _ptr_array(outs, n), ldc, _ptr_array(h0s, n), _ptr_array(h1s, n), _ptr_array(resids, n), ldr,
-                                  _ptr_array(gammas, n), _ptr_array(rowscales, n), rps, N, K, epilogue, TUNE.gemm(), stream())
+                                  _ptr_array(gammas, n), _ptr_array(rowscales, n), rps, N, K, epilogue, TUNE.gemm(),
+                                  _ptr_array(resid_rows, n) if resid_rows is not None else None,
+                                  outs[0].shape[0] if resid_rows is not None else 0, stream())
     if rc == -95:
         return None
     _check(rc, "op_gemm_nt_grouped")
@@ -610,13 +630,17 @@ def colsum_segments(x, seg_cols, outs=None, accumulate=False):
     return outs
 
 
-def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma=None, dbias=None, accumulate=False, g0=None):
+def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma=None, dbias=None, accumulate=False, g0=None,
+              dout_rows=None):
     """dbranch = rowscale*gamma*dout plus the column reductions dgamma / dbias in one pass.  dgamma / dbias: True
     (allocate), a bf16 [N] tensor (write or, with accumulate, add into it) or None (skip).  g0: fp32 [N] that receives
     sum_m rowscale*dout (dbias without the gamma factor: gamma_grad_finish's operand) -- and dbranch is then rowscale*dout WITHOUT
     gamma (the weight-gradient launch's rscale and the gamma-scaled transposed weight carry it)."""
     M, N = dout.shape
-    out = torch.empty_like(dout)
+    if dout_rows is not None:  # dout: a larger matrix, row m of the pass = its row dout_rows[m] (< 0: zeros); the result has M rows
+        assert dout_rows.dtype == torch.int32 and dout_rows.is_contiguous() and dout.is_contiguous()
+        M = dout_rows.numel()
+    out = torch.empty(M, N, dtype=dout.dtype, device=dout.device)
     if dgamma is True:
         dgamma = torch.empty(N, dtype=dout.dtype, device=dout.device)
     if dbias is True:
@@ -626,7 +650,8 @@ def resid_bwd(dout, y=None, gamma=None, rowscale=None, rows_per_sample=0, dgamma
         ws = workspace(lib().op_resid_bwd_workspace_bytes(N), dout.device, "resid")
     assert g0 is None or (g0.dtype == torch.float32 and g0.is_contiguous() and g0.numel() == N)
     _check(lib().op_resid_bwd(ptr(dout), ptr(y if dgamma is not None else None), ptr(gamma), ptr(rowscale), rows_per_sample,
-                              ptr(out), ptr(dgamma), ptr(dbias), ptr(g0), ptr(ws), M, N, int(accumulate), stream()), "op_resid_bwd")
+                              ptr(out), ptr(dgamma), ptr(dbias), ptr(g0), ptr(ws), M, N, int(accumulate), ptr(dout_rows), stream()),
+           "op_resid_bwd")
     return out, dgamma, dbias
 
 
@@ -905,6 +930,18 @@ class KeptRows:
         """Device int32 view: the kept sample numbers of segment i (e.g. to index_select the key-padding rows)."""
         return self.lists[self.off_kept[i]:self.off_kept[i] + self.n_kept[i]]
 
+    def rowmap(self):
+        """Device int32 [total]: the row of the full matrix behind every packed row (-1: a surplus row of a rounded-up segment) -- the
+        table the kernels that read / write THROUGH the packing take (op_rows_map; built once per branch and step, on first use)."""
+        m = getattr(self, "_rowmap", None)
+        if m is None:
+            m = torch.empty(self.total, dtype=torch.int32, device=self.lists.device)
+            c = self._c
+            _check(lib().op_rows_map(ptr(m), ptr(self.lists), self.nseg, c[0], c[1], c[2], c[3], c[4], c[5], self._c_kept, self.total,
+                                     stream()), "op_rows_map")
+            self._rowmap = m
+        return m
+
 
 def pack_kept_lists(plans):
     """plans: [[(src_row0, S, n_samples, kept list)] per segment] per branch -> (int32 CPU tensor with all kept / inverse lists, the
@@ -932,9 +969,13 @@ def rows_gather(src, kr):
 
 
 def rows_merge(base, upd, kr, out=None):
-    """base with the rows of the kept samples replaced by the packed rows `upd`; out=base: in place."""
-    assert base.dim() == 2 and base.is_contiguous() and upd.is_contiguous() and base.shape[0] == kr.full_rows and upd.shape[0] == kr.total
-    assert base.dtype == torch.bfloat16 and upd.dtype == torch.bfloat16 and base.shape[1] == upd.shape[1]
+    """base with the rows of the kept samples replaced by the packed rows `upd`; out=base: in place.  upd=None (out given, not base):
+    only the rows of the DROPPED samples are copied into out (the kept rows were written through KeptRows.rowmap)."""
+    assert base.dim() == 2 and base.is_contiguous() and base.shape[0] == kr.full_rows and base.dtype == torch.bfloat16
+    if upd is None:
+        assert out is not None and out is not base and out.shape == base.shape and out.is_contiguous()
+    else:
+        assert upd.is_contiguous() and upd.shape[0] == kr.total and upd.dtype == torch.bfloat16 and base.shape[1] == upd.shape[1]
     if out is None:
         out = torch.empty_like(base)
     c = kr._c

@@ -707,15 +707,16 @@ class StreamSeg:
         return self.bias.frag if self.bias is not None and self.S <= limit else None
 
 
-def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
+def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True, xmap=None, out=None):
     """x_mid = x + rowscale * g1 * out_proj(subLN(attention(LN1(x))))  on the packed rows x2 [N, H]: LayerNorm, the fused q|k|v
     projection, the sub-LayerNorm and the output projection run over ALL rows in one launch each, the attention core per
     segment.  rowscale: fp32 drop-path multipliers indexed by row // rps (None = 1).  want_y: also write the branch output y1
-    (only the gradient of gamma_1 needs it)."""
+    (only the gradient of gamma_1 needs it).  xmap (hip.KeptRows.rowmap) + out: x2 is the FULL matrix, the branch runs on its rows
+    xmap[r] and writes x_mid for them into `out` (a full matrix; the other rows are the caller's)."""
     H = x2.shape[1]
-    xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep)
+    xln1, mean1, rstd1 = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], want_stats=keep, x_rows=xmap)
     if H % 128 == 0:
-        Nr = x2.shape[0]
+        Nr = xln1.shape[0]
         full = _qkv_rows_that_fill_whole_rounds(Nr, 3 * H) if QKV_ROUND_SPLIT else Nr
         if full < Nr:  # (689.8 / 689.7 -> 687.3 / 687.0 ms on the headline step, same box: profiles/r5_experiments.md section 12)
             qkv = torch.empty(Nr, 3 * H, dtype=x2.dtype, device=x2.device)
@@ -724,10 +725,10 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
         else:
             qkv = hip.gemm_nt(xln1, [P["wq"], P["wk"], P["wv"]], [P["bq"], None, P["bv"]], n_seg=H, N=3 * H)
     else:
-        qkv = torch.empty(x2.shape[0], 3 * H, dtype=x2.dtype, device=x2.device)
+        qkv = torch.empty(xln1.shape[0], 3 * H, dtype=x2.dtype, device=x2.device)
         for i, (w, b) in enumerate(((P["wq"], P["bq"]), (P["wk"], None), (P["wv"], P["bv"]))):
             hip.gemm_nt(xln1, [w], [b] if b is not None else None, out=qkv[:, i * H:(i + 1) * H], ldc=3 * H)
-    attn = torch.empty_like(x2)
+    attn = torch.empty_like(xln1)
     lses = []
     for sg in segs:
         r = slice(sg.row0, sg.end)
@@ -741,9 +742,9 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
         aln, mean_a, rstd_a = hip.layernorm_fwd(attn, P["aln_w"], P["aln_b"], want_stats=keep)
     else:
         aln, mean_a, rstd_a = attn, None, None
-    y1 = torch.empty_like(x2) if keep and want_y else None
+    y1 = torch.empty_like(xln1) if keep and want_y else None
     x_mid = hip.gemm_nt(aln, [P["wo"]], [P["bo"]], epilogue=hip.EPI_RESID, resid=x2, gamma=P["g1"], rowscale=rowscale,
-                        rows_per_sample=rps, h0=y1)
+                        rows_per_sample=rps, h0=y1, out=out, resid_rows=xmap)
     if not keep:
         return x_mid, None
     acts = dict(xln1=xln1, mean1=mean1, rstd1=rstd1, qkv=qkv, attn=attn, aln=aln, mean_a=mean_a, rstd_a=rstd_a, y1=y1)
@@ -753,6 +754,15 @@ def _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=True):
 
 
 QKV_ROUND_SPLIT = os.environ.get("ONEPEACE_QKV_ROUND_SPLIT", "1") != "0"
+# (round 6, ABI 9) a branch that runs on the samples stochastic depth keeps (hip.KeptRows) reads and writes the FULL activation /
+# gradient matrix through the row table (KeptRows.rowmap: LayerNorm forward / backward, op_resid_bwd, the residual epilogue of the
+# branch's last GEMM) instead of through packed copies -- no op_rows_gather / op_rows_merge passes (17.4 ms of the 586 ms step with
+# skip_dropped_branches, profiles/r6_bench_skip_dropped_last_step.txt), the same bits.  "0": round 4's packed copies (A/B, tests).
+SKIP_ROW_TABLES = os.environ.get("ONEPEACE_SKIP_ROW_TABLES", "1") != "0"
+
+
+def _row_tables(kept):
+    return kept is not None and SKIP_ROW_TABLES and not FP8_FFN
 
 
 def _qkv_rows_that_fill_whole_rounds(rows, n_out, cus=256, max_tail=512):
@@ -871,7 +881,7 @@ def _return_grads(names, params, G, direct):
     return out
 
 
-def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs, g0=None):
+def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs, g0=None, rows=None):
     """Gradient of  resid + ps * gamma * (y)  w.r.t. the branch output and -- where they are wanted -- gamma and the last
     Linear's bias, in one pass.  g0 (fp32 [H]): gamma's gradient is NOT taken here (no y: dgamma_from_wgrad_ok); the kernel fills g0
     with sum_m ps * dout for op_gamma_grad_finish instead and returns ps * dout WITHOUT gamma."""
@@ -880,7 +890,8 @@ def _resid_backward(dout, y, gamma, ps, S, gname, bname, direct, G, needs, g0=No
     t = dict(zip(names, tgt))
     dgamma = (t[gname] if acc else True) if gname in t else None
     dbias = (t[bname] if acc else True) if bname in t else None
-    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc, g0=g0)
+    dy, dg, db = hip.resid_bwd(dout, y if dgamma is not None else None, gamma, ps, S, dgamma=dgamma, dbias=dbias, accumulate=acc, g0=g0,
+                               dout_rows=rows)  # (rows: dout is the full matrix, the pass runs on its rows rows[m])
     _finish(direct, G, names, tuple({gname: dg, bname: db}[n] for n in names), acc)
     return dy
 
@@ -962,16 +973,24 @@ class AttnBranchFn(torch.autograd.Function):
         first_param = 7 + nseg
         needs = dict(zip(ATTN_PARAMS, ctx.needs_input_grad[first_param:]))
         x_full = x2
-        if kept is not None:  # the branch runs on the rows of the samples it keeps (segs / rowscale describe THOSE rows)
+        mapped = _row_tables(kept)  # the kept samples' rows through the row table (no packed copy of x, no merge pass)
+        if kept is not None and not mapped:  # the branch runs on the rows of the samples it keeps (segs / rowscale describe THOSE rows)
             x2 = hip.rows_gather(x_full, kept)
-        N, H = x2.shape
+        H = x2.shape[1]
+        N = kept.total if mapped else x2.shape[0]
         scale = (H // heads) ** -0.5
         # gamma_1's gradient from the out-proj weight gradient instead of from the branch output (then y1 is never written)
         ctx.dg_fused = need_grad and dgamma_from_wgrad_ok([N], P["g1"], [P["wo"]], [P["bo"]], needs["g1"], [needs["wo"]])
-        x_mid, acts = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"] and not ctx.dg_fused)
-        if kept is not None:
-            x_mid = hip.rows_merge(x_full, x_mid, kept)
-        ctx.kept = kept
+        if mapped:
+            x_mid = torch.empty_like(x_full)
+            _, acts = _attn_forward(x_full, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"] and not ctx.dg_fused,
+                                    xmap=kept.rowmap(), out=x_mid)
+            hip.rows_merge(x_full, None, kept, out=x_mid)  # (the dropped samples' rows: copied)
+        else:
+            x_mid, acts = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, keep, want_y=needs["g1"] and not ctx.dg_fused)
+            if kept is not None:
+                x_mid = hip.rows_merge(x_full, x_mid, kept)
+        ctx.kept, ctx.mapped = kept, mapped
         ctx.segs, ctx.dims, ctx.n_params, ctx.first_param = segs, (N, H, heads, scale, rps), len(params), first_param
         ctx.direct = ()
         if need_grad:
@@ -1002,31 +1021,34 @@ class AttnBranchFn(torch.autograd.Function):
         needs = {n: bool(ng) and q is not None for n, q, ng in zip(ATTN_PARAMS, params, ctx.needs_input_grad[ctx.first_param:])}
         need_x = bool(ctx.needs_input_grad[0])
         want_dbias = [sg.bias is not None and sg.bias.image.requires_grad for sg in segs]
+        kept, mapped = ctx.kept, ctx.mapped
+        xmap = kept.rowmap() if mapped else None  # (mapped: x2 is the FULL matrix the forward read through the table)
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_a", "rstd_a", "y1", "xln1", "aln"))
             if ctx.cheap:  # the weight-gradient operands that were not kept: the same kernels on the same rows, bit for bit
                 if needs["wq"] or needs["wk"] or needs["wv"]:
-                    A["xln1"] = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"])[0]
+                    A["xln1"] = hip.layernorm_fwd(x2, P["ln1_w"], P["ln1_b"], x_rows=xmap)[0]
                 if needs["wo"] and P["aln_w"] is not None:
                     A["aln"] = hip.layernorm_fwd(A["attn"], P["aln_w"], P["aln_b"])[0]
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True, want_y=not ctx.dg_fused)
+            _, A = _attn_forward(x2, P, segs, heads, scale, rowscale, rps, True, want_y=not ctx.dg_fused, xmap=xmap,
+                                 out=torch.empty_like(x2) if mapped else None)
         if not dx_mid.is_contiguous():
             dx_mid = dx_mid.contiguous()
-        kept, dx_full = ctx.kept, dx_mid
-        if kept is not None:  # rows of dropped samples: the gradient passes through the skip connection untouched
+        dx_full = dx_mid
+        if kept is not None and not mapped:  # rows of dropped samples: the gradient passes through the skip connection untouched
             dx_mid = hip.rows_gather(dx_full, kept)
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
         if ctx.dg_fused:  # dy1 = rowscale * dx_mid, WITHOUT gamma_1 (weight gradient: rscale; input gradient: scaled weight copy)
             g0 = torch.empty(H, dtype=torch.float32, device=dx_mid.device)
-            dy1 = _resid_backward(dx_mid, None, P["g1"], rowscale, rps, "g1", "bo", direct, G, needs, g0=g0)
+            dy1 = _resid_backward(dx_mid, None, P["g1"], rowscale, rps, "g1", "bo", direct, G, needs, g0=g0, rows=xmap)
             rowdot, (rd_wo,) = _rowdot_slots(dx_mid.device, [P["wo"]])
             weight_grad("wo", dy1, A["aln"], side=(P["wo"], rd_wo, P["g1"]),
                         after=_gamma_finish_hook(rowdot, direct["g1"], [(P["bo"], g0)] if P["bo"] is not None else [], True))
             wo_t = _transposed(P["wo"], scale=P["g1"])
         else:
-            dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs)
+            dy1 = _resid_backward(dx_mid, A["y1"], P["g1"], rowscale, rps, "g1", "bo", direct, G, needs, rows=xmap)
             if needs["wo"]:
                 weight_grad("wo", dy1, A["aln"])
             wo_t = None
@@ -1088,12 +1110,17 @@ class AttnBranchFn(torch.autograd.Function):
                 dxln1 = hip.gemm_nt(dqkv, [_transposed(tuple(P[n] for n in cols))])
                 want = needs["ln1_w"] or needs["ln1_b"]
                 (tw, tb), acc = _targets(direct, "ln1_w", "ln1_b") if want else ((None, None), False)
+                # (mapped: the kept samples' rows of a NEW full matrix -- the incoming gradient may be the caller's tensor --, the dropped
+                # samples' rows copied below)
                 dx, dw_, db_ = hip.layernorm_bwd(dxln1, x2, P["ln1_w"], P["ln1_b"], A["mean1"], A["rstd1"], add=dx_mid, dw=tw, db=tb,
-                                                 accumulate=acc, need_wgrad=want)
+                                                 accumulate=acc, need_wgrad=want, dx=torch.empty_like(dx_full) if mapped else None,
+                                                 x_rows=xmap)
                 if want:
                     _finish(direct, G, ("ln1_w", "ln1_b"), (dw_, db_), acc)
         if dx is None and need_x:  # nothing upstream of the residual wanted a gradient: only the skip connection carries one
             dx = dx_full
+        elif dx is not None and mapped:
+            hip.rows_merge(dx_full, None, kept, out=dx)
         elif dx is not None and kept is not None:
             dx = hip.rows_merge(dx_full, dx, kept)
         flush_wgrads()  # the layer's weight gradients (this branch's and the FFN branch's, which ran before it) as one launch
@@ -1246,11 +1273,14 @@ class FfnBranchMultiFn(torch.autograd.Function):
     params: ln2_w, ln2_b, g2, then (w0, w1, fln_w, fln_b, w2, b2) per segment."""
 
     @staticmethod
-    def _compute(x2, segs, pss, params, keep, want_y, grad=None):
+    def _compute(x2, segs, pss, params, keep, want_y, grad=None, xmap=None):
+        """xmap (hip.KeptRows.rowmap, not with the fp8 FFN): x2 is the FULL matrix, the branch runs on its rows xmap[r]; the returned
+        `out` is a full matrix in which the rows of the kept samples are written (the others are the caller's)."""
         nseg = len(segs)
         shared = dict(zip(FFN_SHARED, params[:3]))
         own = [dict(zip(FFN_OWN, params[3 + 6 * i:9 + 6 * i])) for i in range(nseg)]
-        N, H = x2.shape
+        H = x2.shape[1]
+        N = xmap.numel() if xmap is not None else x2.shape[0]
         Fd = own[0]["w0"].shape[0]
         dev, dt = x2.device, x2.dtype
         has_fln = own[0]["fln_w"] is not None
@@ -1260,7 +1290,7 @@ class FfnBranchMultiFn(torch.autograd.Function):
             xln2, mean2, rstd2, (xq, xs) = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep, q8=True)
             gq, gs = torch.empty(N, Fd, dtype=torch.uint8, device=dev), torch.empty(N, dtype=torch.float32, device=dev)
         else:
-            xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep)
+            xln2, mean2, rstd2 = hip.layernorm_fwd(x2, shared["ln2_w"], shared["ln2_b"], want_stats=keep, x_rows=xmap)
         if split:
             hh = torch.empty(N, 2 * Fd, dtype=dt, device=dev)
             g, h0, h1 = None, hh[:, :Fd], hh[:, Fd:]
@@ -1287,9 +1317,9 @@ class FfnBranchMultiFn(torch.autograd.Function):
             if has_fln:
                 hip._check(L.op_layernorm_fwd(hip.ptr(g[r]), hip.ptr(P["fln_w"]), hip.ptr(P["fln_b"]), hip.ptr(gln[r]),
                                               hip.ptr(mean_f[r]) if keep else None, hip.ptr(rstd_f[r]) if keep else None, sg.rows, Fd, 1e-5, 0,
-                                              hip.DT_BF16, hip.stream()), "op_layernorm_fwd")
-        y2 = torch.empty_like(x2) if keep and want_y else None
-        out = torch.empty_like(x2)
+                                              hip.DT_BF16, None, hip.stream()), "op_layernorm_fwd")
+        y2 = torch.empty(N, H, dtype=dt, device=dev) if keep and want_y else None
+        out = torch.empty_like(x2)  # (with xmap: the full matrix)
         rs = [slice(sg.row0, sg.end) for sg in segs]
         if fp8:  # one fp8 launch per modality (the grouped persistent launch is bf16 only)
             for sg, P, r, ps in zip(segs, own, rs, pss):
@@ -1298,14 +1328,17 @@ class FfnBranchMultiFn(torch.autograd.Function):
                                 rows_per_sample=sg.S, h0=y2[r] if y2 is not None else None, out=out[r])
             acts = dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2) if keep else None
             return out, acts
-        grouped = hip.gemm_nt_grouped([gln[r] for r in rs], [P["w2"] for P in own], biases=[P["b2"] for P in own], outs=[out[r] for r in rs],
+        tabs = [xmap[r] for r in rs] if xmap is not None else None  # (row tables: every problem writes ITS rows of the shared full matrix)
+        grouped = hip.gemm_nt_grouped([gln[r] for r in rs], [P["w2"] for P in own], biases=[P["b2"] for P in own],
+                                      outs=[out[r] for r in rs] if tabs is None else [out] * nseg,
                                       epilogue=hip.EPI_RESID, h0s=[y2[r] for r in rs] if y2 is not None else None,
-                                      resids=[x2[r] for r in rs], gammas=[shared["g2"]] * nseg, rowscales=list(pss),
-                                      rows_per_sample=[sg.S for sg in segs])
+                                      resids=[x2[r] for r in rs] if tabs is None else [x2] * nseg, gammas=[shared["g2"]] * nseg,
+                                      rowscales=list(pss), rows_per_sample=[sg.S for sg in segs], resid_rows=tabs)
         if grouped is None:  # shape outside the persistent kernel: one launch per modality
-            for sg, P, r, ps in zip(segs, own, rs, pss):
-                hip.gemm_nt(gln[r], [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x2[r], gamma=shared["g2"], rowscale=ps,
-                            rows_per_sample=sg.S, h0=y2[r] if y2 is not None else None, out=out[r])
+            for i, (sg, P, r, ps) in enumerate(zip(segs, own, rs, pss)):
+                hip.gemm_nt(gln[r], [P["w2"]], [P["b2"]], epilogue=hip.EPI_RESID, resid=x2[r] if tabs is None else x2, gamma=shared["g2"],
+                            rowscale=ps, rows_per_sample=sg.S, h0=y2[r] if y2 is not None else None, out=out[r] if tabs is None else out,
+                            resid_rows=tabs[i] if tabs is not None else None)
         acts = dict(xln2=xln2, mean2=mean2, rstd2=rstd2, h0=h0, h1=h1, gln=gln, mean_f=mean_f, rstd_f=rstd_f, y2=y2) if keep else None
         return out, acts
 
@@ -1318,16 +1351,21 @@ class FfnBranchMultiFn(torch.autograd.Function):
         needs = ctx.needs_input_grad[5:]
         has_fln = params[5] is not None
         x_full = x2
-        if kept is not None:  # the branch runs on the rows of the samples it keeps (segs / pss describe THOSE rows)
+        mapped = _row_tables(kept)  # (see AttnBranchFn.forward)
+        if kept is not None and not mapped:  # the branch runs on the rows of the samples it keeps (segs / pss describe THOSE rows)
             x2 = hip.rows_gather(x_full, kept)
-        N, H = x2.shape
+        H = x2.shape[1]
+        N = kept.total if mapped else x2.shape[0]
         w2s, b2s = [params[3 + 6 * i + 4] for i in range(nseg)], [params[3 + 6 * i + 5] for i in range(nseg)]
         ctx.dg_fused = need_grad and dgamma_from_wgrad_ok([sg.rows for sg in segs], params[2], w2s, b2s, bool(needs[2]),
                                                            [bool(needs[3 + 6 * i + 4]) for i in range(nseg)])
-        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]) and not ctx.dg_fused, grad=bool(int(save_acts) & 2))
-        if kept is not None:
+        out, acts = FfnBranchMultiFn._compute(x2, segs, pss, params, keep, bool(needs[2]) and not ctx.dg_fused, grad=bool(int(save_acts) & 2),
+                                              xmap=kept.rowmap() if mapped else None)
+        if mapped:
+            hip.rows_merge(x_full, None, kept, out=out)  # (the dropped samples' rows: copied)
+        elif kept is not None:
             out = hip.rows_merge(x_full, out, kept)
-        ctx.kept = kept
+        ctx.kept, ctx.mapped = kept, mapped
         ctx.segs, ctx.n_params, ctx.dims = segs, len(params), (N, H, Fd)
         ctx.direct = ()
         names = list(FFN_SHARED) + ["%s@%d" % (n, i) for i in range(nseg) for n in FFN_OWN]
@@ -1360,22 +1398,24 @@ class FfnBranchMultiFn(torch.autograd.Function):
         P = dict(zip(names, params))
         needs = {n: bool(ng) and q is not None for n, q, ng in zip(names, params, ctx.needs_input_grad[5:])}
         need_x = bool(ctx.needs_input_grad[0])
+        kept, mapped = ctx.kept, ctx.mapped
+        xmap = kept.rowmap() if mapped else None  # (mapped: x2 is the FULL matrix the forward read through the table)
         if ctx.act_names is not None:
             A = _restore(ctx, saved_acts, ("mean_f", "rstd_f", "y2", "gln", "xln2"))
             if ctx.cheap:
                 if any(needs["%s@%d" % (n, i)] for i in range(nseg) for n in ("w0", "w1")):
-                    A["xln2"] = hip.layernorm_fwd(x2, P["ln2_w"], P["ln2_b"])[0]
+                    A["xln2"] = hip.layernorm_fwd(x2, P["ln2_w"], P["ln2_b"], x_rows=xmap)[0]
                 if A["gln"] is None and any(needs["w2@%d" % i] for i in range(nseg)):
                     A["gln"] = torch.empty(N, Fd, dtype=x2.dtype, device=x2.device)
                     for i, sg in enumerate(segs):
                         r = slice(sg.row0, sg.end)
                         hip.ln_geglu_fwd(A["h0"][r], A["h1"][r], P["fln_w@%d" % i], P["fln_b@%d" % i], out=A["gln"][r], want_stats=False)
         else:  # recompute (the reference's checkpoint_activations behaviour)
-            _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, not ctx.dg_fused)
+            _, A = FfnBranchMultiFn._compute(x2, segs, pss, params, True, not ctx.dg_fused, xmap=xmap)
         if not dout.is_contiguous():
             dout = dout.contiguous()
-        kept, dout_full = ctx.kept, dout
-        if kept is not None:
+        dout_full = dout
+        if kept is not None and not mapped:
             dout = hip.rows_gather(dout_full, kept)
         G = {}
         weight_grad, direct = _weight_grad_fn(ctx, G)
@@ -1405,8 +1445,9 @@ class FfnBranchMultiFn(torch.autograd.Function):
                 g0 = torch.empty(H, dtype=torch.float32, device=dev)
                 if P[k("b2")] is not None:
                     pairs.append((P[k("b2")], g0))
-            dy2, dg_, db_ = hip.resid_bwd(dout[r], A["y2"][r] if want_g else None, P["g2"], pss[i], sg.S, dgamma=tg if want_g else None,
-                                          dbias=tb if want_b else None, accumulate=(acc_g and want_g) or (acc_b and want_b), g0=g0)
+            dy2, dg_, db_ = hip.resid_bwd(dout_full if mapped else dout[r], A["y2"][r] if want_g else None, P["g2"], pss[i], sg.S,
+                                          dgamma=tg if want_g else None, dbias=tb if want_b else None,
+                                          accumulate=(acc_g and want_g) or (acc_b and want_b), g0=g0, dout_rows=xmap[r] if mapped else None)
             if want_g and not acc_g:
                 dg_tmp = dg_.float() if dg_tmp is None else dg_tmp + dg_.float()
             if want_b:
@@ -1468,11 +1509,13 @@ class FfnBranchMultiFn(torch.autograd.Function):
             want = needs["ln2_w"] or needs["ln2_b"]
             (tw, tb), acc = _targets(direct, "ln2_w", "ln2_b") if want else ((None, None), False)
             dx, dw_, db_ = hip.layernorm_bwd(dxln2, x2, P["ln2_w"], P["ln2_b"], A["mean2"], A["rstd2"], add=dout, dw=tw, db=tb,
-                                             accumulate=acc, need_wgrad=want)
+                                             accumulate=acc, need_wgrad=want, dx=torch.empty_like(dout_full) if mapped else None, x_rows=xmap)
             if want:
                 _finish(direct, G, ("ln2_w", "ln2_b"), (dw_, db_), acc)
         if dx is None and need_x:
             dx = dout_full
+        elif dx is not None and mapped:
+            hip.rows_merge(dout_full, None, kept, out=dx)  # (the dropped samples' rows: the gradient of the skip connection, copied)
         elif dx is not None and kept is not None:
             dx = hip.rows_merge(dout_full, dx, kept)
         grads = _return_grads(names, params, G, direct)

@@ -46,7 +46,7 @@ def test_ctypes_table_matches_header(lib_path):
         assert len(hip.SIGNATURES[name][1]) == nargs, "%s: header has %d args, ctypes table %d" % (
             name, nargs, len(hip.SIGNATURES[name][1]))
     L = hip.lib()
-    assert L.op_abi_version() == 8  # 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4); 5: op_probe_mfma_rate; 6: probes in their own library (round 5); 7: row-dot side product of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish; 8: rscale / op_transpose_scaled: the layer-scale gradient without a division (round 6)
+    assert L.op_abi_version() == 9  # 9: row tables (round 6); 8 and earlier: 2: per-call tune words instead of process-wide knobs; 3: grouped GEMM, ldd of op_ln_geglu_bwd (round 3); 4: op_gemm_tn_grouped (round 4); 5: op_probe_mfma_rate; 6: probes in their own library (round 5); 7: row-dot side product of op_gemm_tn_grouped, g0 of op_resid_bwd, op_gamma_grad_finish; 8: rscale / op_transpose_scaled: the layer-scale gradient without a division (round 6)
 
 
 def test_probe_library_is_separate_from_the_product_library(lib_path):

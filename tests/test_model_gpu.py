@@ -1431,15 +1431,11 @@ def test_recompute_cheap_level_gives_the_same_bits_with_less_kept_memory(lock, f
     assert saved >= 0.9 * 10 * cfg["embed_dim"] * cfg["layers"] * B * (16 + 17), (res[True][1], res[False][1])
 
 
-@pytest.mark.parametrize("flat,recompute", [(False, False), (True, False), (True, True)])
-def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(flat, recompute):
-    """TransformerEncoder.skip_dropped_branches: every residual branch of the lock-step pass is computed for the samples stochastic
-    depth KEEPS only (packed rows, hip.KeptRows) instead of for all samples with the dropped ones multiplied by zero
-    (transformer_layer.py:78-88).  Same masks in both runs: the loss and every gradient must agree within bf16 rounding (the
-    packed GEMMs see other row counts, so tile shapes / split-K may differ; weight gradients sum the same non-zero terms in another
-    order).  The masks include a layer without drop-path, a branch that keeps every sample, one that drops a whole modality
-    (multiplier fallback for that branch) and one that keeps a single sample of a segment."""
-    from one_peace_amd import hip as hipm
+def _skip_dropped_runs(flat, recompute, variants):
+    """Loss, gradients and the number of op_rows_gather calls of one lock-step tri-modal step under fixed stochastic-depth masks, per
+    variant (skip_dropped_branches, ops.SKIP_ROW_TABLES).  The masks include a layer without drop-path, a branch that keeps every
+    sample, one that drops a whole modality (multiplier fallback for that branch) and one that keeps a single sample of a segment."""
+    from one_peace_amd import hip as hipm, ops
     from one_peace_amd.criterions.contrastive import TriModalContrastiveCriterion
     from one_peace_amd.distributed import FlatParameters
     from one_peace_amd.transformer import transformer_encoder as TE
@@ -1458,7 +1454,7 @@ def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(f
     mask[2, 0, :B] = False               # ... that drops the whole text segment (samples 0..B-1): multiplier fallback
     mask[3, 1, B:2 * B] = False
     mask[3, 1, B + 2] = True             # ... that keeps one image sample
-    orig_scales, orig_mask = TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask
+    orig_scales, orig_mask, orig_tables = TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask, ops.SKIP_ROW_TABLES
 
     def fixed_scales(self, nb, device):
         assert nb == 3 * B
@@ -1468,7 +1464,8 @@ def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(f
     TE.TransformerEncoder._draw_keep_mask = staticmethod(lambda pr, n: mask.clone())
     res = {}
     try:
-        for skip in (False, True):
+        for skip, tables in variants:
+            ops.SKIP_ROW_TABLES = tables
             enc = one_peace_encoder_config(drop_path_rate=rate, layer_scale_init_value=1e-1, checkpoint_activations=recompute, **cfg)
             torch.manual_seed(0)
             m = load_synth(OnePeaceRetrievalModel(SimpleNamespace(encoder=enc, copy_rel_pos_table=False), TinyDictionary(1000), "val"))
@@ -1489,20 +1486,48 @@ def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(f
                 torch.cuda.synchronize()
             finally:
                 hipm.rows_gather = orig_gather
-            # 3 layers with drop-path x 2 branches, minus the fallback branch: 5 packed branches, each gathered in forward and backward
-            # (+ once more per branch when the forward is recomputed... the recomputation runs on the saved packed rows: no gather)
-            assert packed["n"] == (10 if skip else 0), packed
-            res[skip] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None})
+            res[(skip, tables)] = (float(loss.detach()), {n: q.grad.detach().float().clone() for n, q in m.named_parameters() if q.grad is not None},
+                                   packed["n"])
     finally:
-        TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask = orig_scales, orig_mask
-    assert abs(res[True][0] - res[False][0]) <= 2e-3 * abs(res[False][0]), (res[True][0], res[False][0])
-    assert set(res[True][1]) == set(res[False][1])
-    worst = ("", 0.0)
-    for n, gd in res[False][1].items():
-        e = float((res[True][1][n] - gd).norm()) / (float(gd.norm()) + 1e-6)
-        worst = max(worst, (n, e), key=lambda t: t[1])
+        TE.TransformerEncoder._draw_path_scales, TE.TransformerEncoder._draw_keep_mask, ops.SKIP_ROW_TABLES = orig_scales, orig_mask, orig_tables
+    return res
+
+
+@pytest.mark.parametrize("flat,recompute", [(False, False), (True, False), (True, True)])
+def test_lock_step_pass_that_skips_dropped_samples_matches_the_multiplier_form(flat, recompute):
+    """TransformerEncoder.skip_dropped_branches: every residual branch of the lock-step pass is computed for the samples stochastic
+    depth KEEPS only (hip.KeptRows; round 6: read and written through the row table) instead of for all samples with the dropped ones
+    multiplied by zero (transformer_layer.py:78-88).  Same masks in both runs: the loss and every gradient must agree within bf16
+    rounding (the packed GEMMs see other row counts, so tile shapes / split-K may differ; weight gradients sum the same non-zero terms
+    in another order)."""
+    res = _skip_dropped_runs(flat, recompute, [(False, True), (True, True)])
+    ref, got = res[(False, True)], res[(True, True)]
+    assert ref[2] == 0 and got[2] == 0, (ref[2], got[2])  # no packed copies any more
+    assert abs(got[0] - ref[0]) <= 2e-3 * abs(ref[0]), (got[0], ref[0])
+    assert set(got[1]) == set(ref[1])
+    for n, gd in ref[1].items():
+        e = float((got[1][n] - gd).norm()) / (float(gd.norm()) + 1e-6)
         assert e <= 3e-2, (n, e)
-    assert len(res[True][1]) > 60, len(res[True][1])
+    assert len(got[1]) > 60, len(got[1])
+
+
+@pytest.mark.parametrize("flat,recompute", [(False, False), (True, False), (True, True)])
+def test_row_tables_give_the_bits_of_the_packed_copies(flat, recompute):
+    """(round 6, ABI 9) The same step with ops.SKIP_ROW_TABLES on (LayerNorm forward / backward, op_resid_bwd and the residual epilogue
+    read and write the full matrix through hip.KeptRows.rowmap) and off (round 4: op_rows_gather in front of, op_rows_merge behind every
+    packed branch, forward and backward): the same loss and the same gradients BIT FOR BIT -- except the bias tables, whose gradient sums
+    fp32 atomics in either form."""
+    res = _skip_dropped_runs(flat, recompute, [(True, False), (True, True)])
+    old, new = res[(True, False)], res[(True, True)]
+    # 3 layers with drop-path x 2 branches, minus the fallback branch: 5 packed branches, each gathered in forward and backward
+    assert old[2] == 10 and new[2] == 0, (old[2], new[2])
+    assert old[0] == new[0], (old[0], new[0])
+    assert set(old[1]) == set(new[1])
+    for n, gd in old[1].items():
+        if "rel_pos_table" in n:
+            assert float((new[1][n] - gd).norm()) <= 1e-3 * float(gd.norm()) + 1e-6, n
+        else:
+            assert torch.equal(new[1][n], gd), (n, float((new[1][n] - gd).abs().max()))
 
 
 def test_skipped_branches_against_the_fp32_oracle_under_the_same_masks():

@@ -1628,3 +1628,126 @@ def test_rows_gather_and_merge_of_kept_samples():
     hip.rows_merge(inplace, upd, kr, out=inplace)
     assert torch.equal(inplace, ref)
     torch.cuda.synchronize()
+
+
+def _kept_rows_case(hip, S, n_samples, keep_seed, pad, cols_unused=None):
+    """Three segments (tokens per sample S[i], samples n_samples[i]) with random kept sets (at least one sample each)."""
+    g = torch.Generator().manual_seed(keep_seed)
+    segs, r0 = [], 0
+    for s, n in zip(S, n_samples):
+        k = [j for j in range(n) if torch.rand((), generator=g).item() < 0.7] or [n - 1]
+        segs.append((r0, s, n, k))
+        r0 += s * n
+    lists, bases = hip.pack_kept_lists([segs])
+    return hip.KeptRows(segs, lists.to("cuda"), bases[0], r0, 1.25, pad=pad), segs, r0
+
+
+@pytest.mark.parametrize("S,n,pad,cols", [((5, 7, 3), (4, 3, 6), 64, 136), ((64, 257, 250), (8, 9, 7), 256, 1536)])
+def test_row_tables_read_and_write_the_full_matrix_like_the_packed_copies(S, n, pad, cols):
+    """(ABI 9) op_rows_map + x_rows of op_layernorm_fwd / _bwd + dout_rows of op_resid_bwd + op_rows_merge without upd: a residual branch
+    on the samples stochastic depth keeps, reading and writing the FULL matrix through the row table -- bit for bit what the packed copies
+    (op_rows_gather before, op_rows_merge behind) give, incl. the zero rows behind every rounded-up segment."""
+    hip = hipmod()
+    kr, segs, rows = _kept_rows_case(hip, S, n, 5, pad)
+    m = kr.rowmap()
+    want = torch.full((kr.total,), -1, dtype=torch.int32)
+    for i, (r0, s, _, k) in enumerate(segs):
+        for j, smp in enumerate(k):
+            want[kr.dst_row0[i] + j * s:kr.dst_row0[i] + (j + 1) * s] = torch.arange(r0 + smp * s, r0 + (smp + 1) * s, dtype=torch.int32)
+    assert torch.equal(m.cpu(), want)
+    x = dev_bf16(rnd(rows, cols, seed=3, scale=2.0))
+    w, b = dev_bf16(1 + 0.1 * rnd(cols, seed=2)), dev_bf16(0.1 * rnd(cols, seed=4))
+    xg = hip.rows_gather(x, kr)
+    for gelu in (False, True):
+        y0, mean0, rstd0 = hip.layernorm_fwd(xg, w, b, gelu=gelu)
+        y1, mean1, rstd1 = hip.layernorm_fwd(x, w, b, gelu=gelu, x_rows=m)
+        assert torch.equal(y0, y1) and torch.equal(mean0, mean1) and torch.equal(rstd0, rstd1)
+    # backward: dy of the packed rows (zero where no sample is), the residual-path gradient `add` of the full matrix
+    dy = dev_bf16(rnd(kr.total, cols, seed=6)) * (m >= 0).unsqueeze(1).to(torch.bfloat16)
+    add = dev_bf16(rnd(rows, cols, seed=7))
+    dxp, dw0, db0 = hip.layernorm_bwd(dy, xg, w, b, mean0, rstd0, add=hip.rows_gather(add, kr))
+    ref = hip.rows_merge(add, dxp, kr)
+    inplace = add.clone()
+    _, dw1, db1 = hip.layernorm_bwd(dy, x, w, b, mean1, rstd1, add=inplace, dx=inplace, x_rows=m)
+    assert torch.equal(inplace, ref) and torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    out = torch.empty_like(add)  # out of place: the mapped rows by the kernel, the dropped samples' rows by the copy
+    hip.layernorm_bwd(dy, x, w, b, mean1, rstd1, add=add, dx=out, x_rows=m)
+    hip.rows_merge(add, None, kr, out=out)
+    assert torch.equal(out, ref)
+    # residual-branch backward reading dout through the table
+    gamma = dev_bf16(0.3 * rnd(cols, seed=8))
+    scale = torch.full((kr.total + 8,), 1.25, dtype=torch.float32, device="cuda")
+    g00, g01 = torch.empty(cols, dtype=torch.float32, device="cuda"), torch.empty(cols, dtype=torch.float32, device="cuda")
+    for kw0, kw1 in ((dict(dbias=True), dict(dbias=True)), (dict(dbias=True, g0=g00), dict(dbias=True, g0=g01))):
+        d0, _, b0_ = hip.resid_bwd(hip.rows_gather(add, kr), None, gamma, scale, 1, **kw0)
+        d1, _, b1_ = hip.resid_bwd(add, None, gamma, scale, 1, dout_rows=m, **kw1)
+        assert torch.equal(d0, d1) and torch.equal(b0_, b1_)
+    assert torch.equal(g00, g01)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("S,n,pad,N,K,bias,y", [
+    ((5, 7, 3), (4, 3, 6), 64, 128, 128, True, True),         # 128 x 128 tiles, a few M-tiles: split-K fold with the epilogue
+    ((64, 257, 250), (8, 9, 7), 256, 1536, 1536, True, False),  # the persistent four-wave kernel (K <= 2048)
+    ((64, 257, 250), (8, 9, 7), 256, 1536, 6144, True, True),   # gemm256v (K > 2048), with the branch output
+    ((64, 257, 250), (8, 9, 7), 64, 1536, 1536, False, False),  # M % 256 != 0: tail rows as a second launch
+    ((16, 17, 20), (6, 6, 6), 64, 256, 256, True, False),     # fewer than 256 tiles of 256 x 256
+])
+def test_residual_epilogue_through_a_row_table(S, n, pad, N, K, bias, y):
+    """(ABI 9) resid_rows of op_gemm_nt: out[rows[m]] = resid[rows[m]] + rowscale * gamma * (A W^T + b)[m] straight into the full matrix
+    (+ the dropped samples' rows copied) == the packed launch on op_rows_gather's copy followed by op_rows_merge, bit for bit, on every
+    kernel the launch plan can pick."""
+    hip = hipmod()
+    kr, segs, rows = _kept_rows_case(hip, S, n, 9, pad)
+    m = kr.rowmap()
+    x = dev_bf16(rnd(rows, N, seed=1))
+    A = dev_bf16(rnd(kr.total, K, seed=2, scale=0.5)) * (m >= 0).unsqueeze(1).to(torch.bfloat16)
+    W, bvec, gamma = dev_bf16(rnd(N, K, seed=3, scale=K ** -0.5)), dev_bf16(0.1 * rnd(N, seed=4)), dev_bf16(0.3 * rnd(N, seed=5))
+    scale = torch.full((kr.total + 8,), 1.25, dtype=torch.float32, device="cuda")
+    h0a = torch.empty(kr.total, N, dtype=torch.bfloat16, device="cuda") if y else None
+    h0b = torch.empty(kr.total, N, dtype=torch.bfloat16, device="cuda") if y else None
+    packed = hip.gemm_nt(A, [W], [bvec] if bias else None, epilogue=hip.EPI_RESID, resid=hip.rows_gather(x, kr), gamma=gamma, rowscale=scale,
+                         rows_per_sample=1, h0=h0a)
+    ref = hip.rows_merge(x, packed, kr)
+    out = torch.empty_like(x)
+    hip.gemm_nt(A, [W], [bvec] if bias else None, epilogue=hip.EPI_RESID, resid=x, gamma=gamma, rowscale=scale, rows_per_sample=1, h0=h0b,
+                out=out, resid_rows=m)
+    hip.rows_merge(x, None, kr, out=out)
+    assert torch.equal(out, ref)
+    if y:
+        assert torch.equal(h0a, h0b)
+    # in place on the residual stream (out = resid): the dropped samples' rows are simply left alone
+    inplace = x.clone()
+    hip.gemm_nt(A, [W], [bvec] if bias else None, epilogue=hip.EPI_RESID, resid=inplace, gamma=gamma, rowscale=scale, rows_per_sample=1,
+                out=inplace, resid_rows=m)
+    assert torch.equal(inplace, ref)
+    torch.cuda.synchronize()
+
+
+def test_grouped_residual_launch_through_row_tables():
+    """(ABI 9) resid_rows of op_gemm_nt_grouped: the three modality FFN down-projections of a layer as ONE launch, each problem writing the
+    rows of ITS kept samples into the shared full matrix == the packed grouped launch + op_rows_merge, bit for bit."""
+    hip = hipmod()
+    N, K = 1536, 512
+    kr, segs, rows = _kept_rows_case(hip, (64, 257, 250), (8, 9, 7), 13, 256)
+    m = kr.rowmap()
+    x = dev_bf16(rnd(rows, N, seed=1))
+    A = dev_bf16(rnd(kr.total, K, seed=2, scale=0.5)) * (m >= 0).unsqueeze(1).to(torch.bfloat16)
+    Ws = [dev_bf16(rnd(N, K, seed=10 + i, scale=K ** -0.5)) for i in range(3)]
+    bs = [dev_bf16(0.1 * rnd(N, seed=20 + i)) for i in range(3)]
+    gamma = dev_bf16(0.3 * rnd(N, seed=5))
+    scale = torch.full((kr.total + 8,), 1.25, dtype=torch.float32, device="cuda")
+    rs = [slice(kr.dst_row0[i], kr.dst_row0[i] + kr.dst_rows[i]) for i in range(3)]
+    xg = hip.rows_gather(x, kr)
+    packed = torch.empty_like(xg)
+    got = hip.gemm_nt_grouped([A[r] for r in rs], Ws, biases=bs, outs=[packed[r] for r in rs], epilogue=hip.EPI_RESID,
+                              resids=[xg[r] for r in rs], gammas=[gamma] * 3, rowscales=[scale] * 3, rows_per_sample=[1, 1, 1])
+    assert got is not None
+    ref = hip.rows_merge(x, packed, kr)
+    out = torch.empty_like(x)
+    got = hip.gemm_nt_grouped([A[r] for r in rs], Ws, biases=bs, outs=[out] * 3, epilogue=hip.EPI_RESID, resids=[x] * 3, gammas=[gamma] * 3,
+                              rowscales=[scale] * 3, rows_per_sample=[1, 1, 1], resid_rows=[m[r] for r in rs])
+    assert got is not None
+    hip.rows_merge(x, None, kr, out=out)
+    assert torch.equal(out, ref)
+    torch.cuda.synchronize()

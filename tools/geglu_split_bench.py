@@ -30,7 +30,7 @@ for M in [int(v) for v in os.environ.get("MS", "32896,16512,8320").split(",")]:
 
     def ln_g():
         hip._check(L.op_layernorm_fwd(hip.ptr(g), hip.ptr(lw), hip.ptr(lb), hip.ptr(y), hip.ptr(mean), hip.ptr(rstd), M, F, 1e-5, 0,
-                                      hip.DT_BF16, hip.stream()), "ln")
+                                      hip.DT_BF16, None, hip.stream()), "ln")
 
     fused_gemm = lambda: hip.gemm_nt(x, [w0, w1], epilogue=hip.EPI_GEGLU, h0=h0, h1=h1, out=g)
     split_gemm = lambda: hip.gemm_nt(x, [w0, w1], n_seg=F, N=2 * F, out=hh)

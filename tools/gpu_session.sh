@@ -8,7 +8,7 @@
 #   bench-extra   --audio-seconds 15, --objective pretrain-vl, --objective pretrain-al lines
 #   configs       --config 1 / 2 / 4 / 4 --fp8 lines
 #   trace         rocprofv3 --kernel-trace of the headline step + last-step summary (tools/trace_summary.py)
-#   trace-cfg4    the same for --config 4
+#   trace-cfg4    the same for --config 4;  trace-skip  the same for the headline step with --skip-dropped
 #   traffic       FETCH_SIZE / WRITE_SIZE of the GEMM family over a bench run (tools/pmc_bench_traffic.sh)
 #   pmc-attn      PMC passes over the attention kernels at S = 257 / B = 128 and S = 785 / B = 64 (tools/pmc_attn.sh)
 #   fp8-ab        config 4: bf16 / fp8 forward only / fp8 forward + input gradients, alternating on one box, with loss curves
@@ -44,8 +44,9 @@ for stage in "$@"; do
         timeout 500 python bench.py --config 4 $fl --steps 20 --warmup 3 --loss-curve --no-cpu-baseline --no-power-probe --no-skip-leg > $O/fp8ab_${v}_$n.txt 2> $O/fp8ab_${v}_$n.err
         line $O/fp8ab_${v}_$n.txt "cfg4-$v"
       done ;;
-    trace|trace-cfg4)
+    trace|trace-cfg4|trace-skip)
       extra=""; name=bench_last_step; [ $stage = trace-cfg4 ] && { extra="--config 4"; name=bench_config4_last_step; }
+      [ $stage = trace-skip ] && { extra="--skip-dropped"; name=bench_skip_dropped_last_step; }
       ( cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/prof_$TAG
         timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $R/bench.py $extra --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-power-probe --no-skip-leg > $O/${name}_under_rocprof.json 2> $O/${name}_under_rocprof.err
         KT=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1); ST=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)

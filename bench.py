@@ -19,8 +19,12 @@ import sys
 import time
 from types import SimpleNamespace
 
-import torch
-import torch.distributed as dist
+# the host driver of the MI355X pool supports dmabuf IPC only: without this RCCL's buffer exchange between the ranks of a node fails with
+# "hipIpcGetMemHandle: invalid argument".  Exported by the image already; set here too, before the HIP runtime comes up.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -60,7 +60,8 @@ class TransformerEncoder(nn.Module):
         self.kept_rows_pad = 256  # packed rows per segment are rounded up to whole 256-row GEMM tiles (zero rows)
         # below these drop rates a branch (attention, FFN) keeps the multiplier form: the two packing passes + the zero rows cost more than
         # the dropped samples' share of the branch (headline step: 0.3 ms against 5.7 ms resp. 12 ms per branch, forward + backward)
-        self.pack_min_drop = (0.055, 0.03)
+        # (round 6, with the row tables: thresholds of (0.03, 0.02) and (0.04, 0.02) measured the same 580.6 ms as these over three alternations)
+        self.pack_min_drop = tuple(float(v) for v in os.environ.get("ONEPEACE_PACK_MIN_DROP", "0.055,0.03").split(","))
 
     def build_encoder_layer(self, cfg, drop_path_rate=0.0):
         return TransformerEncoderLayer(cfg, drop_path_rate=drop_path_rate)

@@ -11,8 +11,8 @@ import csv, glob, sys
 name, M, N, K, resid, cal = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] == "1", float(sys.argv[6])
 f = glob.glob("/tmp/pmcs/**/*counter_collection.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "gemm" in r["Kernel_Name"]]
-kb = sum(float(r["Counter_Value"]) for r in rows) / max(1, len(rows))
-kern = rows[0]["Kernel_Name"].split("(")[0][-24:] if rows else "?"
+kb = sum(float(r["Counter_Value"]) for r in rows) / 6.0  # per LOGICAL launch (nt_shape_run.py makes six): a tail-rows split is two kernels
+kern = "%d kernels per launch" % (len(rows) // 6)
 algo = 2 * (M * K + N * K + (M * N if resid else 0))
 got = kb * 1024 * cal
 print("%-34s M=%6d N=%5d K=%5d  %-24s read %7.1f MB per launch, algorithmic %7.1f MB: %.2f x" % (name, M, N, K, kern, got / 1e6, algo / 1e6, got / algo))

@@ -1751,3 +1751,31 @@ def test_grouped_residual_launch_through_row_tables():
     hip.rows_merge(x, None, kr, out=out)
     assert torch.equal(out, ref)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kept", [[[0, 1, 2, 3]], [[2]], [[0, 3]]])
+def test_row_tables_edge_cases_one_segment(kept):
+    """(ABI 9) One segment of four 256-token samples: every sample kept (a table without -1 entries that is the identity), a single
+    sample kept, the first and the last kept -- LayerNorm through the table, the residual epilogue into the full matrix and the copy of the
+    dropped samples' rows against plain torch indexing."""
+    hip = hipmod()
+    S, n, cols = 256, 4, 512
+    segs = [(0, S, n, kept[0])]
+    lists, bases = hip.pack_kept_lists([segs])
+    kr = hip.KeptRows(segs, lists.to("cuda"), bases[0], S * n, 1.0, pad=256)
+    m = kr.rowmap()
+    want = torch.cat([torch.arange(j * S, (j + 1) * S, dtype=torch.int32) for j in kept[0]])
+    assert kr.total == len(kept[0]) * S and torch.equal(m.cpu(), want)
+    x = dev_bf16(rnd(S * n, cols, seed=1, scale=2.0))
+    w, b = dev_bf16(1 + 0.1 * rnd(cols, seed=2)), dev_bf16(0.1 * rnd(cols, seed=3))
+    y, mean, rstd = hip.layernorm_fwd(x, w, b, x_rows=m)
+    y_ref, mean_ref, rstd_ref = hip.layernorm_fwd(x[m.long()].contiguous(), w, b)
+    assert torch.equal(y, y_ref) and torch.equal(mean, mean_ref) and torch.equal(rstd, rstd_ref)
+    W = dev_bf16(rnd(cols, cols, seed=4, scale=cols ** -0.5))
+    out = torch.empty_like(x)
+    hip.gemm_nt(y, [W], epilogue=hip.EPI_RESID, resid=x, out=out, resid_rows=m)
+    hip.rows_merge(x, None, kr, out=out)
+    ref = x.clone()
+    ref[m.long()] = hip.gemm_nt(y_ref, [W], epilogue=hip.EPI_RESID, resid=x[m.long()].contiguous())
+    assert torch.equal(out, ref)
+    torch.cuda.synchronize()
